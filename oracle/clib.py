@@ -1,0 +1,133 @@
+"""ctypes view of oracle/libv2v_oracle.so (the scalar C restatement).  TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libv2v_oracle.so")
+_lib = None
+
+IN_U8, IN_F32 = 0, 1
+RNG_NONE, RNG_PHILOX, RNG_REPLAY = 0, 1, 2
+BIN_SUM, BIN_BILINEAR = 0, 1
+
+
+class Replay(C.Structure):
+    _fields_ = [("u_init", C.c_void_p), ("u_hot", C.c_void_p), ("g_hot", C.c_void_p), ("g_base", C.c_void_p)]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "v2v_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libv2v_oracle.so"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.oracle_floor_divide.restype = C.c_double
+        _lib.oracle_floor_divide.argtypes = [C.c_double, C.c_double]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def floor_divide(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(np.broadcast_to(b, a.shape), dtype=np.float64)
+    q = np.empty_like(a)
+    lib().oracle_floor_divide_vec(_p(a), _p(b), _p(q), C.c_int64(a.size))
+    return q
+
+
+def philox4x32(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().oracle_philox4x32(c, k, o)
+    return list(o)
+
+
+def bm_pair(a, b):
+    o = (C.c_float * 2)()
+    lib().oracle_bm_pair(C.c_uint32(a), C.c_uint32(b), o)
+    return np.float32(o[0]), np.float32(o[1])
+
+
+def philox_uniform_field(seed, clip_id, field, n_pix, stream=0):
+    out = np.empty(n_pix, dtype=np.float64)
+    lib().oracle_philox_uniform_field(C.c_uint64(seed), C.c_uint32(clip_id & 0xFFFFFFFF), C.c_uint32(field),
+                                      C.c_uint32(stream), C.c_int64(n_pix), _p(out))
+    return out
+
+
+def philox_gauss_field(seed, clip_id, field, n_pix, stream=0):
+    out = np.empty(n_pix, dtype=np.float32)
+    lib().oracle_philox_gauss_field(C.c_uint64(seed), C.c_uint32(clip_id & 0xFFFFFFFF), C.c_uint32(field),
+                                    C.c_uint32(stream), C.c_int64(n_pix), _p(out))
+    return out
+
+
+def esim_voxel(frames, params, luts, *, noise_external=False, rng_mode=RNG_PHILOX, seed=0, clip_id0=0,
+               bin_mode=BIN_SUM, num_bins=5, frames_per_bin=1, replay=None, threads=None):
+    """frames [B,N,H,W] uint8 or float32 (integer-valued); params [5] or [B,5].
+    Returns (voxel float64 [B,L,Tb,H,W] | [B,Tb,H,W], totals int64 [B,2])."""
+    frames = np.ascontiguousarray(frames)
+    b, n, h, w = frames.shape
+    k = n - 1
+    in_dtype = {np.dtype(np.uint8): IN_U8, np.dtype(np.float32): IN_F32}[frames.dtype]
+    if in_dtype == IN_F32:
+        iv = frames.astype(np.int64)
+        assert np.array_equal(iv, frames) and iv.min() >= 0 and iv.max() <= 255, "C oracle is LUT-only"
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    stride = 0 if params.ndim == 1 else 5
+    lut64 = np.ascontiguousarray(luts["lut64"], dtype=np.float64)
+    lut32 = np.ascontiguousarray(luts["lut32"], dtype=np.float32)
+    if bin_mode == BIN_SUM:
+        assert k % (num_bins * frames_per_bin) == 0
+        shape = (b, k // (num_bins * frames_per_bin), num_bins, h, w)
+    else:
+        shape = (b, num_bins, h, w)
+    out = np.zeros(shape, dtype=np.float64)
+    totals = np.zeros((b, 2), dtype=np.int64)
+    L = lib()
+    if replay is not None:
+        assert b == 1 and rng_mode == RNG_REPLAY
+        keep = [np.ascontiguousarray(x, dtype=np.float64) for x in replay]
+        rp = Replay(*[x.ctypes.data for x in keep])
+        rc = L.oracle_esim_voxel_clip(_p(frames), in_dtype, C.c_int64(n), C.c_int64(h * w), _p(lut64), _p(lut32),
+                                      _p(params), int(noise_external), rng_mode, C.c_uint64(seed),
+                                      C.c_uint32(clip_id0), C.byref(rp), bin_mode, num_bins, frames_per_bin,
+                                      _p(out), _p(totals))
+    else:
+        if threads is not None:
+            os.environ["OMP_NUM_THREADS"] = str(threads)
+        rc = L.oracle_esim_voxel_batch(_p(frames), in_dtype, C.c_int64(b), C.c_int64(n), C.c_int64(h * w),
+                                       _p(lut64), _p(lut32), _p(params), C.c_int64(stride), int(noise_external),
+                                       rng_mode, C.c_uint64(seed), C.c_uint64(clip_id0), bin_mode, num_bins,
+                                       frames_per_bin, _p(out), _p(totals))
+    if rc != 0:
+        raise RuntimeError(f"oracle_esim_voxel rc={rc}")
+    return out, totals
+
+
+def make_voxel(ts_us, xs, ys, ps01, num_bins, h, w, interpolate):
+    ts_us = np.ascontiguousarray(ts_us, dtype=np.int64)
+    xs = np.ascontiguousarray(xs, dtype=np.int64)
+    ys = np.ascontiguousarray(ys, dtype=np.int64)
+    ps01 = np.ascontiguousarray(ps01, dtype=np.int8)
+    out = np.zeros((num_bins, h, w), dtype=np.float64)
+    rc = lib().oracle_make_voxel(_p(ts_us), _p(xs), _p(ys), _p(ps01), C.c_int64(ts_us.size), num_bins,
+                                 C.c_int64(h), C.c_int64(w), int(interpolate), _p(out))
+    if rc != 0:
+        raise RuntimeError(f"oracle_make_voxel rc={rc}")
+    return out

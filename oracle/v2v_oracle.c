@@ -1,0 +1,314 @@
+/*
+ * oracle/v2v_oracle.c -- scalar C restatement of the V2V video->voxel hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Built into oracle/libv2v_oracle.so by oracle/Makefile and loaded
+ * (ctypes, oracle/clib.py) only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg.  The product (v2v_amd/, libv2v_hip.so) never links, loads or calls it.
+ *
+ * Parity status: PINNED against the golden vectors in tests/golden/ (captured from the imported
+ * reference; see tests/golden/make_goldens.py) and against oracle/v2v_oracle.py.
+ *
+ * One pixel at a time, one frame pair at a time -- the obviously-correct form of
+ *   data/v2v_core_esim.py:26-69   (ESIM frame-pair simulator)
+ *   data/v2v_datasets.py:363-410  (sum binning of per-pair counts)
+ *   utils/event_utils.py:692-728  (temporal-bilinear weights)
+ *   data/testh5.py:60-90          (make_voxel event-list voxeliser)
+ * np.floor_divide is third-party arithmetic (numpy 2.2.6 npy_divmod); restated below.
+ *
+ * Compile with -ffp-contract=off: the reference never fuses a multiply with an add.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ np.floor_divide (float64) */
+double oracle_floor_divide(double a, double b)
+{
+    if (b == 0.0) return a / b;
+    double mod = fmod(a, b);
+    double div = (a - mod) / b;
+    if (mod != 0.0) {
+        if ((b < 0) != (mod < 0)) { mod += b; div -= 1.0; }
+    }
+    double fl;
+    if (div != 0.0) {
+        fl = floor(div);
+        if (div - fl > 0.5) fl += 1.0;
+    } else {
+        fl = copysign(0.0, a / b);
+    }
+    return fl;
+}
+
+void oracle_floor_divide_vec(const double *a, const double *b, double *q, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) q[i] = oracle_floor_divide(a[i], b[i]);
+}
+
+/* ------------------------------------------------------------------ Philox4x32-10 */
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+void oracle_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+    philox4x32_10(c, key[0], key[1]);
+    memcpy(out, c, sizeof(c));
+}
+
+/* 53-bit uniform, numpy legacy recipe (random_sample): (a>>5, b>>6) */
+static double uniform53(uint32_t a, uint32_t b)
+{
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
+
+static float u32_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static uint32_t float_as_u32(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/*
+ * fp32 Box-Muller written with IEEE-exact primitives only (+ - * fmaf sqrtf and integer ops) so that
+ * gcc on the host and hipcc on gfx950 produce the same bits.  Not taken from the reference (which uses
+ * numpy's MT19937 polar method, impossible to replay at bandwidth on a GPU); this is the definition
+ * of the device-native noise fields.  log polynomial: Cephes logf; sin/cos: Cephes sinf/cosf kernels
+ * on [-pi/4, pi/4], then an exact-sign rotation by (q+1/2)*pi/2.
+ */
+static void bm_pair(uint32_t a, uint32_t b, float *g0, float *g1)
+{
+    /* radius: u1 in (0,1] on a 2^-24 grid */
+    float u1 = (float)((a >> 8) + 1u) * 5.9604644775390625e-08f;
+    uint32_t bits = float_as_u32(u1);
+    int e = (int)(bits >> 23) - 127;
+    float m = u32_as_float((bits & 0x007FFFFFu) | 0x3F800000u);
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    float f = m - 1.0f;
+    float z = f * f;
+    float p = 7.0376836292e-2f;
+    p = fmaf(p, f, -1.1514610310e-1f);
+    p = fmaf(p, f, 1.1676998740e-1f);
+    p = fmaf(p, f, -1.2420140846e-1f);
+    p = fmaf(p, f, 1.4249322787e-1f);
+    p = fmaf(p, f, -1.6668057665e-1f);
+    p = fmaf(p, f, 2.0000714765e-1f);
+    p = fmaf(p, f, -2.4999993993e-1f);
+    p = fmaf(p, f, 3.3333331174e-1f);
+    float y = (p * f) * z;
+    y = fmaf(-0.5f, z, y);
+    float ln_m = f + y;
+    float ln_u = fmaf((float)e, 0.693147182f, ln_m);
+    float t = -2.0f * ln_u;
+    float r = sqrtf(t) * 0.707106769f;
+
+    /* angle: quadrant from the top 2 bits, 24 further bits inside the quadrant */
+    uint32_t q = b >> 30;
+    float yy = (float)((b >> 6) & 0x00FFFFFFu) * 5.9604644775390625e-08f - 0.5f;
+    float x = yy * 1.57079637f;
+    float zz = x * x;
+    float s = -1.9515295891e-4f;
+    s = fmaf(s, zz, 8.3321608736e-3f);
+    s = fmaf(s, zz, -1.6666654611e-1f);
+    s = fmaf(s * zz, x, x);
+    float c = 2.443315711809948e-5f;
+    c = fmaf(c, zz, -1.388731625493765e-3f);
+    c = fmaf(c, zz, 4.166664568298827e-2f);
+    c = fmaf(c * zz, zz, fmaf(-0.5f, zz, 1.0f));
+    /* cosA = sc*h, sinA = ss*h with (sc,ss) = (+,+),(-,+),(-,-),(+,-) for q = 0..3 */
+    uint32_t sc = ((q == 1u) || (q == 2u)) ? 0x80000000u : 0u;
+    uint32_t ss = (q >= 2u) ? 0x80000000u : 0u;
+    float cc = u32_as_float(float_as_u32(c) ^ sc);   /* sc*c */
+    float cs = u32_as_float(float_as_u32(c) ^ ss);   /* ss*c */
+    float sc_s = u32_as_float(float_as_u32(s) ^ sc); /* sc*s */
+    float ss_s = u32_as_float(float_as_u32(s) ^ ss); /* ss*s */
+    float ct = cc - ss_s;
+    float st = cs + sc_s;
+    *g0 = r * ct;
+    *g1 = r * st;
+}
+
+void oracle_bm_pair(uint32_t a, uint32_t b, float out[2]) { bm_pair(a, b, &out[0], &out[1]); }
+
+static double px_uniform53(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream, uint32_t p)
+{
+    uint32_t c[4] = {p >> 1, field, clip, stream};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return (p & 1u) ? uniform53(c[2], c[3]) : uniform53(c[0], c[1]);
+}
+
+static float px_gauss32(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream, uint32_t p)
+{
+    uint32_t c[4] = {p >> 2, field, clip, stream};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    float g0, g1;
+    if ((p >> 1) & 1u) bm_pair(c[2], c[3], &g0, &g1); else bm_pair(c[0], c[1], &g0, &g1);
+    return (p & 1u) ? g1 : g0;
+}
+
+void oracle_philox_uniform_field(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream,
+                                 int64_t n_pix, double *out)
+{
+    for (int64_t p = 0; p < n_pix; ++p) out[p] = px_uniform53(seed, clip, field, stream, (uint32_t)p);
+}
+
+void oracle_philox_gauss_field(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream,
+                               int64_t n_pix, float *out)
+{
+    for (int64_t p = 0; p < n_pix; ++p) out[p] = px_gauss32(seed, clip, field, stream, (uint32_t)p);
+}
+
+/* ------------------------------------------------------------------ ESIM + binning, one clip */
+enum { ORACLE_IN_U8 = 0, ORACLE_IN_F32 = 1 };
+enum { ORACLE_RNG_NONE = 0, ORACLE_RNG_PHILOX = 1, ORACLE_RNG_REPLAY = 2 };
+enum { ORACLE_BIN_SUM = 0, ORACLE_BIN_BILINEAR = 1 };
+
+typedef struct {
+    const double *u_init;  /* [H*W]   rand  #1  (v2v_core_esim.py:29) */
+    const double *u_hot;   /* [H*W]   rand  #2  (:37) */
+    const double *g_hot;   /* [H*W]   randn #1  (:38) */
+    const double *g_base;  /* [K,H*W] randn per pair (:44) */
+} oracle_replay;
+
+/* temporal-bilinear weight of pair k for bin b; same float64 expression as event_utils.py:715-719 */
+static double bil_w(int64_t k, int64_t K, int b, int Tb)
+{
+    double t_norm = ((double)k - 0.0) / ((double)(K - 1) - 0.0) * (double)(Tb - 1);
+    double w = 1.0 - fabs(t_norm - (double)b);
+    return w > 0.0 ? w : 0.0;
+}
+
+/*
+ * frames: one clip [N,H*W] (u8, or float32 holding integers 0..255).
+ * lut64/lut32: golden G1 tables.  params: {pos,neg,base_std,hot_frac,hot_std}.
+ * rng NONE: deterministic debugging mode: u_init = 0.5, never hot, all Gaussians 0.
+ * out: SUM -> [L,Tb,H*W] float64 ; BILINEAR -> [Tb,H*W] float64.  totals[2] += ON, OFF event totals.
+ */
+int oracle_esim_voxel_clip(const void *frames, int in_dtype, int64_t N, int64_t HW,
+                           const double *lut64, const float *lut32, const double params[5],
+                           int noise_external, int rng_mode, uint64_t seed, uint32_t clip_id,
+                           const oracle_replay *rp, int bin_mode, int Tb, int fpb,
+                           double *out, int64_t *totals)
+{
+    const int64_t K = N - 1;
+    if (K < 1 || Tb < 1 || fpb < 1) return -1;
+    if (bin_mode == ORACLE_BIN_SUM && (K % ((int64_t)Tb * fpb)) != 0) return -2;
+    if (bin_mode == ORACLE_BIN_BILINEAR && K < 2) return -3;
+    const double pos = params[0], neg = params[1], base_std = params[2], hot_frac = params[3], hot_std = params[4];
+    const uint8_t *f8 = (const uint8_t *)frames;
+    const float *f32 = (const float *)frames;
+    const int64_t n_out = (bin_mode == ORACLE_BIN_SUM) ? K / fpb : Tb;
+    int64_t on_total = 0, off_total = 0;
+
+    for (int64_t p = 0; p < HW; ++p) {
+        double u0 = 0.5, u1 = 1.0, gh = 0.0;
+        if (rng_mode == ORACLE_RNG_PHILOX) {
+            u0 = px_uniform53(seed, clip_id, 0, 0, (uint32_t)p);
+            u1 = px_uniform53(seed, clip_id, 1, 0, (uint32_t)p);
+            gh = (double)px_gauss32(seed, clip_id, 2, 0, (uint32_t)p);
+        } else if (rng_mode == ORACLE_RNG_REPLAY) {
+            u0 = rp->u_init[p]; u1 = rp->u_hot[p]; gh = rp->g_hot[p];
+        }
+        double pot = u0 * (pos + neg) - neg;                       /* :29 */
+        double hot = (u1 < hot_frac) ? hot_std * gh : 0.0;         /* :37-39 */
+        for (int64_t o = 0; o < n_out; ++o) out[o * HW + p] = 0.0;
+
+        for (int64_t k = 0; k < K; ++k) {
+            if (in_dtype == ORACLE_IN_U8) {
+                double d = lut64[f8[(k + 1) * HW + p]] - lut64[f8[k * HW + p]];
+                pot += d;
+            } else {
+                float a = f32[k * HW + p], b = f32[(k + 1) * HW + p];
+                float d = lut32[(int)b] - lut32[(int)a];           /* float32 subtraction */
+                pot += (double)d;
+            }
+            double g = 0.0;
+            if (rng_mode == ORACLE_RNG_PHILOX) g = (double)px_gauss32(seed, clip_id, 3u + (uint32_t)k, 0, (uint32_t)p);
+            else if (rng_mode == ORACLE_RNG_REPLAY) g = rp->g_base[k * HW + p];
+            double base = base_std * g;                            /* :44 */
+            if (!noise_external) { pot += base; pot += hot; }      /* :48-49 */
+            double on = 0.0, off = 0.0;
+            if (pot >= pos) on = oracle_floor_divide(pot, pos);    /* :51-52 */
+            if (pot <= -neg) off = oracle_floor_divide(-pot, neg); /* :54-55 */
+            pot -= on * pos;                                       /* :57 */
+            pot += off * neg;                                      /* :58 */
+            double vox = on - off;
+            if (noise_external) { vox = vox + base; vox = vox + hot; }
+            on_total += (int64_t)on; off_total += (int64_t)off;
+            if (bin_mode == ORACLE_BIN_SUM) {
+                out[(k / fpb) * HW + p] += vox;                    /* [L,Tb] flattened == k / fpb */
+            } else {
+                for (int b = 0; b < Tb; ++b) {
+                    double w = bil_w(k, K, b, Tb);
+                    double contrib = vox * w;
+                    out[(int64_t)b * HW + p] += contrib;
+                }
+            }
+        }
+    }
+    if (totals) { totals[0] += on_total; totals[1] += off_total; }
+    return 0;
+}
+
+/* Batch driver (OpenMP over clips when built with -fopenmp). frames [B,N,HW]; params [B,5] or stride 0. */
+int oracle_esim_voxel_batch(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t HW,
+                            const double *lut64, const float *lut32, const double *params,
+                            int64_t params_stride, int noise_external, int rng_mode, uint64_t seed,
+                            uint64_t clip_id0, int bin_mode, int Tb, int fpb, double *out,
+                            int64_t *totals /* [B,2] or NULL */)
+{
+    const int64_t K = N - 1;
+    const int64_t out_per_clip = ((bin_mode == ORACLE_BIN_SUM) ? K / fpb : Tb) * HW;
+    const int64_t in_per_clip = N * HW * (in_dtype == ORACLE_IN_U8 ? 1 : 4);
+    int rc = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t c = 0; c < B; ++c) {
+        int64_t t[2] = {0, 0};
+        int r = oracle_esim_voxel_clip((const char *)frames + c * in_per_clip, in_dtype, N, HW, lut64, lut32,
+                                       params + c * params_stride, noise_external, rng_mode, seed,
+                                       (uint32_t)(clip_id0 + (uint64_t)c), NULL, bin_mode, Tb, fpb,
+                                       out + c * out_per_clip, t);
+        if (totals) { totals[2 * c] = t[0]; totals[2 * c + 1] = t[1]; }
+        if (r != 0) {
+#pragma omp critical
+            rc = r;
+        }
+    }
+    return rc;
+}
+
+/* ------------------------------------------------------------------ make_voxel (testh5.py:60-90) */
+/* ts_us: int64 microseconds already shifted to ts[0]=0 (the Python side does the float math that
+ * the reference does in numpy: ((ts-ts[0])*1e6).astype(int64)); ps01 in {0,1}. out [Tb,H,W] float64. */
+int oracle_make_voxel(const int64_t *ts_us, const int64_t *xs, const int64_t *ys, const int8_t *ps01,
+                      int64_t n, int Tb, int64_t H, int64_t W, int interpolate, double *out)
+{
+    memset(out, 0, sizeof(double) * (size_t)Tb * H * W);
+    if (n == 0) return 0;
+    if (!interpolate) {
+        double t_per_bin = ((double)ts_us[n - 1] + 0.001) / (double)Tb;
+        for (int64_t i = 0; i < n; ++i) {
+            uint8_t b = (uint8_t)floor((double)ts_us[i] / t_per_bin);
+            if (b >= Tb) return -4;
+            out[((int64_t)b * H + ys[i]) * W + xs[i]] += (double)(ps01[i] * 2 - 1);
+        }
+    } else {
+        double dt = (double)(ts_us[n - 1] - ts_us[0]);
+        for (int b = 0; b < Tb; ++b)
+            for (int64_t i = 0; i < n; ++i) {
+                double t_norm = (double)(ts_us[i] - ts_us[0]) / (dt + 0.0001) * (double)(Tb - 1);
+                double w = 1.0 - fabs(t_norm - (double)b);
+                if (w < 0.0) w = 0.0;
+                out[((int64_t)b * H + ys[i]) * W + xs[i]] += w * (double)(ps01[i] * 2 - 1);
+            }
+    }
+    return 0;
+}

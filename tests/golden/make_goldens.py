@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/ by IMPORTING THE REFERENCE (build container only).
+
+    python tests/golden/make_goldens.py            # needs /root/reference, writes tests/golden/*.npz
+
+The reference's Python never travels to the GPU box; these fixtures (inputs + the reference's own
+outputs) do.  Everything here is data produced by calling reference functions -- no reference source
+text is stored.  SURVEY.md §8(c) lists the vectors (G1..G11).
+
+Reference entry points exercised:
+  data/v2v_core_esim.py:26-69       EventEmulator.video_to_voxel          (G1-G4, G11)
+  numpy.floor_divide                 as used at v2v_core_esim.py:51,54     (G5)
+  data/v2v_datasets.py:363-410       WebvidDatasetV2.imgs_to_voxels        (G6)
+  utils/event_utils.py:692-728       events_to_voxel                       (G7)
+  data/testh5.py:60-90               TestH5Dataset.make_voxel              (G8)
+  data/v2v_core_v2e.py:556-581       video_to_voxel (v2e)                  (G9)
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+for m in ("cv2", "h5py", "ffmpeg", "event_voxel_builder"):      # absent here; only IO code touches them
+    sys.modules.setdefault(m, types.ModuleType(m))
+sys.modules["event_voxel_builder"].EventVoxelBuilder = object
+sys.path.insert(0, REF)
+
+from data.v2v_core_esim import EventEmulator  # noqa: E402  (pure numpy)
+from data import v2v_core_v2e  # noqa: E402
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+ref_eu = _load("ref_event_utils", os.path.join(REF, "utils/event_utils.py"))
+ref_ds = _load("ref_v2v_datasets", os.path.join(REF, "data/v2v_datasets.py"))
+ref_th5 = _load("ref_testh5", os.path.join(REF, "data/testh5.py"))
+
+from oracle import v2v_oracle as O  # noqa: E402  (only for the synthetic input generator + Philox fields)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print(f"{name}: {os.path.getsize(path)/1024:.1f} KiB")
+
+
+def g1_luts():
+    u8 = np.arange(256, dtype=np.uint8).reshape(1, 16, 16)
+    f32 = np.arange(256, dtype=np.float32).reshape(1, 16, 16)
+    # the reference's own two lines (v2v_core_esim.py:33-34) applied to every intensity, both dtypes
+    from data.v2v_core_esim import reverse_gamma_correction
+    lut64 = np.log(0.001 + reverse_gamma_correction(u8) / 255.0).reshape(256)
+    lut32 = np.log(0.001 + reverse_gamma_correction(f32) / 255.0).reshape(256)
+    assert lut64.dtype == np.float64 and lut32.dtype == np.float32
+    v2e32 = v2v_core_v2e.lin_log(np.arange(256, dtype=np.uint8))
+    assert v2e32.dtype == np.float32
+    save("g1_luts.npz", lut64=lut64, lut32=lut32, v2e32=v2e32)
+
+
+def g2_g3_esim_clean():
+    video = O.synth_clip_s1(8, 128, 128, seed=1234, dtype=np.uint8)        # S1 / BASELINE config 1
+    out = {"video": video, "seeds": np.array([5, 6])}
+    for tag, (cp, cn) in {"sym": (0.2, 0.2), "asym": (0.31, 0.47)}.items():
+        for s in (5, 6):
+            for dt_tag, dt in (("u8", np.uint8), ("f32", np.float32)):
+                np.random.seed(s)
+                v = EventEmulator(cp, cn, 0.0, 0.0, 0.0, False).video_to_voxel(video.astype(dt))
+                assert np.array_equal(v, np.round(v)) and np.abs(v).max() < 127
+                out[f"{tag}_s{s}_{dt_tag}"] = v.astype(np.int8)
+    save("g2_esim_clean.npz", **out)
+
+
+def g4_esim_noisy():
+    video = O.synth_clip_s1(8, 32, 32, seed=77, dtype=np.uint8)
+    out = {"video": video, "params": np.array([0.25, 0.4, 0.05, 0.02, 0.8]), "seed": np.array(42)}
+    for ext in (False, True):
+        for dt_tag, dt in (("u8", np.uint8), ("f32", np.float32)):
+            np.random.seed(42)
+            v = EventEmulator(0.25, 0.4, 0.05, 0.02, 0.8, ext).video_to_voxel(video.astype(dt))
+            out[f"ext{int(ext)}_{dt_tag}"] = v
+    save("g4_esim_noisy.npz", **out)
+
+
+def g5_floor_divide():
+    g = np.random.default_rng(2024)
+    b = g.uniform(0.05, 3.0, size=1500)
+    q = g.integers(1, 60, size=1500).astype(np.float64)
+    a = q * b                                               # near-ties: a is within an ulp or two of q*b
+    a = np.nextafter(a, np.where(g.random(1500) < 0.5, -np.inf, np.inf))
+    a[::3] = (q * b)[::3]
+    a2 = g.uniform(0.0, 40.0, size=500)
+    b2 = g.uniform(0.05, 3.0, size=500)
+    a = np.concatenate([a, a2, [24.550921417593624]])
+    b = np.concatenate([b, b2, [1.2275460708796813]])
+    save("g5_floor_divide.npz", a=a, b=b, q=np.floor_divide(a, b))
+
+
+def g6_imgs_to_voxels():
+    video = O.synth_clip_s1(21, 32, 32, seed=99, dtype=np.uint8)
+    inst = object.__new__(ref_ds.WebvidDatasetV2)
+    inst.load_configs({"sequence_length": 4, "num_bins": 5, "frames_per_bin": 1})
+    np.random.seed(2025)
+    params, vox = inst.imgs_to_voxels(video, 5, 1, 24)
+    assert vox.shape == (4, 5, 32, 32)
+    inst2 = object.__new__(ref_ds.WebvidDatasetV2)
+    inst2.load_configs({"sequence_length": 2, "num_bins": 5, "frames_per_bin": 2, "scale_noise_strength": True})
+    np.random.seed(2026)
+    params2, vox2 = inst2.imgs_to_voxels(video, 5, 2, 24)
+    assert vox2.shape == (2, 5, 32, 32)
+    keys = ["pos_thres", "neg_thres", "base_noise_std", "hot_pixel_fraction", "hot_pixel_std"]
+    save("g6_imgs_to_voxels.npz", video=video, seed=np.array(2025), voxels=vox,
+         params=np.array([params[k] for k in keys]), seed2=np.array(2026), voxels2=vox2,
+         params2=np.array([params2[k] for k in keys]))
+
+
+def g7_bilinear():
+    out = {}
+    g = np.random.default_rng(7)
+    for k in (2, 7, 31, 39):
+        # weights: one unit event per pair at a single pixel
+        xs = np.zeros(k, dtype=np.int64)
+        ys = np.zeros(k, dtype=np.int64)
+        ts = np.arange(k, dtype=np.float64)[:, None]
+        wmat = np.zeros((5, k))
+        for kk in range(k):
+            ps = np.zeros((k, 1))
+            ps[kk] = 1.0
+            wmat[:, kk] = ref_eu.events_to_voxel(xs, ys, ts, ps, 5, sensor_size=(1, 1))[:, 0, 0]
+        out[f"w_K{k}"] = wmat
+        counts = g.integers(-6, 7, size=(k, 16, 16)).astype(np.float64)
+        yy, xx = np.meshgrid(np.arange(16), np.arange(16), indexing="ij")
+        xs = np.tile(xx.reshape(-1), k)
+        ys = np.tile(yy.reshape(-1), k)
+        ts = np.repeat(np.arange(k, dtype=np.float64), 256)[:, None]
+        ps = counts.reshape(-1)[:, None]
+        out[f"counts_K{k}"] = counts.astype(np.int8)
+        out[f"voxel_K{k}"] = ref_eu.events_to_voxel(xs, ys, ts, ps, 5, sensor_size=(16, 16))
+    save("g7_bilinear.npz", **out)
+
+
+def g8_make_voxel():
+    g = np.random.default_rng(8)
+    n = 500
+    ts = np.sort(g.uniform(10.0, 10.05, size=n))
+    xs = g.integers(0, 24, size=n)
+    ys = g.integers(0, 16, size=n)
+    ps = g.integers(0, 2, size=n)
+    stub = types.SimpleNamespace(num_bins=5, H=16, W=24, interpolate_bins=False)
+    disc = ref_th5.TestH5Dataset.make_voxel(stub, [ts, xs, ys, ps])
+    stub.interpolate_bins = True
+    interp = ref_th5.TestH5Dataset.make_voxel(stub, [ts, xs, ys, ps])
+    empty = ref_th5.TestH5Dataset.make_voxel(stub, [ts[:0], xs[:0], ys[:0], ps[:0]])
+    # generic events_to_voxel on a real event list (float ps in {-1,+1})
+    pf = (ps * 2 - 1).astype(np.float64)
+    e2v = ref_eu.events_to_voxel(xs, ys, ts[:, None], pf[:, None], 5, sensor_size=(16, 24))
+    save("g8_make_voxel.npz", ts=ts, xs=xs, ys=ys, ps=ps, discrete=disc, interpolated=interp, empty=empty,
+         events_to_voxel=e2v)
+
+
+def g11_philox_fed():
+    """The reference itself, run on the device-native Philox fields (monkey-patched np.random)."""
+    from oracle import clib
+    clib.build()
+    video = O.synth_clip_s1(8, 32, 32, seed=314, dtype=np.uint8)
+    seed, clip_id = 0x1234ABCD5678, 9
+    out = {"video": video, "seed": np.array(seed, dtype=np.uint64), "clip_id": np.array(clip_id),
+           "params": np.array([0.2, 0.3, 0.04, 0.05, 0.6])}
+    real_rand, real_randn = np.random.rand, np.random.randn
+    for ext in (False, True):
+        for dt_tag, dt in (("u8", np.uint8), ("f32", np.float32)):
+            rng = O.PhiloxFieldRNG(seed, clip_id)
+            np.random.rand, np.random.randn = rng.rand, rng.randn
+            try:
+                v = EventEmulator(0.2, 0.3, 0.04, 0.05, 0.6, ext).video_to_voxel(video.astype(dt))
+            finally:
+                np.random.rand, np.random.randn = real_rand, real_randn
+            out[f"ext{int(ext)}_{dt_tag}"] = v
+    out["gauss_field3"] = clib.philox_gauss_field(seed, clip_id, 3, 1024)
+    out["uniform_field0"] = clib.philox_uniform_field(seed, clip_id, 0, 1024)
+    save("g11_philox_fed.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g11"]
+    fns = {"g1": g1_luts, "g2": g2_g3_esim_clean, "g4": g4_esim_noisy, "g5": g5_floor_divide,
+           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g11": g11_philox_fed}
+    for w in which:
+        fns[w]()
