@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the fused ESIM sim+voxel hot path (BASELINE.json metric:
+"voxel grids/sec (B x Tbins x H x W) at 1/2/4/8 GPU; achieved HBM GB/s vs peak").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (ONE launch of v2v_esim_voxel_hip) over one batch of synthetic clips
+that is already resident in HBM.  Workload at N=1: BASELINE configs[1] -- 256 clips of 32x256x256 float32
+(integer-valued), C+=C-=0.2, 5 temporal-bilinear voxel bins.  With N>1 GPUs every rank gets its own 256
+clips (global clip ids rank*256..), no data-path collective: weak scaling.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (measured copy ceiling ~6290)
+
+WORKLOADS = {
+    # name: (B per GPU, N frames, H, W, torch dtype name, bin mode, Tb, fpb, params)
+    "cfg2_esim_f32_256x32x256x256_bilinear5": (256, 32, 256, 256, "float32", "bilinear", 5, 1, [0.2, 0.2, 0.0, 0.0, 0.0]),
+    "cfg2_noise_on": (256, 32, 256, 256, "float32", "bilinear", 5, 1, [0.2, 0.2, 0.05, 5e-4, 1.0]),
+    "cfg2_u8": (256, 32, 256, 256, "uint8", "bilinear", 5, 1, [0.2, 0.2, 0.0, 0.0, 0.0]),
+    "train_u8_12x201x128x128_sum5": (12, 201, 128, 128, "uint8", "sum", 5, 1, [0.2, 0.2, 0.05, 5e-4, 1.0]),
+    "cfg1_plumbing_u8_1x8x128x128": (1, 8, 128, 128, "uint8", "sum", 7, 1, [0.2, 0.2, 0.0, 0.0, 0.0]),
+}
+DEFAULT_WORKLOAD = "cfg2_esim_f32_256x32x256x256_bilinear5"
+
+
+def cpu_baseline(frames_host, params, bin_mode, tb, fpb, budget_s=12.0):
+    """The oracle (a PORT of the reference's NumPy op sequence, data/v2v_core_esim.py:26-69 + the binning)
+    timed on this box's host cores on a bounded sample of the same clips.  Reported, never the target."""
+    import numpy as np
+    from oracle import v2v_oracle as O
+    n_done, t0 = 0, time.perf_counter()
+    np.random.seed(0)
+    for clip in frames_host:
+        counts = O.esim_video_to_voxel(clip, *params, put_noise_external=False, rng=O.GlobalNumpyRNG, use_lut=False)
+        _ = O.bin_bilinear(counts, tb) if bin_mode == "bilinear" else O.bin_sum(counts, tb, fpb)
+        n_done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    grids = n_done * (1 if bin_mode == "bilinear" else (clip.shape[0] - 1) // (tb * fpb))
+    return {"value": grids / dt, "unit": "voxel grids/s", "cores": 1, "kind": "port",
+            "sample": f"{n_done} of the batch's clips ({'x'.join(map(str, frames_host.shape[1:]))} {frames_host.dtype}), "
+                      f"oracle/v2v_oracle.py NumPy port (pow/log per pixel, float64 state), single thread, {dt:.1f} s"}
+
+
+def cpu_baseline_c(frames_host, params, bin_mode, tb, fpb):
+    """Secondary: the scalar C twin (table-driven) over all host cores with OpenMP."""
+    from oracle import clib, v2v_oracle as O
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    clib.esim_voxel(frames_host, params, O.load_luts(), rng_mode=clib.RNG_PHILOX, seed=1,
+                    bin_mode=clib.BIN_BILINEAR if bin_mode == "bilinear" else clib.BIN_SUM, num_bins=tb,
+                    frames_per_bin=fpb, threads=cores)
+    dt = time.perf_counter() - t0
+    grids = frames_host.shape[0] * (1 if bin_mode == "bilinear" else (frames_host.shape[1] - 1) // (tb * fpb))
+    return {"value": grids / dt, "unit": "voxel grids/s", "cores": cores, "kind": "port",
+            "sample": f"{frames_host.shape[0]} clips, oracle/v2v_oracle.c scalar C port (LUT), OpenMP over clips, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override clips per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)     # RCCL; used for the barrier + max-over-ranks only
+
+    from v2v_amd import esim
+    b, n, h, w, dt_name, bin_mode, tb, fpb, params = WORKLOADS[args.workload]
+    if args.batch:
+        b = args.batch
+    tdtype = getattr(torch, dt_name)
+    clip_id0 = rank * b                                            # batch shard: global clip ids, no exchange
+    frames = esim.synth_clips(b, n, h, w, dtype=tdtype, seed=20240001, clip_id0=clip_id0, device=dev)
+    shape = (b, (n - 1) // (tb * fpb), tb, h, w) if bin_mode == "sum" else (b, tb, h, w)
+    out = torch.empty(shape, dtype=torch.float32, device=dev)
+    ptensor = torch.tensor(params, dtype=torch.float64, device=dev)
+    alg_bytes = esim.algorithmic_bytes(tdtype, b, n, h, w, bin_mode, tb, fpb)
+    grids_per_step = b * (shape[1] if bin_mode == "sum" else 1)
+
+    def step():
+        esim.esim_voxel_batch(frames, ptensor, bin_mode=bin_mode, num_bins=tb, frames_per_bin=fpb, rng_mode="philox",
+                              seed=20240001, clip_id0=clip_id0, out=out, validate=False)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # per-launch HIP events on the stream the kernel is launched on (torch's current stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for s, e in ev:
+        s.record()
+        step()
+        e.record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = sorted(s.elapsed_time(e) for s, e in ev)
+    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # light parity guard outside the timed region: clip 0 of rank 0 against the C oracle
+    parity = None
+    cpu = None
+    cpu_c = None
+    if rank == 0:
+        try:
+            import numpy as np
+            from oracle import clib, v2v_oracle as O
+            clib.build()
+            host = frames[:1].cpu().numpy()
+            want, _ = clib.esim_voxel(host, params, O.load_luts(), rng_mode=clib.RNG_PHILOX, seed=20240001, clip_id0=clip_id0,
+                                      bin_mode=clib.BIN_BILINEAR if bin_mode == "bilinear" else clib.BIN_SUM, num_bins=tb,
+                                      frames_per_bin=fpb)
+            got = out[:1].cpu().numpy().astype(np.float64)
+            parity = "ok" if np.allclose(got, want, rtol=1e-5, atol=1e-5) else "MISMATCH"
+            if world == 1 and not args.no_cpu_baseline:
+                sample = frames[: min(b, 32)].cpu().numpy()
+                cpu = cpu_baseline(sample, params, bin_mode, tb, fpb, budget_s=args.cpu_budget)
+                cpu_c = cpu_baseline_c(sample, params, bin_mode, tb, fpb)
+        except Exception as exc:  # the oracle is a checker; never let it take the measurement down
+            parity = f"unchecked ({type(exc).__name__}: {exc})"
+
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # rocprofv3 --pmc pass, see profiles/README.md
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
+        line = {
+            "metric": "voxel grids/sec", "value": grids_per_step * world * args.steps / elapsed, "unit": "voxel grids/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "clips_per_gpu": b, "frames": n, "height": h, "width": w,
+                       "input_dtype": dt_name, "bin_mode": bin_mode, "num_bins": tb, "frames_per_bin": fpb,
+                       "pos_thres": params[0], "neg_thres": params[1], "base_noise_std": params[2],
+                       "hot_pixel_fraction": params[3], "hot_pixel_std": params[4], "rng": "philox4x32-10 on device",
+                       "sharding": f"batch over {world} GPU(s), no collective", "grid": [tb, h, w]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "esim_voxel_kernel", "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel_ms_avg": kern_avg_ms, "kernel_ms_p10": kern_ms[len(kern_ms) // 10],
+                         "kernel_ms_p50": kern_ms[len(kern_ms) // 2], "kernel_ms_p90": kern_ms[(len(kern_ms) * 9) // 10]},
+            "cpu_baseline": cpu,
+            "cpu_baseline_c_omp": cpu_c,
+            "parity_check": parity,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

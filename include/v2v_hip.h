@@ -1,0 +1,116 @@
+/*
+ * v2v_hip.h -- C ABI of libv2v_hip.so: the MI355X (gfx950) video -> event-count -> voxel-grid hot path.
+ *
+ * This is the drop-in boundary for the one accelerated path of HYLZ-2019/V2V (reference paths below are
+ * relative to the reference checkout).  Every entry point replaces a Python/NumPy function of the
+ * reference; a reference maintainer binds it with a ctypes stub (INTEGRATION.md shows each one).
+ *
+ * Conventions
+ *   - All buffer arguments are DEVICE pointers owned by the caller (PyTorch tensors on the host side).
+ *     The library never allocates, frees or retains caller-visible memory.
+ *   - Every call is asynchronous on the caller's HIP stream (`stream` is a hipStream_t passed as void*;
+ *     NULL = the default stream) and never synchronises.
+ *   - Return value: 0 (V2V_OK) or a negative v2v_status.  No exceptions, no aborts.  A human-readable
+ *     message for the last failure on the calling thread is available from v2v_last_error().
+ *   - No global mutable state except the log-intensity tables (v2v_lut_set) and the per-thread error slot.
+ *   - There is NO CPU implementation behind this ABI.  Without a GPU every compute entry point
+ *     returns V2V_ERR_HIP.
+ */
+#ifndef V2V_HIP_H
+#define V2V_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V2V_ABI_VERSION 1
+
+typedef enum v2v_status {
+    V2V_OK = 0,
+    V2V_ERR_NULL = -1,   /* a required pointer is NULL                                              */
+    V2V_ERR_SHAPE = -2,  /* B,N,H,W out of range, N < 2, strides smaller than the extent            */
+    V2V_ERR_BINS = -3,   /* SUM: (N-1) % (num_bins*frames_per_bin) != 0  (v2v_datasets.py:365)      */
+    V2V_ERR_DTYPE = -4,  /* unsupported in/out dtype                                                */
+    V2V_ERR_MODE = -5,   /* unknown rng / bin mode, or replay fields missing in replay mode         */
+    V2V_ERR_ALIGN = -6,  /* pointer not aligned for its element type                                */
+    V2V_ERR_HIP = -7,    /* HIP runtime error (launch failed, no device); see v2v_last_error()      */
+    V2V_ERR_PARAM = -8   /* invalid scalar parameter                                                */
+} v2v_status;
+
+typedef enum v2v_dtype { V2V_U8 = 0, V2V_F32 = 1, V2V_F64 = 2 } v2v_dtype;
+
+/* Where the simulator's random fields come from (reference: global np.random, v2v_core_esim.py:29,37,38,44) */
+typedef enum v2v_rng_mode {
+    V2V_RNG_NONE = 0,   /* deterministic debug mode: u_init = 0.5, no hot pixels, all Gaussians 0      */
+    V2V_RNG_PHILOX = 1, /* device-native counter RNG keyed by (seed, clip_id, field, pixel): results   */
+                        /* do not depend on batch size or on how the batch is sharded over GPUs        */
+    V2V_RNG_REPLAY = 2  /* caller supplies the fields (e.g. drawn from np.random in the reference's    */
+                        /* order): bit-exact replay of a reference run                                 */
+} v2v_rng_mode;
+
+typedef enum v2v_bin_mode {
+    V2V_BIN_SUM = 0,      /* v2v_datasets.py:399-400: out[B,L,Tb,H,W], each bin = sum of frames_per_bin pairs.  */
+                          /* num_bins = N-1, frames_per_bin = 1 gives EventEmulator.video_to_voxel's [N-1,H,W]. */
+    V2V_BIN_BILINEAR = 1  /* utils/event_utils.py:692-728 weights on pseudo-events at ts = 0..K-1: out[B,Tb,H,W] */
+} v2v_bin_mode;
+
+#define V2V_FLAG_NOISE_EXTERNAL 0x1u /* put_noise_external (v2v_core_esim.py:46,62-65) */
+
+/* Replay fields, all float64 device arrays, one set per clip (clip-major). */
+typedef struct v2v_esim_replay {
+    const double *u_init; /* [B,H*W]     rand  #1: potential init        (v2v_core_esim.py:29) */
+    const double *u_hot;  /* [B,H*W]     rand  #2: hot-pixel mask        (:37)                 */
+    const double *g_hot;  /* [B,H*W]     randn #1: hot-pixel noise       (:38)                 */
+    const double *g_base; /* [B,N-1,H*W] randn per frame pair            (:44)                 */
+} v2v_esim_replay;
+
+/* ---- library info / errors ---------------------------------------------------------------------- */
+int v2v_version(void);                 /* V2V_ABI_VERSION the library was built with */
+const char *v2v_last_error(void);      /* message of the last failure on this thread ("" if none) */
+int v2v_device_count(void);            /* number of visible HIP devices, 0 if none (never fails) */
+
+/* ---- log-intensity tables (replaces reverse_gamma_correction + np.log, v2v_core_esim.py:3-4,33-34) --
+ * lut64[v] / lut32[v] = the reference's log image value for integer intensity v computed in float64 /
+ * float32.  The library ships NumPy's values (golden G1); set lets a deployment re-pin them.
+ * `which`: 0 = ESIM float64, 1 = ESIM float32, 2 = v2e lin_log float32.  Host pointers, 256 entries. */
+int v2v_lut_get(int which, void *dst_host);
+int v2v_lut_set(int which, const void *src_host);
+
+/* ---- fused ESIM simulator + voxel binning ---------------------------------------------------------
+ * Replaces EventEmulator.video_to_voxel (data/v2v_core_esim.py:26-69) fused with the binning of
+ * WebvidDatasetV2.imgs_to_voxels (data/v2v_datasets.py:399-400) or the temporal-bilinear binning of
+ * utils/event_utils.py:events_to_voxel (:692-728), for a whole batch of clips in one launch.
+ *
+ * frames        [B,N,H,W] grayscale (HWC with C=1), dtype V2V_U8 or V2V_F32; rows contiguous;
+ *               clip_stride / frame_stride in ELEMENTS (>= N*H*W / >= H*W).
+ * params        device float64: {pos_thres, neg_thres, base_noise_std, hot_pixel_fraction, hot_pixel_std}
+ *               per clip; params_stride = 5 for [B,5], 0 to broadcast one set.  Thresholds must be > 0.
+ * seed,clip_id0 Philox key and the GLOBAL id of clip 0 of this call (clip b uses clip_id0 + b).
+ * replay        required iff rng_mode == V2V_RNG_REPLAY.
+ * out_voxel     SUM: [B,L,Tb,H,W], L = (N-1)/(Tb*fpb); BILINEAR: [B,Tb,H,W]; dtype V2V_F32 or V2V_F64.
+ * out_counts    optional int64 [B,2]: total ON / OFF events per clip (ADDED to the buffer: zero it first).
+ */
+int v2v_esim_voxel_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W,
+                       int64_t clip_stride, int64_t frame_stride, const double *params, int64_t params_stride,
+                       uint32_t flags, int rng_mode, uint64_t seed, uint64_t clip_id0,
+                       const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
+                       void *out_voxel, int out_dtype, int64_t *out_counts, void *stream);
+
+/* Algorithmic HBM bytes of one v2v_esim_voxel_hip call (input read once + output written once);
+ * the figure bench.py's roofline is computed from.  Returns a negative v2v_status on bad arguments. */
+int64_t v2v_esim_voxel_bytes(int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W, int bin_mode,
+                             int num_bins, int frames_per_bin, int out_dtype);
+
+/* ---- synthetic clips (bench / tests input) --------------------------------------
+ * Fills frames[B,N,H,W] (V2V_U8 or V2V_F32, integer-valued 0..255) with a per-clip low-frequency pattern
+ * translating at a per-clip velocity in [-3,3] px/frame plus N(0,4) pixel noise; clip b is a pure function
+ * of (seed, clip_id0 + b), independent of B. */
+int v2v_synth_clips_hip(void *frames, int dtype, int64_t B, int64_t N, int64_t H, int64_t W, uint64_t seed,
+                        uint64_t clip_id0, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* V2V_HIP_H */

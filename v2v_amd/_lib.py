@@ -1,0 +1,85 @@
+"""ctypes binding of libv2v_hip.so (C ABI in include/v2v_hip.h).  Fails loudly when the library is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  -- imported FIRST so the process uses one HIP runtime (torch's libamdhip64.so.7)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libv2v_hip.so")
+
+# enums of include/v2v_hip.h
+U8, F32, F64 = 0, 1, 2
+RNG_NONE, RNG_PHILOX, RNG_REPLAY = 0, 1, 2
+BIN_SUM, BIN_BILINEAR = 0, 1
+FLAG_NOISE_EXTERNAL = 0x1
+OK, ERR_NULL, ERR_SHAPE, ERR_BINS, ERR_DTYPE, ERR_MODE, ERR_ALIGN, ERR_HIP, ERR_PARAM = 0, -1, -2, -3, -4, -5, -6, -7, -8
+ABI_VERSION = 1
+
+EXPORTS = ("v2v_version", "v2v_last_error", "v2v_device_count", "v2v_lut_get", "v2v_lut_set",
+           "v2v_esim_voxel_hip", "v2v_esim_voxel_bytes", "v2v_synth_clips_hip")
+
+
+class EsimReplay(C.Structure):
+    _fields_ = [("u_init", C.c_void_p), ("u_hot", C.c_void_p), ("g_hot", C.c_void_p), ("g_base", C.c_void_p)]
+
+
+class V2VError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libv2v_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C v2v_amd/csrc`).  v2v_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.v2v_version.restype = C.c_int
+    L.v2v_last_error.restype = C.c_char_p
+    L.v2v_device_count.restype = C.c_int
+    L.v2v_lut_get.argtypes = [C.c_int, C.c_void_p]
+    L.v2v_lut_set.argtypes = [C.c_int, C.c_void_p]
+    L.v2v_esim_voxel_hip.restype = C.c_int
+    L.v2v_esim_voxel_hip.argtypes = [
+        C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,   # frames..frame_stride
+        C.c_void_p, C.c_int64, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64,                        # params..clip_id0
+        C.POINTER(EsimReplay), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.v2v_esim_voxel_bytes.restype = C.c_int64
+    L.v2v_esim_voxel_bytes.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.v2v_synth_clips_hip.restype = C.c_int
+    L.v2v_synth_clips_hip.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_uint64,
+                                      C.c_uint64, C.c_void_p]
+    if L.v2v_version() != ABI_VERSION:
+        raise ImportError(f"libv2v_hip.so ABI {L.v2v_version()} != binding ABI {ABI_VERSION}: rebuild")
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    """Map a v2v_status to the exception the reference would raise at the same spot."""
+    if rc == OK:
+        return
+    msg = lib().v2v_last_error().decode()
+    if rc == ERR_BINS:
+        raise AssertionError(msg)            # reference: `assert (N-1) % (num_bins*frames_per_bin) == 0`
+    if rc in (ERR_SHAPE, ERR_DTYPE, ERR_MODE, ERR_PARAM, ERR_NULL, ERR_ALIGN):
+        raise ValueError(msg)
+    raise V2VError(rc, msg)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("v2v_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,213 @@
+// v2v_capi.hip -- the C ABI of libv2v_hip.so (include/v2v_hip.h).  Argument validation, kernel
+// dispatch on (input dtype, vector width, bin mode, rng mode), error reporting.  Single translation unit:
+// the kernels live in the headers included below.  gfx950 only; no CPU fallback behind any entry point.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/v2v_hip.h"
+#include "v2v_esim.hpp"
+#include "v2v_synth.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    return fail(V2V_ERR_HIP, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+}
+
+bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+template <int IN, int VEC, int BIN>
+hipError_t launch_rng(int rng, const v2v::EsimArgs &a, dim3 grid, size_t lds, hipStream_t s)
+{
+    switch (rng) {
+    case V2V_RNG_NONE: hipLaunchKernelGGL((v2v::esim_voxel_kernel<IN, VEC, BIN, v2v::kRngNone>), grid, dim3(v2v::kBlock), lds, s, a); break;
+    case V2V_RNG_PHILOX: hipLaunchKernelGGL((v2v::esim_voxel_kernel<IN, VEC, BIN, v2v::kRngPhilox>), grid, dim3(v2v::kBlock), lds, s, a); break;
+    default: hipLaunchKernelGGL((v2v::esim_voxel_kernel<IN, VEC, BIN, v2v::kRngReplay>), grid, dim3(v2v::kBlock), lds, s, a); break;
+    }
+    return hipGetLastError();
+}
+
+template <int IN, int VEC>
+hipError_t launch_bin(int bin, int rng, const v2v::EsimArgs &a, dim3 grid, size_t lds, hipStream_t s)
+{
+    return bin == V2V_BIN_SUM ? launch_rng<IN, VEC, v2v::kBinSum>(rng, a, grid, lds, s)
+                              : launch_rng<IN, VEC, v2v::kBinBilinear>(rng, a, grid, lds, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int v2v_version(void) { return V2V_ABI_VERSION; }
+
+const char *v2v_last_error(void) { return g_err; }
+
+int v2v_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int v2v_lut_get(int which, void *dst)
+{
+    if (!dst) return fail(V2V_ERR_NULL, "v2v_lut_get: dst is NULL");
+    hipError_t e;
+    switch (which) {
+    case 0: e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(v2v::g_lut_esim64), sizeof(double) * 256); break;
+    case 1: e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(v2v::g_lut_esim32), sizeof(float) * 256); break;
+    case 2: e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(v2v::g_lut_v2e32), sizeof(float) * 256); break;
+    default: return fail(V2V_ERR_PARAM, "v2v_lut_get: which=%d", which);
+    }
+    if (e != hipSuccess) {
+        // no device: hand back the built-in tables so a host can still inspect what the library ships
+        (void)hipGetLastError();
+        switch (which) {
+        case 0: memcpy(dst, v2v::kLutEsim64, sizeof(double) * 256); break;
+        case 1: memcpy(dst, v2v::kLutEsim32, sizeof(float) * 256); break;
+        default: memcpy(dst, v2v::kLutV2e32, sizeof(float) * 256); break;
+        }
+    }
+    return V2V_OK;
+}
+
+int v2v_lut_set(int which, const void *src)
+{
+    if (!src) return fail(V2V_ERR_NULL, "v2v_lut_set: src is NULL");
+    hipError_t e;
+    switch (which) {
+    case 0: e = hipMemcpyToSymbol(HIP_SYMBOL(v2v::g_lut_esim64), src, sizeof(double) * 256); break;
+    case 1: e = hipMemcpyToSymbol(HIP_SYMBOL(v2v::g_lut_esim32), src, sizeof(float) * 256); break;
+    case 2: e = hipMemcpyToSymbol(HIP_SYMBOL(v2v::g_lut_v2e32), src, sizeof(float) * 256); break;
+    default: return fail(V2V_ERR_PARAM, "v2v_lut_set: which=%d", which);
+    }
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "v2v_lut_set");
+}
+
+int64_t v2v_esim_voxel_bytes(int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W, int bin_mode, int num_bins,
+                             int frames_per_bin, int out_dtype)
+{
+    if (B < 0 || N < 2 || H < 1 || W < 1 || num_bins < 1 || frames_per_bin < 1) return V2V_ERR_SHAPE;
+    const int64_t in_sz = in_dtype == V2V_U8 ? 1 : in_dtype == V2V_F32 ? 4 : 0;
+    const int64_t out_sz = out_dtype == V2V_F32 ? 4 : out_dtype == V2V_F64 ? 8 : 0;
+    if (!in_sz || !out_sz) return V2V_ERR_DTYPE;
+    int64_t planes;
+    if (bin_mode == V2V_BIN_SUM) {
+        if ((N - 1) % ((int64_t)num_bins * frames_per_bin) != 0) return V2V_ERR_BINS;
+        planes = (N - 1) / frames_per_bin;
+    } else if (bin_mode == V2V_BIN_BILINEAR) {
+        planes = num_bins;
+    } else {
+        return V2V_ERR_MODE;
+    }
+    return B * H * W * (N * in_sz + planes * out_sz);
+}
+
+int v2v_esim_voxel_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W,
+                       int64_t clip_stride, int64_t frame_stride, const double *params, int64_t params_stride,
+                       uint32_t flags, int rng_mode, uint64_t seed, uint64_t clip_id0,
+                       const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
+                       void *out_voxel, int out_dtype, int64_t *out_counts, void *stream)
+{
+    if (!frames || !params || !out_voxel) return fail(V2V_ERR_NULL, "v2v_esim_voxel_hip: frames/params/out_voxel is NULL");
+    if (B < 0 || N < 2 || H < 1 || W < 1) return fail(V2V_ERR_SHAPE, "need B>=0, N>=2, H,W>=1 (got B=%lld N=%lld H=%lld W=%lld)", (long long)B, (long long)N, (long long)H, (long long)W);
+    const int64_t HW = H * W, K = N - 1;
+    if (HW > (int64_t)1 << 30 || K > (1 << 20) || B > (int64_t)1 << 31) return fail(V2V_ERR_SHAPE, "H*W, N or B too large");
+    if (frame_stride < HW || clip_stride < (N - 1) * frame_stride + HW) return fail(V2V_ERR_SHAPE, "strides smaller than the extent");
+    if (in_dtype != V2V_U8 && in_dtype != V2V_F32) return fail(V2V_ERR_DTYPE, "in_dtype must be V2V_U8 or V2V_F32");
+    if (out_dtype != V2V_F32 && out_dtype != V2V_F64) return fail(V2V_ERR_DTYPE, "out_dtype must be V2V_F32 or V2V_F64");
+    if (params_stride != 0 && params_stride < 5) return fail(V2V_ERR_PARAM, "params_stride must be 0 or >= 5");
+    if (num_bins < 1 || frames_per_bin < 1) return fail(V2V_ERR_PARAM, "num_bins and frames_per_bin must be >= 1");
+    if (rng_mode < V2V_RNG_NONE || rng_mode > V2V_RNG_REPLAY) return fail(V2V_ERR_MODE, "unknown rng_mode %d", rng_mode);
+    if (rng_mode == V2V_RNG_REPLAY && (!replay || !replay->u_init || !replay->u_hot || !replay->g_hot || !replay->g_base))
+        return fail(V2V_ERR_MODE, "rng_mode REPLAY needs all four replay fields");
+    if (bin_mode == V2V_BIN_SUM) {
+        if (K % ((int64_t)num_bins * frames_per_bin) != 0)
+            return fail(V2V_ERR_BINS, "(N-1)=%lld is not a multiple of num_bins*frames_per_bin=%d", (long long)K, num_bins * frames_per_bin);
+    } else if (bin_mode == V2V_BIN_BILINEAR) {
+        if (K < 2) return fail(V2V_ERR_BINS, "BILINEAR needs at least 2 frame pairs (dt = 0 otherwise)");
+    } else {
+        return fail(V2V_ERR_MODE, "unknown bin_mode %d", bin_mode);
+    }
+    const size_t in_sz = in_dtype == V2V_U8 ? 1 : 4, out_sz = out_dtype == V2V_F32 ? 4 : 8;
+    if (!aligned(frames, in_sz) || !aligned(out_voxel, out_sz) || !aligned(params, 8) || (out_counts && !aligned(out_counts, 8)))
+        return fail(V2V_ERR_ALIGN, "buffer not aligned to its element size");
+    if (B == 0) return V2V_OK;
+
+    // 4 pixels per work-item when every row segment a lane touches is 16-byte (fp32) / 4-byte (u8) aligned
+    const bool vec4 = (HW % 4 == 0) && (frame_stride % 4 == 0) && (clip_stride % 4 == 0) &&
+                      aligned(frames, 4 * in_sz) && aligned(out_voxel, 16);
+    const int vec = vec4 ? 4 : 1;
+
+    v2v::EsimArgs a{};
+    a.frames = frames;
+    a.clip_stride = clip_stride;
+    a.frame_stride = frame_stride;
+    a.params = params;
+    a.params_stride = params_stride;
+    a.out = out_voxel;
+    a.counts = reinterpret_cast<unsigned long long *>(out_counts);
+    if (replay) { a.u_init = replay->u_init; a.u_hot = replay->u_hot; a.g_hot = replay->g_hot; a.g_base = replay->g_base; }
+    a.seed = seed;
+    a.clip_id0 = clip_id0;
+    a.HW = (int32_t)HW;
+    a.K = (int32_t)K;
+    a.Tb = num_bins;
+    a.fpb = frames_per_bin;
+    a.blocks_per_clip = (int32_t)((HW + (int64_t)v2v::kBlock * vec - 1) / ((int64_t)v2v::kBlock * vec));
+    a.noise_external = (flags & V2V_FLAG_NOISE_EXTERNAL) ? 1u : 0u;
+    a.out_f64 = out_dtype == V2V_F64 ? 1u : 0u;
+    const int64_t nblocks = B * a.blocks_per_clip;
+    if (nblocks > 0x7FFFFFFF) return fail(V2V_ERR_SHAPE, "grid too large");
+    const dim3 grid((unsigned)nblocks);
+    const size_t lds = 256 * (in_dtype == V2V_U8 ? sizeof(double) : sizeof(float)) +
+                       (bin_mode == V2V_BIN_BILINEAR ? (size_t)K * (2 * sizeof(double) + sizeof(int)) : 0);
+    if (lds > 160 * 1024) return fail(V2V_ERR_SHAPE, "too many frame pairs for the LDS weight table");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    hipError_t e;
+    if (in_dtype == V2V_U8) e = vec4 ? launch_bin<v2v::kInU8, 4>(bin_mode, rng_mode, a, grid, lds, s) : launch_bin<v2v::kInU8, 1>(bin_mode, rng_mode, a, grid, lds, s);
+    else e = vec4 ? launch_bin<v2v::kInF32, 4>(bin_mode, rng_mode, a, grid, lds, s) : launch_bin<v2v::kInF32, 1>(bin_mode, rng_mode, a, grid, lds, s);
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "esim_voxel_kernel launch");
+}
+
+int v2v_synth_clips_hip(void *frames, int dtype, int64_t B, int64_t N, int64_t H, int64_t W, uint64_t seed,
+                        uint64_t clip_id0, void *stream)
+{
+    if (!frames) return fail(V2V_ERR_NULL, "v2v_synth_clips_hip: frames is NULL");
+    if (B < 0 || N < 1 || H < 1 || W < 1 || W % 4 != 0) return fail(V2V_ERR_SHAPE, "need B>=0, N,H>=1 and W %% 4 == 0");
+    if (dtype != V2V_U8 && dtype != V2V_F32) return fail(V2V_ERR_DTYPE, "dtype must be V2V_U8 or V2V_F32");
+    if (!aligned(frames, dtype == V2V_F32 ? 16 : 4)) return fail(V2V_ERR_ALIGN, "frames must be 16-byte (f32) / 4-byte (u8) aligned");
+    if (B == 0) return V2V_OK;
+    v2v::SynthArgs a{};
+    a.frames = frames;
+    a.seed = seed;
+    a.clip_id0 = clip_id0;
+    a.N = (int32_t)N;
+    a.H = (int32_t)H;
+    a.W = (int32_t)W;
+    a.is_f32 = dtype == V2V_F32;
+    a.total_quads = B * N * H * W / 4;
+    const int64_t nblocks = (a.total_quads + 255) / 256;
+    if (nblocks > 0x7FFFFFFF) return fail(V2V_ERR_SHAPE, "grid too large");
+    hipLaunchKernelGGL(v2v::synth_clips_kernel, dim3((unsigned)nblocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "synth_clips_kernel launch");
+}
+
+}  // extern "C"
