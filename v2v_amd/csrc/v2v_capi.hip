@@ -31,22 +31,31 @@ int hip_fail(hipError_t e, const char *what)
 
 bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
-template <int IN, int VEC, int BIN>
-hipError_t launch_rng(int rng, const v2v::EsimArgs &a, dim3 grid, size_t lds, hipStream_t s)
+template <int IN, int VEC, int BIN, int RNG, bool NOISE>
+hipError_t launch_out(bool out64, const v2v::EsimArgs &a, dim3 grid, size_t lds, hipStream_t s)
 {
-    switch (rng) {
-    case V2V_RNG_NONE: hipLaunchKernelGGL((v2v::esim_voxel_kernel<IN, VEC, BIN, v2v::kRngNone>), grid, dim3(v2v::kBlock), lds, s, a); break;
-    case V2V_RNG_PHILOX: hipLaunchKernelGGL((v2v::esim_voxel_kernel<IN, VEC, BIN, v2v::kRngPhilox>), grid, dim3(v2v::kBlock), lds, s, a); break;
-    default: hipLaunchKernelGGL((v2v::esim_voxel_kernel<IN, VEC, BIN, v2v::kRngReplay>), grid, dim3(v2v::kBlock), lds, s, a); break;
-    }
+    if (out64) hipLaunchKernelGGL((v2v::esim_voxel_kernel<IN, VEC, BIN, RNG, NOISE, true>), grid, dim3(v2v::kBlock), lds, s, a);
+    else hipLaunchKernelGGL((v2v::esim_voxel_kernel<IN, VEC, BIN, RNG, NOISE, false>), grid, dim3(v2v::kBlock), lds, s, a);
     return hipGetLastError();
 }
 
-template <int IN, int VEC>
-hipError_t launch_bin(int bin, int rng, const v2v::EsimArgs &a, dim3 grid, size_t lds, hipStream_t s)
+template <int IN, int VEC, int BIN>
+hipError_t launch_rng(int rng, bool noise, bool out64, const v2v::EsimArgs &a, dim3 grid, size_t lds, hipStream_t s)
 {
-    return bin == V2V_BIN_SUM ? launch_rng<IN, VEC, v2v::kBinSum>(rng, a, grid, lds, s)
-                              : launch_rng<IN, VEC, v2v::kBinBilinear>(rng, a, grid, lds, s);
+    switch (rng) {
+    case V2V_RNG_NONE: return launch_out<IN, VEC, BIN, v2v::kRngNone, false>(out64, a, grid, lds, s);
+    case V2V_RNG_PHILOX:
+        return noise ? launch_out<IN, VEC, BIN, v2v::kRngPhilox, true>(out64, a, grid, lds, s)
+                     : launch_out<IN, VEC, BIN, v2v::kRngPhilox, false>(out64, a, grid, lds, s);
+    default: return launch_out<IN, VEC, BIN, v2v::kRngReplay, true>(out64, a, grid, lds, s);
+    }
+}
+
+template <int IN, int VEC>
+hipError_t launch_bin(int bin, int rng, bool noise, bool out64, const v2v::EsimArgs &a, dim3 grid, size_t lds, hipStream_t s)
+{
+    return bin == V2V_BIN_SUM ? launch_rng<IN, VEC, v2v::kBinSum>(rng, noise, out64, a, grid, lds, s)
+                              : launch_rng<IN, VEC, v2v::kBinBilinear>(rng, noise, out64, a, grid, lds, s);
 }
 
 }  // namespace
@@ -128,7 +137,7 @@ int v2v_esim_voxel_hip(const void *frames, int in_dtype, int64_t B, int64_t N, i
     if (B < 0 || N < 2 || H < 1 || W < 1) return fail(V2V_ERR_SHAPE, "need B>=0, N>=2, H,W>=1 (got B=%lld N=%lld H=%lld W=%lld)", (long long)B, (long long)N, (long long)H, (long long)W);
     const int64_t HW = H * W, K = N - 1;
     if (HW > (int64_t)1 << 30 || K > (1 << 20) || B > (int64_t)1 << 31) return fail(V2V_ERR_SHAPE, "H*W, N or B too large");
-    if (frame_stride < HW || clip_stride < (N - 1) * frame_stride + HW) return fail(V2V_ERR_SHAPE, "strides smaller than the extent");
+    if (frame_stride < HW || (B > 1 && clip_stride < (N - 1) * frame_stride + HW)) return fail(V2V_ERR_SHAPE, "strides smaller than the extent");
     if (in_dtype != V2V_U8 && in_dtype != V2V_F32) return fail(V2V_ERR_DTYPE, "in_dtype must be V2V_U8 or V2V_F32");
     if (out_dtype != V2V_F32 && out_dtype != V2V_F64) return fail(V2V_ERR_DTYPE, "out_dtype must be V2V_F32 or V2V_F64");
     if (params_stride != 0 && params_stride < 5) return fail(V2V_ERR_PARAM, "params_stride must be 0 or >= 5");
@@ -150,7 +159,7 @@ int v2v_esim_voxel_hip(const void *frames, int in_dtype, int64_t B, int64_t N, i
     if (B == 0) return V2V_OK;
 
     // 4 pixels per work-item when every row segment a lane touches is 16-byte (fp32) / 4-byte (u8) aligned
-    const bool vec4 = (HW % 4 == 0) && (frame_stride % 4 == 0) && (clip_stride % 4 == 0) &&
+    const bool vec4 = (HW % 4 == 0) && (frame_stride % 4 == 0) && (B == 1 || clip_stride % 4 == 0) &&
                       aligned(frames, 4 * in_sz) && aligned(out_voxel, 16);
     const int vec = vec4 ? 4 : 1;
 
@@ -171,18 +180,21 @@ int v2v_esim_voxel_hip(const void *frames, int in_dtype, int64_t B, int64_t N, i
     a.fpb = frames_per_bin;
     a.blocks_per_clip = (int32_t)((HW + (int64_t)v2v::kBlock * vec - 1) / ((int64_t)v2v::kBlock * vec));
     a.noise_external = (flags & V2V_FLAG_NOISE_EXTERNAL) ? 1u : 0u;
-    a.out_f64 = out_dtype == V2V_F64 ? 1u : 0u;
     const int64_t nblocks = B * a.blocks_per_clip;
     if (nblocks > 0x7FFFFFFF) return fail(V2V_ERR_SHAPE, "grid too large");
     const dim3 grid((unsigned)nblocks);
+    const bool out64 = out_dtype == V2V_F64;
+    const bool noise = !(flags & V2V_FLAG_NO_NOISE);
+    if (!noise && (flags & V2V_FLAG_NOISE_EXTERNAL)) return fail(V2V_ERR_PARAM, "V2V_FLAG_NO_NOISE and V2V_FLAG_NOISE_EXTERNAL are exclusive");
+    if (!noise && rng_mode == V2V_RNG_REPLAY) return fail(V2V_ERR_PARAM, "V2V_FLAG_NO_NOISE is not available in replay mode");
     const size_t lds = 256 * (in_dtype == V2V_U8 ? sizeof(double) : sizeof(float)) +
-                       (bin_mode == V2V_BIN_BILINEAR ? (size_t)K * (2 * sizeof(double) + sizeof(int)) : 0);
+                       (bin_mode == V2V_BIN_BILINEAR ? (size_t)K * (2 * (out64 ? sizeof(double) : sizeof(float)) + sizeof(int)) : 0);
     if (lds > 160 * 1024) return fail(V2V_ERR_SHAPE, "too many frame pairs for the LDS weight table");
     hipStream_t s = static_cast<hipStream_t>(stream);
 
     hipError_t e;
-    if (in_dtype == V2V_U8) e = vec4 ? launch_bin<v2v::kInU8, 4>(bin_mode, rng_mode, a, grid, lds, s) : launch_bin<v2v::kInU8, 1>(bin_mode, rng_mode, a, grid, lds, s);
-    else e = vec4 ? launch_bin<v2v::kInF32, 4>(bin_mode, rng_mode, a, grid, lds, s) : launch_bin<v2v::kInF32, 1>(bin_mode, rng_mode, a, grid, lds, s);
+    if (in_dtype == V2V_U8) e = vec4 ? launch_bin<v2v::kInU8, 4>(bin_mode, rng_mode, noise, out64, a, grid, lds, s) : launch_bin<v2v::kInU8, 1>(bin_mode, rng_mode, noise, out64, a, grid, lds, s);
+    else e = vec4 ? launch_bin<v2v::kInF32, 4>(bin_mode, rng_mode, noise, out64, a, grid, lds, s) : launch_bin<v2v::kInF32, 1>(bin_mode, rng_mode, noise, out64, a, grid, lds, s);
     return e == hipSuccess ? V2V_OK : hip_fail(e, "esim_voxel_kernel launch");
 }
 

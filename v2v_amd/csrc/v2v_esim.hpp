@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "v2v_rng.hpp"
 
 namespace v2v {
@@ -40,7 +42,7 @@ struct EsimArgs {
     const double *u_init, *u_hot, *g_hot, *g_base;
     uint64_t seed, clip_id0;
     int32_t HW, K, Tb, fpb, blocks_per_clip;
-    uint32_t noise_external, out_f64;
+    uint32_t noise_external;
 };
 
 // Log-intensity tables in device memory (initialised with NumPy's bits, golden G1; re-pinnable through
@@ -54,7 +56,7 @@ static const float kLutEsim32[256] = {V2V_LUT_ESIM32_VALUES};
 static const float kLutV2e32[256] = {V2V_LUT_V2E32_VALUES};
 
 constexpr int kBlock = 256;
-constexpr int kPrefetch = 4;   // frames per register buffer (two buffers ping-pong)
+constexpr int kDepth = 4;      // frames in flight per work-item (register ring, reloaded right after use)
 
 // ------------------------------------------------------------------------------------------------
 // raw input vectors
@@ -68,76 +70,94 @@ template <int IN, int VEC>
 __device__ __forceinline__ Raw<IN, VEC> load_raw(const void *base, int64_t elem_off)
 {
     Raw<IN, VEC> r;
-    if constexpr (IN == kInF32 && VEC == 4) r.v = *reinterpret_cast<const float4 *>(static_cast<const float *>(base) + elem_off);
-    else if constexpr (IN == kInF32) r.v = static_cast<const float *>(base)[elem_off];
-    else if constexpr (VEC == 4) r.v = *reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(base) + elem_off);
+    if constexpr (IN == kInF32 && VEC == 4) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(static_cast<const float *>(base) + elem_off));
+        r.v = make_float4(t.x, t.y, t.z, t.w);
+    } else if constexpr (IN == kInF32) r.v = static_cast<const float *>(base)[elem_off];
+    else if constexpr (VEC == 4) r.v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(base) + elem_off));
     else r.v = static_cast<const uint8_t *>(base)[elem_off];
     return r;
-}
-
-// float32 container, value not an integer in 0..255: the reference's own float32 expression
-// (v2v_core_esim.py:3-4,33-34 evaluated by NumPy in float32); device powf/logf are within 1-2 ulp of NumPy's.
-__device__ __noinline__ float esim_log_generic_f32(float v)
-{
-    const float lin = powf(v / 255.0f, 2.2f) * 255.0f;
-    return logf(0.001f + lin / 255.0f);
 }
 
 template <int IN> struct LutT { using type = double; };
 template <> struct LutT<kInF32> { using type = float; };
 
+template <int VEC>
+__device__ __forceinline__ float raw_f32(const Raw<kInF32, VEC> &r, int j)
+{
+    if constexpr (VEC == 4) return (j == 0) ? r.v.x : (j == 1) ? r.v.y : (j == 2) ? r.v.z : r.v.w;
+    else return r.v;
+}
+
+// Log intensity of the VEC pixels of one raw vector.
+//  u8 : one LDS lookup per pixel (float64 table).
+//  f32: values that are integers in 0..255 take the float32 table (bitwise NumPy's float32 result); anything
+//       else -- detected with a convert/round-trip compare, one wave-level test per vector -- is recomputed with
+//       the reference's float32 expression (v2v_core_esim.py:3-4,33-34).  Device powf/logf are within 1-2 ulp
+//       of NumPy's float32 kernels, hence the 1e-5 count-flip tolerance stated for non-integer content.
 template <int IN, int VEC>
-__device__ __forceinline__ typename LutT<IN>::type pix_log(const Raw<IN, VEC> &r, int j,
-                                                           const typename LutT<IN>::type *lut)
+__device__ __forceinline__ void pix_logs(const Raw<IN, VEC> &r, const typename LutT<IN>::type *lut,
+                                         typename LutT<IN>::type (&out)[VEC])
 {
     if constexpr (IN == kInU8) {
-        uint32_t idx;
-        if constexpr (VEC == 4) idx = (r.v >> (8 * j)) & 0xFFu; else idx = r.v;
-        return lut[idx];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            uint32_t idx;
+            if constexpr (VEC == 4) idx = (r.v >> (8 * j)) & 0xFFu; else idx = r.v;
+            out[j] = lut[idx];
+        }
     } else {
-        float v;
-        if constexpr (VEC == 4) v = (j == 0) ? r.v.x : (j == 1) ? r.v.y : (j == 2) ? r.v.z : r.v.w; else v = r.v;
-        const int i = (int)v;
-        if (__builtin_expect((float)i == v && (unsigned)i < 256u, 1)) return lut[i];
-        return esim_log_generic_f32(v);
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float v = raw_f32<VEC>(r, j);
+            const uint32_t a = (uint32_t)v & 255u;            // saturating convert: always a valid index
+            out[j] = lut[a];
+            bad |= ((float)a != v);                            // non-integer, negative, > 255, NaN
+        }
+        if (__builtin_expect(bad, 0)) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float v = raw_f32<VEC>(r, j);
+                if ((float)((uint32_t)v & 255u) != v) {
+                    const float lin = powf(v / 255.0f, 2.2f) * 255.0f;
+                    out[j] = logf(0.001f + lin / 255.0f);
+                }
+            }
+        }
     }
 }
 
-template <int VEC>
-__device__ __forceinline__ void store_vec(void *out, uint32_t out_f64, int64_t off, const double (&v)[VEC])
+template <int VEC, typename T>
+__device__ __forceinline__ void store_vec(void *out, int64_t off, const T (&v)[VEC])
 {
-    if (out_f64) {
-        double *o = static_cast<double *>(out) + off;
-        if constexpr (VEC == 4) {
-            reinterpret_cast<double2 *>(o)[0] = make_double2(v[0], v[1]);
-            reinterpret_cast<double2 *>(o)[1] = make_double2(v[2], v[3]);
-        } else o[0] = v[0];
+    T *o = static_cast<T *>(out) + off;
+    if constexpr (VEC == 4 && sizeof(T) == 8) {
+        reinterpret_cast<double2 *>(o)[0] = make_double2(v[0], v[1]);
+        reinterpret_cast<double2 *>(o)[1] = make_double2(v[2], v[3]);
+    } else if constexpr (VEC == 4) {
+        *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
-        float *o = static_cast<float *>(out) + off;
-        if constexpr (VEC == 4) *reinterpret_cast<float4 *>(o) = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
-        else o[0] = (float)v[0];
+        o[0] = v[0];
     }
 }
 
-// np.floor_divide(a, b) for a >= b > 0 (numpy npy_divmod): literal form, used only when the quotient is
-// too large for the reciprocal estimate to be within +-1 (never for physical thresholds).
-__device__ __noinline__ double floor_divide_slow(double a, double b)
-{
-    const double mod = fmod(a, b);
-    const double div = (a - mod) / b;
-    double fl = floor(div);
-    if (div - fl > 0.5) fl += 1.0;
-    return fl;
-}
-
-template <int IN, int VEC, int BIN, int RNG>
+// NOISE  : false -> the caller guarantees base_noise_std == 0 and hot_pixel_fraction == 0 for every clip
+//          (V2V_FLAG_NO_NOISE); the noise adds, their registers and the Gaussian generator disappear.
+// OUT64  : true  -> float64 accumulators and output, accumulated exactly like NumPy (product rounded, then
+//                   added): bit-exact against the reference's float64 result.
+//          false -> float32 output.  Integer counts (SUM mode) stay exact; weighted/noisy values are
+//                   accumulated with float32 fma and agree with the float64 result to ~1e-6 relative.
+template <int IN, int VEC, int BIN, int RNG, bool NOISE, bool OUT64>
 __global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
 {
     using lut_t = typename LutT<IN>::type;
+    using acc_t = typename std::conditional<OUT64, double, float>::type;
     extern __shared__ __align__(16) unsigned char s_raw[];
     lut_t *s_lut = reinterpret_cast<lut_t *>(s_raw);
-    double *s_wlo = reinterpret_cast<double *>(s_raw + 256 * sizeof(lut_t));
-    double *s_whi = s_wlo + a.K;
+    acc_t *s_wlo = reinterpret_cast<acc_t *>(s_raw + 256 * sizeof(lut_t));
+    acc_t *s_whi = s_wlo + a.K;
     int *s_seg = reinterpret_cast<int *>(s_whi + a.K);
 
     // ---- workgroup prologue: tables into LDS
@@ -150,10 +170,10 @@ __global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
             int b0 = (int)floor(t_norm);
             if (b0 > a.Tb - 2) b0 = a.Tb - 2;
             if (b0 < 0) b0 = 0;
-            double wl = 1.0 - fabs(t_norm - (double)b0);
-            double wh = 1.0 - fabs(t_norm - (double)(b0 + 1));
-            s_wlo[k] = wl > 0.0 ? wl : 0.0;
-            s_whi[k] = wh > 0.0 ? wh : 0.0;
+            const double wl = 1.0 - fabs(t_norm - (double)b0);
+            const double wh = 1.0 - fabs(t_norm - (double)(b0 + 1));
+            s_wlo[k] = (acc_t)(wl > 0.0 ? wl : 0.0);
+            s_whi[k] = (acc_t)(wh > 0.0 ? wh : 0.0);
             s_seg[k] = b0;
         }
     }
@@ -165,17 +185,17 @@ __global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
     if (p0 >= (uint32_t)a.HW) return;
 
     const double *pp = a.params + (int64_t)clip * a.params_stride;
-    const double pos = pp[0], neg = pp[1], base_std = pp[2], hot_frac = pp[3], hot_std = pp[4];
+    const double pos = pp[0], neg = pp[1];
     const double inv_pos = 1.0 / pos, inv_neg = 1.0 / neg;
+    double base_std = 0.0, hot_frac = 0.0, hot_std = 0.0;
+    if constexpr (NOISE) { base_std = pp[2]; hot_frac = pp[3]; hot_std = pp[4]; }
     const uint32_t clip_id = (uint32_t)(a.clip_id0 + (uint64_t)clip);
-    const bool ext = a.noise_external != 0;
-
-    const int64_t esz = 1;
+    const bool ext = NOISE && a.noise_external != 0;
     const int64_t in_base = (int64_t)clip * a.clip_stride + p0;
-    (void)esz;
 
     // ---- per-pixel state
-    double pot[VEC], hot[VEC];
+    double pot[VEC];
+    double hot[NOISE ? VEC : 1];
     {
         double u0[VEC];
         if constexpr (RNG == kRngPhilox) {
@@ -191,22 +211,25 @@ __global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
         for (int j = 0; j < VEC; ++j) {
             const double scaled = u0[j] * (pos + neg);
             pot[j] = scaled - neg;                                     // v2v_core_esim.py:29
-            hot[j] = 0.0;
         }
-        if constexpr (RNG == kRngPhilox) {
-            if (hot_frac > 0.0) {                                      // uniform: skipping is exact (u >= 0)
-                double u1[VEC];
-                float gh[VEC];
-                field_uniform53<VEC>(a.seed, clip_id, kFieldHotMask, kStreamEsim, p0, u1);
-                field_gauss32<VEC>(a.seed, clip_id, kFieldHotGauss, kStreamEsim, p0, gh);
+        if constexpr (NOISE) {
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) hot[j] = (u1[j] < hot_frac) ? hot_std * (double)gh[j] : 0.0;   // :37-39
-            }
-        } else if constexpr (RNG == kRngReplay) {
+            for (int j = 0; j < VEC; ++j) hot[j] = 0.0;
+            if constexpr (RNG == kRngPhilox) {
+                if (hot_frac > 0.0) {                                  // uniform: skipping is exact (u >= 0)
+                    double u1[VEC];
+                    float gh[VEC];
+                    field_uniform53<VEC>(a.seed, clip_id, kFieldHotMask, kStreamEsim, p0, u1);
+                    field_gauss32<VEC>(a.seed, clip_id, kFieldHotGauss, kStreamEsim, p0, gh);
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const int64_t o = (int64_t)clip * a.HW + p0 + j;
-                hot[j] = (a.u_hot[o] < hot_frac) ? hot_std * a.g_hot[o] : 0.0;
+                    for (int j = 0; j < VEC; ++j) hot[j] = (u1[j] < hot_frac) ? hot_std * (double)gh[j] : 0.0;   // :37-39
+                }
+            } else if constexpr (RNG == kRngReplay) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const int64_t o = (int64_t)clip * a.HW + p0 + j;
+                    hot[j] = (a.u_hot[o] < hot_frac) ? hot_std * a.g_hot[o] : 0.0;
+                }
             }
         }
     }
@@ -214,14 +237,13 @@ __global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
     lut_t lprev[VEC];
     {
         const Raw<IN, VEC> r0 = load_raw<IN, VEC>(a.frames, in_base);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) lprev[j] = pix_log<IN, VEC>(r0, j, s_lut);
+        pix_logs<IN, VEC>(r0, s_lut, lprev);
     }
 
     // ---- binning state
-    double acc_lo[VEC], acc_hi[VEC];
+    acc_t acc_lo[VEC], acc_hi[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { acc_lo[j] = 0.0; acc_hi[j] = 0.0; }
+    for (int j = 0; j < VEC; ++j) { acc_lo[j] = 0; acc_hi[j] = 0; }
     int cur_seg = 0;          // BILINEAR: bin index acc_lo belongs to
     int sub = 0, plane = 0;   // SUM: pairs accumulated into the current plane, plane index
     const int64_t planes_per_clip = (BIN == kBinSum) ? (a.K / a.fpb) : a.Tb;
@@ -233,112 +255,122 @@ __global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
         if constexpr (BIN == kBinBilinear) {
             const int seg = s_seg[k];
             while (cur_seg < seg) {                                    // wave-uniform
-                store_vec<VEC>(a.out, a.out_f64, out_base + (int64_t)cur_seg * a.HW, acc_lo);
+                store_vec<VEC, acc_t>(a.out, out_base + (int64_t)cur_seg * a.HW, acc_lo);
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) { acc_lo[j] = acc_hi[j]; acc_hi[j] = 0.0; }
+                for (int j = 0; j < VEC; ++j) { acc_lo[j] = acc_hi[j]; acc_hi[j] = 0; }
                 ++cur_seg;
             }
         }
-        double base[VEC];
+        double base[NOISE ? VEC : 1];
+        if constexpr (NOISE) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) base[j] = 0.0;
-        if constexpr (RNG == kRngPhilox) {
-            if (base_std != 0.0) {                                     // uniform; 0*g adds nothing
-                float g[VEC];
-                field_gauss32<VEC>(a.seed, clip_id, kFieldBase0 + (uint32_t)k, kStreamEsim, p0, g);
+            for (int j = 0; j < VEC; ++j) base[j] = 0.0;
+            if constexpr (RNG == kRngPhilox) {
+                if (base_std != 0.0) {                                 // uniform; 0*g adds nothing
+                    float g[VEC];
+                    field_gauss32<VEC>(a.seed, clip_id, kFieldBase0 + (uint32_t)k, kStreamEsim, p0, g);
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) base[j] = base_std * (double)g[j];       // :44
+                    for (int j = 0; j < VEC; ++j) base[j] = base_std * (double)g[j];   // :44
+                }
+            } else if constexpr (RNG == kRngReplay) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    base[j] = base_std * a.g_base[((int64_t)clip * a.K + k) * a.HW + p0 + j];
             }
-        } else if constexpr (RNG == kRngReplay) {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j)
-                base[j] = base_std * a.g_base[((int64_t)clip * a.K + k) * a.HW + p0 + j];
         }
-        double wl = 1.0, wh = 0.0;
+        acc_t wl = 1, wh = 0;
         if constexpr (BIN == kBinBilinear) { wl = s_wlo[k]; wh = s_whi[k]; }
+        lut_t ln[VEC];
+        pix_logs<IN, VEC>(raw, s_lut, ln);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const lut_t ln = pix_log<IN, VEC>(raw, j, s_lut);
-            const lut_t d = ln - lprev[j];                             // difference in the input's precision (:42)
-            lprev[j] = ln;
+            const lut_t d = ln[j] - lprev[j];                          // difference in the input's precision (:42)
+            lprev[j] = ln[j];
             double p = pot[j] + (double)d;                             // :43
-            if constexpr (RNG != kRngNone) {
+            if constexpr (NOISE) {
                 if (!ext) { p = p + base[j]; p = p + hot[j]; }         // :48-49
             }
-            double vox = 0.0;
             const bool neg_side = p < 0.0;
             const double mag = fabs(p);
             const double thr = neg_side ? neg : pos;
+            double vox = 0.0;
+            bool fired = false;
             if (mag >= thr) {                                          // p >= C+  or  p <= -C-   (:51-55)
+                // np.floor_divide(mag, thr) == floor of the exact quotient: reciprocal estimate, one sign-exact
+                // fma residual, +-1 correction (valid while the quotient is < 2^40)
                 double q = floor(mag * (neg_side ? inv_neg : inv_pos));
-                if (__builtin_expect(q < 1099511627776.0, 1)) {
-                    const double r = __builtin_fma(-q, thr, mag);      // sign-exact residual
-                    if (r < 0.0) q -= 1.0; else if (r >= thr) q += 1.0;
-                } else {
-                    q = floor_divide_slow(mag, thr);
-                }
+                const double r = __builtin_fma(-q, thr, mag);
+                q += (r < 0.0) ? -1.0 : ((r >= thr) ? 1.0 : 0.0);
                 const double qt = q * thr;
                 const double m2 = mag - qt;                            // :57-58 (product rounded, then subtracted)
                 p = neg_side ? -m2 : m2;
                 vox = neg_side ? -q : q;
+                fired = true;
                 if (want_counts) { if (neg_side) n_off += (uint32_t)q; else n_on += (uint32_t)q; }
             }
             pot[j] = p;
-            if constexpr (RNG != kRngNone) {
-                if (ext) { vox = vox + base[j]; vox = vox + hot[j]; }  // :64-65
+            if constexpr (NOISE) {
+                if (ext) { vox = vox + base[j]; vox = vox + hot[j]; fired = true; }   // :64-65
             }
-            if constexpr (BIN == kBinBilinear) {
-                const double cl = vox * wl, ch = vox * wh;             // bincount adds ps*w (no fma)
-                acc_lo[j] = acc_lo[j] + cl;
-                acc_hi[j] = acc_hi[j] + ch;
-            } else {
-                acc_lo[j] = acc_lo[j] + vox;
+            if (fired) {
+                if constexpr (OUT64) {
+                    if constexpr (BIN == kBinBilinear) {
+                        const double cl = vox * wl, ch = vox * wh;     // bincount adds ps*w (no fma)
+                        acc_lo[j] = acc_lo[j] + cl;
+                        acc_hi[j] = acc_hi[j] + ch;
+                    } else {
+                        acc_lo[j] = acc_lo[j] + vox;
+                    }
+                } else {
+                    const float vf = (float)vox;
+                    if constexpr (BIN == kBinBilinear) {
+                        acc_lo[j] = __builtin_fmaf(vf, wl, acc_lo[j]);
+                        acc_hi[j] = __builtin_fmaf(vf, wh, acc_hi[j]);
+                    } else {
+                        acc_lo[j] = acc_lo[j] + vf;
+                    }
+                }
             }
         }
         if constexpr (BIN == kBinSum) {
             if (++sub == a.fpb) {                                      // wave-uniform
-                store_vec<VEC>(a.out, a.out_f64, out_base + (int64_t)plane * a.HW, acc_lo);
+                store_vec<VEC, acc_t>(a.out, out_base + (int64_t)plane * a.HW, acc_lo);
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) acc_lo[j] = 0.0;
+                for (int j = 0; j < VEC; ++j) acc_lo[j] = 0;
                 sub = 0;
                 ++plane;
             }
         }
     };
 
-    // ---- time loop: register ping-pong, kPrefetch frames per buffer
-    Raw<IN, VEC> bufA[kPrefetch], bufB[kPrefetch];
-    auto load_chunk = [&](Raw<IN, VEC> (&buf)[kPrefetch], int f0) {
+    // ---- time loop: ring of kDepth frames in registers; each slot is reloaded right after it is consumed,
+    //      so kDepth-1 loads (x 1 KiB per wave for fp32 input) stay in flight behind the arithmetic.
+    Raw<IN, VEC> ring[kDepth];
 #pragma unroll
-        for (int u = 0; u < kPrefetch; ++u)
-            if (f0 + u <= a.K) buf[u] = load_raw<IN, VEC>(a.frames, in_base + (int64_t)(f0 + u) * a.frame_stride);
-    };
-    auto run_chunk = [&](const Raw<IN, VEC> (&buf)[kPrefetch], int k0) {
+    for (int u = 0; u < kDepth; ++u)
+        if (1 + u <= a.K) ring[u] = load_raw<IN, VEC>(a.frames, in_base + (int64_t)(1 + u) * a.frame_stride);
+    for (int k0 = 0; k0 < a.K; k0 += kDepth) {
 #pragma unroll
-        for (int u = 0; u < kPrefetch; ++u)
-            if (k0 + u < a.K) step(k0 + u, buf[u]);
-    };
-    load_chunk(bufA, 1);
-    for (int k0 = 0; k0 < a.K; k0 += 2 * kPrefetch) {
-        load_chunk(bufB, k0 + kPrefetch + 1);
-        run_chunk(bufA, k0);
-        if (k0 + kPrefetch < a.K) {
-            load_chunk(bufA, k0 + 2 * kPrefetch + 1);
-            run_chunk(bufB, k0 + kPrefetch);
+        for (int u = 0; u < kDepth; ++u) {
+            const int k = k0 + u;
+            if (k < a.K) {
+                step(k, ring[u]);
+                const int fnext = k + 1 + kDepth;
+                if (fnext <= a.K) ring[u] = load_raw<IN, VEC>(a.frames, in_base + (int64_t)fnext * a.frame_stride);
+            }
         }
     }
 
     // ---- epilogue
     if constexpr (BIN == kBinBilinear) {
-        store_vec<VEC>(a.out, a.out_f64, out_base + (int64_t)cur_seg * a.HW, acc_lo);
-        if (cur_seg + 1 < a.Tb) store_vec<VEC>(a.out, a.out_f64, out_base + (int64_t)(cur_seg + 1) * a.HW, acc_hi);
+        store_vec<VEC, acc_t>(a.out, out_base + (int64_t)cur_seg * a.HW, acc_lo);
+        if (cur_seg + 1 < a.Tb) store_vec<VEC, acc_t>(a.out, out_base + (int64_t)(cur_seg + 1) * a.HW, acc_hi);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) acc_lo[j] = 0.0;
-        for (int b = cur_seg + 2; b < a.Tb; ++b) store_vec<VEC>(a.out, a.out_f64, out_base + (int64_t)b * a.HW, acc_lo);
+        for (int j = 0; j < VEC; ++j) acc_lo[j] = 0;
+        for (int b = cur_seg + 2; b < a.Tb; ++b) store_vec<VEC, acc_t>(a.out, out_base + (int64_t)b * a.HW, acc_lo);
     }
     if (want_counts) {
-        // wave64 reduction, then one atomic per wave and polarity (inactive tail lanes returned early,
-        // so reduce with the active mask semantics of __shfl_down: missing lanes contribute their own value -> use ballot-safe loop)
+        // wave64 reduction over the lanes that own pixels, then one 64-bit atomic per wave and polarity
         unsigned long long on = n_on, off = n_off;
 #pragma unroll
         for (int s = 32; s > 0; s >>= 1) {
