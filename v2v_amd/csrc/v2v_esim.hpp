@@ -158,23 +158,31 @@ __global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
     lut_t *s_lut = reinterpret_cast<lut_t *>(s_raw);
     acc_t *s_wlo = reinterpret_cast<acc_t *>(s_raw + 256 * sizeof(lut_t));
     acc_t *s_whi = s_wlo + a.K;
-    int *s_seg = reinterpret_cast<int *>(s_whi + a.K);
+    int *s_kb = reinterpret_cast<int *>(s_whi + a.K);      // [Tb] first pair index of each bin segment
 
     // ---- workgroup prologue: tables into LDS
     if constexpr (IN == kInU8) s_lut[threadIdx.x] = g_lut_esim64[threadIdx.x];
     else s_lut[threadIdx.x] = g_lut_esim32[threadIdx.x];
     if constexpr (BIN == kBinBilinear) {
-        // weight of pair k for its two neighbouring bins: the float64 expression of event_utils.py:715-719
-        for (int k = threadIdx.x; k < a.K; k += kBlock) {
-            const double t_norm = ((double)k - 0.0) / ((double)(a.K - 1) - 0.0) * (double)(a.Tb - 1);
+        // Pair k contributes to bins seg(k) and seg(k)+1 with the float64 weights of event_utils.py:715-719:
+        // t_norm = (k - 0)/((K-1) - 0)*(Tb-1), w_b = max(0, 1 - |t_norm - b|); every other bin's weight is exactly 0.
+        auto t_of = [&](int k) { return ((double)k - 0.0) / ((double)(a.K - 1) - 0.0) * (double)(a.Tb - 1); };
+        auto seg_of = [&](double t_norm) {
             int b0 = (int)floor(t_norm);
             if (b0 > a.Tb - 2) b0 = a.Tb - 2;
-            if (b0 < 0) b0 = 0;
+            return b0 < 0 ? 0 : b0;
+        };
+        for (int b = threadIdx.x; b < a.Tb; b += kBlock) s_kb[b] = 0x7FFFFFFF;
+        __syncthreads();
+        for (int k = threadIdx.x; k < a.K; k += kBlock) {
+            const double t_norm = t_of(k);
+            const int b0 = seg_of(t_norm);
             const double wl = 1.0 - fabs(t_norm - (double)b0);
             const double wh = 1.0 - fabs(t_norm - (double)(b0 + 1));
             s_wlo[k] = (acc_t)(wl > 0.0 ? wl : 0.0);
             s_whi[k] = (acc_t)(wh > 0.0 ? wh : 0.0);
-            s_seg[k] = b0;
+            const int bprev = k > 0 ? seg_of(t_of(k - 1)) : 0;
+            for (int b = bprev + 1; b <= b0; ++b) s_kb[b] = k;          // seg() is non-decreasing in k
         }
     }
     __syncthreads();
@@ -185,8 +193,11 @@ __global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
     if (p0 >= (uint32_t)a.HW) return;
 
     const double *pp = a.params + (int64_t)clip * a.params_stride;
-    const double pos = pp[0], neg = pp[1];
-    const double inv_pos = 1.0 / pos, inv_neg = 1.0 / neg;
+    // thresholds and their (slightly low) reciprocals live in VGPRs: they are selected per lane by polarity
+    double pos = pp[0], neg = pp[1];
+    // 1/C biased down by 2^-50 so that floor(|p| * inv) never exceeds the true quotient (one-sided correction)
+    double inv_pos = (1.0 / pos) * 0x1.ffffffffffffcp-1, inv_neg = (1.0 / neg) * 0x1.ffffffffffffcp-1;
+    asm volatile("" : "+v"(pos), "+v"(neg), "+v"(inv_pos), "+v"(inv_neg));
     double base_std = 0.0, hot_frac = 0.0, hot_std = 0.0;
     if constexpr (NOISE) { base_std = pp[2]; hot_frac = pp[3]; hot_std = pp[4]; }
     const uint32_t clip_id = (uint32_t)(a.clip_id0 + (uint64_t)clip);
@@ -209,8 +220,8 @@ __global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const double scaled = u0[j] * (pos + neg);
-            pot[j] = scaled - neg;                                     // v2v_core_esim.py:29
+            const double scaled = u0[j] * (pp[0] + pp[1]);
+            pot[j] = scaled - pp[1];                                   // v2v_core_esim.py:29
         }
         if constexpr (NOISE) {
 #pragma unroll
@@ -244,21 +255,25 @@ __global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
     acc_t acc_lo[VEC], acc_hi[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { acc_lo[j] = 0; acc_hi[j] = 0; }
-    int cur_seg = 0;          // BILINEAR: bin index acc_lo belongs to
+    int cur_seg = 0;          // BILINEAR: bin index acc_lo belongs to (wave-uniform)
+    int next_k = 0x7FFFFFFF;  // BILINEAR: first pair of segment cur_seg+1 (wave-uniform, kept scalar)
+    if constexpr (BIN == kBinBilinear) {
+        if (a.Tb >= 3) next_k = __builtin_amdgcn_readfirstlane(s_kb[1]);
+    }
     int sub = 0, plane = 0;   // SUM: pairs accumulated into the current plane, plane index
     const int64_t planes_per_clip = (BIN == kBinSum) ? (a.K / a.fpb) : a.Tb;
     const int64_t out_base = (int64_t)clip * planes_per_clip * a.HW + p0;
-    uint32_t n_on = 0, n_off = 0;
+    uint32_t n_all = 0, n_off = 0;
     const bool want_counts = a.counts != nullptr;
 
     auto step = [&](int k, const Raw<IN, VEC> &raw) {
         if constexpr (BIN == kBinBilinear) {
-            const int seg = s_seg[k];
-            while (cur_seg < seg) {                                    // wave-uniform
+            while (k >= next_k) {                                      // scalar compare; rarely taken
                 store_vec<VEC, acc_t>(a.out, out_base + (int64_t)cur_seg * a.HW, acc_lo);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) { acc_lo[j] = acc_hi[j]; acc_hi[j] = 0; }
                 ++cur_seg;
+                next_k = (cur_seg + 1 <= a.Tb - 2) ? __builtin_amdgcn_readfirstlane(s_kb[cur_seg + 1]) : 0x7FFFFFFF;
             }
         }
         double base[NOISE ? VEC : 1];
@@ -282,6 +297,11 @@ __global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
         if constexpr (BIN == kBinBilinear) { wl = s_wlo[k]; wh = s_whi[k]; }
         lut_t ln[VEC];
         pix_logs<IN, VEC>(raw, s_lut, ln);
+        float qabs[VEC];
+        uint32_t sgns[VEC];
+        // Branch-free per pixel: q = np.floor_divide(|p|, C) is 0 exactly when |p| < C, so the reference's
+        // `where(p >= C+ ...)` / `where(p <= -C- ...)` masks (v2v_core_esim.py:51-55) need no separate test,
+        // and `p -= q*C` with q = 0 leaves p untouched bit for bit.  The four pixels are independent chains.
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const lut_t d = ln[j] - lprev[j];                          // difference in the input's precision (:42)
@@ -290,46 +310,53 @@ __global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
             if constexpr (NOISE) {
                 if (!ext) { p = p + base[j]; p = p + hot[j]; }         // :48-49
             }
-            const bool neg_side = p < 0.0;
+            const uint32_t sgn = (uint32_t)__double2hiint(p) & 0x80000000u;
+            const bool neg_side = sgn != 0u;
             const double mag = fabs(p);
             const double thr = neg_side ? neg : pos;
-            double vox = 0.0;
-            bool fired = false;
-            if (mag >= thr) {                                          // p >= C+  or  p <= -C-   (:51-55)
-                // np.floor_divide(mag, thr) == floor of the exact quotient: reciprocal estimate, one sign-exact
-                // fma residual, +-1 correction (valid while the quotient is < 2^40)
-                double q = floor(mag * (neg_side ? inv_neg : inv_pos));
-                const double r = __builtin_fma(-q, thr, mag);
-                q += (r < 0.0) ? -1.0 : ((r >= thr) ? 1.0 : 0.0);
-                const double qt = q * thr;
-                const double m2 = mag - qt;                            // :57-58 (product rounded, then subtracted)
-                p = neg_side ? -m2 : m2;
-                vox = neg_side ? -q : q;
-                fired = true;
-                if (want_counts) { if (neg_side) n_off += (uint32_t)q; else n_on += (uint32_t)q; }
-            }
-            pot[j] = p;
-            if constexpr (NOISE) {
-                if (ext) { vox = vox + base[j]; vox = vox + hot[j]; fired = true; }   // :64-65
-            }
-            if (fired) {
-                if constexpr (OUT64) {
-                    if constexpr (BIN == kBinBilinear) {
-                        const double cl = vox * wl, ch = vox * wh;     // bincount adds ps*w (no fma)
-                        acc_lo[j] = acc_lo[j] + cl;
-                        acc_hi[j] = acc_hi[j] + ch;
-                    } else {
-                        acc_lo[j] = acc_lo[j] + vox;
-                    }
-                } else {
-                    const float vf = (float)vox;
-                    if constexpr (BIN == kBinBilinear) {
-                        acc_lo[j] = __builtin_fmaf(vf, wl, acc_lo[j]);
-                        acc_hi[j] = __builtin_fmaf(vf, wh, acc_hi[j]);
-                    } else {
-                        acc_lo[j] = acc_lo[j] + vf;
-                    }
+            // floor of the exact quotient (== np.floor_divide for |p|/C < 2^40): low-biased reciprocal estimate,
+            // sign-exact fma residual, one-sided +1 correction
+            double q = floor(mag * (neg_side ? inv_neg : inv_pos));
+            const double r = __builtin_fma(-q, thr, mag);
+            q += (r >= thr) ? 1.0 : 0.0;
+            const double qt = q * thr;
+            const double m2 = mag - qt;                                // :57-58 (product rounded, then subtracted)
+            pot[j] = __hiloint2double((int)((uint32_t)__double2hiint(m2) ^ sgn), __double2loint(m2));
+            const float qf = fmaxf((float)q, 0.0f);                    // NaN potential -> no events (NumPy compares false)
+            qabs[j] = qf;
+            sgns[j] = sgn;
+            if constexpr (OUT64) {
+                double vox = __hiloint2double((int)((uint32_t)__double2hiint(q) ^ sgn), __double2loint(q));
+                vox = (q >= 0.0) ? vox : 0.0;
+                if constexpr (NOISE) {
+                    if (ext) { vox = vox + base[j]; vox = vox + hot[j]; }   // :64-65
                 }
+                if constexpr (BIN == kBinBilinear) {
+                    const double cl = vox * wl, ch = vox * wh;         // bincount adds ps*w (no fma)
+                    acc_lo[j] = acc_lo[j] + cl;
+                    acc_hi[j] = acc_hi[j] + ch;
+                } else {
+                    acc_lo[j] = acc_lo[j] + vox;
+                }
+            } else {
+                float vf = __uint_as_float(__float_as_uint(qf) ^ sgn);
+                if constexpr (NOISE) {
+                    if (ext) { double vox = (double)vf; vox = vox + base[j]; vox = vox + hot[j]; vf = (float)vox; }
+                }
+                if constexpr (BIN == kBinBilinear) {
+                    acc_lo[j] = __builtin_fmaf(vf, wl, acc_lo[j]);
+                    acc_hi[j] = __builtin_fmaf(vf, wh, acc_hi[j]);
+                } else {
+                    acc_lo[j] = acc_lo[j] + vf;
+                }
+            }
+        }
+        if (want_counts) {                                             // wave-uniform
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const uint32_t n = (uint32_t)qabs[j];
+                n_all += n;
+                n_off += sgns[j] ? n : 0u;
             }
         }
         if constexpr (BIN == kBinSum) {
@@ -343,23 +370,29 @@ __global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
         }
     };
 
-    // ---- time loop: ring of kDepth frames in registers; each slot is reloaded right after it is consumed,
-    //      so kDepth-1 loads (x 1 KiB per wave for fp32 input) stay in flight behind the arithmetic.
+    // ---- time loop: ring of kDepth frames in registers; each slot is reloaded right after it is consumed, so
+    //      kDepth-1 loads (x 1 KiB per wave for fp32 input) stay in flight behind the arithmetic.  Loads are
+    //      UNCONDITIONAL (frame index clamped to the last frame) so the compiler can count them and wait with
+    //      vmcnt(kDepth-1) instead of vmcnt(0); the kDepth clamped re-reads at the end of a clip hit in cache.
     Raw<IN, VEC> ring[kDepth];
 #pragma unroll
-    for (int u = 0; u < kDepth; ++u)
-        if (1 + u <= a.K) ring[u] = load_raw<IN, VEC>(a.frames, in_base + (int64_t)(1 + u) * a.frame_stride);
-    for (int k0 = 0; k0 < a.K; k0 += kDepth) {
+    for (int u = 0; u < kDepth; ++u) {
+        const int f = (1 + u <= a.K) ? 1 + u : a.K;
+        ring[u] = load_raw<IN, VEC>(a.frames, in_base + (int64_t)f * a.frame_stride);
+    }
+    int k0 = 0;
+    for (; k0 + kDepth <= a.K; k0 += kDepth) {
 #pragma unroll
         for (int u = 0; u < kDepth; ++u) {
             const int k = k0 + u;
-            if (k < a.K) {
-                step(k, ring[u]);
-                const int fnext = k + 1 + kDepth;
-                if (fnext <= a.K) ring[u] = load_raw<IN, VEC>(a.frames, in_base + (int64_t)fnext * a.frame_stride);
-            }
+            step(k, ring[u]);
+            const int fn = k + 1 + kDepth;
+            ring[u] = load_raw<IN, VEC>(a.frames, in_base + (int64_t)(fn <= a.K ? fn : a.K) * a.frame_stride);
         }
     }
+#pragma unroll
+    for (int u = 0; u < kDepth - 1; ++u)
+        if (k0 + u < a.K) step(k0 + u, ring[u]);
 
     // ---- epilogue
     if constexpr (BIN == kBinBilinear) {
@@ -369,6 +402,7 @@ __global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
         for (int j = 0; j < VEC; ++j) acc_lo[j] = 0;
         for (int b = cur_seg + 2; b < a.Tb; ++b) store_vec<VEC, acc_t>(a.out, out_base + (int64_t)b * a.HW, acc_lo);
     }
+    const uint32_t n_on = n_all - n_off;
     if (want_counts) {
         // wave64 reduction over the lanes that own pixels, then one 64-bit atomic per wave and polarity
         unsigned long long on = n_on, off = n_off;
