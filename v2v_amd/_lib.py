@@ -7,7 +7,7 @@ import os
 import torch  # noqa: F401  -- imported FIRST so the process uses one HIP runtime (torch's libamdhip64.so.7)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libv2v_hip.so")
+LIB_PATH = os.environ.get("V2V_HIP_LIB") or os.path.join(_HERE, "libv2v_hip.so")   # override: kernel sweeps only
 
 # enums of include/v2v_hip.h
 U8, F32, F64 = 0, 1, 2

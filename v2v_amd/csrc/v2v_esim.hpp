@@ -55,8 +55,18 @@ static const double kLutEsim64[256] = {V2V_LUT_ESIM64_VALUES};
 static const float kLutEsim32[256] = {V2V_LUT_ESIM32_VALUES};
 static const float kLutV2e32[256] = {V2V_LUT_V2E32_VALUES};
 
+// Tunables (overridable at build time for sweeps: make EXTRA="-DV2V_DEPTH=3 -DV2V_MIN_WAVES=4")
+#ifndef V2V_DEPTH
+#define V2V_DEPTH 4
+#endif
+#ifndef V2V_MIN_WAVES
+#define V2V_MIN_WAVES 1
+#endif
+#ifndef V2V_NT_LOADS
+#define V2V_NT_LOADS 1
+#endif
 constexpr int kBlock = 256;
-constexpr int kDepth = 4;      // frames in flight per work-item (register ring, reloaded right after use)
+constexpr int kDepth = V2V_DEPTH;   // frames in flight per work-item (register ring, reloaded right after use)
 
 // ------------------------------------------------------------------------------------------------
 // raw input vectors
@@ -72,7 +82,11 @@ __device__ __forceinline__ Raw<IN, VEC> load_raw(const void *base, int64_t elem_
     Raw<IN, VEC> r;
     if constexpr (IN == kInF32 && VEC == 4) {
         typedef float f32x4 __attribute__((ext_vector_type(4)));
+#if V2V_NT_LOADS
         const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(static_cast<const float *>(base) + elem_off));
+#else
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(static_cast<const float *>(base) + elem_off);
+#endif
         r.v = make_float4(t.x, t.y, t.z, t.w);
     } else if constexpr (IN == kInF32) r.v = static_cast<const float *>(base)[elem_off];
     else if constexpr (VEC == 4) r.v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(base) + elem_off));
@@ -112,7 +126,9 @@ __device__ __forceinline__ void pix_logs(const Raw<IN, VEC> &r, const typename L
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float v = raw_f32<VEC>(r, j);
-            const uint32_t a = (uint32_t)v & 255u;            // saturating convert: always a valid index
+            // v + 2^23 puts an integer v in 0..255 into the low mantissa byte (one cheap add instead of a
+            // convert); the byte is always a valid index, and converting it back exposes every other input
+            const uint32_t a = __float_as_uint(v + 8388608.0f) & 255u;
             out[j] = lut[a];
             bad |= ((float)a != v);                            // non-integer, negative, > 255, NaN
         }
@@ -120,7 +136,7 @@ __device__ __forceinline__ void pix_logs(const Raw<IN, VEC> &r, const typename L
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const float v = raw_f32<VEC>(r, j);
-                if ((float)((uint32_t)v & 255u) != v) {
+                if ((float)(__float_as_uint(v + 8388608.0f) & 255u) != v) {
                     const float lin = powf(v / 255.0f, 2.2f) * 255.0f;
                     out[j] = logf(0.001f + lin / 255.0f);
                 }
@@ -150,7 +166,7 @@ __device__ __forceinline__ void store_vec(void *out, int64_t off, const T (&v)[V
 //          false -> float32 output.  Integer counts (SUM mode) stay exact; weighted/noisy values are
 //                   accumulated with float32 fma and agree with the float64 result to ~1e-6 relative.
 template <int IN, int VEC, int BIN, int RNG, bool NOISE, bool OUT64>
-__global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
+__global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const EsimArgs a)
 {
     using lut_t = typename LutT<IN>::type;
     using acc_t = typename std::conditional<OUT64, double, float>::type;
@@ -266,7 +282,9 @@ __global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
     uint32_t n_all = 0, n_off = 0;
     const bool want_counts = a.counts != nullptr;
 
-    auto step = [&](int k, const Raw<IN, VEC> &raw) {
+    // SYM (compile-time tag): C+ == C- for this clip (wave-uniform), so no per-lane threshold selection.
+    auto step = [&](auto sym_tag, int k, const Raw<IN, VEC> &raw) {
+        constexpr bool SYM = decltype(sym_tag)::value;
         if constexpr (BIN == kBinBilinear) {
             while (k >= next_k) {                                      // scalar compare; rarely taken
                 store_vec<VEC, acc_t>(a.out, out_base + (int64_t)cur_seg * a.HW, acc_lo);
@@ -297,11 +315,14 @@ __global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
         if constexpr (BIN == kBinBilinear) { wl = s_wlo[k]; wh = s_whi[k]; }
         lut_t ln[VEC];
         pix_logs<IN, VEC>(raw, s_lut, ln);
-        float qabs[VEC];
-        uint32_t sgns[VEC];
+
         // Branch-free per pixel: q = np.floor_divide(|p|, C) is 0 exactly when |p| < C, so the reference's
         // `where(p >= C+ ...)` / `where(p <= -C- ...)` masks (v2v_core_esim.py:51-55) need no separate test,
-        // and `p -= q*C` with q = 0 leaves p untouched bit for bit.  The four pixels are independent chains.
+        // and `p -= q*C` with q = 0 leaves p untouched bit for bit.  The VEC pixels are independent chains.
+        // Phase A: new potential, polarity, reciprocal quotient estimate and its sign-exact fma residual.
+        double mag[VEC], thr[VEC], q[VEC], r[VEC];
+        uint32_t sgn[VEC];
+        bool fix = false;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const lut_t d = ln[j] - lprev[j];                          // difference in the input's precision (:42)
@@ -310,24 +331,34 @@ __global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
             if constexpr (NOISE) {
                 if (!ext) { p = p + base[j]; p = p + hot[j]; }         // :48-49
             }
-            const uint32_t sgn = (uint32_t)__double2hiint(p) & 0x80000000u;
-            const bool neg_side = sgn != 0u;
-            const double mag = fabs(p);
-            const double thr = neg_side ? neg : pos;
-            // floor of the exact quotient (== np.floor_divide for |p|/C < 2^40): low-biased reciprocal estimate,
-            // sign-exact fma residual, one-sided +1 correction
-            double q = floor(mag * (neg_side ? inv_neg : inv_pos));
-            const double r = __builtin_fma(-q, thr, mag);
-            q += (r >= thr) ? 1.0 : 0.0;
-            const double qt = q * thr;
-            const double m2 = mag - qt;                                // :57-58 (product rounded, then subtracted)
-            pot[j] = __hiloint2double((int)((uint32_t)__double2hiint(m2) ^ sgn), __double2loint(m2));
-            const float qf = fmaxf((float)q, 0.0f);                    // NaN potential -> no events (NumPy compares false)
-            qabs[j] = qf;
-            sgns[j] = sgn;
+            sgn[j] = (uint32_t)__double2hiint(p) & 0x80000000u;
+            mag[j] = fabs(p);
+            double inv;
+            if constexpr (SYM) { thr[j] = pos; inv = inv_pos; }
+            else { const bool neg_side = sgn[j] != 0u; thr[j] = neg_side ? neg : pos; inv = neg_side ? inv_neg : inv_pos; }
+            // inv is biased low, so the estimate never exceeds the true quotient; it is short by one only when
+            // |p|/C sits within ~1e-15 above an integer -- and then (or for a NaN potential) r < C fails
+            q[j] = floor(mag[j] * inv);
+            r[j] = __builtin_fma(-q[j], thr[j], mag[j]);
+            fix |= !(r[j] < thr[j]);
+        }
+        if (__builtin_expect(fix, 0)) {                                // rare: exact multiples, NaN
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                if (r[j] >= thr[j]) q[j] += 1.0;
+                else if (!(r[j] < thr[j])) q[j] = 0.0;                 // NaN potential: NumPy's compares are false -> no events
+            }
+        }
+        // Phase B: reset the potential (v2v_core_esim.py:57-58), signed count, binning.
+        float qabs[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const double qt = q[j] * thr[j];
+            const double m2 = mag[j] - qt;                             // product rounded, then subtracted (no fma)
+            pot[j] = __hiloint2double((int)((uint32_t)__double2hiint(m2) ^ sgn[j]), __double2loint(m2));
             if constexpr (OUT64) {
-                double vox = __hiloint2double((int)((uint32_t)__double2hiint(q) ^ sgn), __double2loint(q));
-                vox = (q >= 0.0) ? vox : 0.0;
+                double vox = __hiloint2double((int)((uint32_t)__double2hiint(q[j]) ^ sgn[j]), __double2loint(q[j]));
+                qabs[j] = (float)q[j];
                 if constexpr (NOISE) {
                     if (ext) { vox = vox + base[j]; vox = vox + hot[j]; }   // :64-65
                 }
@@ -339,7 +370,9 @@ __global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
                     acc_lo[j] = acc_lo[j] + vox;
                 }
             } else {
-                float vf = __uint_as_float(__float_as_uint(qf) ^ sgn);
+                const float qf = (float)q[j];
+                qabs[j] = qf;
+                float vf = __uint_as_float(__float_as_uint(qf) ^ sgn[j]);
                 if constexpr (NOISE) {
                     if (ext) { double vox = (double)vf; vox = vox + base[j]; vox = vox + hot[j]; vf = (float)vox; }
                 }
@@ -356,7 +389,7 @@ __global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
             for (int j = 0; j < VEC; ++j) {
                 const uint32_t n = (uint32_t)qabs[j];
                 n_all += n;
-                n_off += sgns[j] ? n : 0u;
+                n_off += sgn[j] ? n : 0u;
             }
         }
         if constexpr (BIN == kBinSum) {
@@ -374,25 +407,29 @@ __global__ void __launch_bounds__(kBlock) esim_voxel_kernel(const EsimArgs a)
     //      kDepth-1 loads (x 1 KiB per wave for fp32 input) stay in flight behind the arithmetic.  Loads are
     //      UNCONDITIONAL (frame index clamped to the last frame) so the compiler can count them and wait with
     //      vmcnt(kDepth-1) instead of vmcnt(0); the kDepth clamped re-reads at the end of a clip hit in cache.
-    Raw<IN, VEC> ring[kDepth];
-#pragma unroll
-    for (int u = 0; u < kDepth; ++u) {
-        const int f = (1 + u <= a.K) ? 1 + u : a.K;
-        ring[u] = load_raw<IN, VEC>(a.frames, in_base + (int64_t)f * a.frame_stride);
-    }
-    int k0 = 0;
-    for (; k0 + kDepth <= a.K; k0 += kDepth) {
+    auto run = [&](auto sym_tag) {
+        Raw<IN, VEC> ring[kDepth];
 #pragma unroll
         for (int u = 0; u < kDepth; ++u) {
-            const int k = k0 + u;
-            step(k, ring[u]);
-            const int fn = k + 1 + kDepth;
-            ring[u] = load_raw<IN, VEC>(a.frames, in_base + (int64_t)(fn <= a.K ? fn : a.K) * a.frame_stride);
+            const int f = (1 + u <= a.K) ? 1 + u : a.K;
+            ring[u] = load_raw<IN, VEC>(a.frames, in_base + (int64_t)f * a.frame_stride);
         }
-    }
+        int k0 = 0;
+        for (; k0 + kDepth <= a.K; k0 += kDepth) {
 #pragma unroll
-    for (int u = 0; u < kDepth - 1; ++u)
-        if (k0 + u < a.K) step(k0 + u, ring[u]);
+            for (int u = 0; u < kDepth; ++u) {
+                const int k = k0 + u;
+                step(sym_tag, k, ring[u]);
+                const int fn = k + 1 + kDepth;
+                ring[u] = load_raw<IN, VEC>(a.frames, in_base + (int64_t)(fn <= a.K ? fn : a.K) * a.frame_stride);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kDepth - 1; ++u)
+            if (k0 + u < a.K) step(sym_tag, k0 + u, ring[u]);
+    };
+    if (pp[0] == pp[1]) run(std::true_type{});                         // wave-uniform (per clip)
+    else run(std::false_type{});
 
     // ---- epilogue
     if constexpr (BIN == kBinBilinear) {
