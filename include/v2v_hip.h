@@ -112,6 +112,22 @@ int64_t v2v_esim_voxel_bytes(int in_dtype, int64_t B, int64_t N, int64_t H, int6
 int v2v_synth_clips_hip(void *frames, int dtype, int64_t B, int64_t N, int64_t H, int64_t W, uint64_t seed,
                         uint64_t clip_id0, void *stream);
 
+/* ---- event list -> voxel grid -------------------------------------------------------------------------
+ * Replaces TestH5Dataset.make_voxel (data/testh5.py:60-90; same function at scripts/visualize_esim_sample.py:
+ * 113-135) and events_to_voxel (utils/event_utils.py:692-728, temporal_bilinear=True).
+ * ts float64 seconds (ascending), xs/ys int64 pixel coordinates, ps float64 (make_voxel modes: 0/1 polarity
+ * flags, mapped to -1/+1 like the reference; BILINEAR mode: signed weights used as they are).
+ * out_voxel float64 [num_bins,H,W] is zeroed by the call (an empty list gives zeros, testh5.py:63-64).
+ * dropped   uint64 device word: number of events outside the sensor / bin range (NumPy would raise IndexError).
+ * Interpolated sums use float64 atomics: per-event terms are NumPy's bits, summation order is not. */
+typedef enum v2v_event_mode {
+    V2V_EV_MAKE_VOXEL_DISCRETE = 0, /* testh5.py:71-74  */
+    V2V_EV_MAKE_VOXEL_INTERP = 1,   /* testh5.py:75-81  */
+    V2V_EV_BILINEAR = 2             /* event_utils.py:713-727 */
+} v2v_event_mode;
+int v2v_events_to_voxel_hip(const double *ts, const int64_t *xs, const int64_t *ys, const double *ps, int64_t n, int mode,
+                            int num_bins, int64_t H, int64_t W, double *out_voxel, uint64_t *dropped, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

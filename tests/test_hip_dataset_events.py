@@ -1,0 +1,143 @@
+"""GPU tests of the wider drop-in surface: event-list voxelisers (make_voxel / events_to_voxel) against the
+reference's golden outputs, and the WebvidDatasetV2-compatible dataset against the oracle + the sample contract."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import v2v_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------ G8: make_voxel / events_to_voxel
+def test_g8_make_voxel_discrete_exact_interp_1e12(golden):
+    from v2v_amd import voxel
+    g = golden("g8_make_voxel.npz")
+    evs = [g["ts"], g["xs"], g["ys"], g["ps"]]
+    disc = voxel.make_voxel(evs, 16, 24, num_bins=5, interpolate_bins=False)
+    assert disc.dtype == np.float64 and np.array_equal(disc, g["discrete"])            # +-1 adds: exact
+    interp = voxel.make_voxel(evs, 16, 24, num_bins=5, interpolate_bins=True)
+    np.testing.assert_allclose(interp, g["interpolated"], rtol=1e-12, atol=1e-12)       # same terms, atomic sum order
+    empty = voxel.make_voxel([a[:0] for a in evs], 16, 24)
+    assert empty.shape == (5, 16, 24) and not empty.any()
+
+    class Stub(voxel.MakeVoxelMixin):
+        num_bins, H, W, interpolate_bins = 5, 16, 24, False
+    assert np.array_equal(Stub().make_voxel(evs), g["discrete"])                        # testh5.py:60 signature
+    pf = (g["ps"] * 2 - 1).astype(np.float64)
+    e2v = voxel.events_to_voxel(g["xs"], g["ys"], g["ts"][:, None], pf[:, None], 5, sensor_size=(16, 24))
+    np.testing.assert_allclose(e2v, g["events_to_voxel"], rtol=1e-12, atol=1e-12)
+    t = voxel.make_voxel([torch.from_numpy(a).cuda() for a in evs], 16, 24, 5, False)
+    assert t.is_cuda and t.dtype == torch.float64 and np.array_equal(t.cpu().numpy(), g["discrete"])
+
+
+def test_make_voxel_large_random_vs_oracle(oracle_c):
+    from v2v_amd import voxel
+    g = np.random.default_rng(5)
+    n, h, w = 200_000, 180, 240
+    ts = np.sort(g.uniform(3.0, 3.04, size=n))
+    xs, ys, ps = g.integers(0, w, n), g.integers(0, h, n), g.integers(0, 2, n)
+    want = O.make_voxel([ts, xs, ys, ps], 5, h, w, False)
+    assert np.array_equal(voxel.make_voxel([ts, xs, ys, ps], h, w, 5, False), want)
+    want_i = O.make_voxel([ts, xs, ys, ps], 5, h, w, True)
+    np.testing.assert_allclose(voxel.make_voxel([ts, xs, ys, ps], h, w, 5, True), want_i, rtol=1e-11, atol=1e-11)
+    with pytest.raises(IndexError):
+        voxel.make_voxel([ts[:10], xs[:10] + w, ys[:10], ps[:10]], h, w)
+
+
+# ------------------------------------------------------------------ dataset drop-in
+def _frames(ds, sample_idx, start, end, crop_before, min_i, min_j, flip, need_h, need_w):
+    g = np.random.default_rng(1000 + start)           # own generator: must not touch the global stream
+    base = g.uniform(0, 255, size=(need_h, need_w))
+    out = []
+    for _ in range(end - start):
+        base = np.clip(base + g.normal(0, 6, size=base.shape), 0, 255)
+        f = base.astype(np.uint8)
+        out.append((f[:, ::-1] if flip else f)[..., None].copy())
+    return out
+
+
+def _make_ds(tmp_path, **cfg):
+    from v2v_amd.datasets import WebvidDatasetV2
+    lst = tmp_path / "videos.txt"
+    lst.write_text("clip_a.mp4 450 0.2 0.3\nclip_b.mp4 300 0.25 0.25\n")
+    base = {"video_list_file": str(lst), "sequence_length": 4, "crop_size": 32, "data_source_name": "webvid",
+            "frame_source": _frames, "video_size": (1280, 720), "video_reader": "opencv"}
+    base.update(cfg)
+    return WebvidDatasetV2(str(tmp_path), base)
+
+
+@pytest.mark.parametrize("extra", [{}, {"output_additional_frame": True}, {"output_additional_evs": True},
+                                   {"frames_per_bin": 2, "put_noise_external": True}])
+def test_dataset_sample_equals_oracle_replay(tmp_path, extra):
+    ds = _make_ds(tmp_path, sim_rng="numpy", **extra)
+    seen = {}
+    orig = ds.imgs_to_voxels
+
+    def spy(imgs, *a, **k):
+        seen["state"] = np.random.get_state()
+        seen["imgs"] = imgs.cpu().numpy()
+        return orig(imgs, *a, **k)
+    ds.imgs_to_voxels = spy
+    np.random.seed(77)
+    sample = ds[1]
+    L = 4
+    n_frames = L + 1 if extra.get("output_additional_frame") else L
+    n_ev = L + 1 if extra.get("output_additional_evs") else L
+    assert set(sample) == {"frame", "events", "data_source_idx", "v2e_params"}
+    assert sample["frame"].shape == (n_frames, 1, 32, 32) and sample["frame"].dtype == torch.float32
+    assert sample["events"].shape == (n_ev, 5, 32, 32) and sample["events"].dtype == torch.float32
+    assert 0 <= float(sample["frame"].min()) and float(sample["frame"].max()) <= 1
+    assert sample["data_source_idx"].dtype == torch.int64 and sample["data_source_idx"].ndim == 0 and int(sample["data_source_idx"]) == 11
+    # oracle: same RNG state, same frames -> same parameters and voxels (reference semantics, v2v_datasets.py:363-410)
+    np.random.set_state(seen["state"])
+    params, vox = O.imgs_to_voxels(seen["imgs"], 5, ds.frames_per_bin, put_noise_external=ds.put_noise_external, use_lut=True)
+    assert sample["v2e_params"] == params
+    np.testing.assert_allclose(sample["events"].numpy(), vox[:n_ev], rtol=1e-5, atol=1e-5)
+    if not ds.put_noise_external:
+        assert np.array_equal(sample["events"].numpy(), vox[:n_ev].astype(np.float32))   # integer counts: exact
+    # frame indexing (i+1)*frames_per_img (or i*frames_per_img with the additional frame), /255
+    imgs = seen["imgs"][ds.frames_per_img:] if extra.get("output_additional_evs") else seen["imgs"]
+    fpi = ds.frames_per_img
+    pick = [i * fpi for i in range(L + 1)] if extra.get("output_additional_frame") else [(i + 1) * fpi for i in range(L)]
+    assert np.array_equal(sample["frame"][:, 0].numpy(), imgs[pick].astype(np.float32) / 255)
+
+
+def test_dataset_default_collate_contract_g10(tmp_path):
+    """what train.py's DataLoader (default collate, train.py:52-65) hands to forward_sequence."""
+    from torch.utils.data import ConcatDataset, DataLoader
+    ds = _make_ds(tmp_path, sim_rng="philox", max_samples_per_shot=2, step_size=20)
+    assert len(ds) == 4
+    wrapped = ConcatDataset([ConcatDataset([ds])])                 # data_interface.py:21,27 wraps twice
+    np.random.seed(3)
+    batch = next(iter(DataLoader(wrapped, batch_size=2, shuffle=False, num_workers=0, drop_last=True)))
+    assert batch["frame"].shape == (2, 4, 1, 32, 32) and batch["frame"].dtype == torch.float32
+    assert batch["events"].shape == (2, 4, 5, 32, 32) and batch["events"].dtype == torch.float32
+    assert batch["data_source_idx"].shape == (2,) and batch["data_source_idx"].dtype == torch.int64
+    assert set(batch["v2e_params"]) == {"pos_thres", "neg_thres", "base_noise_std", "hot_pixel_fraction", "hot_pixel_std"}
+    assert all(v.shape == (2,) and v.dtype == torch.float64 for v in batch["v2e_params"].values())
+    assert torch.equal(batch["events"], batch["events"].round())   # noise is internal: integer counts
+
+
+def test_dataset_fixed_seed_is_deterministic_and_restores_state(tmp_path):
+    ds = _make_ds(tmp_path, fixed_seed=123, sim_rng="philox")
+    np.random.seed(1)
+    before = np.random.get_state()[1].copy()
+    a = ds[0]
+    assert np.array_equal(np.random.get_state()[1], before)         # global stream untouched (v2v_datasets.py:235-239,358-359)
+    np.random.seed(999)
+    b = ds[0]
+    assert torch.equal(a["events"], b["events"]) and a["v2e_params"] == b["v2e_params"]
+    assert not torch.equal(a["events"], ds[1]["events"])
+
+
+def test_imgs_to_voxels_numpy_in_numpy_out(tmp_path, golden):
+    g = golden("g6_imgs_to_voxels.npz")
+    ds = _make_ds(tmp_path, sim_rng="numpy")
+    np.random.seed(int(g["seed"]))
+    params, vox = ds.imgs_to_voxels(g["video"], 5, 1, 24)
+    keys = ["pos_thres", "neg_thres", "base_noise_std", "hot_pixel_fraction", "hot_pixel_std"]
+    assert np.array_equal(np.array([params[k] for k in keys]), g["params"])
+    assert isinstance(vox, np.ndarray) and vox.dtype == np.float64 and np.array_equal(vox, g["voxels"])
+    with pytest.raises(AssertionError):
+        ds.imgs_to_voxels(g["video"][:20], 5, 1, 24)

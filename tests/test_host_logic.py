@@ -1,0 +1,73 @@
+"""Host-side logic of the drop-in surface that needs no GPU: config defaults, sample indexing, parameter draws."""
+import numpy as np
+import pytest
+
+
+def _mk_list(tmp_path, rows):
+    p = tmp_path / "videos.txt"
+    p.write_text("\n".join(" ".join(map(str, r)) for r in rows) + "\n")
+    return str(p)
+
+
+def test_config_defaults_mirror_reference(tmp_path):
+    from v2v_amd.datasets import WebvidDatasetV2, data_sources
+    ds = WebvidDatasetV2(str(tmp_path), {"video_list_file": _mk_list(tmp_path, [["a.mp4", 450, 0.2, 0.3]]),
+                                         "data_source_name": "webvid"})
+    # defaults table of data/v2v_datasets.py:26-92
+    assert (ds.FPS, ds.L, ds.num_bins, ds.frames_per_bin) == (30, 40, 5, 1)
+    assert ds.frames_per_img == 5 and ds.frames_per_seq == 200 and ds.step_size == 200
+    assert ds.threshold_range == [0.05, 2] and ds.max_thres_pos_neg_gap == 1.5
+    assert ds.base_noise_std_range == [0, 0.2] and ds.hot_pixel_fraction_range == [0, 0.001] and ds.hot_pixel_std_range == [0, 0.2]
+    assert ds.keep_top_percentile == 0.54 and ds.max_resize_scale == 1.3 and ds.random_flip is True
+    assert ds.data_source_idx == 11 == data_sources.index("webvid")            # utils/data.py:7
+    # sample index: range(0, 450-200-1, 200) = [0, 200] capped by max_samples_per_shot = 1
+    assert len(ds) == 1 and ds.sample_begin_idx[0] == 0
+
+
+def test_sample_indexing_and_asserts(tmp_path):
+    from v2v_amd.datasets import WebvidDatasetV2
+    lst = _mk_list(tmp_path, [["a.mp4", 450, 0.2, 0.3], ["b.mp4", 120, 0.1, 0.1], ["c.mp4", 1000, 0.4, 0.5]])
+    ds = WebvidDatasetV2("/data", {"video_list_file": lst, "sequence_length": 4, "max_samples_per_shot": 3, "step_size": 30})
+    # frames_per_seq = 20: a -> range(0,429,30)[:3], b -> range(0,99,30)[:3], c -> [:3]
+    assert list(ds.sample_begin_idx) == [0, 30, 60] * 3
+    assert list(ds.sample_video_name[:3]) == ["a.mp4"] * 3 and ds.sample_pos_thres[3] == 0.1
+    half = WebvidDatasetV2("/data", {"video_list_file": lst, "sequence_length": 4, "max_samples_per_shot": 3,
+                                     "step_size": 30, "subsample_ratio": 0.5})
+    assert len(half) == 4
+    ev = WebvidDatasetV2("/data", {"video_list_file": lst, "sequence_length": 4, "output_additional_evs": True})
+    assert ev.frames_per_seq == 25
+    for bad in ({"video_reader": "pyav"}, {"color_mode": "rgb"}, {"sequence_length": 0}, {"video_degrade": "blur"}):
+        with pytest.raises(AssertionError):
+            WebvidDatasetV2("/data", dict({"video_list_file": lst}, **bad))
+
+
+def test_param_sampling_order_matches_golden(golden):
+    """The six draws of imgs_to_voxels (v2v_datasets.py:369-381) reproduce the reference's parameters for its seed."""
+    from v2v_amd.datasets import sample_sim_params
+    g = golden("g6_imgs_to_voxels.npz")
+    keys = ["pos_thres", "neg_thres", "base_noise_std", "hot_pixel_fraction", "hot_pixel_std"]
+    np.random.seed(int(g["seed"]))
+    p = sample_sim_params([0.05, 2], 1.5, [0, 0.2], [0, 0.001], [0, 0.2])
+    assert np.array_equal(np.array([p[k] for k in keys]), g["params"])
+    np.random.seed(int(g["seed2"]))
+    p2 = sample_sim_params([0.05, 2], 1.5, [0, 0.2], [0, 0.001], [0, 0.2], scale_noise_strength=True)
+    assert np.array_equal(np.array([p2[k] for k in keys]), g["params2"])
+    fixed = sample_sim_params([0.05, 2], 1.5, [0, 0.2], [0, 0.001], [0, 0.2], use_fixed_thresholds=True, pos_thres=0.3, neg_thres=0.4)
+    assert fixed["pos_thres"] == 0.3 and fixed["neg_thres"] == 0.4
+
+
+def test_bgr_to_gray_matches_oracle():
+    from oracle import v2v_oracle as O
+    from v2v_amd.datasets import bgr_to_gray
+    img = np.random.default_rng(0).integers(0, 256, size=(3, 8, 9, 3), dtype=np.uint8)
+    assert np.array_equal(bgr_to_gray(img), O.bgr_to_gray(img)) and bgr_to_gray(img).dtype == np.uint8
+
+
+def test_events_to_voxel_rejects_broken_reference_branch():
+    import torch
+    from v2v_amd import voxel
+    with pytest.raises(NotImplementedError):
+        voxel.events_to_voxel([0], [0], [0.0], [1.0], 5, temporal_bilinear=False)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            voxel.make_voxel([np.zeros(0), np.zeros(0, int), np.zeros(0, int), np.zeros(0, int)], 4, 4)

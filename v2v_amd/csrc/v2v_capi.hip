@@ -9,6 +9,7 @@
 
 #include "../../include/v2v_hip.h"
 #include "v2v_esim.hpp"
+#include "v2v_events.hpp"
 #include "v2v_synth.hpp"
 
 namespace {
@@ -220,6 +221,32 @@ int v2v_synth_clips_hip(void *frames, int dtype, int64_t B, int64_t N, int64_t H
     hipLaunchKernelGGL(v2v::synth_clips_kernel, dim3((unsigned)nblocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? V2V_OK : hip_fail(e, "synth_clips_kernel launch");
+}
+
+int v2v_events_to_voxel_hip(const double *ts, const int64_t *xs, const int64_t *ys, const double *ps, int64_t n, int mode,
+                            int num_bins, int64_t H, int64_t W, double *out_voxel, uint64_t *dropped, void *stream)
+{
+    if (!out_voxel || !dropped) return fail(V2V_ERR_NULL, "v2v_events_to_voxel_hip: out_voxel/dropped is NULL");
+    if (n < 0 || H < 1 || W < 1 || num_bins < 1 || num_bins > 255) return fail(V2V_ERR_SHAPE, "need n>=0, H,W>=1, 1<=num_bins<=255");
+    if (mode < V2V_EV_MAKE_VOXEL_DISCRETE || mode > V2V_EV_BILINEAR) return fail(V2V_ERR_MODE, "unknown event mode %d", mode);
+    if (n > 0 && (!ts || !xs || !ys || !ps)) return fail(V2V_ERR_NULL, "v2v_events_to_voxel_hip: event arrays are NULL");
+    if (!aligned(out_voxel, 8) || !aligned(dropped, 8) || !aligned(ts, 8) || !aligned(xs, 8) || !aligned(ys, 8) || !aligned(ps, 8))
+        return fail(V2V_ERR_ALIGN, "buffers must be 8-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(out_voxel, 0, sizeof(double) * (size_t)num_bins * H * W, s);   // empty list -> zeros (testh5.py:63-64)
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(out_voxel)");
+    e = hipMemsetAsync(dropped, 0, sizeof(uint64_t), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dropped)");
+    if (n == 0) return V2V_OK;
+    v2v::EventArgs a{};
+    a.ts = ts; a.xs = xs; a.ys = ys; a.ps = ps; a.n = n; a.mode = mode; a.Tb = num_bins; a.H = H; a.W = W;
+    a.out = out_voxel;
+    a.dropped = reinterpret_cast<unsigned long long *>(dropped);
+    const int64_t nblocks = (n + 255) / 256;
+    if (nblocks > 0x7FFFFFFF) return fail(V2V_ERR_SHAPE, "too many events for one launch");
+    hipLaunchKernelGGL(v2v::events_to_voxel_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, a);
+    e = hipGetLastError();
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "events_to_voxel_kernel launch");
 }
 
 }  // extern "C"

@@ -1,0 +1,72 @@
+// v2v_events.hpp -- event-list -> voxel-grid scatter kernels (gfx950).
+//
+// Replaces the NumPy scatter voxelisers of the reference:
+//   data/testh5.py:60-90            TestH5Dataset.make_voxel  (== scripts/visualize_esim_sample.py:113-135)
+//   utils/event_utils.py:692-728    events_to_voxel (temporal_bilinear=True) + events_to_image :155-174
+// One work-item per event; float64 global atomics (global_atomic_add_f64) into the [Tb,H,W] grid.  Discrete
+// bins add +-1 (order-independent, exact).  Interpolated bins add float64 weights whose per-event values are
+// bitwise NumPy's (same IEEE expression); only the summation ORDER differs from np.add.at / np.bincount, so
+// sums agree to ~1e-15 relative (tested at 1e-12), far inside the 1e-5 bar.
+// Bound: atomic throughput (8 B per event and touched bin), not HBM streaming; events outside the sensor are
+// dropped and counted in `dropped` (the Python wrapper raises IndexError like NumPy when it is non-zero).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace v2v {
+
+enum { kEvMakeVoxelDiscrete = 0, kEvMakeVoxelInterp = 1, kEvBilinear = 2 };
+
+struct EventArgs {
+    const double *ts;
+    const int64_t *xs, *ys;
+    const double *ps;
+    int64_t n;
+    int32_t mode, Tb;
+    int64_t H, W;
+    double *out;
+    unsigned long long *dropped;
+};
+
+__global__ void __launch_bounds__(256) events_to_voxel_kernel(const EventArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const int64_t x = a.xs[i], y = a.ys[i];
+    if (x < 0 || x >= a.W || y < 0 || y >= a.H) { atomicAdd(a.dropped, 1ull); return; }
+    const double t0 = a.ts[0], t1 = a.ts[a.n - 1], t = a.ts[i];
+    double *cell = a.out + y * a.W + x;
+    const int64_t plane = a.H * a.W;
+    if (a.mode == kEvBilinear) {
+        // event_utils.py:713-719: dt = ts[-1]-ts[0]; t_norm = (ts-ts[0])/dt*(B-1); w_b = max(0, 1-|t_norm-b|)
+        const double dt = t1 - t0;
+        const double t_norm = (t - t0) / dt * (double)(a.Tb - 1);
+        const double p = a.ps[i];
+        int b0 = (int)floor(t_norm);
+        for (int b = (b0 < 0 ? 0 : b0); b <= b0 + 1 && b < a.Tb; ++b) {
+            const double w = 1.0 - fabs(t_norm - (double)b);
+            if (w > 0.0) atomicAdd(cell + (int64_t)b * plane, p * w);
+        }
+        return;
+    }
+    // make_voxel (testh5.py:67-82): ps {0,1} -> {-1,+1}; ts -> int64 microseconds since the first event
+    const double pol = (double)((int)(int8_t)a.ps[i] * 2 - 1);
+    const int64_t tus = (int64_t)((t - t0) * 1e6);
+    const int64_t tus_last = (int64_t)((t1 - t0) * 1e6);
+    if (a.mode == kEvMakeVoxelDiscrete) {
+        const double t_per_bin = ((double)tus_last + 0.001) / (double)a.Tb;
+        const uint8_t b = (uint8_t)(int64_t)floor((double)tus / t_per_bin);     // .astype(np.uint8)
+        if (b < a.Tb) atomicAdd(cell + (int64_t)b * plane, pol);
+        else atomicAdd(a.dropped, 1ull);
+    } else {
+        const double dt = (double)(tus_last - 0);
+        const double t_norm = (double)(tus - 0) / (dt + 0.0001) * (double)(a.Tb - 1);
+        const int b0 = (int)floor(t_norm);
+        for (int b = (b0 < 0 ? 0 : b0); b <= b0 + 1 && b < a.Tb; ++b) {
+            const double w = 1.0 - fabs(t_norm - (double)b);
+            if (w > 0.0) atomicAdd(cell + (int64_t)b * plane, w * pol);
+        }
+    }
+}
+
+}  // namespace v2v

@@ -1,0 +1,77 @@
+"""Event-list -> voxel-grid: host side of v2v_events_to_voxel_hip.
+
+Mirrors (same names, argument order, shapes and dtypes):
+    make_voxel(evs, H, W, num_bins=5, interpolate_bins=True)     scripts/visualize_esim_sample.py:113-135
+    MakeVoxelMixin.make_voxel(self, evs)                         data/testh5.py:60-90  (TestH5Dataset.make_voxel)
+    events_to_voxel(xs, ys, ts, ps, B, sensor_size, temporal_bilinear)   utils/event_utils.py:692-728
+NumPy in -> NumPy float64 out; CUDA tensors in -> CUDA float64 tensor out.  The scatter runs in the HIP kernel
+(v2v_amd/csrc/v2v_events.hpp); nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _dev(x, dtype, device):
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=dtype).contiguous().reshape(-1)
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(x).reshape(-1)), device=device).to(dtype)
+
+
+def _scatter(ts, xs, ys, ps, mode, num_bins, h, w, device, check_bounds=True):
+    _lib.require_gpu()
+    ts_d = _dev(ts, torch.float64, device)
+    xs_d = _dev(xs, torch.int64, device)
+    ys_d = _dev(ys, torch.int64, device)
+    ps_d = _dev(ps, torch.float64, device)
+    n = ts_d.numel()
+    if not (xs_d.numel() == n and ys_d.numel() == n and ps_d.numel() == n):
+        raise AssertionError("len(xs)==len(ys)==len(ts)==len(ps) violated")      # event_utils.py:710
+    out = torch.empty((num_bins, h, w), dtype=torch.float64, device=device)
+    dropped = torch.empty((1,), dtype=torch.int64, device=device)
+    with torch.cuda.device(out.device):
+        rc = _lib.lib().v2v_events_to_voxel_hip(
+            C.c_void_p(ts_d.data_ptr()) if n else None, C.c_void_p(xs_d.data_ptr()) if n else None,
+            C.c_void_p(ys_d.data_ptr()) if n else None, C.c_void_p(ps_d.data_ptr()) if n else None, n, mode, num_bins,
+            h, w, C.c_void_p(out.data_ptr()), C.c_void_p(dropped.data_ptr()), _lib.stream_ptr())
+    _lib.check(rc)
+    if check_bounds and n and int(dropped.item()) != 0:
+        raise IndexError(f"{int(dropped.item())} event(s) outside the {h}x{w} sensor / {num_bins} bins")   # np.add.at would raise
+    return out
+
+
+def make_voxel(evs, H, W, num_bins=5, interpolate_bins=True, device="cuda"):
+    """evs = [ts, xs, ys, ps] (ps in {0,1}) -> [num_bins,H,W] float64.  scripts/visualize_esim_sample.py:113-135."""
+    ts, xs, ys, ps = evs
+    is_np = not isinstance(ts, torch.Tensor)
+    if isinstance(ts, torch.Tensor) and ts.is_cuda:
+        device = ts.device
+    mode = _lib.EV_MAKE_VOXEL_INTERP if interpolate_bins else _lib.EV_MAKE_VOXEL_DISCRETE
+    out = _scatter(ts, xs, ys, ps, mode, num_bins, H, W, device)
+    return out.cpu().numpy() if is_np else out
+
+
+class MakeVoxelMixin:
+    """`make_voxel(self, evs)` exactly as TestH5Dataset.make_voxel (data/testh5.py:60-90): reads self.num_bins,
+    self.H, self.W, self.interpolate_bins."""
+
+    def make_voxel(self, evs):
+        return make_voxel(evs, self.H, self.W, self.num_bins, self.interpolate_bins)
+
+
+def events_to_voxel(xs, ys, ts, ps, B, sensor_size=(180, 240), temporal_bilinear=True, device="cuda"):
+    """utils/event_utils.py:692-728.  ts/ps may be 1-D or the [N,1] columns the reference requires.
+    temporal_bilinear=False is broken in the reference (undefined `weights`): NotImplementedError here;
+    discrete bins are make_voxel(..., interpolate_bins=False)."""
+    if not temporal_bilinear:
+        raise NotImplementedError("the reference's temporal_bilinear=False branch references an undefined variable")
+    is_np = not isinstance(ts, torch.Tensor)
+    if isinstance(ts, torch.Tensor) and ts.is_cuda:
+        device = ts.device
+    out = _scatter(ts, xs, ys, ps, _lib.EV_BILINEAR, B, sensor_size[0], sensor_size[1], device)
+    return out.cpu().numpy() if is_np else out
