@@ -112,6 +112,40 @@ int64_t v2v_esim_voxel_bytes(int in_dtype, int64_t B, int64_t N, int64_t H, int6
 int v2v_synth_clips_hip(void *frames, int dtype, int64_t B, int64_t N, int64_t H, int64_t W, uint64_t seed,
                         uint64_t clip_id0, void *stream);
 
+/* ---- v2e-derived DVS model fused with voxel binning (BASELINE config 3) -----------------------------------
+ * Replaces video_to_voxel (data/v2v_core_v2e.py:556-581) around EventEmulator.generate_events (:401-553): lin-log
+ * table, intensity-dependent IIR low-pass, leak current, per-pixel random ON/OFF thresholds, Poisson shot noise,
+ * refractory cap (intended semantics min(count, int(dt/refractory)); the reference's own line raises TypeError).
+ * `params` is a HOST struct (the arguments of the reference's video_to_voxel, same for every clip of the call).
+ * uint8_wrap = 1 reproduces the reference's uint8 wrap in (frame+20)/275 for uint8 input (v2v_core_v2e.py:184-190).
+ * rng_mode: V2V_RNG_PHILOX (device-native fields; needs `workspace` of v2v_v2e_workspace_bytes() when
+ * shot_noise_rate_hz > 0) or V2V_RNG_REPLAY (fields drawn by NumPy in the reference's order: bit-exact replay).
+ * Output / binning / counts exactly as v2v_esim_voxel_hip. */
+typedef enum v2v_v2e_threshold_model {
+    V2V_V2E_PN_RELATED = 0,                  /* "pn_related"                    */
+    V2V_V2E_SPATIAL_INDEPENDENT = 1,          /* "spatial_independent"           */
+    V2V_V2E_SPATIAL_TEMPORAL_INDEPENDENT = 2  /* "spatial_temporal_independent"  */
+} v2v_v2e_threshold_model;
+typedef struct v2v_v2e_params {
+    double fps;
+    int threshold_model;
+    double thres_mean_mean, thres_mean_std, thres_diff_mean, thres_diff_std;
+    double cutoff_hz, leak_rate_hz, refractory_period_s, shot_noise_rate_hz, leak_jitter_fraction, noise_rate_cov_decades;
+    int uint8_wrap;
+} v2v_v2e_params;
+typedef struct v2v_v2e_replay {   /* device pointers */
+    const double *pos_thres, *neg_thres; /* clipped thresholds: [B,H*W] (stride 0) or [B,N-1,H*W] (temporal model)      */
+    int64_t thres_frame_stride;          /* 0, or H*W for spatial_temporal_independent                                  */
+    const float *noise_rate;             /* [B,H*W]  exp(ln10*cov*randn) as NumPy computed it (float32)                 */
+    const double *leak_randn;            /* [B,N-1,H*W] or NULL when leak_rate_hz == 0                                  */
+    const int64_t *shot_pos, *shot_neg;  /* [B,N-1,H*W] Poisson counts or NULL when shot_noise_rate_hz == 0             */
+} v2v_v2e_replay;
+int64_t v2v_v2e_workspace_bytes(int64_t B, int64_t N);
+int v2v_v2e_voxel_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W, int64_t clip_stride,
+                      int64_t frame_stride, const v2v_v2e_params *params, int rng_mode, uint64_t seed, uint64_t clip_id0,
+                      const v2v_v2e_replay *replay, int bin_mode, int num_bins, int frames_per_bin, void *out_voxel,
+                      int out_dtype, int64_t *out_counts, void *workspace, void *stream);
+
 /* ---- event list -> voxel grid -------------------------------------------------------------------------
  * Replaces TestH5Dataset.make_voxel (data/testh5.py:60-90; same function at scripts/visualize_esim_sample.py:
  * 113-135) and events_to_voxel (utils/event_utils.py:692-728, temporal_bilinear=True).

@@ -131,3 +131,74 @@ def make_voxel(ts_us, xs, ys, ps01, num_bins, h, w, interpolate):
     if rc != 0:
         raise RuntimeError(f"oracle_make_voxel rc={rc}")
     return out
+
+
+# ---------------------------------------------------------------- v2e model
+V2E_MODELS = {"pn_related": 0, "spatial_independent": 1, "spatial_temporal_independent": 2}
+
+
+class V2EParams(C.Structure):
+    _fields_ = [("fps", C.c_double), ("threshold_model", C.c_int), ("thres_mean_mean", C.c_double),
+                ("thres_mean_std", C.c_double), ("thres_diff_mean", C.c_double), ("thres_diff_std", C.c_double),
+                ("cutoff_hz", C.c_double), ("leak_rate_hz", C.c_double), ("refractory_period_s", C.c_double),
+                ("shot_noise_rate_hz", C.c_double), ("leak_jitter_fraction", C.c_double),
+                ("noise_rate_cov_decades", C.c_double), ("uint8_wrap", C.c_int)]
+
+
+class V2EReplay(C.Structure):
+    _fields_ = [("pos_thres", C.c_void_p), ("neg_thres", C.c_void_p), ("thres_frame_stride", C.c_int64),
+                ("noise_rate", C.c_void_p), ("leak_randn", C.c_void_p), ("shot_pos", C.c_void_p), ("shot_neg", C.c_void_p)]
+
+
+def v2e_params(FPS, threshold_model, thres_mean_mean, thres_mean_std, thres_diff_mean, thres_diff_std, cutoff_hz,
+               leak_rate_hz, refractory_period_s, shot_noise_rate_hz, leak_jitter_fraction, noise_rate_cov_decades,
+               uint8_wrap=True):
+    return V2EParams(float(FPS), V2E_MODELS[threshold_model], thres_mean_mean, thres_mean_std, thres_diff_mean,
+                     thres_diff_std, cutoff_hz, leak_rate_hz, refractory_period_s, shot_noise_rate_hz,
+                     leak_jitter_fraction, noise_rate_cov_decades, int(bool(uint8_wrap)))
+
+
+def v2e_replay_arrays(record, k, hw):
+    """Pack the fields recorded by oracle.v2v_oracle.v2e_video_to_voxel(record=...) for one clip."""
+    pt = np.ascontiguousarray(np.stack(record["pos_thres"]).reshape(-1, hw), dtype=np.float64)
+    nt = np.ascontiguousarray(np.stack(record["neg_thres"]).reshape(-1, hw), dtype=np.float64)
+    temporal = pt.shape[0] > 1
+    if temporal:                       # entry 0 is the _init draw (never used for events); frames 1..N-1 follow
+        pt, nt = np.ascontiguousarray(pt[1:]), np.ascontiguousarray(nt[1:])
+    arrs = {"pos_thres": pt, "neg_thres": nt, "stride": hw if temporal else 0,
+            "noise_rate": np.ascontiguousarray(record["noise_rate"].reshape(hw), dtype=np.float32),
+            "leak_randn": np.ascontiguousarray(np.stack(record["leak_randn"]).reshape(k, hw), dtype=np.float64) if record["leak_randn"] else None,
+            "shot_pos": np.ascontiguousarray(np.stack(record["shot_pos"]).reshape(k, hw), dtype=np.int64),
+            "shot_neg": np.ascontiguousarray(np.stack(record["shot_neg"]).reshape(k, hw), dtype=np.int64)}
+    return arrs
+
+
+def v2e_voxel(frames, params: V2EParams, luts, *, rng_mode=RNG_PHILOX, seed=0, clip_id0=0, bin_mode=BIN_SUM, num_bins=5,
+              frames_per_bin=1, replay=None):
+    """frames [B,N,H,W] uint8 / float32 (integer-valued) -> (float64 voxels, totals[B,2])."""
+    frames = np.ascontiguousarray(frames)
+    b, n, h, w = frames.shape
+    k = n - 1
+    in_dtype = {np.dtype(np.uint8): IN_U8, np.dtype(np.float32): IN_F32}[frames.dtype]
+    lut = np.ascontiguousarray(luts["v2e32"], dtype=np.float32)
+    shape = (b, k // (num_bins * frames_per_bin), num_bins, h, w) if bin_mode == BIN_SUM else (b, num_bins, h, w)
+    out = np.zeros(shape, dtype=np.float64)
+    totals = np.zeros((b, 2), dtype=np.int64)
+    L = lib()
+    if replay is not None:
+        assert b == 1
+        keep = replay
+        rp = V2EReplay(keep["pos_thres"].ctypes.data, keep["neg_thres"].ctypes.data, keep["stride"],
+                       keep["noise_rate"].ctypes.data,
+                       keep["leak_randn"].ctypes.data if keep["leak_randn"] is not None else None,
+                       keep["shot_pos"].ctypes.data, keep["shot_neg"].ctypes.data)
+        rc = L.oracle_v2e_voxel_clip(_p(frames), in_dtype, C.c_int64(n), C.c_int64(h * w), _p(lut), C.byref(params),
+                                     RNG_REPLAY, C.c_uint64(seed), C.c_uint32(clip_id0), C.byref(rp), bin_mode, num_bins,
+                                     frames_per_bin, _p(out), _p(totals))
+    else:
+        rc = L.oracle_v2e_voxel_batch(_p(frames), in_dtype, C.c_int64(b), C.c_int64(n), C.c_int64(h * w), _p(lut),
+                                      C.byref(params), C.c_uint64(seed), C.c_uint64(clip_id0), bin_mode, num_bins,
+                                      frames_per_bin, _p(out), _p(totals))
+    if rc != 0:
+        raise RuntimeError(f"oracle_v2e_voxel rc={rc}")
+    return out, totals

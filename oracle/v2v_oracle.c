@@ -17,6 +17,7 @@
  *
  * Compile with -ffp-contract=off: the reference never fuses a multiply with an add.
  */
+#define _GNU_SOURCE
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -276,6 +277,283 @@ int oracle_esim_voxel_batch(const void *frames, int in_dtype, int64_t B, int64_t
                                        params + c * params_stride, noise_external, rng_mode, seed,
                                        (uint32_t)(clip_id0 + (uint64_t)c), NULL, bin_mode, Tb, fpb,
                                        out + c * out_per_clip, t);
+        if (totals) { totals[2 * c] = t[0]; totals[2 * c + 1] = t[1]; }
+        if (r != 0) {
+#pragma omp critical
+            rc = r;
+        }
+    }
+    return rc;
+}
+
+/* ------------------------------------------------------------------ v2e model (data/v2v_core_v2e.py) */
+/* exp(-lam), lam >= 0, from IEEE-exact primitives only (same definition on the device): used by the native
+ * Poisson sampler, which is NOT NumPy's (NumPy's consumes a data-dependent number of MT19937 draws). */
+static double exp_neg(double lam)
+{
+    const double x = -lam;
+    if (x < -745.0) return 0.0;
+    const double k = rint(x * 1.4426950408889634);
+    double r = fma(-k, 0.693147180369123816490e+00, x);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;                 /* 1/13! */
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const int ki = (int)k;                          /* -1075 .. 0 */
+    if (ki < -1022) return 0.0;
+    uint64_t bits = (uint64_t)(1023 + ki) << 52;
+    double scale; memcpy(&scale, &bits, 8);
+    return p * scale;
+}
+double oracle_exp_neg(double lam) { return exp_neg(lam); }
+
+/* Poisson by inversion from one 53-bit uniform (native mode). */
+static double poisson_inv(double lam, double u)
+{
+    if (!(lam > 0.0)) return 0.0;
+    double p = exp_neg(lam), s = p, x = 0.0;
+    while (u > s && x < 1000.0) { x += 1.0; p = p * lam / x; s += p; }
+    return x;
+}
+double oracle_poisson_inv(double lam, double u) { return poisson_inv(lam, u); }
+
+/* expf for the log-normal noise-rate array (native mode; NumPy's float32 exp is a SIMD kernel we cannot match
+ * bit for bit, so native mode defines its own from IEEE-exact primitives). */
+static float expf_det(float x)
+{
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    const float k = rintf(x * 1.44269502f);
+    float r = fmaf(-k, 0.693359375f, x);
+    r = fmaf(-k, -2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    p = fmaf(p, r2, r) + 1.0f;
+    return p * u32_as_float((uint32_t)(127 + (int)k) << 23);
+}
+float oracle_expf_det(float x) { return expf_det(x); }
+
+enum { V2E_PN_RELATED = 0, V2E_SPATIAL_INDEPENDENT = 1, V2E_SPATIAL_TEMPORAL_INDEPENDENT = 2 };
+enum { V2E_F_THRES_A = 0, V2E_F_THRES_B = 1, V2E_F_NOISE_RATE = 2, V2E_F_FRAME0 = 16, V2E_F_STRIDE = 8 };
+#define V2E_STREAM 1u
+
+typedef struct {
+    double fps;
+    int threshold_model;
+    double thres_mean_mean, thres_mean_std, thres_diff_mean, thres_diff_std;
+    double cutoff_hz, leak_rate_hz, refractory_period_s, shot_noise_rate_hz, leak_jitter_fraction, noise_rate_cov_decades;
+    int uint8_wrap;
+} oracle_v2e_params;
+
+typedef struct {
+    const double *pos_thres, *neg_thres;   /* [HW] or [K,HW] (frame stride below) after clipping */
+    int64_t thres_frame_stride;
+    const float *noise_rate;               /* [HW] */
+    const double *leak_randn;              /* [K,HW] or NULL */
+    const int64_t *shot_pos, *shot_neg;    /* [K,HW] or NULL */
+} oracle_v2e_replay;
+
+static double v2e_floor_divide(double a, double b) { return oracle_floor_divide(a, b); }
+
+/* thresholds of pixel p for frame field base `fb` (static: V2E_F_THRES_A) -- native mode */
+static void v2e_native_thres(const oracle_v2e_params *P, uint64_t seed, uint32_t clip, uint32_t fa, uint32_t p,
+                             double *pt, double *nt)
+{
+    const double ga = (double)px_gauss32(seed, clip, fa, V2E_STREAM, p);
+    const double gb = (double)px_gauss32(seed, clip, fa + 1u, V2E_STREAM, p);
+    double a, b;
+    if (P->threshold_model == V2E_PN_RELATED) {
+        const double mean = P->thres_mean_mean + P->thres_mean_std * ga;   /* normal(loc,scale) = loc + scale*g */
+        const double diff = P->thres_diff_mean + P->thres_diff_std * gb;
+        a = mean + (diff / 2); b = mean - (diff / 2);
+    } else {
+        a = P->thres_mean_mean + P->thres_mean_std * ga;
+        b = P->thres_mean_mean + P->thres_mean_std * gb;
+    }
+    *pt = a < 0.01 ? 0.01 : a;             /* np.clip(a_min=0.01) */
+    *nt = b < 0.01 ? 0.01 : b;
+}
+
+static double v2e_inten01_u8(uint8_t x, int wrap)
+{
+    return wrap ? (double)(uint8_t)(x + 20) / 275. : ((double)x + 20.0) / 275.;
+}
+
+/*
+ * One clip.  frames [N,HW] u8 or f32 (integer-valued).  lut = golden G1 v2e32.  rng: PHILOX or REPLAY.
+ * out: SUM -> [K/fpb, HW] ; BILINEAR -> [Tb, HW] (float64).  Follows generate_events (v2v_core_v2e.py:401-553)
+ * pixel by pixel with NumPy's dtype promotions made explicit (lp32 / base32 flags, see oracle/v2v_oracle.py).
+ */
+int oracle_v2e_voxel_clip(const void *frames, int in_dtype, int64_t N, int64_t HW, const float *lut,
+                          const oracle_v2e_params *P, int rng_mode, uint64_t seed, uint32_t clip_id,
+                          const oracle_v2e_replay *rp, int bin_mode, int Tb, int fpb, double *out, int64_t *totals)
+{
+    const int64_t K = N - 1;
+    if (K < 1 || Tb < 1 || fpb < 1) return -1;
+    if (bin_mode == ORACLE_BIN_SUM && (K % ((int64_t)Tb * fpb)) != 0) return -2;
+    if (bin_mode == ORACLE_BIN_BILINEAR && K < 2) return -3;
+    if (rng_mode != ORACLE_RNG_PHILOX && rng_mode != ORACLE_RNG_REPLAY) return -4;
+    const uint8_t *f8 = (const uint8_t *)frames;
+    const float *f32 = (const float *)frames;
+    const int in_f32 = in_dtype == ORACLE_IN_F32;
+    const int lp32 = (P->cutoff_hz <= 0) || in_f32;
+    const int base32 = lp32 && !(P->leak_rate_hz > 0);
+    const int temporal = P->threshold_model == V2E_SPATIAL_TEMPORAL_INDEPENDENT;
+    const double pos_nominal = P->thres_mean_mean + P->thres_diff_mean / 2;
+    const double neg_nominal = P->thres_mean_mean - P->thres_diff_mean / 2;
+    const double tau = P->cutoff_hz > 0 ? 1 / (M_PI * 2 * P->cutoff_hz) : 0.0;
+    const int64_t n_out = (bin_mode == ORACLE_BIN_SUM) ? K / fpb : Tb;
+    const int shot = P->shot_noise_rate_hz > 0;
+    int64_t on_total = 0, off_total = 0;
+
+    /* native shot noise: per-frame sums of the intensity/threshold factors in 2^32 fixed point (order-free) */
+    int64_t *sum_pos = NULL, *sum_neg = NULL;
+    if (shot && rng_mode == ORACLE_RNG_PHILOX) {
+        sum_pos = (int64_t *)calloc((size_t)K, sizeof(int64_t));
+        sum_neg = (int64_t *)calloc((size_t)K, sizeof(int64_t));
+        for (int64_t p = 0; p < HW; ++p) {
+            double pt, nt;
+            v2e_native_thres(P, seed, clip_id, V2E_F_THRES_A, (uint32_t)p, &pt, &nt);
+            for (int64_t k = 0; k < K; ++k) {
+                const int64_t i = k + 1;
+                if (temporal) v2e_native_thres(P, seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * i), (uint32_t)p, &pt, &nt);
+                double fac;
+                if (in_f32) { const float i01 = (f32[i * HW + p] + 20.0f) / 275.0f; fac = (double)(1.0f - 0.75f * i01); }
+                else fac = 1 - 0.75 * v2e_inten01_u8(f8[i * HW + p], P->uint8_wrap);
+                sum_pos[k] += llrint(fac * (pos_nominal / pt) * 4294967296.0);
+                sum_neg[k] += llrint(fac * (neg_nominal / nt) * 4294967296.0);
+            }
+        }
+    }
+
+    for (int64_t p = 0; p < HW; ++p) {
+        for (int64_t o = 0; o < n_out; ++o) out[o * HW + p] = 0.0;
+        /* frame 0: lp = base = lin_log(frame0) (the low-pass update with delta_time = 0 is the identity) */
+        const int x0 = in_f32 ? (int)f32[p] : (int)f8[p];
+        double lp64 = (double)lut[x0], base64 = lp64;
+        float lp_f = lut[x0], base_f = lp_f;
+        double pt, nt;
+        float nrate;
+        if (rng_mode == ORACLE_RNG_PHILOX) {
+            v2e_native_thres(P, seed, clip_id, V2E_F_THRES_A, (uint32_t)p, &pt, &nt);
+            const float g = px_gauss32(seed, clip_id, V2E_F_NOISE_RATE, V2E_STREAM, (uint32_t)p);
+            nrate = expf_det((float)(2.302585092994046 * P->noise_rate_cov_decades) * g);
+        } else {
+            pt = rp->pos_thres[p]; nt = rp->neg_thres[p]; nrate = rp->noise_rate[p];
+        }
+        for (int64_t k = 0; k < K; ++k) {
+            const int64_t i = k + 1;
+            const double dt = (double)i / P->fps - (double)(i - 1) / P->fps;      /* t_frame - t_previous */
+            if (temporal) {
+                if (rng_mode == ORACLE_RNG_PHILOX) v2e_native_thres(P, seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * i), (uint32_t)p, &pt, &nt);
+                else { pt = rp->pos_thres[k * rp->thres_frame_stride + p]; nt = rp->neg_thres[k * rp->thres_frame_stride + p]; }
+            }
+            const float log_new = in_f32 ? lut[(int)f32[i * HW + p]] : lut[f8[i * HW + p]];
+            double i01_64 = 0.0; float i01_32 = 0.0f;
+            if (in_f32) i01_32 = (f32[i * HW + p] + 20.0f) / 275.0f;
+            else i01_64 = v2e_inten01_u8(f8[i * HW + p], P->uint8_wrap);
+            if (P->cutoff_hz > 0) {                                               /* low_pass_filter */
+                if (in_f32) {
+                    float eps = i01_32 * (float)(dt / tau);
+                    if (eps > 1.0f) eps = 1.0f;
+                    const float a = (1.0f - eps) * lp_f, b = eps * log_new;
+                    lp_f = a + b;
+                } else {
+                    double eps = i01_64 * (dt / tau);
+                    if (eps > 1.0) eps = 1.0;
+                    const double a = (1 - eps) * lp64, b = eps * (double)log_new;
+                    lp64 = a + b;
+                }
+            } else {
+                lp_f = log_new;
+            }
+            if (P->leak_rate_hz > 0) {                                            /* subtract_leak_current */
+                double g;
+                if (rng_mode == ORACLE_RNG_PHILOX) g = (double)px_gauss32(seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * i + 2), V2E_STREAM, (uint32_t)p);
+                else g = rp->leak_randn[k * HW + p];
+                const float a32 = (float)P->leak_rate_hz * nrate;
+                const double curr = (double)a32 * (1 - P->leak_jitter_fraction * g);
+                const double dl = dt * curr * pt;
+                base64 = base64 - dl;                                             /* base is float64 whenever leak > 0 */
+            }
+            double diff;
+            if (lp32 && base32) { const float d = lp_f - base_f; diff = (double)d; }
+            else diff = (lp32 ? (double)lp_f : lp64) - base64;
+            const double pos_frame = diff > 0 ? diff : (diff == diff ? 0.0 : diff);
+            const double nd = -diff;
+            const double neg_frame = nd > 0 ? nd : (nd == nd ? 0.0 : nd);
+            double fpos = v2e_floor_divide(pos_frame, pt);
+            double fneg = v2e_floor_divide(neg_frame, nt);
+            if (shot) {
+                double sp, sn;
+                if (rng_mode == ORACLE_RNG_PHILOX) {
+                    double fac;
+                    if (in_f32) fac = (double)(1.0f - 0.75f * i01_32); else fac = 1 - 0.75 * i01_64;
+                    const double mean_p = ((double)sum_pos[k] / 4294967296.0) / (double)HW;
+                    const double mean_n = ((double)sum_neg[k] / 4294967296.0) / (double)HW;
+                    const double f = (P->shot_noise_rate_hz / 2) * dt;
+                    const double lam_p = fac * (pos_nominal / pt) / mean_p * f;
+                    const double lam_n = fac * (neg_nominal / nt) / mean_n * f;
+                    sp = poisson_inv(lam_p, px_uniform53(seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * i + 3), V2E_STREAM, (uint32_t)p));
+                    sn = poisson_inv(lam_n, px_uniform53(seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * i + 4), V2E_STREAM, (uint32_t)p));
+                } else {
+                    sp = (double)rp->shot_pos[k * HW + p]; sn = (double)rp->shot_neg[k * HW + p];
+                }
+                fpos = fpos + sp; fneg = fneg + sn;
+            }
+            if (P->refractory_period_s > 0) {
+                const double cap = (double)(int)(dt / P->refractory_period_s);
+                if (fpos > cap) fpos = cap;
+                if (fneg > cap) fneg = cap;
+            }
+            if (base32) {                                                          /* in-place += on a float32 array */
+                base_f = (float)((double)base_f + fpos * pt);
+                base_f = (float)((double)base_f - fneg * nt);
+            } else {
+                base64 = base64 + fpos * pt;
+                base64 = base64 - fneg * nt;
+            }
+            const double vox = fpos - fneg;
+            on_total += (int64_t)fpos; off_total += (int64_t)fneg;
+            if (bin_mode == ORACLE_BIN_SUM) out[(k / fpb) * HW + p] += vox;
+            else for (int b = 0; b < Tb; ++b) { const double c = vox * bil_w(k, K, b, Tb); out[(int64_t)b * HW + p] += c; }
+        }
+    }
+    free(sum_pos); free(sum_neg);
+    if (totals) { totals[0] += on_total; totals[1] += off_total; }
+    return 0;
+}
+
+int oracle_v2e_voxel_batch(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t HW, const float *lut,
+                           const oracle_v2e_params *P, uint64_t seed, uint64_t clip_id0, int bin_mode, int Tb, int fpb,
+                           double *out, int64_t *totals)
+{
+    const int64_t K = N - 1;
+    const int64_t out_per_clip = ((bin_mode == ORACLE_BIN_SUM) ? K / fpb : Tb) * HW;
+    const int64_t in_per_clip = N * HW * (in_dtype == ORACLE_IN_U8 ? 1 : 4);
+    int rc = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t c = 0; c < B; ++c) {
+        int64_t t[2] = {0, 0};
+        int r = oracle_v2e_voxel_clip((const char *)frames + c * in_per_clip, in_dtype, N, HW, lut, P, ORACLE_RNG_PHILOX,
+                                      seed, (uint32_t)(clip_id0 + (uint64_t)c), NULL, bin_mode, Tb, fpb,
+                                      out + c * out_per_clip, t);
         if (totals) { totals[2 * c] = t[0]; totals[2 * c + 1] = t[1]; }
         if (r != 0) {
 #pragma omp critical

@@ -365,3 +365,128 @@ def synth_clip_s1(n=8, h=128, w=128, seed=1234, dtype=np.uint8):
         base = np.clip(base + g.normal(0, 12, size=(h, w)), 0, 255)
         frames.append(base.astype(np.uint8))
     return np.stack(frames).astype(dtype)
+
+
+# ----------------------------------------------------------------------------------------
+# v2e-derived DVS model (reference: data/v2v_core_v2e.py -- "deprecated" per its own header :1, BASELINE config 3)
+# ----------------------------------------------------------------------------------------
+
+V2E_MODELS = ("pn_related", "spatial_independent", "spatial_temporal_independent")
+
+
+class V2ERng:
+    """Random source of the v2e model.  Default: the global legacy np.random stream, like the reference
+    (seeded by np.random.seed(seed) in its constructor, v2v_core_v2e.py:312-314)."""
+    normal = staticmethod(lambda loc, scale, shape: np.random.normal(loc=loc, scale=scale, size=shape))
+    randn = staticmethod(lambda h, w: np.random.randn(h, w))
+    poisson = staticmethod(lambda lam: np.random.poisson(lam))
+
+
+def v2e_video_to_voxel(video, FPS, threshold_model, thres_mean_mean, thres_mean_std, thres_diff_mean, thres_diff_std,
+                       cutoff_hz, leak_rate_hz, refractory_period_s, shot_noise_rate_hz, leak_jitter_fraction,
+                       noise_rate_cov_decades, seed=None, rng=V2ERng, use_lut=False, record=None):
+    """video_to_voxel of v2v_core_v2e.py:556-581 around EventEmulator.generate_events (:401-553).
+
+    Array dtypes are left to NumPy exactly as in the reference (they depend on the input dtype, on cutoff_hz and on
+    leak_rate_hz: SURVEY §4).  Deviations from the literal reference, both forced by reference defects:
+      * refractory_period_s > 0: the reference raises TypeError (np.clip without a_min, :534-537); the intended
+        semantics min(count, int(dt/refractory)) is implemented.
+      * threshold_model 'spatial_independent_temporal_changing' crashes in the reference (:423-426): rejected.
+    `record` (dict) receives the random fields in draw order, for replay on the GPU."""
+    if threshold_model not in V2E_MODELS:
+        raise ValueError(f"unsupported threshold_model {threshold_model!r}")
+    if seed is not None and rng is V2ERng:
+        np.random.seed(seed)                                                   # :312-314
+    pos_nominal = thres_mean_mean + thres_diff_mean / 2                        # :294-295
+    neg_nominal = thres_mean_mean - thres_diff_mean / 2
+    n, h, w = video.shape
+    rec = record if record is not None else {}
+    for key in ("pos_thres", "neg_thres", "leak_randn", "shot_pos", "shot_neg"):
+        rec[key] = []
+
+    def clip_thres(pt, nt):                                                    # change_pos_neg_thres :392-399
+        pt = np.clip(pt, a_min=0.01, a_max=None)
+        nt = np.clip(nt, a_min=0.01, a_max=None)
+        return pt, nt, np.divide(pos_nominal, pt), np.divide(neg_nominal, nt)
+
+    lp = base = pos_thres = neg_thres = pos_pre = neg_pre = noise_rate = None
+    t_prev = 0.0
+    out = []
+    for i in range(n):
+        frame = video[i]
+        t_frame = i / FPS
+        if threshold_model == "spatial_temporal_independent":                  # :417-421 (also runs on frame 0, then _init redraws)
+            pt = rng.normal(thres_mean_mean, thres_mean_std, frame.shape)
+            nt = rng.normal(thres_mean_mean, thres_mean_std, frame.shape)
+            pos_thres, neg_thres, pos_pre, neg_pre = clip_thres(pt, nt)
+        delta_time = t_frame - t_prev                                          # :440 (t_prev stays 0 through frame 1)
+        log_new = (load_luts()["v2e32"][frame.astype(np.int64)] if use_lut else v2e_linlog_direct(frame))   # :445
+        inten01 = None
+        if cutoff_hz > 0 or shot_noise_rate_hz > 0:
+            inten01 = (frame + 20) / 275.                                      # :184-190,455 (uint8 input wraps, as in the reference)
+        if base is None:
+            lp = log_new                                                       # :465
+        if cutoff_hz > 0:                                                      # low_pass_filter :139-182
+            tau = 1 / (math.pi * 2 * cutoff_hz)
+            eps = inten01 * (delta_time / tau)
+            eps = np.clip(eps, a_min=None, a_max=1)
+            lp = (1 - eps) * lp + eps * log_new
+        else:
+            lp = log_new
+        if base is None:                                                       # _init :317-349
+            if threshold_model == "pn_related":
+                pn_mean = rng.normal(thres_mean_mean, thres_mean_std, frame.shape)
+                pn_diff = rng.normal(thres_diff_mean, thres_diff_std, frame.shape)
+                pt, nt = pn_mean + (pn_diff / 2), pn_mean - (pn_diff / 2)
+            else:
+                pt = rng.normal(thres_mean_mean, thres_mean_std, frame.shape)
+                nt = rng.normal(thres_mean_mean, thres_mean_std, frame.shape)
+            pos_thres, neg_thres, pos_pre, neg_pre = clip_thres(pt, nt)
+            noise_rate = rng.randn(h, w).astype(np.float32)
+            noise_rate = np.exp(math.log(10) * noise_rate_cov_decades * noise_rate)
+            rec["noise_rate"] = noise_rate
+            rec["pos_thres"].append(pos_thres)
+            rec["neg_thres"].append(neg_thres)
+            base = lp                                                          # :476 (aliases lp; lp is rebound every frame)
+            base = base.copy()
+            continue
+        if threshold_model == "spatial_temporal_independent":
+            rec["pos_thres"].append(pos_thres)
+            rec["neg_thres"].append(neg_thres)
+        if leak_rate_hz > 0:                                                   # subtract_leak_current :192-211
+            g = rng.randn(h, w)
+            rec["leak_randn"].append(g)
+            curr = leak_rate_hz * noise_rate * (1 - leak_jitter_fraction * g)
+            base = base - delta_time * curr * pos_thres
+        diff = lp - base                                                       # :502
+        pos_frame = np.clip(diff, a_min=0, a_max=None)                         # compute_event_map :42-62
+        neg_frame = np.clip(-diff, a_min=0, a_max=None)
+        pos_ev = np.floor_divide(pos_frame, pos_thres)
+        neg_ev = np.floor_divide(neg_frame, neg_thres)
+        if shot_noise_rate_hz > 0:                                             # generate_shot_noise :65-105
+            inten_factor = 1 - (1 - 0.25) * inten01
+            pos_factor = inten_factor * pos_pre
+            pos_pix = pos_factor / np.mean(pos_factor)
+            neg_factor = inten_factor * neg_pre
+            neg_pix = neg_factor / np.mean(neg_factor)
+            f = (shot_noise_rate_hz / 2) * delta_time
+            sp = rng.poisson(pos_pix * f)
+            sn = rng.poisson(neg_pix * f)
+            rec.setdefault("shot_lambda_pos", []).append(pos_pix * f)
+            rec.setdefault("shot_lambda_neg", []).append(neg_pix * f)
+        else:
+            sp = np.zeros_like(pos_ev)
+            sn = np.zeros_like(neg_ev)
+        rec["shot_pos"].append(sp)
+        rec["shot_neg"].append(sn)
+        fpos = pos_ev + sp
+        fneg = neg_ev + sn
+        if refractory_period_s > 0:                                            # intended semantics of :534-537
+            cap = int(delta_time / refractory_period_s)
+            fpos = np.minimum(fpos, cap)
+            fneg = np.minimum(fneg, cap)
+        base += fpos * pos_thres                                               # :547 (in place: keeps base's dtype)
+        base -= fneg * neg_thres                                               # :548
+        t_prev = t_frame
+        out.append(fpos - fneg)
+    return np.array(out)

@@ -192,9 +192,74 @@ def g11_philox_fed():
     save("g11_philox_fed.npz", **out)
 
 
+def g9_v2e():
+    """The reference's v2e video_to_voxel (data/v2v_core_v2e.py:556-581) with np.random.{normal,randn,poisson}
+    wrapped so the drawn fields are recorded in draw order (the values still come from the real seeded stream)."""
+    video = O.synth_clip_s1(8, 24, 24, seed=909, dtype=np.uint8)
+    cases = {
+        "pn_clean_u8": (np.uint8, "pn_related", 0, 0, 0, 0),
+        "pn_noisy_u8": (np.uint8, "pn_related", 30, 0.1, 0, 5.0),
+        "pn_noisy_f32": (np.float32, "pn_related", 30, 0.1, 0, 5.0),
+        "si_leak_u8": (np.uint8, "spatial_independent", 0, 0.1, 0, 0),
+        "si_cut_f32": (np.float32, "spatial_independent", 30, 0, 0, 0),
+        "sti_noisy_u8": (np.uint8, "spatial_temporal_independent", 30, 0.1, 0, 5.0),
+        "sti_shot_f32": (np.float32, "spatial_temporal_independent", 0, 0, 0, 5.0),
+    }
+    out = {"video": video, "case_names": np.array(list(cases))}
+    real = (np.random.normal, np.random.randn, np.random.poisson)
+    for name, (dt, model, cutoff, leak, refr, shot) in cases.items():
+        rec = {"normal": [], "randn": [], "poisson": []}
+
+        def normal(loc=0.0, scale=1.0, size=None):
+            v = real[0](loc=loc, scale=scale, size=size); rec["normal"].append(v); return v
+
+        def randn(*shape):
+            v = real[1](*shape); rec["randn"].append(v); return v
+
+        def poisson(lam):
+            v = real[2](lam); rec["poisson"].append(v); return v
+        np.random.normal, np.random.randn, np.random.poisson = normal, randn, poisson
+        try:
+            vox = v2v_core_v2e.video_to_voxel(video.astype(dt), 24, model, 0.5, 0.1, 0.0, 0.1, cutoff, leak, refr, shot,
+                                              0.1, 0.1, seed=11)
+        finally:
+            np.random.normal, np.random.randn, np.random.poisson = real
+        out[f"{name}__args"] = np.array([24, list(O.V2E_MODELS).index(model), 0.5, 0.1, 0.0, 0.1, cutoff, leak, refr, shot, 0.1, 0.1])
+        out[f"{name}__dtype"] = np.array(np.dtype(dt).name)
+        out[f"{name}__voxels"] = vox.astype(np.int16)
+        assert np.array_equal(vox, vox.astype(np.int16))
+        # Replay-ready fields, derived from the recorded draws with the reference's own expressions
+        # (_init :328-349, change_pos_neg_thres :392-399) -- derived HERE because np.exp(float32) is a SIMD
+        # kernel whose last bit may differ on another host.
+        import math
+        temporal = model == "spatial_temporal_independent"
+        normals = rec["normal"][2:] if temporal else rec["normal"]          # temporal: frame 0 pre-draw is discarded
+        pts, nts = [], []
+        for a, b in zip(normals[0::2], normals[1::2]):
+            if model == "pn_related":
+                pt, nt = a + (b / 2), a - (b / 2)
+            else:
+                pt, nt = a, b
+            pts.append(np.clip(pt, a_min=0.01, a_max=None))
+            nts.append(np.clip(nt, a_min=0.01, a_max=None))
+        k = video.shape[0] - 1
+        out[f"{name}__pos_thres"] = np.stack(pts[1:] if temporal else pts)   # temporal: per frame 1..N-1
+        out[f"{name}__neg_thres"] = np.stack(nts[1:] if temporal else nts)
+        out[f"{name}__noise_rate"] = np.exp(math.log(10) * 0.1 * rec["randn"][0].astype(np.float32))
+        assert out[f"{name}__noise_rate"].dtype == np.float32
+        if leak > 0:
+            out[f"{name}__leak_randn"] = np.stack(rec["randn"][1:])
+            assert len(rec["randn"]) == 1 + k
+        if shot > 0:
+            out[f"{name}__shot_pos"] = np.stack(rec["poisson"][0::2])
+            out[f"{name}__shot_neg"] = np.stack(rec["poisson"][1::2])
+            assert len(rec["poisson"]) == 2 * k
+    save("g9_v2e.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11"]
     fns = {"g1": g1_luts, "g2": g2_g3_esim_clean, "g4": g4_esim_noisy, "g5": g5_floor_divide,
-           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g11": g11_philox_fed}
+           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed}
     for w in which:
         fns[w]()

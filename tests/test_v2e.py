@@ -1,0 +1,169 @@
+"""v2e model (BASELINE config 3): oracle vs the reference's golden outputs (CPU), HIP vs goldens and oracle (GPU)."""
+import numpy as np
+import pytest
+
+from oracle import v2v_oracle as O
+
+ARG_NAMES = ("FPS", "threshold_model", "thres_mean_mean", "thres_mean_std", "thres_diff_mean", "thres_diff_std", "cutoff_hz",
+             "leak_rate_hz", "refractory_period_s", "shot_noise_rate_hz", "leak_jitter_fraction", "noise_rate_cov_decades")
+CASES = ["pn_clean_u8", "pn_noisy_u8", "pn_noisy_f32", "si_leak_u8", "si_cut_f32", "sti_noisy_u8", "sti_shot_f32"]
+
+
+def _case(g, name):
+    a = g[f"{name}__args"]
+    args = [a[0], O.V2E_MODELS[int(a[1])]] + [float(x) for x in a[2:]]
+    video = g["video"].astype(np.dtype(str(g[f"{name}__dtype"])))
+    fields = {k: g[f"{name}__{k}"] for k in ("pos_thres", "neg_thres", "noise_rate", "leak_randn", "shot_pos", "shot_neg")
+              if f"{name}__{k}" in g}
+    if args[1] != "spatial_temporal_independent":          # static thresholds are stored as a stack of one
+        fields["pos_thres"], fields["neg_thres"] = fields["pos_thres"][0], fields["neg_thres"][0]
+    return video, args, fields, g[f"{name}__voxels"].astype(np.float64)
+
+
+class _Replay:
+    """Feeds the recorded draws back in order (normal -> already-clipped thresholds cannot be un-clipped, so the
+    oracle is driven through its own RNG hooks with the raw stream instead: see test below)."""
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_g9_numpy_oracle_reproduces_reference_from_seed(golden, name):
+    """Same seed, same global stream -> the NumPy restatement must equal the reference's output."""
+    g = golden("g9_v2e.npz")
+    video, args, fields, want = _case(g, name)
+    rec = {}
+    got = O.v2e_video_to_voxel(video, *args, seed=11, use_lut=True, record=rec)
+    assert np.array_equal(got, want)
+    # and the fields it drew are the ones the reference drew (pins the draw ORDER)
+    pt = np.stack(rec["pos_thres"])
+    assert np.array_equal(pt[1:] if pt.shape[0] > 1 else pt[0], fields["pos_thres"])
+    if "leak_randn" in fields:
+        assert np.array_equal(np.stack(rec["leak_randn"]), fields["leak_randn"])
+    if "shot_pos" in fields:
+        assert np.array_equal(np.stack(rec["shot_pos"]), fields["shot_pos"]) and np.array_equal(np.stack(rec["shot_neg"]), fields["shot_neg"])
+    # np.exp(float32) may differ by an ulp across hosts; the golden holds the reference's bits
+    assert np.all(np.abs(rec["noise_rate"] - fields["noise_rate"]) <= np.spacing(fields["noise_rate"]))
+
+
+def _replay_arrays(fields, k, hw):
+    return {"pos_thres": np.ascontiguousarray(fields["pos_thres"].reshape(-1, hw), dtype=np.float64),
+            "neg_thres": np.ascontiguousarray(fields["neg_thres"].reshape(-1, hw), dtype=np.float64),
+            "stride": hw if fields["pos_thres"].ndim == 3 else 0,
+            "noise_rate": np.ascontiguousarray(fields["noise_rate"].reshape(hw), dtype=np.float32),
+            "leak_randn": np.ascontiguousarray(fields["leak_randn"].reshape(k, hw)) if "leak_randn" in fields else None,
+            "shot_pos": np.ascontiguousarray(fields.get("shot_pos", np.zeros((k, hw), np.int64)).reshape(k, hw), dtype=np.int64),
+            "shot_neg": np.ascontiguousarray(fields.get("shot_neg", np.zeros((k, hw), np.int64)).reshape(k, hw), dtype=np.int64)}
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_g9_c_oracle_replay(golden, oracle_c, luts, name):
+    g = golden("g9_v2e.npz")
+    video, args, fields, want = _case(g, name)
+    k, hw = video.shape[0] - 1, video.shape[1] * video.shape[2]
+    got, totals = oracle_c.v2e_voxel(video[None], oracle_c.v2e_params(*args), luts, rng_mode=oracle_c.RNG_REPLAY,
+                                     bin_mode=oracle_c.BIN_SUM, num_bins=k, replay=_replay_arrays(fields, k, hw))
+    assert np.array_equal(got[0, 0], want)
+
+
+def test_refractory_known_answers(oracle_c, luts):
+    """The reference's refractory line raises; intended semantics = min(count, int(dt/refractory)).
+    Hand-checkable: a 0 -> 255 step with tiny thresholds saturates every pixel at the cap."""
+    video = np.zeros((3, 4, 4), dtype=np.uint8)
+    video[1:] = 255
+    args = [24, "spatial_independent", 0.05, 0.0, 0.0, 0.0, 0, 0, 1 / 240, 0, 0.0, 0.0]
+    got = O.v2e_video_to_voxel(video, *args, seed=1, use_lut=True)
+    assert np.all(got[0] == int((1 / 24) / (1 / 240))) and int((1 / 24) / (1 / 240)) in (9, 10)
+    c, _ = oracle_c.v2e_voxel(video[None], oracle_c.v2e_params(*args), luts, seed=1, bin_mode=oracle_c.BIN_SUM, num_bins=2)
+    assert np.array_equal(c[0, 0, 0], got[0])       # std = 0 -> thresholds are exactly 0.05 in native mode too
+
+
+def test_native_det_functions_accuracy(oracle_c):
+    import ctypes as C
+    L = oracle_c.lib()
+    L.oracle_exp_neg.restype = C.c_double
+    L.oracle_exp_neg.argtypes = [C.c_double]
+    L.oracle_expf_det.restype = C.c_float
+    L.oracle_expf_det.argtypes = [C.c_float]
+    L.oracle_poisson_inv.restype = C.c_double
+    L.oracle_poisson_inv.argtypes = [C.c_double, C.c_double]
+    assert max(abs(L.oracle_exp_neg(x) - np.exp(-x)) / np.exp(-x) for x in np.linspace(0, 60, 601)) < 1e-15
+    assert max(abs(L.oracle_expf_det(float(x)) - np.exp(x)) / np.exp(x) for x in np.linspace(-6, 6, 601)) < 3e-7
+    u = np.random.default_rng(0).random(20000)
+    for lam in (0.05, 0.104, 1.7):
+        x = np.array([L.oracle_poisson_inv(lam, float(v)) for v in u])
+        assert abs(x.mean() - lam) < 4 * np.sqrt(lam / u.size) and abs(x.var() - lam) < 0.1 * lam + 0.01
+
+
+# ------------------------------------------------------------------ GPU
+gpu = pytest.mark.gpu
+
+
+@gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_replay_equals_reference_golden(golden, name):
+    import torch
+    from v2v_amd import v2e
+    g = golden("g9_v2e.npz")
+    video, args, fields, want = _case(g, name)
+    params = v2e.make_params(*args)
+    k = video.shape[0] - 1
+    rep = {kk: torch.from_numpy(np.ascontiguousarray(a))[None] for kk, a in fields.items()}
+    out = v2e.v2e_voxel_batch(torch.from_numpy(video)[None].cuda(), params, bin_mode="sum", num_bins=k, rng_mode="replay",
+                              replay=rep, out_dtype=torch.float64)
+    assert np.array_equal(out[0, 0].cpu().numpy(), want)
+
+
+@gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_video_to_voxel_dropin_numpy_stream(golden, name):
+    """Full drop-in call: seed -> host draws in the reference's order -> GPU.  np.exp(float32) of the leak-rate
+    factor is host-SIMD dependent (<= 1 ulp), so allow a vanishing number of flipped counts."""
+    from v2v_amd import v2e
+    g = golden("g9_v2e.npz")
+    video, args, fields, want = _case(g, name)
+    got = v2e.video_to_voxel(video, *args, seed=11, rng="numpy")
+    assert got.dtype == np.float64 and got.shape == want.shape
+    assert np.count_nonzero(got != want) <= 2
+
+
+@gpu
+@pytest.mark.parametrize("dt", [np.uint8, np.float32])
+@pytest.mark.parametrize("model,cutoff,leak,refr,shot", [("pn_related", 30, 0.1, 0, 5.0), ("spatial_independent", 0, 0, 0, 0),
+                                                          ("spatial_temporal_independent", 30, 0.1, 1 / 240, 5.0),
+                                                          ("pn_related", 0, 0.1, 0, 0)])
+@pytest.mark.parametrize("bin_mode", ["sum", "bilinear"])
+def test_hip_philox_equals_c_oracle(oracle_c, luts, dt, model, cutoff, leak, refr, shot, bin_mode):
+    import torch
+    from v2v_amd import v2e
+    b, n, h, w = 3, 11, 24, 40
+    video = np.stack([O.synth_clip_s1(n, h, w, seed=300 + i, dtype=dt) for i in range(b)])
+    args = [24, model, 0.5, 0.1, 0.0, 0.1, cutoff, leak, refr, shot, 0.1, 0.1]
+    bm = oracle_c.BIN_SUM if bin_mode == "sum" else oracle_c.BIN_BILINEAR
+    want, totals = oracle_c.v2e_voxel(video, oracle_c.v2e_params(*args), luts, seed=0xABCDEF123, clip_id0=5, bin_mode=bm,
+                                      num_bins=5, frames_per_bin=2 if bin_mode == "sum" else 1)
+    counts = torch.zeros((b, 2), dtype=torch.int64, device="cuda")
+    got = v2e.v2e_voxel_batch(torch.from_numpy(video).cuda(), v2e.make_params(*args), bin_mode=bin_mode, num_bins=5,
+                              frames_per_bin=2 if bin_mode == "sum" else 1, seed=0xABCDEF123, clip_id0=5,
+                              out_dtype=torch.float64, counts=counts)
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(counts.cpu().numpy(), totals)
+    got32 = v2e.v2e_voxel_batch(torch.from_numpy(video).cuda(), v2e.make_params(*args), bin_mode=bin_mode, num_bins=5,
+                                frames_per_bin=2 if bin_mode == "sum" else 1, seed=0xABCDEF123, clip_id0=5)
+    np.testing.assert_allclose(got32.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    # batch / shard invariance
+    part = v2e.v2e_voxel_batch(torch.from_numpy(video[1:]).cuda(), v2e.make_params(*args), bin_mode=bin_mode, num_bins=5,
+                               frames_per_bin=2 if bin_mode == "sum" else 1, seed=0xABCDEF123, clip_id0=6, out_dtype=torch.float64)
+    assert torch.equal(part, got[1:])
+
+
+@gpu
+def test_hip_v2e_errors():
+    import torch
+    from v2v_amd import v2e
+    with pytest.raises(ValueError):
+        v2e.make_params(24, "spatial_independent_temporal_changing", 0.5, 0.1, 0, 0.1, 0, 0, 0, 0, 0.1, 0.1)
+    f = torch.zeros((1, 8, 8, 8), dtype=torch.uint8, device="cuda")
+    p = v2e.make_params(24, "pn_related", 0.5, 0.1, 0, 0.1, 0, 0, 0, 0, 0.1, 0.1)
+    with pytest.raises(AssertionError):
+        v2e.v2e_voxel_batch(f, p, num_bins=5)
+    with pytest.raises(ValueError):
+        v2e.v2e_voxel_batch(f, p, num_bins=7, rng_mode="replay")

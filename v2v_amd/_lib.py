@@ -19,12 +19,29 @@ OK, ERR_NULL, ERR_SHAPE, ERR_BINS, ERR_DTYPE, ERR_MODE, ERR_ALIGN, ERR_HIP, ERR_
 ABI_VERSION = 1
 
 EXPORTS = ("v2v_version", "v2v_last_error", "v2v_device_count", "v2v_lut_get", "v2v_lut_set",
-           "v2v_esim_voxel_hip", "v2v_esim_voxel_bytes", "v2v_synth_clips_hip", "v2v_events_to_voxel_hip")
+           "v2v_esim_voxel_hip", "v2v_esim_voxel_bytes", "v2v_synth_clips_hip", "v2v_events_to_voxel_hip",
+           "v2v_v2e_voxel_hip", "v2v_v2e_workspace_bytes")
 EV_MAKE_VOXEL_DISCRETE, EV_MAKE_VOXEL_INTERP, EV_BILINEAR = 0, 1, 2
 
 
 class EsimReplay(C.Structure):
     _fields_ = [("u_init", C.c_void_p), ("u_hot", C.c_void_p), ("g_hot", C.c_void_p), ("g_base", C.c_void_p)]
+
+
+class V2EParams(C.Structure):
+    _fields_ = [("fps", C.c_double), ("threshold_model", C.c_int), ("thres_mean_mean", C.c_double),
+                ("thres_mean_std", C.c_double), ("thres_diff_mean", C.c_double), ("thres_diff_std", C.c_double),
+                ("cutoff_hz", C.c_double), ("leak_rate_hz", C.c_double), ("refractory_period_s", C.c_double),
+                ("shot_noise_rate_hz", C.c_double), ("leak_jitter_fraction", C.c_double),
+                ("noise_rate_cov_decades", C.c_double), ("uint8_wrap", C.c_int)]
+
+
+class V2EReplay(C.Structure):
+    _fields_ = [("pos_thres", C.c_void_p), ("neg_thres", C.c_void_p), ("thres_frame_stride", C.c_int64),
+                ("noise_rate", C.c_void_p), ("leak_randn", C.c_void_p), ("shot_pos", C.c_void_p), ("shot_neg", C.c_void_p)]
+
+
+V2E_MODELS = {"pn_related": 0, "spatial_independent": 1, "spatial_temporal_independent": 2}
 
 
 class V2VError(RuntimeError):
@@ -63,6 +80,12 @@ def lib():
     L.v2v_events_to_voxel_hip.restype = C.c_int
     L.v2v_events_to_voxel_hip.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                           C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.v2v_v2e_workspace_bytes.restype = C.c_int64
+    L.v2v_v2e_workspace_bytes.argtypes = [C.c_int64, C.c_int64]
+    L.v2v_v2e_voxel_hip.restype = C.c_int
+    L.v2v_v2e_voxel_hip.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                    C.POINTER(V2EParams), C.c_int, C.c_uint64, C.c_uint64, C.POINTER(V2EReplay), C.c_int,
+                                    C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     if L.v2v_version() != ABI_VERSION:
         raise ImportError(f"libv2v_hip.so ABI {L.v2v_version()} != binding ABI {ABI_VERSION}: rebuild")
     _lib = L

@@ -10,6 +10,7 @@
 #include "../../include/v2v_hip.h"
 #include "v2v_esim.hpp"
 #include "v2v_events.hpp"
+#include "v2v_v2e.hpp"
 #include "v2v_synth.hpp"
 
 namespace {
@@ -57,6 +58,29 @@ hipError_t launch_bin(int bin, int rng, bool noise, bool out64, const v2v::EsimA
 {
     return bin == V2V_BIN_SUM ? launch_rng<IN, VEC, v2v::kBinSum>(rng, noise, out64, a, grid, lds, s)
                               : launch_rng<IN, VEC, v2v::kBinBilinear>(rng, noise, out64, a, grid, lds, s);
+}
+
+template <int IN, int VEC, int BIN, int RNG>
+hipError_t launch_v2e_out(bool out64, const v2v::V2eArgs &a, dim3 grid, size_t lds, hipStream_t s)
+{
+    if (out64) hipLaunchKernelGGL((v2v::v2e_voxel_kernel<IN, VEC, BIN, RNG, true>), grid, dim3(v2v::kBlock), lds, s, a);
+    else hipLaunchKernelGGL((v2v::v2e_voxel_kernel<IN, VEC, BIN, RNG, false>), grid, dim3(v2v::kBlock), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int IN, int VEC>
+hipError_t launch_v2e(int bin, int rng, bool out64, bool presum, const v2v::V2eArgs &a, dim3 grid, size_t lds, hipStream_t s)
+{
+    if (presum) {
+        hipLaunchKernelGGL((v2v::v2e_shot_sum_kernel<IN, VEC>), grid, dim3(v2v::kBlock), 0, s, a);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (bin == V2V_BIN_SUM)
+        return rng == V2V_RNG_PHILOX ? launch_v2e_out<IN, VEC, v2v::kBinSum, v2v::kRngPhilox>(out64, a, grid, lds, s)
+                                     : launch_v2e_out<IN, VEC, v2v::kBinSum, v2v::kRngReplay>(out64, a, grid, lds, s);
+    return rng == V2V_RNG_PHILOX ? launch_v2e_out<IN, VEC, v2v::kBinBilinear, v2v::kRngPhilox>(out64, a, grid, lds, s)
+                                 : launch_v2e_out<IN, VEC, v2v::kBinBilinear, v2v::kRngReplay>(out64, a, grid, lds, s);
 }
 
 }  // namespace
@@ -221,6 +245,87 @@ int v2v_synth_clips_hip(void *frames, int dtype, int64_t B, int64_t N, int64_t H
     hipLaunchKernelGGL(v2v::synth_clips_kernel, dim3((unsigned)nblocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? V2V_OK : hip_fail(e, "synth_clips_kernel launch");
+}
+
+int64_t v2v_v2e_workspace_bytes(int64_t B, int64_t N)
+{
+    if (B < 0 || N < 2) return V2V_ERR_SHAPE;
+    return B * (N - 1) * 2 * (int64_t)sizeof(int64_t);
+}
+
+int v2v_v2e_voxel_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W, int64_t clip_stride,
+                      int64_t frame_stride, const v2v_v2e_params *params, int rng_mode, uint64_t seed, uint64_t clip_id0,
+                      const v2v_v2e_replay *replay, int bin_mode, int num_bins, int frames_per_bin, void *out_voxel,
+                      int out_dtype, int64_t *out_counts, void *workspace, void *stream)
+{
+    if (!frames || !params || !out_voxel) return fail(V2V_ERR_NULL, "v2v_v2e_voxel_hip: frames/params/out_voxel is NULL");
+    if (B < 0 || N < 2 || H < 1 || W < 1) return fail(V2V_ERR_SHAPE, "need B>=0, N>=2, H,W>=1");
+    const int64_t HW = H * W, K = N - 1;
+    if (HW > (int64_t)1 << 30 || K > (1 << 20) || B > (int64_t)1 << 31) return fail(V2V_ERR_SHAPE, "H*W, N or B too large");
+    if (frame_stride < HW || (B > 1 && clip_stride < (N - 1) * frame_stride + HW)) return fail(V2V_ERR_SHAPE, "strides smaller than the extent");
+    if (in_dtype != V2V_U8 && in_dtype != V2V_F32) return fail(V2V_ERR_DTYPE, "in_dtype must be V2V_U8 or V2V_F32");
+    if (out_dtype != V2V_F32 && out_dtype != V2V_F64) return fail(V2V_ERR_DTYPE, "out_dtype must be V2V_F32 or V2V_F64");
+    if (num_bins < 1 || frames_per_bin < 1) return fail(V2V_ERR_PARAM, "num_bins and frames_per_bin must be >= 1");
+    if (rng_mode != V2V_RNG_PHILOX && rng_mode != V2V_RNG_REPLAY) return fail(V2V_ERR_MODE, "v2e rng_mode must be PHILOX or REPLAY");
+    if (params->threshold_model < V2V_V2E_PN_RELATED || params->threshold_model > V2V_V2E_SPATIAL_TEMPORAL_INDEPENDENT)
+        return fail(V2V_ERR_MODE, "unsupported threshold_model %d (spatial_independent_temporal_changing crashes in the reference)", params->threshold_model);
+    if (!(params->fps > 0)) return fail(V2V_ERR_PARAM, "fps must be > 0");
+    const bool shot = params->shot_noise_rate_hz > 0, leak = params->leak_rate_hz > 0;
+    const bool temporal = params->threshold_model == V2V_V2E_SPATIAL_TEMPORAL_INDEPENDENT;
+    if (rng_mode == V2V_RNG_REPLAY) {
+        if (!replay || !replay->pos_thres || !replay->neg_thres || !replay->noise_rate || (leak && !replay->leak_randn) ||
+            (shot && (!replay->shot_pos || !replay->shot_neg)))
+            return fail(V2V_ERR_MODE, "rng_mode REPLAY: missing replay field");
+        if (temporal != (replay->thres_frame_stride != 0)) return fail(V2V_ERR_MODE, "thres_frame_stride must be H*W for the temporal model, 0 otherwise");
+    }
+    const bool presum = shot && rng_mode == V2V_RNG_PHILOX;
+    if (presum && !workspace) return fail(V2V_ERR_NULL, "native shot noise needs a workspace of v2v_v2e_workspace_bytes()");
+    if (bin_mode == V2V_BIN_SUM) {
+        if (K % ((int64_t)num_bins * frames_per_bin) != 0)
+            return fail(V2V_ERR_BINS, "(N-1)=%lld is not a multiple of num_bins*frames_per_bin=%d", (long long)K, num_bins * frames_per_bin);
+    } else if (bin_mode == V2V_BIN_BILINEAR) {
+        if (K < 2) return fail(V2V_ERR_BINS, "BILINEAR needs at least 2 frame pairs");
+    } else {
+        return fail(V2V_ERR_MODE, "unknown bin_mode %d", bin_mode);
+    }
+    const size_t in_sz = in_dtype == V2V_U8 ? 1 : 4, out_sz = out_dtype == V2V_F32 ? 4 : 8;
+    if (!aligned(frames, in_sz) || !aligned(out_voxel, out_sz) || (out_counts && !aligned(out_counts, 8)) || (workspace && !aligned(workspace, 8)))
+        return fail(V2V_ERR_ALIGN, "buffer not aligned to its element size");
+    if (B == 0) return V2V_OK;
+    const bool vec4 = (HW % 4 == 0) && (frame_stride % 4 == 0) && (B == 1 || clip_stride % 4 == 0) &&
+                      aligned(frames, 4 * in_sz) && aligned(out_voxel, 16);
+    const int vec = vec4 ? 4 : 1;
+    v2v::V2eArgs a{};
+    a.frames = frames; a.clip_stride = clip_stride; a.frame_stride = frame_stride;
+    a.out = out_voxel;
+    a.counts = reinterpret_cast<unsigned long long *>(out_counts);
+    a.shot_sums = presum ? static_cast<long long *>(workspace) : nullptr;
+    if (replay) {
+        a.r_pos_thres = replay->pos_thres; a.r_neg_thres = replay->neg_thres; a.r_thres_frame_stride = replay->thres_frame_stride;
+        a.r_noise_rate = replay->noise_rate; a.r_leak_randn = replay->leak_randn;
+        a.r_shot_pos = reinterpret_cast<const long long *>(replay->shot_pos);
+        a.r_shot_neg = reinterpret_cast<const long long *>(replay->shot_neg);
+    }
+    a.seed = seed; a.clip_id0 = clip_id0;
+    a.HW = (int32_t)HW; a.K = (int32_t)K; a.Tb = num_bins; a.fpb = frames_per_bin;
+    a.blocks_per_clip = (int32_t)((HW + (int64_t)v2v::kBlock * vec - 1) / ((int64_t)v2v::kBlock * vec));
+    static_assert(sizeof(v2v::V2eParams) == sizeof(v2v_v2e_params), "v2e params layout");
+    memcpy(&a.P, params, sizeof(a.P));
+    const int64_t nblocks = B * a.blocks_per_clip;
+    if (nblocks > 0x7FFFFFFF) return fail(V2V_ERR_SHAPE, "grid too large");
+    const bool out64 = out_dtype == V2V_F64;
+    const size_t lds = 256 * sizeof(float) + (bin_mode == V2V_BIN_BILINEAR ? (size_t)K * (2 * (out64 ? sizeof(double) : sizeof(float)) + sizeof(int)) : 0);
+    if (lds > 160 * 1024) return fail(V2V_ERR_SHAPE, "too many frame pairs for the LDS weight table");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (presum) {
+        const hipError_t e0 = hipMemsetAsync(workspace, 0, (size_t)v2v_v2e_workspace_bytes(B, N), s);
+        if (e0 != hipSuccess) return hip_fail(e0, "hipMemsetAsync(workspace)");
+    }
+    const dim3 grid((unsigned)nblocks);
+    hipError_t e;
+    if (in_dtype == V2V_U8) e = vec4 ? launch_v2e<v2v::kInU8, 4>(bin_mode, rng_mode, out64, presum, a, grid, lds, s) : launch_v2e<v2v::kInU8, 1>(bin_mode, rng_mode, out64, presum, a, grid, lds, s);
+    else e = vec4 ? launch_v2e<v2v::kInF32, 4>(bin_mode, rng_mode, out64, presum, a, grid, lds, s) : launch_v2e<v2v::kInF32, 1>(bin_mode, rng_mode, out64, presum, a, grid, lds, s);
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "v2e kernel launch");
 }
 
 int v2v_events_to_voxel_hip(const double *ts, const int64_t *xs, const int64_t *ys, const double *ps, int64_t n, int mode,

@@ -1,0 +1,445 @@
+// v2v_v2e.hpp -- v2e-derived DVS pixel model fused with voxel binning (gfx950).  BASELINE config 3.
+//
+// Replaces data/v2v_core_v2e.py: video_to_voxel (:556-581) around EventEmulator.generate_events (:401-553) with
+// lin_log (:108-137, effective formula float32(log(x/255+0.01)) -> 256-entry table, golden G1),
+// rescale_intensity_frame (:184-190), low_pass_filter (:139-182), subtract_leak_current (:192-211),
+// compute_event_map (:42-62), generate_shot_noise (:65-105), _init / change_pos_neg_thres (:317-349, :392-399).
+//
+// Same mapping as the ESIM kernel: one work-item owns VEC adjacent pixels of one clip and streams the frames;
+// per-pixel state (low-passed log intensity, memorised base, ON/OFF thresholds, leak rate) lives in registers.
+// NumPy's dtype promotions are part of the reference's semantics and are reproduced explicitly:
+//   lp32   = (cutoff_hz <= 0) || float32 input     low-passed frame is float32, else float64
+//   base32 = lp32 && leak_rate_hz == 0              memorised frame is float32 (in-place += rounds to float32)
+// Shot noise needs the per-frame mean of (intensity factor x threshold factor) over the whole clip frame:
+// a pre-pass kernel accumulates it in 2^32 fixed point (order-independent, so the CPU oracle and any launch
+// geometry agree bit for bit); native Poisson sampling is inversion from one Philox uniform with an exp(-lambda)
+// built from IEEE-exact operations.  Replay mode takes NumPy-drawn fields instead (bit-exact reference replay).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "v2v_esim.hpp"
+
+namespace v2v {
+
+enum { kV2ePnRelated = 0, kV2eSpatialIndependent = 1, kV2eSpatialTemporalIndependent = 2 };
+enum : uint32_t { kV2eFThresA = 0, kV2eFThresB = 1, kV2eFNoiseRate = 2, kV2eFFrame0 = 16, kV2eFStride = 8 };
+
+struct V2eParams {            // mirrors v2v_v2e_params (include/v2v_hip.h)
+    double fps;
+    int threshold_model;
+    double thres_mean_mean, thres_mean_std, thres_diff_mean, thres_diff_std;
+    double cutoff_hz, leak_rate_hz, refractory_period_s, shot_noise_rate_hz, leak_jitter_fraction, noise_rate_cov_decades;
+    int uint8_wrap;
+};
+
+struct V2eArgs {
+    const void *frames;
+    int64_t clip_stride, frame_stride;
+    void *out;
+    unsigned long long *counts;
+    long long *shot_sums;                    // [B,K,2] fixed-point sums (native shot noise) or nullptr
+    const double *r_pos_thres, *r_neg_thres; // replay
+    int64_t r_thres_frame_stride;
+    const float *r_noise_rate;
+    const double *r_leak_randn;
+    const long long *r_shot_pos, *r_shot_neg;
+    uint64_t seed, clip_id0;
+    int32_t HW, K, Tb, fpb, blocks_per_clip;
+    V2eParams P;
+};
+
+__device__ __forceinline__ double exp_neg_det(double lam)
+{
+    const double x = -lam;
+    if (x < -745.0) return 0.0;
+    const double k = __builtin_rint(x * 1.4426950408889634);
+    double r = __builtin_fma(-k, 0.693147180369123816490e+00, x);
+    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = __builtin_fma(p, r, 1.0 / 479001600.0);
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const int ki = (int)k;
+    if (ki < -1022) return 0.0;
+    return p * __longlong_as_double((long long)(1023 + ki) << 52);
+}
+
+__device__ __forceinline__ double poisson_inv(double lam, double u)
+{
+    if (!(lam > 0.0)) return 0.0;
+    double p = exp_neg_det(lam), s = p, x = 0.0;
+    while (u > s && x < 1000.0) { x += 1.0; p = p * lam / x; s += p; }
+    return x;
+}
+
+__device__ __forceinline__ float expf_det(float x)
+{
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    const float k = __builtin_rintf(x * 1.44269502f);
+    float r = __builtin_fmaf(-k, 0.693359375f, x);
+    r = __builtin_fmaf(-k, -2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    p = __builtin_fmaf(p, r2, r) + 1.0f;
+    return p * __uint_as_float((uint32_t)(127 + (int)k) << 23);
+}
+
+// ON/OFF thresholds of VEC pixels from two Gaussian fields (normal(loc,scale) = loc + scale*g), clipped at 0.01
+template <int VEC>
+__device__ __forceinline__ void v2e_native_thres(const V2eParams &P, uint64_t seed, uint32_t clip, uint32_t fa, uint32_t p0,
+                                                 double (&pt)[VEC], double (&nt)[VEC])
+{
+    float ga[VEC], gb[VEC];
+    field_gauss32<VEC>(seed, clip, fa, kStreamV2e, p0, ga);
+    field_gauss32<VEC>(seed, clip, fa + 1u, kStreamV2e, p0, gb);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        double a, b;
+        if (P.threshold_model == kV2ePnRelated) {
+            const double sa = P.thres_mean_std * (double)ga[j], sb = P.thres_diff_std * (double)gb[j];
+            const double mean = P.thres_mean_mean + sa, diff = P.thres_diff_mean + sb;
+            a = mean + (diff / 2);
+            b = mean - (diff / 2);
+        } else {
+            const double sa = P.thres_mean_std * (double)ga[j], sb = P.thres_mean_std * (double)gb[j];
+            a = P.thres_mean_mean + sa;
+            b = P.thres_mean_mean + sb;
+        }
+        pt[j] = a < 0.01 ? 0.01 : a;
+        nt[j] = b < 0.01 ? 0.01 : b;
+    }
+}
+
+template <int IN, int VEC>
+__device__ __forceinline__ void v2e_pixels(const Raw<IN, VEC> &r, float (&x)[VEC])
+{
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        if constexpr (IN == kInU8) { if constexpr (VEC == 4) x[j] = (float)((r.v >> (8 * j)) & 0xFFu); else x[j] = (float)r.v; }
+        else x[j] = raw_f32<VEC>(r, j);
+    }
+}
+
+// intensity factor 1 - 0.75*inten01 in the dtype NumPy gives it (float64 for uint8 input, float32 for float32 input)
+template <int IN>
+__device__ __forceinline__ void v2e_inten(float x, int wrap, double &i01_64, float &i01_32, double &fac)
+{
+    if constexpr (IN == kInU8) {
+        const uint32_t xi = (uint32_t)x;
+        i01_64 = wrap ? (double)((xi + 20u) & 0xFFu) / 275. : ((double)xi + 20.0) / 275.;
+        i01_32 = 0.0f;
+        const double t = 0.75 * i01_64;
+        fac = 1 - t;
+    } else {
+        i01_32 = (x + 20.0f) / 275.0f;
+        i01_64 = 0.0;
+        const float t = 0.75f * i01_32;
+        fac = (double)(1.0f - t);
+    }
+}
+
+__device__ __forceinline__ float v2e_linlog(float x, const float *lut)
+{
+    const uint32_t a = __float_as_uint(x + 8388608.0f) & 255u;
+    if (__builtin_expect((float)a == x, 1)) return lut[a];
+    return (float)log((double)x / 255 + 0.01);          // non-integer content: within 1 ulp of NumPy's float64 log
+}
+
+// ---- pre-pass: per (clip, frame) fixed-point sums of the shot-noise factors (native mode only)
+template <int IN, int VEC>
+__global__ void __launch_bounds__(kBlock) v2e_shot_sum_kernel(const V2eArgs a)
+{
+    const int clip = blockIdx.x / a.blocks_per_clip;
+    const int blk = blockIdx.x - clip * a.blocks_per_clip;
+    const uint32_t p0 = (uint32_t)(blk * kBlock + threadIdx.x) * VEC;
+    const bool active = p0 < (uint32_t)a.HW;
+    const V2eParams &P = a.P;
+    const uint32_t clip_id = (uint32_t)(a.clip_id0 + (uint64_t)clip);
+    const double pos_nominal = P.thres_mean_mean + P.thres_diff_mean / 2, neg_nominal = P.thres_mean_mean - P.thres_diff_mean / 2;
+    const bool temporal = P.threshold_model == kV2eSpatialTemporalIndependent;
+    double pt[VEC], nt[VEC];
+    if (active) v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFThresA, p0, pt, nt);
+    const int64_t in_base = (int64_t)clip * a.clip_stride + p0;
+    for (int k = 0; k < a.K; ++k) {
+        long long sp = 0, sn = 0;
+        if (active) {
+            const int i = k + 1;
+            if (temporal) v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i, p0, pt, nt);
+            const Raw<IN, VEC> raw = load_raw<IN, VEC>(a.frames, in_base + (int64_t)i * a.frame_stride);
+            float x[VEC];
+            v2e_pixels<IN, VEC>(raw, x);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                double i64, fac; float i32;
+                v2e_inten<IN>(x[j], P.uint8_wrap, i64, i32, fac);
+                const double fp = fac * (pos_nominal / pt[j]), fn = fac * (neg_nominal / nt[j]);
+                sp += __double2ll_rn(fp * 4294967296.0);
+                sn += __double2ll_rn(fn * 4294967296.0);
+            }
+        }
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) { sp += __shfl_down(sp, s, 64); sn += __shfl_down(sn, s, 64); }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&a.shot_sums[((int64_t)clip * a.K + k) * 2]), (unsigned long long)sp);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&a.shot_sums[((int64_t)clip * a.K + k) * 2 + 1]), (unsigned long long)sn);
+        }
+    }
+}
+
+template <int IN, int VEC, int BIN, int RNG, bool OUT64>
+__global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
+{
+    using acc_t = typename std::conditional<OUT64, double, float>::type;
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    float *s_lut = reinterpret_cast<float *>(s_raw);
+    acc_t *s_wlo = reinterpret_cast<acc_t *>(s_raw + 256 * sizeof(float));
+    acc_t *s_whi = s_wlo + a.K;
+    int *s_seg = reinterpret_cast<int *>(s_whi + a.K);
+    s_lut[threadIdx.x] = g_lut_v2e32[threadIdx.x];
+    if constexpr (BIN == kBinBilinear) {
+        for (int k = threadIdx.x; k < a.K; k += kBlock) {
+            const double t_norm = ((double)k - 0.0) / ((double)(a.K - 1) - 0.0) * (double)(a.Tb - 1);
+            int b0 = (int)floor(t_norm);
+            if (b0 > a.Tb - 2) b0 = a.Tb - 2;
+            if (b0 < 0) b0 = 0;
+            const double wl = 1.0 - fabs(t_norm - (double)b0), wh = 1.0 - fabs(t_norm - (double)(b0 + 1));
+            s_wlo[k] = (acc_t)(wl > 0.0 ? wl : 0.0);
+            s_whi[k] = (acc_t)(wh > 0.0 ? wh : 0.0);
+            s_seg[k] = b0;
+        }
+    }
+    __syncthreads();
+
+    const int clip = blockIdx.x / a.blocks_per_clip;
+    const int blk = blockIdx.x - clip * a.blocks_per_clip;
+    const uint32_t p0 = (uint32_t)(blk * kBlock + threadIdx.x) * VEC;
+    if (p0 >= (uint32_t)a.HW) return;
+    const V2eParams &P = a.P;
+    const uint32_t clip_id = (uint32_t)(a.clip_id0 + (uint64_t)clip);
+    const bool lp32 = (P.cutoff_hz <= 0) || (IN == kInF32);
+    const bool base32 = lp32 && !(P.leak_rate_hz > 0);
+    const bool temporal = P.threshold_model == kV2eSpatialTemporalIndependent;
+    const bool shot = P.shot_noise_rate_hz > 0;
+    const double pos_nominal = P.thres_mean_mean + P.thres_diff_mean / 2, neg_nominal = P.thres_mean_mean - P.thres_diff_mean / 2;
+    const double tau = P.cutoff_hz > 0 ? 1 / (3.141592653589793 * 2 * P.cutoff_hz) : 0.0;
+    const int64_t in_base = (int64_t)clip * a.clip_stride + p0;
+    const int64_t pix_base = (int64_t)clip * a.HW + p0;
+
+    // ---- frame 0: lp = base = lin_log(frame 0); thresholds; log-normal leak-rate factor (_init :317-349)
+    double lp64[VEC], base64[VEC], pt[VEC], nt[VEC];
+    float lp_f[VEC], base_f[VEC], nrate[VEC];
+    {
+        const Raw<IN, VEC> r0 = load_raw<IN, VEC>(a.frames, in_base);
+        float x[VEC];
+        v2e_pixels<IN, VEC>(r0, x);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { lp_f[j] = base_f[j] = v2e_linlog(x[j], s_lut); lp64[j] = base64[j] = (double)lp_f[j]; }
+    }
+    if constexpr (RNG == kRngPhilox) {
+        v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFThresA, p0, pt, nt);
+        float g[VEC];
+        field_gauss32<VEC>(a.seed, clip_id, kV2eFNoiseRate, kStreamV2e, p0, g);
+        const float c = (float)(2.302585092994046 * P.noise_rate_cov_decades);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) nrate[j] = expf_det(c * g[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            // static thresholds [B,HW]; per-frame ones ([B,K,HW]) are fetched inside the time loop
+            pt[j] = a.r_thres_frame_stride ? 1.0 : a.r_pos_thres[pix_base + j];
+            nt[j] = a.r_thres_frame_stride ? 1.0 : a.r_neg_thres[pix_base + j];
+            nrate[j] = a.r_noise_rate[pix_base + j];
+        }
+    }
+
+    acc_t acc_lo[VEC], acc_hi[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { acc_lo[j] = 0; acc_hi[j] = 0; }
+    int cur_seg = 0, sub = 0, plane = 0;
+    const int64_t planes_per_clip = (BIN == kBinSum) ? (a.K / a.fpb) : a.Tb;
+    const int64_t out_base = (int64_t)clip * planes_per_clip * a.HW + p0;
+    uint32_t n_on = 0, n_off = 0;
+    const bool want_counts = a.counts != nullptr;
+
+    Raw<IN, VEC> nxt = load_raw<IN, VEC>(a.frames, in_base + a.frame_stride);
+    for (int k = 0; k < a.K; ++k) {
+        const int i = k + 1;
+        const Raw<IN, VEC> raw = nxt;
+        nxt = load_raw<IN, VEC>(a.frames, in_base + (int64_t)(i + 1 <= a.K ? i + 1 : a.K) * a.frame_stride);
+        if constexpr (BIN == kBinBilinear) {
+            const int seg = __builtin_amdgcn_readfirstlane(s_seg[k]);
+            while (cur_seg < seg) {
+                store_vec<VEC, acc_t>(a.out, out_base + (int64_t)cur_seg * a.HW, acc_lo);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) { acc_lo[j] = acc_hi[j]; acc_hi[j] = 0; }
+                ++cur_seg;
+            }
+        }
+        const double dt = (double)i / P.fps - (double)(i - 1) / P.fps;                  // t_frame - t_previous (:440)
+        if (temporal) {                                                                 // thresholds redrawn per frame (:417-421)
+            if constexpr (RNG == kRngPhilox) v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i, p0, pt, nt);
+            else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const int64_t o = ((int64_t)clip * a.K + k) * a.HW + p0 + j;
+                    pt[j] = a.r_pos_thres[o];
+                    nt[j] = a.r_neg_thres[o];
+                }
+            }
+        }
+        float gleak[VEC];
+        double u_sp[VEC], u_sn[VEC];
+        double mean_p = 1.0, mean_n = 1.0;
+        if constexpr (RNG == kRngPhilox) {
+            if (P.leak_rate_hz > 0) field_gauss32<VEC>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i + 2u, kStreamV2e, p0, gleak);
+            if (shot) {
+                field_uniform53<VEC>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i + 3u, kStreamV2e, p0, u_sp);
+                field_uniform53<VEC>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i + 4u, kStreamV2e, p0, u_sn);
+                mean_p = ((double)a.shot_sums[((int64_t)clip * a.K + k) * 2] / 4294967296.0) / (double)a.HW;
+                mean_n = ((double)a.shot_sums[((int64_t)clip * a.K + k) * 2 + 1] / 4294967296.0) / (double)a.HW;
+            }
+        }
+        float x[VEC];
+        v2e_pixels<IN, VEC>(raw, x);
+        const acc_t wl = BIN == kBinBilinear ? s_wlo[k] : (acc_t)1, wh = BIN == kBinBilinear ? s_whi[k] : (acc_t)0;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float log_new = v2e_linlog(x[j], s_lut);                              // lin_log (:445)
+            double i01_64, fac; float i01_32;
+            v2e_inten<IN>(x[j], P.uint8_wrap, i01_64, i01_32, fac);
+            if (P.cutoff_hz > 0) {                                                      // low_pass_filter (:139-182)
+                if constexpr (IN == kInF32) {
+                    float eps = i01_32 * (float)(dt / tau);
+                    eps = eps > 1.0f ? 1.0f : eps;
+                    const float ta = (1.0f - eps) * lp_f[j], tb = eps * log_new;
+                    lp_f[j] = ta + tb;
+                } else {
+                    double eps = i01_64 * (dt / tau);
+                    eps = eps > 1.0 ? 1.0 : eps;
+                    const double ta = (1 - eps) * lp64[j], tb = eps * (double)log_new;
+                    lp64[j] = ta + tb;
+                }
+            } else {
+                lp_f[j] = log_new;
+            }
+            if (P.leak_rate_hz > 0) {                                                   // subtract_leak_current (:192-211)
+                double g;
+                if constexpr (RNG == kRngPhilox) g = (double)gleak[j];
+                else g = a.r_leak_randn[((int64_t)clip * a.K + k) * a.HW + p0 + j];
+                const float a32 = (float)P.leak_rate_hz * nrate[j];
+                const double jit = P.leak_jitter_fraction * g;
+                const double curr = (double)a32 * (1 - jit);
+                const double dl = dt * curr * pt[j];
+                base64[j] = base64[j] - dl;
+            }
+            double diff;
+            if (lp32 && base32) { const float d = lp_f[j] - base_f[j]; diff = (double)d; }
+            else diff = (lp32 ? (double)lp_f[j] : lp64[j]) - base64[j];
+            // compute_event_map (:42-62): floor_divide(clip(+-diff, 0), thres); exact floor via reciprocal + fma residual
+            const double nd = -diff;
+            const double pos_frame = diff > 0 ? diff : (diff == diff ? 0.0 : diff);
+            const double neg_frame = nd > 0 ? nd : (nd == nd ? 0.0 : nd);
+            const double inv_p = (1.0 / pt[j]) * 0x1.ffffffffffffcp-1, inv_n = (1.0 / nt[j]) * 0x1.ffffffffffffcp-1;
+            double fpos = floor(pos_frame * inv_p), fneg = floor(neg_frame * inv_n);
+            { const double r = __builtin_fma(-fpos, pt[j], pos_frame); if (r >= pt[j]) fpos += 1.0; else if (!(r < pt[j])) fpos = pos_frame / pt[j]; }
+            { const double r = __builtin_fma(-fneg, nt[j], neg_frame); if (r >= nt[j]) fneg += 1.0; else if (!(r < nt[j])) fneg = neg_frame / nt[j]; }
+            if (shot) {                                                                 // generate_shot_noise (:65-105)
+                double sp, sn;
+                if constexpr (RNG == kRngPhilox) {
+                    const double f = (P.shot_noise_rate_hz / 2) * dt;
+                    const double lam_p = fac * (pos_nominal / pt[j]) / mean_p * f;
+                    const double lam_n = fac * (neg_nominal / nt[j]) / mean_n * f;
+                    sp = poisson_inv(lam_p, u_sp[j]);
+                    sn = poisson_inv(lam_n, u_sn[j]);
+                } else {
+                    const int64_t o = ((int64_t)clip * a.K + k) * a.HW + p0 + j;
+                    sp = (double)a.r_shot_pos[o];
+                    sn = (double)a.r_shot_neg[o];
+                }
+                fpos = fpos + sp;
+                fneg = fneg + sn;
+            }
+            if (P.refractory_period_s > 0) {                                            // intended semantics of :534-537
+                const double cap = (double)(int)(dt / P.refractory_period_s);
+                fpos = fpos > cap ? cap : fpos;
+                fneg = fneg > cap ? cap : fneg;
+            }
+            if (base32) {                                                               // in-place += on a float32 array (:547-548)
+                const double up = fpos * pt[j];
+                base_f[j] = (float)((double)base_f[j] + up);
+                const double dn = fneg * nt[j];
+                base_f[j] = (float)((double)base_f[j] - dn);
+            } else {
+                const double up = fpos * pt[j];
+                base64[j] = base64[j] + up;
+                const double dn = fneg * nt[j];
+                base64[j] = base64[j] - dn;
+            }
+            const double vox = fpos - fneg;
+            if (want_counts) { n_on += (uint32_t)fpos; n_off += (uint32_t)fneg; }
+            if constexpr (OUT64) {
+                if constexpr (BIN == kBinBilinear) {
+                    const double cl = vox * wl, ch = vox * wh;
+                    acc_lo[j] = acc_lo[j] + cl;
+                    acc_hi[j] = acc_hi[j] + ch;
+                } else {
+                    acc_lo[j] = acc_lo[j] + vox;
+                }
+            } else {
+                const float vf = (float)vox;
+                if constexpr (BIN == kBinBilinear) {
+                    acc_lo[j] = __builtin_fmaf(vf, wl, acc_lo[j]);
+                    acc_hi[j] = __builtin_fmaf(vf, wh, acc_hi[j]);
+                } else {
+                    acc_lo[j] = acc_lo[j] + vf;
+                }
+            }
+        }
+        if constexpr (BIN == kBinSum) {
+            if (++sub == a.fpb) {
+                store_vec<VEC, acc_t>(a.out, out_base + (int64_t)plane * a.HW, acc_lo);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc_lo[j] = 0;
+                sub = 0;
+                ++plane;
+            }
+        }
+    }
+    if constexpr (BIN == kBinBilinear) {
+        store_vec<VEC, acc_t>(a.out, out_base + (int64_t)cur_seg * a.HW, acc_lo);
+        if (cur_seg + 1 < a.Tb) store_vec<VEC, acc_t>(a.out, out_base + (int64_t)(cur_seg + 1) * a.HW, acc_hi);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc_lo[j] = 0;
+        for (int b = cur_seg + 2; b < a.Tb; ++b) store_vec<VEC, acc_t>(a.out, out_base + (int64_t)b * a.HW, acc_lo);
+    }
+    if (want_counts) {
+        unsigned long long on = n_on, off = n_off;
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) {
+            const unsigned long long o1 = __shfl_down(on, s, 64), o2 = __shfl_down(off, s, 64);
+            const int src = (int)(threadIdx.x & 63) + s;
+            const bool src_active = src < 64 && (uint32_t)((blk * kBlock + (threadIdx.x & ~63) + src)) * VEC < (uint32_t)a.HW;
+            if (src_active) { on += o1; off += o2; }
+        }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&a.counts[2 * clip], on); atomicAdd(&a.counts[2 * clip + 1], off); }
+    }
+}
+
+}  // namespace v2v
