@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the fused ESIM sim+voxel hot path (BASELINE.json metric:
+"""bench.py -- headline benchmark of the fused sim+voxel hot path (BASELINE.json metric:
 "voxel grids/sec (B x Tbins x H x W) at 1/2/4/8 GPU; achieved HBM GB/s vs peak").
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
@@ -9,6 +9,8 @@ A "step" is one pass of the hot path (ONE launch of v2v_esim_voxel_hip) over one
 that is already resident in HBM.  Workload at N=1: BASELINE configs[1] -- 256 clips of 32x256x256 float32
 (integer-valued), C+=C-=0.2, 5 temporal-bilinear voxel bins.  With N>1 GPUs every rank gets its own 256
 clips (global clip ids rank*256..), no data-path collective: weak scaling.  Rank 0 prints ONE JSON line.
+Other --workload values (the remaining BASELINE configs and variants) are parity-test cases and secondary
+measurements, not the headline.
 """
 import argparse
 import json
@@ -22,49 +24,67 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (measured copy ceiling ~6290)
 
+V2E_NOISY = [24, "pn_related", 0.5, 0.1, 0.0, 0.1, 30, 0.1, 0, 5.0, 0.1, 0.1]     # SURVEY §8d S3 (v2v_core_v2e.py:365-375,600)
 WORKLOADS = {
-    # name: (B per GPU, N frames, H, W, torch dtype name, bin mode, Tb, fpb, params)
-    "cfg2_esim_f32_256x32x256x256_bilinear5": (256, 32, 256, 256, "float32", "bilinear", 5, 1, [0.2, 0.2, 0.0, 0.0, 0.0]),
-    "cfg2_noise_on": (256, 32, 256, 256, "float32", "bilinear", 5, 1, [0.2, 0.2, 0.05, 5e-4, 1.0]),
-    "cfg2_u8": (256, 32, 256, 256, "uint8", "bilinear", 5, 1, [0.2, 0.2, 0.0, 0.0, 0.0]),
-    "train_u8_12x201x128x128_sum5": (12, 201, 128, 128, "uint8", "sum", 5, 1, [0.2, 0.2, 0.05, 5e-4, 1.0]),
-    "cfg1_plumbing_u8_1x8x128x128": (1, 8, 128, 128, "uint8", "sum", 7, 1, [0.2, 0.2, 0.0, 0.0, 0.0]),
+    "cfg2_esim_f32_256x32x256x256_bilinear5": dict(model="esim", b=256, n=32, h=256, w=256, dtype="float32", bin="bilinear", tb=5, fpb=1,
+                                                   params=[0.2, 0.2, 0.0, 0.0, 0.0]),
+    "cfg2_noise_on": dict(model="esim", b=256, n=32, h=256, w=256, dtype="float32", bin="bilinear", tb=5, fpb=1,
+                          params=[0.2, 0.2, 0.05, 5e-4, 1.0]),
+    "cfg2_u8": dict(model="esim", b=256, n=32, h=256, w=256, dtype="uint8", bin="bilinear", tb=5, fpb=1, params=[0.2, 0.2, 0.0, 0.0, 0.0]),
+    "cfg2_asym": dict(model="esim", b=256, n=32, h=256, w=256, dtype="float32", bin="bilinear", tb=5, fpb=1,
+                      params=[0.2, 0.3, 0.0, 0.0, 0.0]),
+    "cfg3_v2e_f32_256x32x256x256_bilinear5": dict(model="v2e", b=256, n=32, h=256, w=256, dtype="float32", bin="bilinear", tb=5, fpb=1,
+                                                  params=V2E_NOISY),
+    "cfg3_v2e_u8": dict(model="v2e", b=256, n=32, h=256, w=256, dtype="uint8", bin="bilinear", tb=5, fpb=1, params=V2E_NOISY),
+    "cfg4_u8_256x41x256x256_sum5": dict(model="esim", b=256, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1,
+                                        params=[0.2, 0.3, 0.05, 5e-4, 1.0]),
+    "train_u8_12x201x128x128_sum5": dict(model="esim", b=12, n=201, h=128, w=128, dtype="uint8", bin="sum", tb=5, fpb=1,
+                                         params=[0.2, 0.2, 0.05, 5e-4, 1.0]),
+    "cfg1_plumbing_u8_1x8x128x128": dict(model="esim", b=1, n=8, h=128, w=128, dtype="uint8", bin="sum", tb=7, fpb=1,
+                                         params=[0.2, 0.2, 0.0, 0.0, 0.0]),
 }
 DEFAULT_WORKLOAD = "cfg2_esim_f32_256x32x256x256_bilinear5"
 
 
-def cpu_baseline(frames_host, params, bin_mode, tb, fpb, budget_s=12.0):
-    """The oracle (a PORT of the reference's NumPy op sequence, data/v2v_core_esim.py:26-69 + the binning)
-    timed on this box's host cores on a bounded sample of the same clips.  Reported, never the target."""
+def cpu_baseline(frames_host, wl, budget_s=12.0):
+    """The oracle (a PORT of the reference's NumPy op sequence, data/v2v_core_esim.py:26-69 or data/v2v_core_v2e.py,
+    + the binning) timed on this box's host cores on a bounded sample of the same clips.  Reported, never the target."""
     import numpy as np
     from oracle import v2v_oracle as O
     n_done, t0 = 0, time.perf_counter()
     np.random.seed(0)
     for clip in frames_host:
-        counts = O.esim_video_to_voxel(clip, *params, put_noise_external=False, rng=O.GlobalNumpyRNG, use_lut=False)
-        _ = O.bin_bilinear(counts, tb) if bin_mode == "bilinear" else O.bin_sum(counts, tb, fpb)
+        if wl["model"] == "esim":
+            counts = O.esim_video_to_voxel(clip, *wl["params"], put_noise_external=False, rng=O.GlobalNumpyRNG, use_lut=False)
+        else:
+            counts = O.v2e_video_to_voxel(clip, *wl["params"], seed=None)
+        _ = O.bin_bilinear(counts, wl["tb"]) if wl["bin"] == "bilinear" else O.bin_sum(counts, wl["tb"], wl["fpb"])
         n_done += 1
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    grids = n_done * (1 if bin_mode == "bilinear" else (clip.shape[0] - 1) // (tb * fpb))
+    grids = n_done * (1 if wl["bin"] == "bilinear" else (frames_host.shape[1] - 1) // (wl["tb"] * wl["fpb"]))
     return {"value": grids / dt, "unit": "voxel grids/s", "cores": 1, "kind": "port",
             "sample": f"{n_done} of the batch's clips ({'x'.join(map(str, frames_host.shape[1:]))} {frames_host.dtype}), "
-                      f"oracle/v2v_oracle.py NumPy port (pow/log per pixel, float64 state), single thread, {dt:.1f} s"}
+                      f"oracle/v2v_oracle.py NumPy port of the reference's op sequence (float64 state), single thread, {dt:.1f} s"}
 
 
-def cpu_baseline_c(frames_host, params, bin_mode, tb, fpb):
-    """Secondary: the scalar C twin (table-driven) over all host cores with OpenMP."""
+def cpu_baseline_c(frames_host, wl):
+    """Secondary: the scalar C twin (table-driven) over all host cores with OpenMP over clips."""
     from oracle import clib, v2v_oracle as O
     cores = os.cpu_count() or 1
+    bm = clib.BIN_BILINEAR if wl["bin"] == "bilinear" else clib.BIN_SUM
     t0 = time.perf_counter()
-    clib.esim_voxel(frames_host, params, O.load_luts(), rng_mode=clib.RNG_PHILOX, seed=1,
-                    bin_mode=clib.BIN_BILINEAR if bin_mode == "bilinear" else clib.BIN_SUM, num_bins=tb,
-                    frames_per_bin=fpb, threads=cores)
+    if wl["model"] == "esim":
+        clib.esim_voxel(frames_host, wl["params"], O.load_luts(), rng_mode=clib.RNG_PHILOX, seed=1, bin_mode=bm,
+                        num_bins=wl["tb"], frames_per_bin=wl["fpb"], threads=cores)
+    else:
+        clib.v2e_voxel(frames_host, clib.v2e_params(*wl["params"]), O.load_luts(), seed=1, bin_mode=bm, num_bins=wl["tb"],
+                       frames_per_bin=wl["fpb"])
     dt = time.perf_counter() - t0
-    grids = frames_host.shape[0] * (1 if bin_mode == "bilinear" else (frames_host.shape[1] - 1) // (tb * fpb))
+    grids = frames_host.shape[0] * (1 if wl["bin"] == "bilinear" else (frames_host.shape[1] - 1) // (wl["tb"] * wl["fpb"]))
     return {"value": grids / dt, "unit": "voxel grids/s", "cores": cores, "kind": "port",
-            "sample": f"{frames_host.shape[0]} clips, oracle/v2v_oracle.c scalar C port (LUT), OpenMP over clips, {dt:.1f} s"}
+            "sample": f"{frames_host.shape[0]} clips, oracle/v2v_oracle.c scalar C port (table-driven), OpenMP over clips, {dt:.1f} s"}
 
 
 def main():
@@ -79,47 +99,48 @@ def main():
     args = ap.parse_args()
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from v2v_amd import esim, sharding
+    rank, local_rank, world = sharding.env_rank_world()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)     # RCCL; used for the barrier + max-over-ranks only
+    dist = sharding.init_process_group("nccl", dev)        # RCCL; used for the barrier + max-over-ranks only
 
-    from v2v_amd import esim
-    b, n, h, w, dt_name, bin_mode, tb, fpb, params = WORKLOADS[args.workload]
-    if args.batch:
-        b = args.batch
-    tdtype = getattr(torch, dt_name)
-    clip_id0 = rank * b                                            # batch shard: global clip ids, no exchange
+    wl = WORKLOADS[args.workload]
+    b = args.batch or wl["b"]
+    n, h, w, bin_mode, tb, fpb, params = wl["n"], wl["h"], wl["w"], wl["bin"], wl["tb"], wl["fpb"], wl["params"]
+    tdtype = getattr(torch, wl["dtype"])
+    shard = sharding.weak_shard(b, rank, world)            # batch shard: global clip ids, no exchange
+    clip_id0 = shard.lo
     frames = esim.synth_clips(b, n, h, w, dtype=tdtype, seed=20240001, clip_id0=clip_id0, device=dev)
     shape = (b, (n - 1) // (tb * fpb), tb, h, w) if bin_mode == "sum" else (b, tb, h, w)
     out = torch.empty(shape, dtype=torch.float32, device=dev)
-    ptensor = torch.tensor(params, dtype=torch.float64, device=dev)
     alg_bytes = esim.algorithmic_bytes(tdtype, b, n, h, w, bin_mode, tb, fpb)
     grids_per_step = b * (shape[1] if bin_mode == "sum" else 1)
 
-    def step():
-        esim.esim_voxel_batch(frames, ptensor, bin_mode=bin_mode, num_bins=tb, frames_per_bin=fpb, rng_mode="philox",
-                              seed=20240001, clip_id0=clip_id0, out=out, validate=False,
-                              no_noise=(params[2] == 0 and params[3] <= 0))
+    if wl["model"] == "esim":
+        ptensor = torch.tensor(params, dtype=torch.float64, device=dev)
+        kernel_name = "esim_voxel_kernel"
 
-    def barrier():
-        if dist is not None:
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize()
+        def step():
+            esim.esim_voxel_batch(frames, ptensor, bin_mode=bin_mode, num_bins=tb, frames_per_bin=fpb, rng_mode="philox",
+                                  seed=20240001, clip_id0=clip_id0, out=out, validate=False,
+                                  no_noise=(params[2] == 0 and params[3] <= 0))
+    else:
+        from v2v_amd import v2e
+        vparams = v2e.make_params(*params)
+        kernel_name = "v2e_voxel_kernel (+ v2e_shot_sum_kernel pre-pass)"
+
+        def step():
+            v2e.v2e_voxel_batch(frames, vparams, bin_mode=bin_mode, num_bins=tb, frames_per_bin=fpb, rng_mode="philox",
+                                seed=20240001, clip_id0=clip_id0, out=out)
 
     for _ in range(args.warmup):
         step()
-    barrier()
+    sharding.barrier(dist, local_rank)
     # per-launch HIP events on the stream the kernel is launched on (torch's current stream)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
@@ -128,34 +149,32 @@ def main():
         step()
         e.record()
     torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    sharding.barrier(dist, local_rank)
+    elapsed = sharding.max_over_ranks(dist, time.perf_counter() - t0, dev)
     kern_ms = sorted(s.elapsed_time(e) for s, e in ev)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
-    # light parity guard outside the timed region: clip 0 of rank 0 against the C oracle
-    parity = None
-    cpu = None
-    cpu_c = None
+    # light parity guard outside the timed region (clip 0 of rank 0 against the C oracle) + the CPU baseline
+    parity = cpu = cpu_c = None
     if rank == 0:
         try:
             import numpy as np
             from oracle import clib, v2v_oracle as O
             clib.build()
             host = frames[:1].cpu().numpy()
-            want, _ = clib.esim_voxel(host, params, O.load_luts(), rng_mode=clib.RNG_PHILOX, seed=20240001, clip_id0=clip_id0,
-                                      bin_mode=clib.BIN_BILINEAR if bin_mode == "bilinear" else clib.BIN_SUM, num_bins=tb,
-                                      frames_per_bin=fpb)
+            bm = clib.BIN_BILINEAR if bin_mode == "bilinear" else clib.BIN_SUM
+            if wl["model"] == "esim":
+                want, _ = clib.esim_voxel(host, params, O.load_luts(), rng_mode=clib.RNG_PHILOX, seed=20240001,
+                                          clip_id0=clip_id0, bin_mode=bm, num_bins=tb, frames_per_bin=fpb)
+            else:
+                want, _ = clib.v2e_voxel(host, clib.v2e_params(*params), O.load_luts(), seed=20240001, clip_id0=clip_id0,
+                                         bin_mode=bm, num_bins=tb, frames_per_bin=fpb)
             got = out[:1].cpu().numpy().astype(np.float64)
             parity = "ok" if np.allclose(got, want, rtol=1e-5, atol=1e-5) else "MISMATCH"
             if world == 1 and not args.no_cpu_baseline:
                 sample = frames[: min(b, 256)].cpu().numpy()
-                cpu = cpu_baseline(sample, params, bin_mode, tb, fpb, budget_s=args.cpu_budget)
-                cpu_c = cpu_baseline_c(sample, params, bin_mode, tb, fpb)
+                cpu = cpu_baseline(sample, wl, budget_s=args.cpu_budget)
+                cpu_c = cpu_baseline_c(sample, wl)
         except Exception as exc:  # the oracle is a checker; never let it take the measurement down
             parity = f"unchecked ({type(exc).__name__}: {exc})"
 
@@ -173,14 +192,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": args.workload, "clips_per_gpu": b, "frames": n, "height": h, "width": w,
-                       "input_dtype": dt_name, "bin_mode": bin_mode, "num_bins": tb, "frames_per_bin": fpb,
-                       "pos_thres": params[0], "neg_thres": params[1], "base_noise_std": params[2],
-                       "hot_pixel_fraction": params[3], "hot_pixel_std": params[4], "rng": "philox4x32-10 on device",
+            "config": {"workload": args.workload, "model": wl["model"], "clips_per_gpu": b, "frames": n, "height": h, "width": w,
+                       "input_dtype": wl["dtype"], "bin_mode": bin_mode, "num_bins": tb, "frames_per_bin": fpb,
+                       "sim_params": params, "rng": "philox4x32-10 on device",
                        "sharding": f"batch over {world} GPU(s), no collective", "grid": [tb, h, w]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "esim_voxel_kernel", "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel": kernel_name, "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_ms_avg": kern_avg_ms, "kernel_ms_p10": kern_ms[len(kern_ms) // 10],
                          "kernel_ms_p50": kern_ms[len(kern_ms) // 2], "kernel_ms_p90": kern_ms[(len(kern_ms) * 9) // 10]},
             "cpu_baseline": cpu,

@@ -68,6 +68,15 @@ for name in ("SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "S
     v = counter("pmc_sq", name)
     if v:
         sq[name] = sum(v) / len(v)
+for name in ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE",
+             "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY"):
+    v = counter("pmc_sq2", name)
+    if v:
+        sq[name] = sum(v) / len(v)
+for name in ("GRBM_GUI_ACTIVE", "GRBM_COUNT"):
+    v = counter("pmc_grbm", name)
+    if v:
+        sq[name] = sum(v) / len(v)
 summary["sq_counters_per_launch"] = sq
 for tag in ("stats", "pmc_fetch", "pmc_write", "pmc_sq"):
     p = os.path.join(out_dir, f"bench_under_{tag}.json")

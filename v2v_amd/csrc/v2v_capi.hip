@@ -44,6 +44,16 @@ hipError_t launch_out(bool out64, const v2v::EsimArgs &a, dim3 grid, size_t lds,
 template <int IN, int VEC, int BIN>
 hipError_t launch_rng(int rng, bool noise, bool out64, const v2v::EsimArgs &a, dim3 grid, size_t lds, hipStream_t s)
 {
+#ifdef V2V_SWEEP_MINIMAL   // kernel-tuning builds (tools/sweep_variants.sh): only what bench.py's cfg2 workloads launch
+    if constexpr (VEC == 4 && BIN == v2v::kBinBilinear) {
+        if (rng == V2V_RNG_PHILOX && !out64) {
+            if (noise) hipLaunchKernelGGL((v2v::esim_voxel_kernel<IN, VEC, BIN, v2v::kRngPhilox, true, false>), grid, dim3(v2v::kBlock), lds, s, a);
+            else hipLaunchKernelGGL((v2v::esim_voxel_kernel<IN, VEC, BIN, v2v::kRngPhilox, false, false>), grid, dim3(v2v::kBlock), lds, s, a);
+            return hipGetLastError();
+        }
+    }
+    return hipErrorInvalidValue;
+#else
     switch (rng) {
     case V2V_RNG_NONE: return launch_out<IN, VEC, BIN, v2v::kRngNone, false>(out64, a, grid, lds, s);
     case V2V_RNG_PHILOX:
@@ -51,6 +61,7 @@ hipError_t launch_rng(int rng, bool noise, bool out64, const v2v::EsimArgs &a, d
                      : launch_out<IN, VEC, BIN, v2v::kRngPhilox, false>(out64, a, grid, lds, s);
     default: return launch_out<IN, VEC, BIN, v2v::kRngReplay, true>(out64, a, grid, lds, s);
     }
+#endif
 }
 
 template <int IN, int VEC>
@@ -71,6 +82,9 @@ hipError_t launch_v2e_out(bool out64, const v2v::V2eArgs &a, dim3 grid, size_t l
 template <int IN, int VEC>
 hipError_t launch_v2e(int bin, int rng, bool out64, bool presum, const v2v::V2eArgs &a, dim3 grid, size_t lds, hipStream_t s)
 {
+#ifdef V2V_SWEEP_MINIMAL
+    return hipErrorInvalidValue;
+#endif
     if (presum) {
         hipLaunchKernelGGL((v2v::v2e_shot_sum_kernel<IN, VEC>), grid, dim3(v2v::kBlock), 0, s, a);
         const hipError_t e = hipGetLastError();
