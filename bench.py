@@ -30,6 +30,8 @@ WORKLOADS = {
                                                    params=[0.2, 0.2, 0.0, 0.0, 0.0]),
     "cfg2_noise_on": dict(model="esim", b=256, n=32, h=256, w=256, dtype="float32", bin="bilinear", tb=5, fpb=1,
                           params=[0.2, 0.2, 0.05, 5e-4, 1.0]),
+    "cfg2_noise_on_fast": dict(model="esim", b=256, n=32, h=256, w=256, dtype="float32", bin="bilinear", tb=5, fpb=1,
+                               params=[0.2, 0.2, 0.05, 5e-4, 1.0], rng="philox_fast"),
     "cfg2_u8": dict(model="esim", b=256, n=32, h=256, w=256, dtype="uint8", bin="bilinear", tb=5, fpb=1, params=[0.2, 0.2, 0.0, 0.0, 0.0]),
     "cfg2_asym": dict(model="esim", b=256, n=32, h=256, w=256, dtype="float32", bin="bilinear", tb=5, fpb=1,
                       params=[0.2, 0.3, 0.0, 0.0, 0.0]),
@@ -126,7 +128,7 @@ def main():
         kernel_name = "esim_voxel_kernel"
 
         def step():
-            esim.esim_voxel_batch(frames, ptensor, bin_mode=bin_mode, num_bins=tb, frames_per_bin=fpb, rng_mode="philox",
+            esim.esim_voxel_batch(frames, ptensor, bin_mode=bin_mode, num_bins=tb, frames_per_bin=fpb, rng_mode=wl.get("rng", "philox"),
                                   seed=20240001, clip_id0=clip_id0, out=out, validate=False,
                                   no_noise=(params[2] == 0 and params[3] <= 0))
     else:
@@ -170,7 +172,10 @@ def main():
                 want, _ = clib.v2e_voxel(host, clib.v2e_params(*params), O.load_luts(), seed=20240001, clip_id0=clip_id0,
                                          bin_mode=bm, num_bins=tb, frames_per_bin=fpb)
             got = out[:1].cpu().numpy().astype(np.float64)
-            parity = "ok" if np.allclose(got, want, rtol=1e-5, atol=1e-5) else "MISMATCH"
+            if wl.get("rng") == "philox_fast":   # different (hardware-transcendental) noise field: distributional parity only
+                parity = "statistical: |sum| ratio %.4f" % (np.abs(got).sum() / max(np.abs(want).sum(), 1e-9))
+            else:
+                parity = "ok" if np.allclose(got, want, rtol=1e-5, atol=1e-5) else "MISMATCH"
             if world == 1 and not args.no_cpu_baseline:
                 sample = frames[: min(b, 256)].cpu().numpy()
                 cpu = cpu_baseline(sample, wl, budget_s=args.cpu_budget)

@@ -46,8 +46,11 @@ typedef enum v2v_rng_mode {
     V2V_RNG_NONE = 0,   /* deterministic debug mode: u_init = 0.5, no hot pixels, all Gaussians 0      */
     V2V_RNG_PHILOX = 1, /* device-native counter RNG keyed by (seed, clip_id, field, pixel): results   */
                         /* do not depend on batch size or on how the batch is sharded over GPUs        */
-    V2V_RNG_REPLAY = 2  /* caller supplies the fields (e.g. drawn from np.random in the reference's    */
+    V2V_RNG_REPLAY = 2, /* caller supplies the fields (e.g. drawn from np.random in the reference's    */
                         /* order): bit-exact replay of a reference run                                 */
+    V2V_RNG_PHILOX_FAST = 3 /* ESIM only: like PHILOX, but the per-pair base-noise Gaussians come from   */
+                        /* Philox4x32-7 + hardware log/sqrt/sin/cos (not reproducible on a CPU): same     */
+                        /* distribution, ~4x cheaper noise; parity for this mode is statistical          */
 } v2v_rng_mode;
 
 typedef enum v2v_bin_mode {

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("V2V_HIP_LIB") or os.path.join(_HERE, "libv2v_hip.so")
 
 # enums of include/v2v_hip.h
 U8, F32, F64 = 0, 1, 2
-RNG_NONE, RNG_PHILOX, RNG_REPLAY = 0, 1, 2
+RNG_NONE, RNG_PHILOX, RNG_REPLAY, RNG_PHILOX_FAST = 0, 1, 2, 3
 BIN_SUM, BIN_BILINEAR = 0, 1
 FLAG_NOISE_EXTERNAL = 0x1
 FLAG_NO_NOISE = 0x2

@@ -46,6 +46,10 @@ hipError_t launch_rng(int rng, bool noise, bool out64, const v2v::EsimArgs &a, d
 {
 #ifdef V2V_SWEEP_MINIMAL   // kernel-tuning builds (tools/sweep_variants.sh): only what bench.py's cfg2 workloads launch
     if constexpr (VEC == 4 && BIN == v2v::kBinBilinear) {
+        if (rng == V2V_RNG_PHILOX_FAST && !out64) {
+            hipLaunchKernelGGL((v2v::esim_voxel_kernel<IN, VEC, BIN, v2v::kRngPhiloxFast, true, false>), grid, dim3(v2v::kBlock), lds, s, a);
+            return hipGetLastError();
+        }
         if (rng == V2V_RNG_PHILOX && !out64) {
             if (noise) hipLaunchKernelGGL((v2v::esim_voxel_kernel<IN, VEC, BIN, v2v::kRngPhilox, true, false>), grid, dim3(v2v::kBlock), lds, s, a);
             else hipLaunchKernelGGL((v2v::esim_voxel_kernel<IN, VEC, BIN, v2v::kRngPhilox, false, false>), grid, dim3(v2v::kBlock), lds, s, a);
@@ -59,6 +63,7 @@ hipError_t launch_rng(int rng, bool noise, bool out64, const v2v::EsimArgs &a, d
     case V2V_RNG_PHILOX:
         return noise ? launch_out<IN, VEC, BIN, v2v::kRngPhilox, true>(out64, a, grid, lds, s)
                      : launch_out<IN, VEC, BIN, v2v::kRngPhilox, false>(out64, a, grid, lds, s);
+    case V2V_RNG_PHILOX_FAST: return launch_out<IN, VEC, BIN, v2v::kRngPhiloxFast, true>(out64, a, grid, lds, s);
     default: return launch_out<IN, VEC, BIN, v2v::kRngReplay, true>(out64, a, grid, lds, s);
     }
 #endif
@@ -181,7 +186,7 @@ int v2v_esim_voxel_hip(const void *frames, int in_dtype, int64_t B, int64_t N, i
     if (out_dtype != V2V_F32 && out_dtype != V2V_F64) return fail(V2V_ERR_DTYPE, "out_dtype must be V2V_F32 or V2V_F64");
     if (params_stride != 0 && params_stride < 5) return fail(V2V_ERR_PARAM, "params_stride must be 0 or >= 5");
     if (num_bins < 1 || frames_per_bin < 1) return fail(V2V_ERR_PARAM, "num_bins and frames_per_bin must be >= 1");
-    if (rng_mode < V2V_RNG_NONE || rng_mode > V2V_RNG_REPLAY) return fail(V2V_ERR_MODE, "unknown rng_mode %d", rng_mode);
+    if (rng_mode < V2V_RNG_NONE || rng_mode > V2V_RNG_PHILOX_FAST) return fail(V2V_ERR_MODE, "unknown rng_mode %d", rng_mode);
     if (rng_mode == V2V_RNG_REPLAY && (!replay || !replay->u_init || !replay->u_hot || !replay->g_hot || !replay->g_base))
         return fail(V2V_ERR_MODE, "rng_mode REPLAY needs all four replay fields");
     if (bin_mode == V2V_BIN_SUM) {
@@ -224,6 +229,7 @@ int v2v_esim_voxel_hip(const void *frames, int in_dtype, int64_t B, int64_t N, i
     const dim3 grid((unsigned)nblocks);
     const bool out64 = out_dtype == V2V_F64;
     const bool noise = !(flags & V2V_FLAG_NO_NOISE);
+    if (!noise && rng_mode == V2V_RNG_PHILOX_FAST) rng_mode = V2V_RNG_PHILOX;   // no Gaussians drawn: the modes coincide
     if (!noise && (flags & V2V_FLAG_NOISE_EXTERNAL)) return fail(V2V_ERR_PARAM, "V2V_FLAG_NO_NOISE and V2V_FLAG_NOISE_EXTERNAL are exclusive");
     if (!noise && rng_mode == V2V_RNG_REPLAY) return fail(V2V_ERR_PARAM, "V2V_FLAG_NO_NOISE is not available in replay mode");
     const size_t lds = 256 * (in_dtype == V2V_U8 ? sizeof(double) : sizeof(float)) +

@@ -29,7 +29,7 @@
 namespace v2v {
 
 enum { kInU8 = 0, kInF32 = 1 };
-enum { kRngNone = 0, kRngPhilox = 1, kRngReplay = 2 };
+enum { kRngNone = 0, kRngPhilox = 1, kRngReplay = 2, kRngPhiloxFast = 3 };
 enum { kBinSum = 0, kBinBilinear = 1 };
 
 struct EsimArgs {
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
     double hot[NOISE ? VEC : 1];
     {
         double u0[VEC];
-        if constexpr (RNG == kRngPhilox) {
+        if constexpr (RNG == kRngPhilox || RNG == kRngPhiloxFast) {
             field_uniform53<VEC>(a.seed, clip_id, kFieldPotInit, kStreamEsim, p0, u0);
         } else if constexpr (RNG == kRngReplay) {
 #pragma unroll
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
         if constexpr (NOISE) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) hot[j] = 0.0;
-            if constexpr (RNG == kRngPhilox) {
+            if constexpr (RNG == kRngPhilox || RNG == kRngPhiloxFast) {
                 if (hot_frac > 0.0) {                                  // uniform: skipping is exact (u >= 0)
                     double u1[VEC];
                     float gh[VEC];
@@ -298,10 +298,11 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
         if constexpr (NOISE) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) base[j] = 0.0;
-            if constexpr (RNG == kRngPhilox) {
+            if constexpr (RNG == kRngPhilox || RNG == kRngPhiloxFast) {
                 if (base_std != 0.0) {                                 // uniform; 0*g adds nothing
                     float g[VEC];
-                    field_gauss32<VEC>(a.seed, clip_id, kFieldBase0 + (uint32_t)k, kStreamEsim, p0, g);
+                    if constexpr (RNG == kRngPhiloxFast) field_gauss32_fast<VEC>(a.seed, clip_id, kFieldBase0 + (uint32_t)k, kStreamEsim, p0, g);
+                    else field_gauss32<VEC>(a.seed, clip_id, kFieldBase0 + (uint32_t)k, kStreamEsim, p0, g);
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) base[j] = base_std * (double)g[j];   // :44
                 }

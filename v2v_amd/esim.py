@@ -17,7 +17,7 @@ from . import _lib
 _TORCH_IN = {torch.uint8: _lib.U8, torch.float32: _lib.F32}
 _OUT = {torch.float32: _lib.F32, torch.float64: _lib.F64}
 BIN_MODES = {"sum": _lib.BIN_SUM, "bilinear": _lib.BIN_BILINEAR}
-RNG_MODES = {"none": _lib.RNG_NONE, "philox": _lib.RNG_PHILOX, "replay": _lib.RNG_REPLAY}
+RNG_MODES = {"none": _lib.RNG_NONE, "philox": _lib.RNG_PHILOX, "replay": _lib.RNG_REPLAY, "philox_fast": _lib.RNG_PHILOX_FAST}
 
 
 def _params_tensor(params, batch: int, device):
