@@ -103,6 +103,15 @@ int v2v_esim_voxel_hip(const void *frames, int in_dtype, int64_t B, int64_t N, i
                        const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
                        void *out_voxel, int out_dtype, int64_t *out_counts, void *stream);
 
+/* Same, with an optional per-clip RNG key: clip_keys = device uint64 [B,2] = {seed, clip id} of every clip (NULL ->
+ * seed / clip_id0 + b).  Lets a collate step simulate independently-seeded samples in ONE launch with exactly the
+ * result each sample gets when simulated alone (v2v_amd.datasets.SimulatingCollator). */
+int v2v_esim_voxel_keyed_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W,
+                             int64_t clip_stride, int64_t frame_stride, const double *params, int64_t params_stride,
+                             uint32_t flags, int rng_mode, uint64_t seed, uint64_t clip_id0, const uint64_t *clip_keys,
+                             const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
+                             void *out_voxel, int out_dtype, int64_t *out_counts, void *stream);
+
 /* Algorithmic HBM bytes of one v2v_esim_voxel_hip call (input read once + output written once);
  * the figure bench.py's roofline is computed from.  Returns a negative v2v_status on bad arguments. */
 int64_t v2v_esim_voxel_bytes(int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W, int bin_mode,

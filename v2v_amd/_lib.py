@@ -19,7 +19,7 @@ OK, ERR_NULL, ERR_SHAPE, ERR_BINS, ERR_DTYPE, ERR_MODE, ERR_ALIGN, ERR_HIP, ERR_
 ABI_VERSION = 1
 
 EXPORTS = ("v2v_version", "v2v_last_error", "v2v_device_count", "v2v_lut_get", "v2v_lut_set",
-           "v2v_esim_voxel_hip", "v2v_esim_voxel_bytes", "v2v_synth_clips_hip", "v2v_events_to_voxel_hip",
+           "v2v_esim_voxel_hip", "v2v_esim_voxel_keyed_hip", "v2v_esim_voxel_bytes", "v2v_synth_clips_hip", "v2v_events_to_voxel_hip",
            "v2v_v2e_voxel_hip", "v2v_v2e_workspace_bytes")
 EV_MAKE_VOXEL_DISCRETE, EV_MAKE_VOXEL_INTERP, EV_BILINEAR = 0, 1, 2
 
@@ -71,6 +71,11 @@ def lib():
     L.v2v_esim_voxel_hip.argtypes = [
         C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,   # frames..frame_stride
         C.c_void_p, C.c_int64, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64,                        # params..clip_id0
+        C.POINTER(EsimReplay), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.v2v_esim_voxel_keyed_hip.restype = C.c_int
+    L.v2v_esim_voxel_keyed_hip.argtypes = [
+        C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+        C.c_void_p, C.c_int64, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p,
         C.POINTER(EsimReplay), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.v2v_esim_voxel_bytes.restype = C.c_int64
     L.v2v_esim_voxel_bytes.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]

@@ -177,6 +177,17 @@ int v2v_esim_voxel_hip(const void *frames, int in_dtype, int64_t B, int64_t N, i
                        const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
                        void *out_voxel, int out_dtype, int64_t *out_counts, void *stream)
 {
+    return v2v_esim_voxel_keyed_hip(frames, in_dtype, B, N, H, W, clip_stride, frame_stride, params, params_stride, flags,
+                                    rng_mode, seed, clip_id0, nullptr, replay, bin_mode, num_bins, frames_per_bin, out_voxel,
+                                    out_dtype, out_counts, stream);
+}
+
+int v2v_esim_voxel_keyed_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W,
+                             int64_t clip_stride, int64_t frame_stride, const double *params, int64_t params_stride,
+                             uint32_t flags, int rng_mode, uint64_t seed, uint64_t clip_id0, const uint64_t *clip_keys,
+                             const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
+                             void *out_voxel, int out_dtype, int64_t *out_counts, void *stream)
+{
     if (!frames || !params || !out_voxel) return fail(V2V_ERR_NULL, "v2v_esim_voxel_hip: frames/params/out_voxel is NULL");
     if (B < 0 || N < 2 || H < 1 || W < 1) return fail(V2V_ERR_SHAPE, "need B>=0, N>=2, H,W>=1 (got B=%lld N=%lld H=%lld W=%lld)", (long long)B, (long long)N, (long long)H, (long long)W);
     const int64_t HW = H * W, K = N - 1;
@@ -218,6 +229,7 @@ int v2v_esim_voxel_hip(const void *frames, int in_dtype, int64_t B, int64_t N, i
     if (replay) { a.u_init = replay->u_init; a.u_hot = replay->u_hot; a.g_hot = replay->g_hot; a.g_base = replay->g_base; }
     a.seed = seed;
     a.clip_id0 = clip_id0;
+    a.clip_keys = reinterpret_cast<const unsigned long long *>(clip_keys);
     a.HW = (int32_t)HW;
     a.K = (int32_t)K;
     a.Tb = num_bins;

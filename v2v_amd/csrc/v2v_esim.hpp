@@ -41,6 +41,7 @@ struct EsimArgs {
     unsigned long long *counts;            // [B,2] or nullptr
     const double *u_init, *u_hot, *g_hot, *g_base;
     uint64_t seed, clip_id0;
+    const unsigned long long *clip_keys;   // optional [B,2] per-clip {seed, clip id}: overrides seed / clip_id0 + b
     int32_t HW, K, Tb, fpb, blocks_per_clip;
     uint32_t noise_external;
 };
@@ -216,7 +217,8 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
     asm volatile("" : "+v"(pos), "+v"(neg), "+v"(inv_pos), "+v"(inv_neg));
     double base_std = 0.0, hot_frac = 0.0, hot_std = 0.0;
     if constexpr (NOISE) { base_std = pp[2]; hot_frac = pp[3]; hot_std = pp[4]; }
-    const uint32_t clip_id = (uint32_t)(a.clip_id0 + (uint64_t)clip);
+    const uint64_t seed_ = a.clip_keys ? a.clip_keys[2 * clip] : a.seed;
+    const uint32_t clip_id = a.clip_keys ? (uint32_t)a.clip_keys[2 * clip + 1] : (uint32_t)(a.clip_id0 + (uint64_t)clip);
     const bool ext = NOISE && a.noise_external != 0;
     const int64_t in_base = (int64_t)clip * a.clip_stride + p0;
 
@@ -226,7 +228,7 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
     {
         double u0[VEC];
         if constexpr (RNG == kRngPhilox || RNG == kRngPhiloxFast) {
-            field_uniform53<VEC>(a.seed, clip_id, kFieldPotInit, kStreamEsim, p0, u0);
+            field_uniform53<VEC>(seed_, clip_id, kFieldPotInit, kStreamEsim, p0, u0);
         } else if constexpr (RNG == kRngReplay) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) u0[j] = a.u_init[(int64_t)clip * a.HW + p0 + j];
@@ -246,8 +248,8 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
                 if (hot_frac > 0.0) {                                  // uniform: skipping is exact (u >= 0)
                     double u1[VEC];
                     float gh[VEC];
-                    field_uniform53<VEC>(a.seed, clip_id, kFieldHotMask, kStreamEsim, p0, u1);
-                    field_gauss32<VEC>(a.seed, clip_id, kFieldHotGauss, kStreamEsim, p0, gh);
+                    field_uniform53<VEC>(seed_, clip_id, kFieldHotMask, kStreamEsim, p0, u1);
+                    field_gauss32<VEC>(seed_, clip_id, kFieldHotGauss, kStreamEsim, p0, gh);
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) hot[j] = (u1[j] < hot_frac) ? hot_std * (double)gh[j] : 0.0;   // :37-39
                 }
@@ -301,8 +303,8 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
             if constexpr (RNG == kRngPhilox || RNG == kRngPhiloxFast) {
                 if (base_std != 0.0) {                                 // uniform; 0*g adds nothing
                     float g[VEC];
-                    if constexpr (RNG == kRngPhiloxFast) field_gauss32_fast<VEC>(a.seed, clip_id, kFieldBase0 + (uint32_t)k, kStreamEsim, p0, g);
-                    else field_gauss32<VEC>(a.seed, clip_id, kFieldBase0 + (uint32_t)k, kStreamEsim, p0, g);
+                    if constexpr (RNG == kRngPhiloxFast) field_gauss32_fast<VEC>(seed_, clip_id, kFieldBase0 + (uint32_t)k, kStreamEsim, p0, g);
+                    else field_gauss32<VEC>(seed_, clip_id, kFieldBase0 + (uint32_t)k, kStreamEsim, p0, g);
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) base[j] = base_std * (double)g[j];   // :44
                 }

@@ -129,6 +129,10 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
         self.output_device = g("output_device", "cpu")
         self.frame_source = g("frame_source", None)
         self.video_size = g("video_size", None)
+        # defer_sim: __getitem__ does the host work only (decode, crop, parameter draws) and returns the raw clip;
+        # SimulatingCollator then simulates the whole batch in ONE launch in the main process, so DataLoader workers
+        # may be fork()ed (they never touch HIP).  Results are identical to the per-sample path.
+        self.defer_sim = g("defer_sim", False)
 
     def __init__(self, dataset_path, configs):
         self.load_configs(configs)
@@ -290,9 +294,17 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
 
         pos = self.sample_pos_thres[sample_idx] if self.use_fixed_thresholds else None
         neg = self.sample_neg_thres[sample_idx] if self.use_fixed_thresholds else None
-        dev = torch.device(self.sim_device)
-        v2e_params, voxels = self.imgs_to_voxels(torch.from_numpy(np.ascontiguousarray(gray)).to(dev), self.num_bins,
-                                                 self.frames_per_bin, 24, pos, neg)                    # [L(+1),Tb,H,W] f32
+        if self.defer_sim:
+            assert (gray.shape[0] - 1) % (self.num_bins * self.frames_per_bin) == 0
+            v2e_params = sample_sim_params(self.threshold_range, self.max_thres_pos_neg_gap, self.base_noise_std_range,
+                                           self.hot_pixel_fraction_range, self.hot_pixel_std_range, self.use_fixed_thresholds,
+                                           pos, neg, self.scale_noise_strength, self.put_noise_external)
+            sim_seed = int(np.random.randint(0, 2**31 - 1))       # same draw order as imgs_to_voxels(sim_rng='philox')
+            voxels = None
+        else:
+            dev = torch.device(self.sim_device)
+            v2e_params, voxels = self.imgs_to_voxels(torch.from_numpy(np.ascontiguousarray(gray)).to(dev), self.num_bins,
+                                                     self.frames_per_bin, 24, pos, neg)                # [L(+1),Tb,H,W] f32
         if self.output_additional_evs:
             all_imgs = all_imgs[self.frames_per_img:]
         if not self.output_additional_frame:
@@ -301,14 +313,96 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
             pick = [i * self.frames_per_img for i in range(img_cnt + 1)]                                # :334-338
         frames = torch.from_numpy(all_imgs[pick]).to(torch.float32).permute(0, 3, 1, 2) / 255           # [L,C,H,W] in [0,1]
         n_ev = img_cnt + 1 if self.output_additional_evs else img_cnt
-        events = voxels[:n_ev]
         out_dev = torch.device(self.output_device)
-        sequence = {
-            "frame": frames.to(out_dev).contiguous(),
-            "events": events.to(out_dev).contiguous(),
-            "data_source_idx": torch.tensor(self.data_source_idx),
-            "v2e_params": v2e_params,
-        }
+        if self.defer_sim:
+            keys = ("pos_thres", "neg_thres", "base_noise_std", "hot_pixel_fraction", "hot_pixel_std")
+            sequence = {
+                "frame": frames.contiguous(),
+                "sim_frames": torch.from_numpy(np.ascontiguousarray(gray)),                            # uint8 [N,H,W]
+                "sim_params": torch.tensor([v2e_params[k] for k in keys], dtype=torch.float64),
+                "sim_key": torch.tensor([sim_seed, 0], dtype=torch.int64),
+                "data_source_idx": torch.tensor(self.data_source_idx),
+                "v2e_params": v2e_params,
+            }
+        else:
+            sequence = {
+                "frame": frames.to(out_dev).contiguous(),
+                "events": voxels[:n_ev].to(out_dev).contiguous(),
+                "data_source_idx": torch.tensor(self.data_source_idx),
+                "v2e_params": v2e_params,
+            }
         if old_state is not None:
             np.random.set_state(old_state)
         return sequence
+
+
+class SimulatingCollator:
+    """`collate_fn` that replaces default_collate + per-sample simulation with ONE fused launch per batch
+    (the north_star's "V2VDataset collate").  Use with a dataset configured `defer_sim: true`:
+
+        loader = DataLoader(dataset, batch_size=B, num_workers=9, collate_fn=SimulatingCollator.from_configs(cfg))
+
+    Workers decode/crop and draw the parameters; this runs in the main process: stack the uint8 clips, one pinned
+    H2D copy, one v2v_esim_voxel_keyed_hip launch with per-clip {seed, clip id} keys.  Every sample gets exactly the
+    voxels the per-sample path (`defer_sim: false`, sim_rng 'philox') produces for the same draws."""
+
+    def __init__(self, num_bins=5, frames_per_bin=1, put_noise_external=False, output_additional_evs=False,
+                 device="cuda", output_device=None, rng_mode="philox"):
+        self.num_bins, self.frames_per_bin = num_bins, frames_per_bin
+        self.put_noise_external = put_noise_external
+        self.output_additional_evs = output_additional_evs
+        self.device = torch.device(device)
+        self.output_device = torch.device(output_device) if output_device is not None else self.device
+        self.rng_mode = rng_mode
+
+    @classmethod
+    def from_configs(cls, configs, **kw):
+        args = dict(num_bins=configs.get("num_bins", 5), frames_per_bin=configs.get("frames_per_bin", 1),
+                    put_noise_external=configs.get("put_noise_external", False),
+                    output_additional_evs=configs.get("output_additional_evs", False),
+                    device=configs.get("sim_device", "cuda"), output_device=configs.get("output_device", None))
+        args.update(kw)
+        return cls(**args)
+
+    def __call__(self, samples):
+        """collate_fn form.  NOTE: a DataLoader runs collate_fn INSIDE its workers, so use this only with
+        num_workers=0 or spawn-started workers; with fork()ed workers wrap the loader in SimulatingLoader instead."""
+        from torch.utils.data import default_collate
+        return self.simulate(default_collate(samples))
+
+    def simulate(self, batch):
+        """batch = default-collated deferred samples (sim_frames [B,N,H,W] uint8, sim_params [B,5], sim_key [B,2])."""
+        batch = dict(batch)
+        clips, params, keys = batch.pop("sim_frames"), batch.pop("sim_params"), batch.pop("sim_key")
+        if self.device.type == "cuda" and not clips.is_cuda:
+            try:                                   # page-locked staging when the host allows it (RLIMIT_MEMLOCK)
+                clips = clips.pin_memory().to(self.device, non_blocking=True)
+            except RuntimeError:
+                clips = clips.to(self.device)
+        pa = params.cpu().numpy()
+        no_noise = bool((pa[:, 2] == 0).all() and (pa[:, 3] <= 0).all())
+        vox = esim.esim_voxel_batch(clips, params.to(self.device), bin_mode="sum", num_bins=self.num_bins,
+                                    frames_per_bin=self.frames_per_bin, rng_mode=self.rng_mode, clip_keys=keys,
+                                    put_noise_external=self.put_noise_external, no_noise=no_noise)   # [B,L(+1),Tb,H,W]
+        batch["events"] = vox.to(self.output_device)
+        batch["frame"] = batch["frame"].to(self.output_device)
+        return batch
+
+
+class SimulatingLoader:
+    """Wraps a DataLoader over a `defer_sim: true` dataset: fork()ed workers decode, crop and default-collate raw
+    uint8 clips; the simulation of each batch (ONE fused launch) happens here, in the process that owns the GPU.
+
+        loader = SimulatingLoader(DataLoader(dataset, batch_size=B, num_workers=9), SimulatingCollator.from_configs(cfg))
+        for batch in loader: ...        # same dict as the reference's loader: frame, events, data_source_idx, v2e_params
+    """
+
+    def __init__(self, loader, collator: SimulatingCollator):
+        self.loader, self.collator = loader, collator
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for raw in self.loader:
+            yield self.collator.simulate(raw)

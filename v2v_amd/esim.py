@@ -41,7 +41,7 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
                      put_noise_external: bool = False, out_dtype: torch.dtype = torch.float32,
                      out: Optional[torch.Tensor] = None, counts: Optional[torch.Tensor] = None,
                      replay: Optional[Sequence[torch.Tensor]] = None, validate: bool = True,
-                     no_noise: Optional[bool] = None) -> torch.Tensor:
+                     no_noise: Optional[bool] = None, clip_keys: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Simulate a batch of clips and bin the events, in one kernel launch on the current stream.
 
     frames  [B,N,H,W] uint8 or float32 CUDA tensor (grayscale; dims 2,3 contiguous).
@@ -49,6 +49,8 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
             (EventEmulator's constructor arguments, data/v2v_core_esim.py:8-16).
     Returns [B,L,Tb,H,W] ("sum", data/v2v_datasets.py:399-400) or [B,Tb,H,W] ("bilinear").
     counts  optional int64 [B,2] tensor; ON/OFF event totals per clip are ADDED into it.
+    clip_keys  optional int64 [B,2] tensor of per-clip {seed, clip id} (overrides seed / clip_id0 + b): clip b then
+            gets exactly the result of simulating it alone with that seed and clip id.
     no_noise  True asserts base_noise_std == 0 and hot_pixel_fraction == 0 for every clip, which selects the
             kernel variant without the noise adds (identical results).  Default: detected from `params` when
             they are host values, False when `params` is already a device tensor.
@@ -103,13 +105,18 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
         if counts.dtype != torch.int64 or tuple(counts.shape) != (b, 2) or not counts.is_contiguous() \
                 or counts.device != frames.device:
             raise ValueError("counts must be a contiguous int64 [B,2] tensor on the frames' device")
+    if clip_keys is not None:
+        clip_keys = torch.as_tensor(clip_keys).to(device=frames.device, dtype=torch.int64).contiguous()
+        if tuple(clip_keys.shape) != (b, 2):
+            raise ValueError("clip_keys must be [B,2] (seed, clip id)")
     with torch.cuda.device(frames.device):
-        rc = _lib.lib().v2v_esim_voxel_hip(
+        rc = _lib.lib().v2v_esim_voxel_keyed_hip(
             C.c_void_p(frames.data_ptr()), _TORCH_IN[frames.dtype], b, n, h, w,
             frames.stride(0) if b > 1 else n * frames.stride(1), frames.stride(1),
             C.c_void_p(p.data_ptr()), pstride,
             (_lib.FLAG_NOISE_EXTERNAL if put_noise_external else 0) | (_lib.FLAG_NO_NOISE if no_noise else 0),
             RNG_MODES[rng_mode], C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_uint64(clip_id0),
+            C.c_void_p(clip_keys.data_ptr()) if clip_keys is not None else None,
             C.byref(rp) if rp is not None else None, BIN_MODES[bin_mode], num_bins, frames_per_bin,
             C.c_void_p(out.data_ptr()), _OUT[out.dtype],
             C.c_void_p(counts.data_ptr()) if counts is not None else None, _lib.stream_ptr())
