@@ -349,6 +349,23 @@ static float expf_det(float x)
 }
 float oracle_expf_det(float x) { return expf_det(x); }
 
+/* Native shot-noise sampler: float32 inversion from one 24-bit uniform (word p&3 of Philox block p>>2). */
+static float px_uniform24(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream, uint32_t p)
+{
+    uint32_t c[4] = {p >> 2, field, clip, stream};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return (float)(c[p & 3u] >> 8) * 5.9604644775390625e-08f;
+}
+
+static float poisson_inv_f32(float lam, float u)
+{
+    if (!(lam > 0.0f)) return 0.0f;
+    float p = expf_det(-lam), s = p, x = 0.0f;
+    while (u > s && x < 64.0f) { x += 1.0f; p = p * (lam / x); s = s + p; }
+    return x;
+}
+float oracle_poisson_inv_f32(float lam, float u) { return poisson_inv_f32(lam, u); }
+
 enum { V2E_PN_RELATED = 0, V2E_SPATIAL_INDEPENDENT = 1, V2E_SPATIAL_TEMPORAL_INDEPENDENT = 2 };
 enum { V2E_F_THRES_A = 0, V2E_F_THRES_B = 1, V2E_F_NOISE_RATE = 2, V2E_F_FRAME0 = 16, V2E_F_STRIDE = 8 };
 #define V2E_STREAM 1u
@@ -505,13 +522,15 @@ int oracle_v2e_voxel_clip(const void *frames, int in_dtype, int64_t N, int64_t H
                 if (rng_mode == ORACLE_RNG_PHILOX) {
                     double fac;
                     if (in_f32) fac = (double)(1.0f - 0.75f * i01_32); else fac = 1 - 0.75 * i01_64;
+                    /* lambda = (intensity factor * threshold factor) * (rate/2 * dt / frame mean); float32 inversion */
                     const double mean_p = ((double)sum_pos[k] / 4294967296.0) / (double)HW;
                     const double mean_n = ((double)sum_neg[k] / 4294967296.0) / (double)HW;
                     const double f = (P->shot_noise_rate_hz / 2) * dt;
-                    const double lam_p = fac * (pos_nominal / pt) / mean_p * f;
-                    const double lam_n = fac * (neg_nominal / nt) / mean_n * f;
-                    sp = poisson_inv(lam_p, px_uniform53(seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * i + 3), V2E_STREAM, (uint32_t)p));
-                    sn = poisson_inv(lam_n, px_uniform53(seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * i + 4), V2E_STREAM, (uint32_t)p));
+                    const double scale_p = f / mean_p, scale_n = f / mean_n;
+                    const double lam_p = (fac * (pos_nominal / pt)) * scale_p;
+                    const double lam_n = (fac * (neg_nominal / nt)) * scale_n;
+                    sp = (double)poisson_inv_f32((float)lam_p, px_uniform24(seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * i + 3), V2E_STREAM, (uint32_t)p));
+                    sn = (double)poisson_inv_f32((float)lam_n, px_uniform24(seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * i + 4), V2E_STREAM, (uint32_t)p));
                 } else {
                     sp = (double)rp->shot_pos[k * HW + p]; sn = (double)rp->shot_neg[k * HW + p];
                 }

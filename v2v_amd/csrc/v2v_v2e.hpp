@@ -83,6 +83,35 @@ __device__ __forceinline__ double poisson_inv(double lam, double u)
     return x;
 }
 
+__device__ __forceinline__ float expf_det(float x);
+
+// native shot noise: float32 inversion from one 24-bit uniform
+__device__ __forceinline__ float poisson_inv_f32(float lam, float u)
+{
+    if (!(lam > 0.0f)) return 0.0f;
+    float p = expf_det(-lam), s = p, x = 0.0f;
+    while (u > s && x < 64.0f) { x += 1.0f; p = p * (lam / x); s = s + p; }
+    return x;
+}
+
+template <int VEC>
+__device__ __forceinline__ void field_uniform24(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream, uint32_t p0,
+                                                float (&u)[VEC])
+{
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    if constexpr (VEC == 1) {
+        const u32x4 w = philox4x32_10(p0 >> 2, field, clip, stream, k0, k1);
+        const uint32_t j = p0 & 3u;
+        u[0] = (float)((j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w) >> 8) * 5.9604644775390625e-08f;
+    } else {
+        const u32x4 w = philox4x32_10(p0 >> 2, field, clip, stream, k0, k1);
+        u[0] = (float)(w.x >> 8) * 5.9604644775390625e-08f;
+        u[1] = (float)(w.y >> 8) * 5.9604644775390625e-08f;
+        u[2] = (float)(w.z >> 8) * 5.9604644775390625e-08f;
+        u[3] = (float)(w.w >> 8) * 5.9604644775390625e-08f;
+    }
+}
+
 __device__ __forceinline__ float expf_det(float x)
 {
     if (x < -87.0f) return 0.0f;
@@ -174,14 +203,18 @@ __global__ void __launch_bounds__(kBlock) v2e_shot_sum_kernel(const V2eArgs a)
     const uint32_t clip_id = (uint32_t)(a.clip_id0 + (uint64_t)clip);
     const double pos_nominal = P.thres_mean_mean + P.thres_diff_mean / 2, neg_nominal = P.thres_mean_mean - P.thres_diff_mean / 2;
     const bool temporal = P.threshold_model == kV2eSpatialTemporalIndependent;
-    double pt[VEC], nt[VEC];
-    if (active) v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFThresA, p0, pt, nt);
+    double pt[VEC], nt[VEC], pre_p[VEC], pre_n[VEC];
+    auto derive = [&]() {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { pre_p[j] = pos_nominal / pt[j]; pre_n[j] = neg_nominal / nt[j]; }
+    };
+    if (active) { v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFThresA, p0, pt, nt); derive(); }
     const int64_t in_base = (int64_t)clip * a.clip_stride + p0;
     for (int k = 0; k < a.K; ++k) {
         long long sp = 0, sn = 0;
         if (active) {
             const int i = k + 1;
-            if (temporal) v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i, p0, pt, nt);
+            if (temporal) { v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i, p0, pt, nt); derive(); }
             const Raw<IN, VEC> raw = load_raw<IN, VEC>(a.frames, in_base + (int64_t)i * a.frame_stride);
             float x[VEC];
             v2e_pixels<IN, VEC>(raw, x);
@@ -189,7 +222,7 @@ __global__ void __launch_bounds__(kBlock) v2e_shot_sum_kernel(const V2eArgs a)
             for (int j = 0; j < VEC; ++j) {
                 double i64, fac; float i32;
                 v2e_inten<IN>(x[j], P.uint8_wrap, i64, i32, fac);
-                const double fp = fac * (pos_nominal / pt[j]), fn = fac * (neg_nominal / nt[j]);
+                const double fp = fac * pre_p[j], fn = fac * pre_n[j];
                 sp += __double2ll_rn(fp * 4294967296.0);
                 sn += __double2ll_rn(fn * 4294967296.0);
             }
@@ -269,6 +302,20 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
         }
     }
 
+    // per-pixel constants derived from the thresholds (recomputed per frame only for the temporal model):
+    // low-biased reciprocals for the exact floor-divide, and the shot-noise threshold factors nominal/threshold
+    double inv_p[VEC], inv_n[VEC], pre_p[VEC], pre_n[VEC];
+    auto derive_thres = [&]() {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            inv_p[j] = (1.0 / pt[j]) * 0x1.ffffffffffffcp-1;
+            inv_n[j] = (1.0 / nt[j]) * 0x1.ffffffffffffcp-1;
+            pre_p[j] = pos_nominal / pt[j];
+            pre_n[j] = neg_nominal / nt[j];
+        }
+    };
+    derive_thres();
+
     acc_t acc_lo[VEC], acc_hi[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { acc_lo[j] = 0; acc_hi[j] = 0; }
@@ -305,17 +352,21 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
             }
         }
         float gleak[VEC];
-        double u_sp[VEC], u_sn[VEC];
-        double mean_p = 1.0, mean_n = 1.0;
+        float u_sp[VEC], u_sn[VEC];
+        double scale_p = 0.0, scale_n = 0.0;
         if constexpr (RNG == kRngPhilox) {
             if (P.leak_rate_hz > 0) field_gauss32<VEC>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i + 2u, kStreamV2e, p0, gleak);
             if (shot) {
-                field_uniform53<VEC>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i + 3u, kStreamV2e, p0, u_sp);
-                field_uniform53<VEC>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i + 4u, kStreamV2e, p0, u_sn);
-                mean_p = ((double)a.shot_sums[((int64_t)clip * a.K + k) * 2] / 4294967296.0) / (double)a.HW;
-                mean_n = ((double)a.shot_sums[((int64_t)clip * a.K + k) * 2 + 1] / 4294967296.0) / (double)a.HW;
+                field_uniform24<VEC>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i + 3u, kStreamV2e, p0, u_sp);
+                field_uniform24<VEC>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i + 4u, kStreamV2e, p0, u_sn);
+                const double mean_p = ((double)a.shot_sums[((int64_t)clip * a.K + k) * 2] / 4294967296.0) / (double)a.HW;
+                const double mean_n = ((double)a.shot_sums[((int64_t)clip * a.K + k) * 2 + 1] / 4294967296.0) / (double)a.HW;
+                const double f = (P.shot_noise_rate_hz / 2) * dt;
+                scale_p = f / mean_p;                                                // wave-uniform: 2 divisions per frame
+                scale_n = f / mean_n;
             }
         }
+        if (temporal) derive_thres();
         float x[VEC];
         v2e_pixels<IN, VEC>(raw, x);
         const acc_t wl = BIN == kBinBilinear ? s_wlo[k] : (acc_t)1, wh = BIN == kBinBilinear ? s_whi[k] : (acc_t)0;
@@ -356,18 +407,16 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
             const double nd = -diff;
             const double pos_frame = diff > 0 ? diff : (diff == diff ? 0.0 : diff);
             const double neg_frame = nd > 0 ? nd : (nd == nd ? 0.0 : nd);
-            const double inv_p = (1.0 / pt[j]) * 0x1.ffffffffffffcp-1, inv_n = (1.0 / nt[j]) * 0x1.ffffffffffffcp-1;
-            double fpos = floor(pos_frame * inv_p), fneg = floor(neg_frame * inv_n);
+            double fpos = floor(pos_frame * inv_p[j]), fneg = floor(neg_frame * inv_n[j]);
             { const double r = __builtin_fma(-fpos, pt[j], pos_frame); if (r >= pt[j]) fpos += 1.0; else if (!(r < pt[j])) fpos = pos_frame / pt[j]; }
             { const double r = __builtin_fma(-fneg, nt[j], neg_frame); if (r >= nt[j]) fneg += 1.0; else if (!(r < nt[j])) fneg = neg_frame / nt[j]; }
             if (shot) {                                                                 // generate_shot_noise (:65-105)
                 double sp, sn;
                 if constexpr (RNG == kRngPhilox) {
-                    const double f = (P.shot_noise_rate_hz / 2) * dt;
-                    const double lam_p = fac * (pos_nominal / pt[j]) / mean_p * f;
-                    const double lam_n = fac * (neg_nominal / nt[j]) / mean_n * f;
-                    sp = poisson_inv(lam_p, u_sp[j]);
-                    sn = poisson_inv(lam_n, u_sn[j]);
+                    const double lam_p = (fac * pre_p[j]) * scale_p;
+                    const double lam_n = (fac * pre_n[j]) * scale_n;
+                    sp = (double)poisson_inv_f32((float)lam_p, u_sp[j]);
+                    sn = (double)poisson_inv_f32((float)lam_n, u_sn[j]);
                 } else {
                     const int64_t o = ((int64_t)clip * a.K + k) * a.HW + p0 + j;
                     sp = (double)a.r_shot_pos[o];
