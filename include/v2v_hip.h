@@ -174,6 +174,11 @@ typedef enum v2v_event_mode {
 int v2v_events_to_voxel_hip(const double *ts, const int64_t *xs, const int64_t *ys, const double *ps, int64_t n, int mode,
                             int num_bins, int64_t H, int64_t W, double *out_voxel, uint64_t *dropped, void *stream);
 
+/* float32 twin: replaces events_to_voxel_torch (utils/event_utils.py:466-507; only caller data/dataset.py:328).
+ * ts/ps float32, out float32 [num_bins,H,W]; discrete != 0 selects the `temporal_bilinear=False` branch (:502-505). */
+int v2v_events_to_voxel_f32_hip(const float *ts, const int64_t *xs, const int64_t *ys, const float *ps, int64_t n, int discrete,
+                                int num_bins, int64_t H, int64_t W, float *out_voxel, uint64_t *dropped, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -169,6 +169,23 @@ def g8_make_voxel():
          events_to_voxel=e2v)
 
 
+def g12_events_to_voxel_torch():
+    """events_to_voxel_torch (utils/event_utils.py:466-507), both branches, float32 CPU tensors."""
+    import torch
+    g = np.random.default_rng(12)
+    n = 600
+    ts = np.sort(g.uniform(0.0, 0.03, size=n)).astype(np.float32)
+    xs = g.integers(0, 24, size=n)
+    ys = g.integers(0, 16, size=n)
+    ps = (g.integers(0, 2, size=n) * 2 - 1).astype(np.float32)
+    tt, tp = torch.from_numpy(ts), torch.from_numpy(ps)
+    tx, ty = torch.from_numpy(xs), torch.from_numpy(ys)
+    bil = ref_eu.events_to_voxel_torch(tx, ty, tt, tp, 5, sensor_size=(16, 24), temporal_bilinear=True)
+    disc = ref_eu.events_to_voxel_torch(tx, ty, tt, tp, 5, sensor_size=(16, 24), temporal_bilinear=False)
+    assert bil.dtype == torch.float32 and disc.dtype == torch.float32
+    save("g12_events_to_voxel_torch.npz", ts=ts, xs=xs, ys=ys, ps=ps, bilinear=bil.numpy(), discrete=disc.numpy())
+
+
 def g11_philox_fed():
     """The reference itself, run on the device-native Philox fields (monkey-patched np.random)."""
     from oracle import clib
@@ -258,8 +275,8 @@ def g9_v2e():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12"]
     fns = {"g1": g1_luts, "g2": g2_g3_esim_clean, "g4": g4_esim_noisy, "g5": g5_floor_divide,
-           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed}
+           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g12": g12_events_to_voxel_torch}
     for w in which:
         fns[w]()

@@ -181,3 +181,15 @@ def test_clip_keys_equal_individual_launches():
     for i in range(3):
         alone = E.esim_voxel_batch(frames[i:i + 1], p[i].tolist(), seed=int(keys[i, 0]), clip_id0=int(keys[i, 1]))
         assert torch.equal(got[i], alone[0])
+
+
+def test_g12_events_to_voxel_torch(golden):
+    """float32 torch twin (event_utils.py:466-507): same per-event float32 terms, atomic float32 sums."""
+    from v2v_amd import voxel
+    g = golden("g12_events_to_voxel_torch.npz")
+    args = [torch.from_numpy(g[k]) for k in ("xs", "ys", "ts", "ps")]
+    bil = voxel.events_to_voxel_torch(*args, 5, sensor_size=(16, 24))
+    assert bil.is_cuda and bil.dtype == torch.float32 and bil.shape == (5, 16, 24)
+    np.testing.assert_allclose(bil.cpu().numpy(), g["bilinear"], rtol=1e-5, atol=1e-5)
+    disc = voxel.events_to_voxel_torch(*args, 5, sensor_size=(16, 24), temporal_bilinear=False)
+    assert np.array_equal(disc.cpu().numpy(), g["discrete"])                      # +-1 sums: exact

@@ -69,4 +69,43 @@ __global__ void __launch_bounds__(256) events_to_voxel_kernel(const EventArgs a)
     }
 }
 
+// ---- float32 twin: events_to_voxel_torch (utils/event_utils.py:466-507) + events_to_image_torch (:330-376) --------
+// Per-event terms are computed in float32 exactly as torch does on the CPU (IEEE division/multiply); the
+// accumulation is float32 atomics, i.e. index_put_(accumulate=True) with a different (and, as in torch on a GPU,
+// unspecified) summation order.
+struct EventArgsF32 {
+    const float *ts;
+    const int64_t *xs, *ys;
+    const float *ps;
+    int64_t n;
+    int32_t discrete, Tb;
+    int64_t H, W;
+    float *out;
+    unsigned long long *dropped;
+};
+
+__global__ void __launch_bounds__(256) events_to_voxel_f32_kernel(const EventArgsF32 a)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const int64_t x = a.xs[i], y = a.ys[i];
+    if (x < 0 || x >= a.W || y < 0 || y >= a.H) { atomicAdd(a.dropped, 1ull); return; }
+    const float t0 = a.ts[0], dt = a.ts[a.n - 1] - t0, t = a.ts[i], p = a.ps[i];
+    float *cell = a.out + y * a.W + x;
+    const int64_t plane = a.H * a.W;
+    if (a.discrete) {                                        // :502-505
+        const float t_per_bin = (dt + 0.001f) / (float)a.Tb;
+        const int b = (int)floorf((t - t0) / t_per_bin);
+        if (b >= 0 && b < a.Tb) atomicAdd(cell + (int64_t)b * plane, p);
+        else atomicAdd(a.dropped, 1ull);
+        return;
+    }
+    const float t_norm = (t - t0) / dt * (float)(a.Tb - 1);  // :491
+    const int b0 = (int)floorf(t_norm);
+    for (int b = (b0 < 0 ? 0 : b0); b <= b0 + 1 && b < a.Tb; ++b) {
+        const float w = 1.0f - fabsf(t_norm - (float)b);     // :495-496
+        if (w > 0.0f) atomicAdd(cell + (int64_t)b * plane, p * w);
+    }
+}
+
 }  // namespace v2v

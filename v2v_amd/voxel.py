@@ -75,3 +75,31 @@ def events_to_voxel(xs, ys, ts, ps, B, sensor_size=(180, 240), temporal_bilinear
         device = ts.device
     out = _scatter(ts, xs, ys, ps, _lib.EV_BILINEAR, B, sensor_size[0], sensor_size[1], device)
     return out.cpu().numpy() if is_np else out
+
+
+def events_to_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(180, 240), temporal_bilinear=True):
+    """utils/event_utils.py:466-507 (float32 torch twin; only caller data/dataset.py:328).  Tensors in, float32 tensor
+    [B,H,W] out on `device` (default: a CUDA device -- the scatter runs in the HIP kernel)."""
+    _lib.require_gpu()
+    assert len(xs) == len(ys) and len(ys) == len(ts) and len(ts) == len(ps)                       # :487
+    dev = torch.device(device) if device is not None else (xs.device if getattr(xs, "is_cuda", False) else torch.device("cuda"))
+    if dev.type != "cuda":
+        raise RuntimeError("events_to_voxel_torch runs on the GPU only (no CPU fallback)")
+    ts_d = _dev(ts, torch.float32, dev)
+    ps_d = _dev(ps, torch.float32, dev)
+    xs_d = _dev(xs, torch.int64, dev)
+    ys_d = _dev(ys, torch.int64, dev)
+    n = ts_d.numel()
+    h, w = sensor_size
+    out = torch.empty((B, h, w), dtype=torch.float32, device=dev)
+    dropped = torch.empty((1,), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().v2v_events_to_voxel_f32_hip(
+            C.c_void_p(ts_d.data_ptr()) if n else None, C.c_void_p(xs_d.data_ptr()) if n else None,
+            C.c_void_p(ys_d.data_ptr()) if n else None, C.c_void_p(ps_d.data_ptr()) if n else None, n,
+            0 if temporal_bilinear else 1, B, h, w, C.c_void_p(out.data_ptr()), C.c_void_p(dropped.data_ptr()),
+            _lib.stream_ptr())
+    _lib.check(rc)
+    if n and int(dropped.item()) != 0:
+        raise IndexError(f"{int(dropped.item())} event(s) outside the sensor / bin range")
+    return out
