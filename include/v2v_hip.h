@@ -174,6 +174,20 @@ typedef enum v2v_event_mode {
 int v2v_events_to_voxel_hip(const double *ts, const int64_t *xs, const int64_t *ys, const double *ps, int64_t n, int mode,
                             int num_bins, int64_t H, int64_t W, double *out_voxel, uint64_t *dropped, void *stream);
 
+/* ---- decode-side front-end ("next" row) ----------------------------------------------------
+ * Replaces the per-frame host loop of WebvidDatasetV2.read_video (data/v2v_datasets.py:191-224: [cvtColor BGR2GRAY]
+ * -> crop -> cv2.resize INTER_LINEAR -> [flip] -> shake crop) and the pause-index gather + gray extraction of
+ * __getitem__ (:311-316) for frames that are already decoded and on the device.
+ * src [T,Hs,Ws,Cs] uint8 (Cs = 3 BGR or 1); frame_idx [N] int32 = decoded frame shown by each simulator frame;
+ * shake_di/dj [T] int32 (>= 0) or NULL; out_gray [N,crop,crop] uint8 (simulator input); out_imgs [N,crop,crop,C]
+ * uint8 or NULL.  gray_first != 0: color_mode 'gray' (cvtColor before the resize); 0 with Cs == 3:
+ * 'gray_in_bgr_out' (resize BGR, gray = bgr_to_gray, v2v_datasets.py:19-22).
+ * PARITY UNPINNED against OpenCV (absent here): bit-exact against the restatement in oracle/frontend_oracle.py. */
+int v2v_frontend_hip(const uint8_t *src, int64_t T, int64_t Hs, int64_t Ws, int64_t Cs, int64_t min_i, int64_t min_j,
+                     int64_t crop_before, int64_t need_h, int64_t need_w, int64_t crop, int flip, int gray_first,
+                     const int32_t *frame_idx, int64_t N, const int32_t *shake_di, const int32_t *shake_dj, uint8_t *out_imgs,
+                     uint8_t *out_gray, void *stream);
+
 /* float32 twin: replaces events_to_voxel_torch (utils/event_utils.py:466-507; only caller data/dataset.py:328).
  * ts/ps float32, out float32 [num_bins,H,W]; discrete != 0 selects the `temporal_bilinear=False` branch (:502-505). */
 int v2v_events_to_voxel_f32_hip(const float *ts, const int64_t *xs, const int64_t *ys, const float *ps, int64_t n, int discrete,

@@ -1,0 +1,98 @@
+"""CPU restatement of the decode-side front-end.  TEST INFRASTRUCTURE ONLY.
+
+Reference flow: data/v2v_datasets.py:191-224 (per decoded frame: [cvtColor BGR2GRAY] -> crop -> cv2.resize
+INTER_LINEAR -> [flip] ; then per-frame shake crop), :311-316 (pause-index gather, gray = channel 0 or bgr_to_gray).
+
+PARITY UNPINNED for the OpenCV pieces: cv2 is a third-party dependency that is absent from /root/reference and from
+this image (requirements.txt lists opencv-python unpinned), so cv2.resize / cv2.cvtColor cannot be run here and no
+golden vectors exist.  What is restated below is OpenCV's published 8-bit algorithm (modules/imgproc/src/resize.cpp:
+float source coordinate (dx+0.5)*scale-0.5, 11-bit fixed-point weights, two-pass int32 accumulation with the
+(>>4, >>16, +2, >>2) vertical rounding; exact 2x2 box average when both scales are exactly 2; color.cpp: BGR2GRAY
+with 14-bit coefficients 1868/9617/4899).  bgr_to_gray (np.dot + truncation, v2v_datasets.py:19-22) is the reference's
+own NumPy code; its BLAS summation order is not a fixed scalar formula, so it is restated as
+multiply-add left to right and agrees with np.dot on all but ~1e-5 of colours.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+COEF_BITS = 11
+COEF_SCALE = 1 << COEF_BITS
+
+
+def _coeffs(ssize: int, dsize: int):
+    """Source index and the two fixed-point weights per destination index (OpenCV resize.cpp, linear, 8u)."""
+    inv_scale = float(dsize) / float(ssize)
+    scale = 1.0 / inv_scale
+    d = np.arange(dsize, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    lo = s < 0
+    f[lo] = 0.0
+    s[lo] = 0
+    hi = s >= ssize - 1
+    f[hi] = 0.0
+    s[hi] = ssize - 1
+    a0 = np.rint((np.float32(1.0) - f) * np.float32(COEF_SCALE)).astype(np.int64)     # saturate_cast<short>(cvRound)
+    a1 = np.rint(f * np.float32(COEF_SCALE)).astype(np.int64)
+    s1 = np.minimum(s + 1, ssize - 1)
+    return s, s1, a0, a1
+
+
+def cv_resize_linear_u8(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    """src [H,W] or [H,W,C] uint8 -> [dh,dw(,C)] uint8, cv2.resize(..., interpolation=INTER_LINEAR) semantics."""
+    squeeze = src.ndim == 2
+    if squeeze:
+        src = src[..., None]
+    h, w, c = src.shape
+    if w == 2 * dw and h == 2 * dh:                      # INTER_LINEAR with exact 2x decimation runs the area fast path
+        s = src.astype(np.int64)
+        out = (s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2
+        out = out.astype(np.uint8)
+        return out[..., 0] if squeeze else out
+    sx, sx1, a0, a1 = _coeffs(w, dw)
+    sy, sy1, b0, b1 = _coeffs(h, dh)
+    s = src.astype(np.int64)
+    hres = s[:, sx, :] * a0[None, :, None] + s[:, sx1, :] * a1[None, :, None]          # [H,dw,C] int
+    r0, r1 = hres[sy], hres[sy1]                                                         # [dh,dw,C]
+    out = (((b0[:, None, None] * (r0 >> 4)) >> 16) + ((b1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    out = np.clip(out, 0, 255).astype(np.uint8)
+    return out[..., 0] if squeeze else out
+
+
+def cv_bgr2gray_u8(img: np.ndarray) -> np.ndarray:
+    """cv2.cvtColor(img, COLOR_BGR2GRAY) for uint8 (14-bit fixed point)."""
+    b, g, r = (img[..., k].astype(np.int64) for k in range(3))
+    return ((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+
+
+def bgr_to_gray_scalar(img: np.ndarray) -> np.ndarray:
+    """v2v_datasets.py:19-22 as a scalar formula: float64 multiply-add left to right, truncating cast."""
+    b, g, r = (img[..., k].astype(np.float64) for k in range(3))
+    return ((b * 0.5870 + g * 0.1140) + r * 0.2989).astype(np.uint8)
+
+
+def frontend(raw, crop_before, min_i, min_j, flip, crop_size, img_idxes, all_di=None, all_dj=None, color_mode="gray"):
+    """raw: list/array of decoded frames [T,Hs,Ws,3] uint8 (BGR).  Returns (all_imgs [N,crop,crop,C], gray [N,crop,crop]).
+    Mirrors read_video (:145-225) + the gather of __getitem__ (:311-316)."""
+    t = len(raw)
+    all_di = np.zeros(t, dtype=np.int64) if all_di is None else np.asarray(all_di) - np.min(all_di)
+    all_dj = np.zeros(t, dtype=np.int64) if all_dj is None else np.asarray(all_dj) - np.min(all_dj)
+    need_h = crop_size + int(all_di.max())
+    need_w = crop_size + int(all_dj.max())
+    frames = []
+    for k in range(t):
+        f = raw[k]
+        if color_mode == "gray":
+            f = cv_bgr2gray_u8(f)
+        f = f[min_i:min_i + crop_before, min_j:min_j + crop_before, ...]
+        f = cv_resize_linear_u8(f, need_w, need_h)
+        if flip:
+            f = f[:, ::-1]
+        if color_mode == "gray":
+            f = f[..., None]
+        frames.append(f[all_di[k]:all_di[k] + crop_size, all_dj[k]:all_dj[k] + crop_size, :])
+    all_imgs = np.stack([frames[i] for i in img_idxes])
+    gray = all_imgs[..., 0] if color_mode == "gray" else bgr_to_gray_scalar(all_imgs)
+    return all_imgs, gray

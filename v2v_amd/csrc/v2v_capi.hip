@@ -10,6 +10,7 @@
 #include "../../include/v2v_hip.h"
 #include "v2v_esim.hpp"
 #include "v2v_events.hpp"
+#include "v2v_frontend.hpp"
 #include "v2v_v2e.hpp"
 #include "v2v_synth.hpp"
 
@@ -384,6 +385,35 @@ int v2v_events_to_voxel_hip(const double *ts, const int64_t *xs, const int64_t *
     hipLaunchKernelGGL(v2v::events_to_voxel_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, a);
     e = hipGetLastError();
     return e == hipSuccess ? V2V_OK : hip_fail(e, "events_to_voxel_kernel launch");
+}
+
+int v2v_frontend_hip(const uint8_t *src, int64_t T, int64_t Hs, int64_t Ws, int64_t Cs, int64_t min_i, int64_t min_j,
+                     int64_t crop_before, int64_t need_h, int64_t need_w, int64_t crop, int flip, int gray_first,
+                     const int32_t *frame_idx, int64_t N, const int32_t *shake_di, const int32_t *shake_dj, uint8_t *out_imgs,
+                     uint8_t *out_gray, void *stream)
+{
+    if (!src || !frame_idx || !out_gray) return fail(V2V_ERR_NULL, "v2v_frontend_hip: src/frame_idx/out_gray is NULL");
+    if (T < 1 || N < 0 || Hs < 1 || Ws < 1 || (Cs != 1 && Cs != 3)) return fail(V2V_ERR_SHAPE, "need T>=1, N>=0, Hs,Ws>=1, Cs in {1,3}");
+    if (crop_before < 1 || crop < 1 || need_h < crop || need_w < crop) return fail(V2V_ERR_SHAPE, "need crop_before>=1 and need_h,need_w >= crop >= 1");
+    if (min_i < 0 || min_j < 0 || min_i + crop_before > Hs || min_j + crop_before > Ws) return fail(V2V_ERR_SHAPE, "crop rectangle outside the frame");
+    if ((shake_di == nullptr) != (shake_dj == nullptr)) return fail(V2V_ERR_NULL, "shake_di and shake_dj must both be given or both be NULL");
+    if (!shake_di && (need_h != crop || need_w != crop)) return fail(V2V_ERR_SHAPE, "need_h/need_w differ from crop but no shake offsets");
+    if (!aligned(frame_idx, 4) || (shake_di && (!aligned(shake_di, 4) || !aligned(shake_dj, 4)))) return fail(V2V_ERR_ALIGN, "index arrays must be 4-byte aligned");
+    if (N == 0) return V2V_OK;
+    v2v::FrontendArgs a{};
+    a.src = src; a.T = (int32_t)T; a.Hs = (int32_t)Hs; a.Ws = (int32_t)Ws; a.Cs = (int32_t)Cs;
+    a.min_i = (int32_t)min_i; a.min_j = (int32_t)min_j; a.crop_before = (int32_t)crop_before;
+    a.need_h = (int32_t)need_h; a.need_w = (int32_t)need_w; a.crop = (int32_t)crop;
+    a.flip = flip ? 1 : 0; a.gray_first = gray_first ? 1 : 0;
+    a.frame_idx = frame_idx; a.di = shake_di; a.dj = shake_dj; a.N = (int32_t)N;
+    a.Cout = (gray_first || Cs == 1) ? 1 : 3;
+    a.out_imgs = out_imgs; a.out_gray = out_gray;
+    const int64_t total = N * crop * crop;
+    const int64_t nblocks = (total + 255) / 256;
+    if (nblocks > 0x7FFFFFFF) return fail(V2V_ERR_SHAPE, "grid too large");
+    hipLaunchKernelGGL(v2v::frontend_kernel, dim3((unsigned)nblocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "frontend_kernel launch");
 }
 
 int v2v_events_to_voxel_f32_hip(const float *ts, const int64_t *xs, const int64_t *ys, const float *ps, int64_t n, int discrete,

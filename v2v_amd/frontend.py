@@ -1,0 +1,52 @@
+"""Decode-side front-end on the GPU: host side of v2v_frontend_hip.
+
+`prepare_clip` takes decoded frames that are already on the device and does what WebvidDatasetV2.read_video +
+the gather in __getitem__ do on the host (data/v2v_datasets.py:191-224, :311-316): [BGR->gray] -> crop ->
+bilinear resize -> [flip] -> shake crop -> pause-index gather -> gray.  Output feeds esim_voxel_batch directly.
+PARITY UNPINNED against OpenCV (not available here); bit-exact against oracle/frontend_oracle.py's restatement.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def prepare_clip(raw: torch.Tensor, crop_before: int, min_i: int, min_j: int, flip: bool, crop_size: int, img_idxes,
+                 all_di=None, all_dj=None, color_mode: str = "gray", want_imgs: bool = True):
+    """raw [T,Hs,Ws,C] uint8 CUDA (C = 3 BGR or 1).  Returns (all_imgs [N,crop,crop,Cout] uint8 or None,
+    gray [N,crop,crop] uint8), both CUDA tensors."""
+    _lib.require_gpu()
+    if raw.ndim != 4 or raw.dtype != torch.uint8 or not raw.is_cuda:
+        raise ValueError("raw must be a [T,Hs,Ws,C] uint8 CUDA tensor")
+    assert color_mode in ["gray", "gray_in_bgr_out"]                          # v2v_datasets.py:76
+    raw = raw.contiguous()
+    t, hs, ws, cs = raw.shape
+    dev = raw.device
+    idx = torch.as_tensor(np.asarray(img_idxes, dtype=np.int32), device=dev)
+    n = idx.numel()
+    if n and (int(idx.min()) < 0 or int(idx.max()) >= t):
+        raise IndexError("img_idxes outside the decoded frames")
+    di = dj = None
+    need_h = need_w = crop_size
+    if all_di is not None:
+        di_h = np.asarray(all_di, dtype=np.int64) - int(np.min(all_di))         # :217-218
+        dj_h = np.asarray(all_dj, dtype=np.int64) - int(np.min(all_dj))
+        need_h, need_w = crop_size + int(di_h.max()), crop_size + int(dj_h.max())
+        di = torch.as_tensor(di_h.astype(np.int32), device=dev)
+        dj = torch.as_tensor(dj_h.astype(np.int32), device=dev)
+    gray_first = color_mode == "gray"
+    cout = 1 if (gray_first or cs == 1) else 3
+    imgs = torch.empty((n, crop_size, crop_size, cout), dtype=torch.uint8, device=dev) if want_imgs else None
+    gray = torch.empty((n, crop_size, crop_size), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().v2v_frontend_hip(
+            C.c_void_p(raw.data_ptr()), t, hs, ws, cs, min_i, min_j, crop_before, need_h, need_w, crop_size, int(bool(flip)),
+            int(gray_first), C.c_void_p(idx.data_ptr()), n, C.c_void_p(di.data_ptr()) if di is not None else None,
+            C.c_void_p(dj.data_ptr()) if dj is not None else None, C.c_void_p(imgs.data_ptr()) if imgs is not None else None,
+            C.c_void_p(gray.data_ptr()), _lib.stream_ptr())
+    _lib.check(rc)
+    return imgs, gray
