@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
+    ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses cuda:0 (tests the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -107,9 +109,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = sharding.init_process_group("nccl", dev)        # RCCL; used for the barrier + max-over-ranks only
+    dist = sharding.init_process_group(args.backend, dev)  # RCCL; used for the barrier + max-over-ranks only
 
     wl = WORKLOADS[args.workload]
     b = args.batch or wl["b"]

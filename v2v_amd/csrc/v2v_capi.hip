@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/v2v_hip.h"
@@ -215,8 +216,12 @@ int v2v_esim_voxel_keyed_hip(const void *frames, int in_dtype, int64_t B, int64_
     if (B == 0) return V2V_OK;
 
     // 4 pixels per work-item when every row segment a lane touches is 16-byte (fp32) / 4-byte (u8) aligned
-    const bool vec4 = (HW % 4 == 0) && (frame_stride % 4 == 0) && (B == 1 || clip_stride % 4 == 0) &&
-                      aligned(frames, 4 * in_sz) && aligned(out_voxel, 16);
+    bool vec4 = (HW % 4 == 0) && (frame_stride % 4 == 0) && (B == 1 || clip_stride % 4 == 0) &&
+                aligned(frames, 4 * in_sz) && aligned(out_voxel, 16);
+    // Small batches (the reference's training shape, 12 clips of 128x128 = 768 waves) are issue-bound on one wave per
+    // SIMD; measured: 1 pixel per work-item (4x the waves) is SLOWER (0.19 vs 0.16 ms) because the per-4-pixel RNG
+    // block is then recomputed per pixel.  Batch more clips instead.  V2V_FORCE_VEC=1|4 overrides (tuning only).
+    if (const char *fv = getenv("V2V_FORCE_VEC")) { if (fv[0] == '1') vec4 = false; else if (fv[0] == '4' && (HW % 4 == 0)) vec4 = true; }
     const int vec = vec4 ? 4 : 1;
 
     v2v::EsimArgs a{};
