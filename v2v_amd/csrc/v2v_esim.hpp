@@ -123,7 +123,7 @@ __device__ __forceinline__ void pix_logs(const Raw<IN, VEC> &r, const typename L
             out[j] = lut[idx];
         }
     } else {
-        bool bad = false;
+        unsigned long long bad = 0;                            // wave-level mask (SGPR pair): any lane, any pixel
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float v = raw_f32<VEC>(r, j);
@@ -131,9 +131,9 @@ __device__ __forceinline__ void pix_logs(const Raw<IN, VEC> &r, const typename L
             // convert); the byte is always a valid index, and converting it back exposes every other input
             const uint32_t a = __float_as_uint(v + 8388608.0f) & 255u;
             out[j] = lut[a];
-            bad |= ((float)a != v);                            // non-integer, negative, > 255, NaN
+            bad |= __ballot((float)a != v);                    // non-integer, negative, > 255, NaN
         }
-        if (__builtin_expect(bad, 0)) {
+        if (__builtin_expect(bad != 0, 0)) {                   // scalar test; lanes with clean pixels skip the bodies below
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const float v = raw_f32<VEC>(r, j);
