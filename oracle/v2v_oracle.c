@@ -17,7 +17,9 @@
  *
  * Compile with -ffp-contract=off: the reference never fuses a multiply with an add.
  */
+#ifndef _GNU_SOURCE
 #define _GNU_SOURCE
+#endif
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -213,8 +215,10 @@ int oracle_esim_voxel_clip(const void *frames, int in_dtype, int64_t N, int64_t 
         double u0 = 0.5, u1 = 1.0, gh = 0.0;
         if (rng_mode == ORACLE_RNG_PHILOX) {
             u0 = px_uniform53(seed, clip_id, 0, 0, (uint32_t)p);
-            u1 = px_uniform53(seed, clip_id, 1, 0, (uint32_t)p);
-            gh = (double)px_gauss32(seed, clip_id, 2, 0, (uint32_t)p);
+            if (hot_frac > 0.0) {          /* u >= 0: no hot pixel can exist otherwise */
+                u1 = px_uniform53(seed, clip_id, 1, 0, (uint32_t)p);
+                gh = (double)px_gauss32(seed, clip_id, 2, 0, (uint32_t)p);
+            }
         } else if (rng_mode == ORACLE_RNG_REPLAY) {
             u0 = rp->u_init[p]; u1 = rp->u_hot[p]; gh = rp->g_hot[p];
         }
@@ -232,7 +236,7 @@ int oracle_esim_voxel_clip(const void *frames, int in_dtype, int64_t N, int64_t 
                 pot += (double)d;
             }
             double g = 0.0;
-            if (rng_mode == ORACLE_RNG_PHILOX) g = (double)px_gauss32(seed, clip_id, 3u + (uint32_t)k, 0, (uint32_t)p);
+            if (rng_mode == ORACLE_RNG_PHILOX) { if (base_std != 0.0) g = (double)px_gauss32(seed, clip_id, 3u + (uint32_t)k, 0, (uint32_t)p); }   /* 0*g adds nothing */
             else if (rng_mode == ORACLE_RNG_REPLAY) g = rp->g_base[k * HW + p];
             double base = base_std * g;                            /* :44 */
             if (!noise_external) { pot += base; pot += hot; }      /* :48-49 */
