@@ -188,6 +188,15 @@ int v2v_frontend_hip(const uint8_t *src, int64_t T, int64_t Hs, int64_t Ws, int6
                      const int32_t *frame_idx, int64_t N, const int32_t *shake_di, const int32_t *shake_dj, uint8_t *out_imgs,
                      uint8_t *out_gray, void *stream);
 
+/* ---- voxel post-ops of the consumer ("next" row) ------------------------------------------------
+ * Replaces normalize_batch_voxel (model/train_utils.py:147-166: per-sample torch.kthvalue at int(0.01*M) / int(0.99*M),
+ * clamp(min=1), where(v > 0, v/pos_max, v/neg_max)) fused with the zero padding of H,W to multiples of `pad_to`
+ * (model/train_utils.py:322-326).  voxel float32 [B,planes,H,W] (planes = T*C); out float32 [B,planes,Hp,Wp].
+ * The k-th values are exact (3-pass radix select); workspace of v2v_postops_workspace_bytes(B) needed iff normalize. */
+int64_t v2v_postops_workspace_bytes(int64_t B);
+int v2v_normalize_pad_hip(const float *voxel, int64_t B, int64_t planes, int64_t H, int64_t W, int normalize, int pad_to,
+                          float *out, void *workspace, void *stream);
+
 /* float32 twin: replaces events_to_voxel_torch (utils/event_utils.py:466-507; only caller data/dataset.py:328).
  * ts/ps float32, out float32 [num_bins,H,W]; discrete != 0 selects the `temporal_bilinear=False` branch (:502-505). */
 int v2v_events_to_voxel_f32_hip(const float *ts, const int64_t *xs, const int64_t *ys, const float *ps, int64_t n, int discrete,

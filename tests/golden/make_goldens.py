@@ -186,6 +186,25 @@ def g12_events_to_voxel_torch():
     save("g12_events_to_voxel_torch.npz", ts=ts, xs=xs, ys=ys, ps=ps, bilinear=bil.numpy(), discrete=disc.numpy())
 
 
+def g13_normalize_batch_voxel():
+    """normalize_batch_voxel (model/train_utils.py:147-166).  The module needs torchvision/torchmetrics/skimage, which
+    are absent, so ONLY that function is compiled from the reference file (AST extraction at run time; no source kept)."""
+    import ast
+    import torch
+    path = os.path.join(REF, "model/train_utils.py")
+    tree = ast.parse(open(path).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "normalize_batch_voxel"]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), path, "exec"), ns)
+    g = np.random.default_rng(13)
+    counts = np.round(g.normal(0, 2.5, size=(3, 4, 5, 20, 24))).astype(np.float32)          # integer-valued like SUM voxels
+    counts[1] *= 0.2                                                                          # sample whose 1 %/99 % values are < 1
+    soft = g.normal(0, 3.0, size=(2, 2, 5, 17, 19)).astype(np.float32)                       # bilinear / noisy voxels
+    out = {"counts": counts, "counts_norm": ns["normalize_batch_voxel"](torch.from_numpy(counts)).numpy(),
+           "soft": soft, "soft_norm": ns["normalize_batch_voxel"](torch.from_numpy(soft)).numpy()}
+    save("g13_normalize_batch_voxel.npz", **out)
+
+
 def g11_philox_fed():
     """The reference itself, run on the device-native Philox fields (monkey-patched np.random)."""
     from oracle import clib
@@ -275,8 +294,9 @@ def g9_v2e():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13"]
     fns = {"g1": g1_luts, "g2": g2_g3_esim_clean, "g4": g4_esim_noisy, "g5": g5_floor_divide,
-           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g12": g12_events_to_voxel_torch}
+           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g12": g12_events_to_voxel_torch,
+           "g13": g13_normalize_batch_voxel}
     for w in which:
         fns[w]()

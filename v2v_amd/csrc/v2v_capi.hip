@@ -3,6 +3,7 @@
 // the kernels live in the headers included below.  gfx950 only; no CPU fallback behind any entry point.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +13,7 @@
 #include "v2v_esim.hpp"
 #include "v2v_events.hpp"
 #include "v2v_frontend.hpp"
+#include "v2v_postops.hpp"
 #include "v2v_v2e.hpp"
 #include "v2v_synth.hpp"
 
@@ -419,6 +421,48 @@ int v2v_frontend_hip(const uint8_t *src, int64_t T, int64_t Hs, int64_t Ws, int6
     hipLaunchKernelGGL(v2v::frontend_kernel, dim3((unsigned)nblocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? V2V_OK : hip_fail(e, "frontend_kernel launch");
+}
+
+int64_t v2v_postops_workspace_bytes(int64_t B)
+{
+    if (B < 0) return V2V_ERR_SHAPE;
+    return B * 2 * ((int64_t)sizeof(v2v::SelectState) + (int64_t)v2v::kSelBins * (int64_t)sizeof(unsigned int));
+}
+
+int v2v_normalize_pad_hip(const float *voxel, int64_t B, int64_t planes, int64_t H, int64_t W, int normalize, int pad_to,
+                          float *out, void *workspace, void *stream)
+{
+    if (!voxel || !out) return fail(V2V_ERR_NULL, "v2v_normalize_pad_hip: voxel/out is NULL");
+    if (B < 0 || planes < 1 || H < 1 || W < 1 || pad_to < 1) return fail(V2V_ERR_SHAPE, "need B>=0, planes,H,W,pad_to>=1");
+    if (normalize && !workspace) return fail(V2V_ERR_NULL, "normalisation needs a workspace of v2v_postops_workspace_bytes(B)");
+    if (!aligned(voxel, 4) || !aligned(out, 4) || (workspace && !aligned(workspace, 16))) return fail(V2V_ERR_ALIGN, "buffers misaligned");
+    if (B == 0) return V2V_OK;
+    const int64_t per_sample = planes * H * W;
+    // torch.kthvalue is 1-based: max_k = int(0.99*M), min_k = int(0.01*M) (model/train_utils.py:153-154)
+    const int64_t max_k = (int64_t)(0.99 * (double)per_sample), min_k = (int64_t)(0.01 * (double)per_sample);
+    if (normalize && (min_k < 1 || max_k < 1)) return fail(V2V_ERR_SHAPE, "k-th value undefined: fewer than 100 elements per sample (torch.kthvalue would raise)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Hp = (int)((H + pad_to - 1) / pad_to * pad_to), Wp = (int)((W + pad_to - 1) / pad_to * pad_to);
+    v2v::SelectState *st = static_cast<v2v::SelectState *>(workspace);
+    if (normalize) {
+        unsigned int *hist = reinterpret_cast<unsigned int *>(st + B * 2);
+        hipError_t e = hipMemsetAsync(hist, 0, sizeof(unsigned int) * (size_t)B * 2 * v2v::kSelBins, s);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(hist)");
+        hipLaunchKernelGGL(v2v::select_init_kernel, dim3((unsigned)((B * 2 + 255) / 256)), dim3(256), 0, s, st, B * 2,
+                           (uint64_t)(min_k - 1), (uint64_t)(max_k - 1));
+        const unsigned gx = (unsigned)std::min<int64_t>((per_sample + 256 * 8 - 1) / (256 * 8), 512);
+        const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+        for (int p = 0; p < 3; ++p) {
+            hipLaunchKernelGGL(v2v::select_hist_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, voxel, per_sample, st, hist, shifts[p], bits[p]);
+            hipLaunchKernelGGL(v2v::select_pick_kernel, dim3((unsigned)(B * 2)), dim3(256), 0, s, st, hist, shifts[p], bits[p]);
+        }
+    }
+    const int64_t per_out = planes * Hp * Wp;
+    const unsigned gx2 = (unsigned)std::min<int64_t>((per_out + 256 * 4 - 1) / (256 * 4), 2048);
+    hipLaunchKernelGGL(v2v::normalize_pad_kernel, dim3(gx2, (unsigned)B), dim3(256), 0, s, voxel, out, st, normalize ? 1 : 0, planes,
+                       (int)H, (int)W, Hp, Wp);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "normalize_pad launch");
 }
 
 int v2v_events_to_voxel_f32_hip(const float *ts, const int64_t *xs, const int64_t *ys, const float *ps, int64_t n, int discrete,
