@@ -1,0 +1,70 @@
+"""Size-independent properties at BASELINE config-2 scale (no oracle needed) + the bench.py output contract."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_potential_conservation_full_size(luts):
+    """Noise-free ESIM: every pixel's potential stays in (-C-, C+) after each reset, so
+    L(last) - L(first) - sum_k (on_k*C+ - off_k*C-) = p_final - p_init  lies in (-(C+ + C-), C+ + C-).
+    Checked on 32 clips of the full 32x256x256 shape for symmetric and asymmetric thresholds, both input dtypes."""
+    from v2v_amd import esim as E
+    b, n, h, w = 32, 32, 256, 256
+    lut = torch.from_numpy(luts["lut64"]).cuda()
+    for dtype in (torch.uint8, torch.float32):
+        frames = E.synth_clips(b, n, h, w, dtype=dtype, seed=77)
+        for cp, cn in ((0.2, 0.2), (0.15, 0.4)):
+            raw = E.esim_voxel_batch(frames, [cp, cn, 0, 0, 0], bin_mode="sum", num_bins=n - 1, seed=3, out_dtype=torch.float64)[:, 0]
+            on = raw.clamp(min=0).sum(dim=1)
+            off = (-raw).clamp(min=0).sum(dim=1)
+            dl = lut[frames[:, -1].long()] - lut[frames[:, 0].long()]
+            resid = dl - (on * cp - off * cn)
+            assert float(resid.abs().max()) < cp + cn + 1e-9
+            # and the residual really is "final minus initial potential": initial is uniform in [-C-, C+)
+            assert float(resid.max()) > 0.5 * (cp + cn) * 0.5 and float(resid.min()) < -0.25 * (cp + cn)
+
+
+def test_linearity_of_binning_modes():
+    """SUM with fpb=f equals the sum of f consecutive fpb=1 planes; bilinear bins are a fixed linear map of the raw
+    per-pair counts (weights sum to 1 per pair)."""
+    from v2v_amd import esim as E
+    frames = E.synth_clips(8, 41, 128, 128, dtype=torch.uint8, seed=5)
+    p = [0.2, 0.3, 0.05, 1e-3, 0.8]
+    raw = E.esim_voxel_batch(frames, p, bin_mode="sum", num_bins=40, frames_per_bin=1, seed=9)          # [8,1,40,H,W]
+    s5 = E.esim_voxel_batch(frames, p, bin_mode="sum", num_bins=5, frames_per_bin=2, seed=9)            # [8,4,5,H,W]
+    assert torch.equal(s5, raw.reshape(8, 4, 5, 2, 128, 128).sum(dim=3))
+    bil = E.esim_voxel_batch(frames, p, bin_mode="bilinear", num_bins=5, seed=9, out_dtype=torch.float64)
+    k = torch.arange(40, dtype=torch.float64, device="cuda")
+    t_norm = k / 39 * 4
+    wts = torch.stack([(1 - (t_norm - bb).abs()).clamp(min=0) for bb in range(5)])                      # [5,40]
+    want = torch.einsum("bk,nkhw->nbhw", wts, raw[:, 0].double())
+    torch.testing.assert_close(bil, want, rtol=1e-12, atol=1e-12)
+
+
+def test_bench_contract_json():
+    """bench.py prints ONE JSON line with the contract's keys (small batch so it runs in seconds)."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "8",
+                          "--cpu-budget", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert d["parity_check"] == "ok"
+    assert abs(d["value"] - 8 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
