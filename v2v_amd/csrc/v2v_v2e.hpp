@@ -166,9 +166,10 @@ __device__ __forceinline__ void v2e_pixels(const Raw<IN, VEC> &r, float (&x)[VEC
     }
 }
 
-// intensity factor 1 - 0.75*inten01 in the dtype NumPy gives it (float64 for uint8 input, float32 for float32 input)
+// intensity terms in the dtype NumPy gives them (float64 for uint8 input, float32 for float32 input):
+//   inten01 = (x + 20)/275 (uint8 input wraps like the reference when uint8_wrap), fac = 1 - 0.75*inten01
 template <int IN>
-__device__ __forceinline__ void v2e_inten(float x, int wrap, double &i01_64, float &i01_32, double &fac)
+__device__ __forceinline__ void v2e_inten_direct(float x, int wrap, double &i01_64, float &i01_32, double &fac)
 {
     if constexpr (IN == kInU8) {
         const uint32_t xi = (uint32_t)x;
@@ -184,6 +185,39 @@ __device__ __forceinline__ void v2e_inten(float x, int wrap, double &i01_64, flo
     }
 }
 
+// Both terms depend only on the 8-bit intensity: each workgroup tabulates them once in LDS with the expressions
+// above (bitwise the same values), replacing a float64 division per pixel and frame by two LDS reads.
+struct V2eIntenTables { double *i01_64; double *fac; float *i01_32; };
+
+template <int IN>
+__device__ __forceinline__ void v2e_inten(float x, int wrap, const V2eIntenTables &tb, double &i01_64, float &i01_32, double &fac)
+{
+    const uint32_t a = __float_as_uint(x + 8388608.0f) & 255u;
+    if (__builtin_expect((float)a == x, 1)) {
+        fac = tb.fac[a];
+        if constexpr (IN == kInU8) { i01_64 = tb.i01_64[a]; i01_32 = 0.0f; }
+        else { i01_32 = tb.i01_32[a]; i01_64 = 0.0; }
+    } else {
+        v2e_inten_direct<IN>(x, wrap, i01_64, i01_32, fac);
+    }
+}
+
+template <int IN>
+__device__ __forceinline__ V2eIntenTables v2e_build_tables(unsigned char *base, int wrap)
+{
+    V2eIntenTables tb;
+    tb.i01_64 = reinterpret_cast<double *>(base);
+    tb.fac = tb.i01_64 + 256;
+    tb.i01_32 = reinterpret_cast<float *>(tb.fac + 256);
+    double a64, f; float a32;
+    v2e_inten_direct<IN>((float)threadIdx.x, wrap, a64, a32, f);
+    tb.i01_64[threadIdx.x] = a64;
+    tb.fac[threadIdx.x] = f;
+    tb.i01_32[threadIdx.x] = a32;
+    return tb;
+}
+constexpr int kV2eTableBytes = 256 * (8 + 8 + 4);
+
 __device__ __forceinline__ float v2e_linlog(float x, const float *lut)
 {
     const uint32_t a = __float_as_uint(x + 8388608.0f) & 255u;
@@ -195,6 +229,9 @@ __device__ __forceinline__ float v2e_linlog(float x, const float *lut)
 template <int IN, int VEC>
 __global__ void __launch_bounds__(kBlock) v2e_shot_sum_kernel(const V2eArgs a)
 {
+    __shared__ __align__(16) unsigned char s_tab[kV2eTableBytes];
+    const V2eIntenTables tb = v2e_build_tables<IN>(s_tab, a.P.uint8_wrap);
+    __syncthreads();
     const int clip = blockIdx.x / a.blocks_per_clip;
     const int blk = blockIdx.x - clip * a.blocks_per_clip;
     const uint32_t p0 = (uint32_t)(blk * kBlock + threadIdx.x) * VEC;
@@ -221,7 +258,7 @@ __global__ void __launch_bounds__(kBlock) v2e_shot_sum_kernel(const V2eArgs a)
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 double i64, fac; float i32;
-                v2e_inten<IN>(x[j], P.uint8_wrap, i64, i32, fac);
+                v2e_inten<IN>(x[j], P.uint8_wrap, tb, i64, i32, fac);
                 const double fp = fac * pre_p[j], fn = fac * pre_n[j];
                 sp += __double2ll_rn(fp * 4294967296.0);
                 sn += __double2ll_rn(fn * 4294967296.0);
@@ -246,6 +283,8 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
     acc_t *s_whi = s_wlo + a.K;
     int *s_seg = reinterpret_cast<int *>(s_whi + a.K);
     s_lut[threadIdx.x] = g_lut_v2e32[threadIdx.x];
+    __shared__ __align__(16) unsigned char s_tab[kV2eTableBytes];
+    const V2eIntenTables tb = v2e_build_tables<IN>(s_tab, a.P.uint8_wrap);
     if constexpr (BIN == kBinBilinear) {
         for (int k = threadIdx.x; k < a.K; k += kBlock) {
             const double t_norm = ((double)k - 0.0) / ((double)(a.K - 1) - 0.0) * (double)(a.Tb - 1);
@@ -340,6 +379,8 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
             }
         }
         const double dt = (double)i / P.fps - (double)(i - 1) / P.fps;                  // t_frame - t_previous (:440)
+        const double dt_tau = P.cutoff_hz > 0 ? dt / tau : 0.0;                         // wave-uniform
+        const float dt_tau32 = (float)dt_tau;
         if (temporal) {                                                                 // thresholds redrawn per frame (:417-421)
             if constexpr (RNG == kRngPhilox) v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i, p0, pt, nt);
             else {
@@ -374,15 +415,15 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
         for (int j = 0; j < VEC; ++j) {
             const float log_new = v2e_linlog(x[j], s_lut);                              // lin_log (:445)
             double i01_64, fac; float i01_32;
-            v2e_inten<IN>(x[j], P.uint8_wrap, i01_64, i01_32, fac);
+            v2e_inten<IN>(x[j], P.uint8_wrap, tb, i01_64, i01_32, fac);
             if (P.cutoff_hz > 0) {                                                      // low_pass_filter (:139-182)
                 if constexpr (IN == kInF32) {
-                    float eps = i01_32 * (float)(dt / tau);
+                    float eps = i01_32 * dt_tau32;
                     eps = eps > 1.0f ? 1.0f : eps;
                     const float ta = (1.0f - eps) * lp_f[j], tb = eps * log_new;
                     lp_f[j] = ta + tb;
                 } else {
-                    double eps = i01_64 * (dt / tau);
+                    double eps = i01_64 * dt_tau;
                     eps = eps > 1.0 ? 1.0 : eps;
                     const double ta = (1 - eps) * lp64[j], tb = eps * (double)log_new;
                     lp64[j] = ta + tb;
