@@ -40,6 +40,10 @@ WORKLOADS = {
     "cfg3_v2e_u8": dict(model="v2e", b=256, n=32, h=256, w=256, dtype="uint8", bin="bilinear", tb=5, fpb=1, params=V2E_NOISY),
     "cfg4_u8_256x41x256x256_sum5": dict(model="esim", b=256, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1,
                                         params=[0.2, 0.3, 0.05, 5e-4, 1.0]),
+    # BASELINE config 4 (per GPU): decoded 720p BGR frames resident in HBM -> GPU front-end (cvtColor, crop, resize to
+    # 256x256, flip) -> fused sim + sum binning.  41 frames so that (N-1) % 5 == 0 as the reference asserts.
+    "cfg4_pipeline_720p_to_256_41f_sum5": dict(model="pipeline", b=24, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1,
+                                               params=[0.2, 0.3, 0.05, 5e-4, 1.0], src_hw=(720, 1280)),
     "train_u8_12x201x128x128_sum5": dict(model="esim", b=12, n=201, h=128, w=128, dtype="uint8", bin="sum", tb=5, fpb=1,
                                          params=[0.2, 0.2, 0.05, 5e-4, 1.0]),
     "cfg1_plumbing_u8_1x8x128x128": dict(model="esim", b=1, n=8, h=128, w=128, dtype="uint8", bin="sum", tb=7, fpb=1,
@@ -57,6 +61,8 @@ def cpu_baseline(frames_host, wl, budget_s=12.0):
     np.random.seed(0)
     for clip in frames_host:
         if wl["model"] == "esim":
+            counts = O.esim_video_to_voxel(clip, *wl["params"], put_noise_external=False, rng=O.GlobalNumpyRNG, use_lut=False)
+        elif wl["model"] == "pipeline":
             counts = O.esim_video_to_voxel(clip, *wl["params"], put_noise_external=False, rng=O.GlobalNumpyRNG, use_lut=False)
         else:
             counts = O.v2e_video_to_voxel(clip, *wl["params"], seed=None)
@@ -77,7 +83,7 @@ def cpu_baseline_c(frames_host, wl):
     cores = os.cpu_count() or 1
     bm = clib.BIN_BILINEAR if wl["bin"] == "bilinear" else clib.BIN_SUM
     t0 = time.perf_counter()
-    if wl["model"] == "esim":
+    if wl["model"] in ("esim", "pipeline"):
         clib.esim_voxel(frames_host, wl["params"], O.load_luts(), rng_mode=clib.RNG_PHILOX, seed=1, bin_mode=bm,
                         num_bins=wl["tb"], frames_per_bin=wl["fpb"], threads=cores)
     else:
@@ -121,13 +127,41 @@ def main():
     tdtype = getattr(torch, wl["dtype"])
     shard = sharding.weak_shard(b, rank, world)            # batch shard: global clip ids, no exchange
     clip_id0 = shard.lo
-    frames = esim.synth_clips(b, n, h, w, dtype=tdtype, seed=20240001, clip_id0=clip_id0, device=dev)
+    if wl["model"] == "pipeline":
+        import numpy as np
+        from v2v_amd import frontend
+        sh, sw = wl["src_hw"]
+        gray_video = esim.synth_clips(b, n, sh, sw, dtype=torch.uint8, seed=20240001, clip_id0=clip_id0, device=dev)
+        raw = gray_video.unsqueeze(-1).expand(b, n, sh, sw, 3).contiguous()              # decoded BGR frames [B,T,720,1280,3]
+        del gray_video
+        g = np.random.default_rng(20240001 + rank)
+        keep_h = int(sh * 0.54)                                                          # keep_top_percentile (v2v_datasets.py:73)
+        min_scale = max(0, h / keep_h, h / sw)
+        scale = g.uniform(min_scale, max(1.3, min_scale), size=b)                        # :260-272
+        cb = (h / scale).astype(np.int64)
+        table = np.stack([[g.integers(0, keep_h - c + 1), g.integers(0, sw - c + 1), c, int(g.random() > 0.5)] for c in cb]).astype(np.int32)
+        idx = np.tile(np.arange(n, dtype=np.int32), (b, 1))
+        table_d, idx_d = torch.as_tensor(table, device=dev), torch.as_tensor(idx, device=dev)
+        frames = frontend.prepare_clips_batch(raw, table_d, idx_d, h, "gray", validate=False)[1]
+        src_bytes = int((cb.astype(np.int64) ** 2).sum()) * 3 * n
+    else:
+        frames = esim.synth_clips(b, n, h, w, dtype=tdtype, seed=20240001, clip_id0=clip_id0, device=dev)
     shape = (b, (n - 1) // (tb * fpb), tb, h, w) if bin_mode == "sum" else (b, tb, h, w)
     out = torch.empty(shape, dtype=torch.float32, device=dev)
     alg_bytes = esim.algorithmic_bytes(tdtype, b, n, h, w, bin_mode, tb, fpb)
     grids_per_step = b * (shape[1] if bin_mode == "sum" else 1)
 
-    if wl["model"] == "esim":
+    if wl["model"] == "pipeline":
+        ptensor = torch.tensor(params, dtype=torch.float64, device=dev)
+        kernel_name = "frontend_kernel + esim_voxel_kernel"
+        alg_bytes += src_bytes + b * n * h * w                 # source crop regions read once + uint8 clips written once
+        gray_buf = frames
+
+        def step():
+            gray = frontend.prepare_clips_batch(raw, table_d, idx_d, h, "gray", validate=False)[1]
+            esim.esim_voxel_batch(gray, ptensor, bin_mode=bin_mode, num_bins=tb, frames_per_bin=fpb, rng_mode="philox",
+                                  seed=20240001, clip_id0=clip_id0, out=out, validate=False, no_noise=False)
+    elif wl["model"] == "esim":
         ptensor = torch.tensor(params, dtype=torch.float64, device=dev)
         kernel_name = "esim_voxel_kernel"
 
@@ -169,7 +203,7 @@ def main():
             clib.build()
             host = frames[:1].cpu().numpy()
             bm = clib.BIN_BILINEAR if bin_mode == "bilinear" else clib.BIN_SUM
-            if wl["model"] == "esim":
+            if wl["model"] in ("esim", "pipeline"):
                 want, _ = clib.esim_voxel(host, params, O.load_luts(), rng_mode=clib.RNG_PHILOX, seed=20240001,
                                           clip_id0=clip_id0, bin_mode=bm, num_bins=tb, frames_per_bin=fpb)
             else:

@@ -188,6 +188,12 @@ int v2v_frontend_hip(const uint8_t *src, int64_t T, int64_t Hs, int64_t Ws, int6
                      const int32_t *frame_idx, int64_t N, const int32_t *shake_di, const int32_t *shake_dj, uint8_t *out_imgs,
                      uint8_t *out_gray, void *stream);
 
+/* Batch form: src [B,T,Hs,Ws,Cs], frame_idx [B,N], clip_table device int32 [B,4] = {min_i, min_j, crop_before, flip}
+ * per clip (no shake: the resize target is crop x crop); outputs [B,N,crop,crop(,C)].  One launch for the batch. */
+int v2v_frontend_batch_hip(const uint8_t *src, int64_t B, int64_t T, int64_t Hs, int64_t Ws, int64_t Cs, const int32_t *clip_table,
+                           int64_t crop, int gray_first, const int32_t *frame_idx, int64_t N, uint8_t *out_imgs, uint8_t *out_gray,
+                           void *stream);
+
 /* ---- voxel post-ops of the consumer ("next" row) ------------------------------------------------
  * Replaces normalize_batch_voxel (model/train_utils.py:147-166: per-sample torch.kthvalue at int(0.01*M) / int(0.99*M),
  * clamp(min=1), where(v > 0, v/pos_max, v/neg_max)) fused with the zero padding of H,W to multiples of `pad_to`

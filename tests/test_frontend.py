@@ -57,3 +57,22 @@ def test_hip_frontend_feeds_simulator():
     assert vox.shape == (1, 1, 5, 64, 64) and torch.equal(vox, vox.round())
     with pytest.raises(ValueError):
         frontend.prepare_clip(raw, 200, 4, 9, False, 64, [0])           # crop rectangle outside the frame
+
+
+@pytest.mark.gpu
+def test_hip_frontend_batch_equals_single_clip_calls():
+    import torch
+    from v2v_amd import frontend
+    g = np.random.default_rng(3)
+    b, t, hs, ws, crop = 3, 6, 90, 120, 32
+    raw = torch.from_numpy(g.integers(0, 256, size=(b, t, hs, ws, 3), dtype=np.uint8)).cuda()
+    table = np.array([[5, 7, 64, 0], [0, 0, 80, 1], [20, 40, 41, 1]], dtype=np.int32)
+    idx = np.array([[0, 1, 2, 3, 4, 5, 5], [0, 0, 1, 2, 3, 4, 5], [0, 1, 1, 1, 2, 3, 4]], dtype=np.int32)
+    for mode in ("gray", "gray_in_bgr_out"):
+        imgs, gray = frontend.prepare_clips_batch(raw, table, idx, crop, mode, want_imgs=True)
+        for c in range(b):
+            i1, g1 = frontend.prepare_clip(raw[c], int(table[c, 2]), int(table[c, 0]), int(table[c, 1]), bool(table[c, 3]), crop,
+                                           idx[c], color_mode=mode)
+            assert torch.equal(gray[c], g1) and torch.equal(imgs[c], i1)
+    with pytest.raises(ValueError):
+        frontend.prepare_clips_batch(raw, np.array([[0, 0, 200, 0]] * 3), idx, crop)

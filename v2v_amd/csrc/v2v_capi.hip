@@ -423,6 +423,29 @@ int v2v_frontend_hip(const uint8_t *src, int64_t T, int64_t Hs, int64_t Ws, int6
     return e == hipSuccess ? V2V_OK : hip_fail(e, "frontend_kernel launch");
 }
 
+int v2v_frontend_batch_hip(const uint8_t *src, int64_t B, int64_t T, int64_t Hs, int64_t Ws, int64_t Cs, const int32_t *clip_table,
+                           int64_t crop, int gray_first, const int32_t *frame_idx, int64_t N, uint8_t *out_imgs, uint8_t *out_gray,
+                           void *stream)
+{
+    if (!src || !frame_idx || !out_gray || !clip_table) return fail(V2V_ERR_NULL, "v2v_frontend_batch_hip: src/clip_table/frame_idx/out_gray is NULL");
+    if (B < 0 || T < 1 || N < 0 || Hs < 1 || Ws < 1 || (Cs != 1 && Cs != 3) || crop < 1) return fail(V2V_ERR_SHAPE, "need B>=0, T>=1, N>=0, Hs,Ws,crop>=1, Cs in {1,3}");
+    if (!aligned(frame_idx, 4) || !aligned(clip_table, 4)) return fail(V2V_ERR_ALIGN, "index arrays must be 4-byte aligned");
+    if (B == 0 || N == 0) return V2V_OK;
+    v2v::FrontendArgs a{};
+    a.src = src; a.T = (int32_t)T; a.Hs = (int32_t)Hs; a.Ws = (int32_t)Ws; a.Cs = (int32_t)Cs;
+    a.need_h = a.need_w = a.crop = (int32_t)crop;
+    a.gray_first = gray_first ? 1 : 0;
+    a.frame_idx = frame_idx; a.N = (int32_t)N;
+    a.Cout = (gray_first || Cs == 1) ? 1 : 3;
+    a.out_imgs = out_imgs; a.out_gray = out_gray;
+    a.clip_table = clip_table;                     // the crop rectangles are validated by the caller (device-resident table)
+    const int64_t nblocks = (N * crop * crop + 255) / 256;
+    if (nblocks > 0x7FFFFFFF || B > 65535) return fail(V2V_ERR_SHAPE, "grid too large");
+    hipLaunchKernelGGL(v2v::frontend_kernel, dim3((unsigned)nblocks, (unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "frontend_kernel (batch) launch");
+}
+
 int64_t v2v_postops_workspace_bytes(int64_t B)
 {
     if (B < 0) return V2V_ERR_SHAPE;

@@ -25,6 +25,8 @@ struct FrontendArgs {
     int32_t N, Cout;                        // Cout = 1 (gray_first or Cs == 1) or 3
     uint8_t *out_imgs;                      // [N,crop,crop,Cout] or nullptr
     uint8_t *out_gray;                      // [N,crop,crop]
+    // batch form: blockIdx.y = clip; every pointer above advances by one clip; per-clip crop parameters
+    const int32_t *clip_table;              // [B,4] {min_i, min_j, crop_before, flip} or nullptr (scalars above)
 };
 
 struct Coef { int s0, s1, a0, a1; };
@@ -51,11 +53,25 @@ __device__ __forceinline__ int bgr2gray_cv(const uint8_t *p)
     return ((int)p[0] * 1868 + (int)p[1] * 9617 + (int)p[2] * 4899 + (1 << 13)) >> 14;
 }
 
-__global__ void __launch_bounds__(256) frontend_kernel(const FrontendArgs a)
+__global__ void __launch_bounds__(256) frontend_kernel(const FrontendArgs a_in)
 {
+    
+FrontendArgs a = a_in;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t per_frame = (int64_t)a.crop * a.crop;
     if (gid >= (int64_t)a.N * per_frame) return;
+    {
+        const int64_t clip = blockIdx.y;
+        a.src += clip * a.T * a.Hs * a.Ws * a.Cs;
+        a.frame_idx += clip * a.N;
+        if (a.di) { a.di += clip * a.T; a.dj += clip * a.T; }
+        if (a.out_imgs) a.out_imgs += clip * a.N * per_frame * a.Cout;
+        a.out_gray += clip * a.N * per_frame;
+        if (a.clip_table) {
+            const int32_t *t4 = a.clip_table + clip * 4;
+            a.min_i = t4[0]; a.min_j = t4[1]; a.crop_before = t4[2]; a.flip = t4[3];
+        }
+    }
     const int n = (int)(gid / per_frame);
     const int rem = (int)(gid - (int64_t)n * per_frame);
     const int y = rem / a.crop, x = rem - y * a.crop;
