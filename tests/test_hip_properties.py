@@ -68,3 +68,27 @@ def test_bench_contract_json():
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     assert d["parity_check"] == "ok"
     assert abs(d["value"] - 8 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+
+
+def test_shapes_at_the_edges_vs_oracle(oracle_c, luts):
+    """The reference's training shape (201 frames, 128x128, 40x5 bins), an odd-sized frame (scalar path, 101x203),
+    and many tiny clips in one launch -- all bit-exact against the scalar C oracle."""
+    from oracle import v2v_oracle as O
+    from v2v_amd import esim as E
+    p = [0.17, 0.23, 0.06, 1e-3, 0.9]
+    train = O.synth_clip_s1(201, 128, 128, seed=1, dtype=np.uint8)[None]
+    want, tot = oracle_c.esim_voxel(train, p, luts, seed=11, clip_id0=3, bin_mode=oracle_c.BIN_SUM, num_bins=5, frames_per_bin=1)
+    c = torch.zeros((1, 2), dtype=torch.int64, device="cuda")
+    got = E.esim_voxel_batch(torch.from_numpy(train).cuda(), p, num_bins=5, seed=11, clip_id0=3, counts=c)
+    assert got.shape == (1, 40, 5, 128, 128) and np.array_equal(got.cpu().numpy(), want) and np.array_equal(c.cpu().numpy(), tot)
+    odd = O.synth_clip_s1(12, 101, 203, seed=2, dtype=np.float32)[None]
+    want, _ = oracle_c.esim_voxel(odd, p, luts, seed=5, bin_mode=oracle_c.BIN_BILINEAR, num_bins=4)
+    got = E.esim_voxel_batch(torch.from_numpy(odd).cuda(), p, bin_mode="bilinear", num_bins=4, seed=5, out_dtype=torch.float64)
+    assert np.array_equal(got.cpu().numpy(), want)
+    tiny = np.stack([O.synth_clip_s1(6, 8, 8, seed=100 + i, dtype=np.uint8) for i in range(300)])
+    params = np.tile(np.array(p), (300, 1))
+    params[:, 0] += np.arange(300) * 1e-3
+    want, tot = oracle_c.esim_voxel(tiny, params, luts, seed=9, clip_id0=1000, bin_mode=oracle_c.BIN_SUM, num_bins=5)
+    c = torch.zeros((300, 2), dtype=torch.int64, device="cuda")
+    got = E.esim_voxel_batch(torch.from_numpy(tiny).cuda(), params, num_bins=5, seed=9, clip_id0=1000, counts=c)
+    assert np.array_equal(got.cpu().numpy(), want) and np.array_equal(c.cpu().numpy(), tot)
