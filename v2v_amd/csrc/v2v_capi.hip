@@ -415,7 +415,8 @@ int v2v_frontend_hip(const uint8_t *src, int64_t T, int64_t Hs, int64_t Ws, int6
     a.frame_idx = frame_idx; a.di = shake_di; a.dj = shake_dj; a.N = (int32_t)N;
     a.Cout = (gray_first || Cs == 1) ? 1 : 3;
     a.out_imgs = out_imgs; a.out_gray = out_gray;
-    const int64_t total = N * crop * crop;
+    a.src_end = src + T * Hs * Ws * Cs;
+    const int64_t total = N * crop * ((crop + v2v::kFrontPx - 1) / v2v::kFrontPx);
     const int64_t nblocks = (total + 255) / 256;
     if (nblocks > 0x7FFFFFFF) return fail(V2V_ERR_SHAPE, "grid too large");
     hipLaunchKernelGGL(v2v::frontend_kernel, dim3((unsigned)nblocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
@@ -438,8 +439,9 @@ int v2v_frontend_batch_hip(const uint8_t *src, int64_t B, int64_t T, int64_t Hs,
     a.frame_idx = frame_idx; a.N = (int32_t)N;
     a.Cout = (gray_first || Cs == 1) ? 1 : 3;
     a.out_imgs = out_imgs; a.out_gray = out_gray;
+    a.src_end = src + B * T * Hs * Ws * Cs;
     a.clip_table = clip_table;                     // the crop rectangles are validated by the caller (device-resident table)
-    const int64_t nblocks = (N * crop * crop + 255) / 256;
+    const int64_t nblocks = (N * crop * ((crop + v2v::kFrontPx - 1) / v2v::kFrontPx) + 255) / 256;
     if (nblocks > 0x7FFFFFFF || B > 65535) return fail(V2V_ERR_SHAPE, "grid too large");
     hipLaunchKernelGGL(v2v::frontend_kernel, dim3((unsigned)nblocks, (unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     const hipError_t e = hipGetLastError();

@@ -27,14 +27,14 @@ struct FrontendArgs {
     uint8_t *out_gray;                      // [N,crop,crop]
     // batch form: blockIdx.y = clip; every pointer above advances by one clip; per-clip crop parameters
     const int32_t *clip_table;              // [B,4] {min_i, min_j, crop_before, flip} or nullptr (scalars above)
+    const uint8_t *src_end;                 // one past the last source byte (bounds the 8-byte neighbour loads)
 };
 
 struct Coef { int s0, s1, a0, a1; };
 
-__device__ __forceinline__ Coef resize_coef(int d, int ssize, int dsize)
+// OpenCV's source coordinate and 11-bit weights for destination index d; `scale` = 1.0 / ((double)dsize / ssize)
+__device__ __forceinline__ Coef resize_coef(int d, int ssize, double scale)
 {
-    const double inv_scale = (double)dsize / (double)ssize;
-    const double scale = 1.0 / inv_scale;
     float f = (float)(((double)d + 0.5) * scale - 0.5);
     int s = (int)floorf(f);
     f = f - (float)s;
@@ -53,13 +53,15 @@ __device__ __forceinline__ int bgr2gray_cv(const uint8_t *p)
     return ((int)p[0] * 1868 + (int)p[1] * 9617 + (int)p[2] * 4899 + (1 << 13)) >> 14;
 }
 
+constexpr int kFrontPx = 4;    // horizontally adjacent output pixels per work-item (one packed 4-byte gray store)
+
 __global__ void __launch_bounds__(256) frontend_kernel(const FrontendArgs a_in)
 {
-    
-FrontendArgs a = a_in;
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    FrontendArgs a = a_in;
+    const int qpr = (a.crop + kFrontPx - 1) / kFrontPx;          // work-items per output row
     const int64_t per_frame = (int64_t)a.crop * a.crop;
-    if (gid >= (int64_t)a.N * per_frame) return;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (int64_t)a.N * a.crop * qpr) return;
     {
         const int64_t clip = blockIdx.y;
         a.src += clip * a.T * a.Hs * a.Ws * a.Cs;
@@ -72,40 +74,74 @@ FrontendArgs a = a_in;
             a.min_i = t4[0]; a.min_j = t4[1]; a.crop_before = t4[2]; a.flip = t4[3];
         }
     }
-    const int n = (int)(gid / per_frame);
-    const int rem = (int)(gid - (int64_t)n * per_frame);
-    const int y = rem / a.crop, x = rem - y * a.crop;
+    const int n = (int)(gid / ((int64_t)a.crop * qpr));
+    const int rem = (int)(gid - (int64_t)n * a.crop * qpr);
+    const int y = rem / qpr, x0 = (rem - y * qpr) * kFrontPx;
     const int t = a.frame_idx[n];
     const int Y = y + (a.di ? a.di[t] : 0);
-    int X = x + (a.dj ? a.dj[t] : 0);
-    if (a.flip) X = a.need_w - 1 - X;
-    const uint8_t *frame = a.src + (int64_t)t * a.Hs * a.Ws * a.Cs;
-    auto src_px = [&](int sy, int sx, int c) -> int {
-        const uint8_t *p = frame + ((int64_t)(a.min_i + sy) * a.Ws + (a.min_j + sx)) * a.Cs;
-        if (a.gray_first && a.Cs == 3) return bgr2gray_cv(p);
-        return p[c];
+    const int dj = a.dj ? a.dj[t] : 0;
+    const uint8_t *frame = a.src + ((int64_t)t * a.Hs * a.Ws + (int64_t)a.min_i * a.Ws + a.min_j) * a.Cs;
+    const bool gray3 = a.gray_first && a.Cs == 3;
+    auto src_px = [&](const uint8_t *row, int sx, int c) -> int {
+        const uint8_t *p = row + (int64_t)sx * a.Cs;
+        return gray3 ? bgr2gray_cv(p) : (int)p[c];
     };
-    int vals[3];
     const bool area2 = (a.crop_before == 2 * a.need_w) && (a.crop_before == 2 * a.need_h);
-    if (area2) {
-        for (int c = 0; c < a.Cout; ++c)
-            vals[c] = (src_px(2 * Y, 2 * X, c) + src_px(2 * Y, 2 * X + 1, c) + src_px(2 * Y + 1, 2 * X, c) + src_px(2 * Y + 1, 2 * X + 1, c) + 2) >> 2;
-    } else {
-        const Coef cx = resize_coef(X, a.crop_before, a.need_w), cy = resize_coef(Y, a.crop_before, a.need_h);
-        for (int c = 0; c < a.Cout; ++c) {
-            const int r0 = src_px(cy.s0, cx.s0, c) * cx.a0 + src_px(cy.s0, cx.s1, c) * cx.a1;
-            const int r1 = src_px(cy.s1, cx.s0, c) * cx.a0 + src_px(cy.s1, cx.s1, c) * cx.a1;
-            int v = (((cy.a0 * (r0 >> 4)) >> 16) + ((cy.a1 * (r1 >> 4)) >> 16) + 2) >> 2;
-            vals[c] = v < 0 ? 0 : (v > 255 ? 255 : v);
+    const double scale_x = 1.0 / ((double)a.need_w / (double)a.crop_before);
+    const double scale_y = 1.0 / ((double)a.need_h / (double)a.crop_before);
+    Coef cy{};
+    if (!area2) cy = resize_coef(Y, a.crop_before, scale_y);
+    const uint8_t *row0 = frame + (int64_t)(area2 ? 2 * Y : cy.s0) * a.Ws * a.Cs;
+    const uint8_t *row1 = frame + (int64_t)(area2 ? 2 * Y + 1 : cy.s1) * a.Ws * a.Cs;
+    uint32_t packed = 0;
+    const int64_t obase = (int64_t)n * per_frame + (int64_t)y * a.crop + x0;
+#pragma unroll
+    for (int j = 0; j < kFrontPx; ++j) {
+        const int x = x0 + j;
+        if (x >= a.crop) break;
+        int X = x + dj;
+        if (a.flip) X = a.need_w - 1 - X;
+        int vals[3];
+        if (area2) {
+            for (int c = 0; c < a.Cout; ++c)
+                vals[c] = (src_px(row0, 2 * X, c) + src_px(row0, 2 * X + 1, c) + src_px(row1, 2 * X, c) + src_px(row1, 2 * X + 1, c) + 2) >> 2;
+        } else {
+            const Coef cx = resize_coef(X, a.crop_before, scale_x);
+            const uint8_t *p0 = row0 + (int64_t)cx.s0 * 3, *p1 = row1 + (int64_t)cx.s0 * 3;
+            if (gray3 && cx.s1 == cx.s0 + 1 && p0 + 8 <= a.src_end && p1 + 8 <= a.src_end) {
+                // both horizontal neighbours are 6 contiguous bytes (B,G,R,B,G,R): one unaligned 8-byte load per row
+                // instead of six byte loads (the texture-address unit, not bandwidth, bounds this kernel)
+                uint64_t w0, w1;
+                __builtin_memcpy(&w0, p0, 8);
+                __builtin_memcpy(&w1, p1, 8);
+                auto g2 = [](uint64_t w, int sh) -> int {
+                    return ((int)((w >> sh) & 255) * 1868 + (int)((w >> (sh + 8)) & 255) * 9617 + (int)((w >> (sh + 16)) & 255) * 4899 + (1 << 13)) >> 14;
+                };
+                const int r0 = g2(w0, 0) * cx.a0 + g2(w0, 24) * cx.a1;
+                const int r1 = g2(w1, 0) * cx.a0 + g2(w1, 24) * cx.a1;
+                const int v = (((cy.a0 * (r0 >> 4)) >> 16) + ((cy.a1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                vals[0] = v < 0 ? 0 : (v > 255 ? 255 : v);
+            } else
+            for (int c = 0; c < a.Cout; ++c) {
+                const int r0 = src_px(row0, cx.s0, c) * cx.a0 + src_px(row0, cx.s1, c) * cx.a1;
+                const int r1 = src_px(row1, cx.s0, c) * cx.a0 + src_px(row1, cx.s1, c) * cx.a1;
+                const int v = (((cy.a0 * (r0 >> 4)) >> 16) + ((cy.a1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                vals[c] = v < 0 ? 0 : (v > 255 ? 255 : v);
+            }
         }
+        if (a.out_imgs) for (int c = 0; c < a.Cout; ++c) a.out_imgs[(obase + j) * a.Cout + c] = (uint8_t)vals[c];
+        int gray = vals[0];
+        if (a.Cout == 3) {                                   // bgr_to_gray (v2v_datasets.py:19-22): float64, truncating cast
+            const double s01 = (double)vals[0] * 0.5870 + (double)vals[1] * 0.1140;
+            gray = (int)(uint8_t)(s01 + (double)vals[2] * 0.2989);
+        }
+        packed |= (uint32_t)(gray & 0xFF) << (8 * j);
     }
-    if (a.out_imgs) for (int c = 0; c < a.Cout; ++c) a.out_imgs[gid * a.Cout + c] = (uint8_t)vals[c];
-    int gray = vals[0];
-    if (a.Cout == 3) {                                       // bgr_to_gray (v2v_datasets.py:19-22): float64, truncating cast
-        const double s01 = (double)vals[0] * 0.5870 + (double)vals[1] * 0.1140;
-        gray = (int)(uint8_t)(s01 + (double)vals[2] * 0.2989);
+    if ((a.crop % kFrontPx) == 0 && (reinterpret_cast<uintptr_t>(a.out_gray) % 4) == 0) {
+        *reinterpret_cast<uint32_t *>(a.out_gray + obase) = packed;
+    } else {
+        for (int j = 0; j < kFrontPx && x0 + j < a.crop; ++j) a.out_gray[obase + j] = (uint8_t)(packed >> (8 * j));
     }
-    a.out_gray[gid] = (uint8_t)gray;
 }
 
 }  // namespace v2v
