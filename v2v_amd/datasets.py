@@ -65,8 +65,10 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
     """Same constructor, config keys, defaults, `__len__`, `__getitem__` contract as the reference class.
 
     Extra (optional) config keys understood by this implementation only:
-        sim_rng        'philox' (default; device RNG keyed by a seed drawn from np.random per sample) or 'numpy'
-                       (fields drawn on the host from the global stream in the reference's order: bit-exact replay)
+        sim_rng        'philox' (default; device RNG keyed by a seed drawn from np.random per sample), 'philox_fast'
+                       (same, noise Gaussians from the hardware transcendental units: ~30 % faster noisy launches,
+                       distributional parity only) or 'numpy' (fields drawn on the host from the global stream in
+                       the reference's order: bit-exact replay)
         sim_device     device of the simulator launch, default 'cuda'
         output_device  'cpu' (default: what default_collate / pin_memory expect) or 'cuda' (skip the round trip)
         frame_source   callable(dataset, sample_idx, start_frame, end_frame, crop_size_before_resize, min_i, min_j,
@@ -124,7 +126,7 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
         self.degrade_ratio = g("degrade_ratio", 0)
         # ---- this implementation's own knobs
         self.sim_rng = g("sim_rng", "philox")
-        assert self.sim_rng in ["philox", "numpy"]
+        assert self.sim_rng in ["philox", "philox_fast", "numpy"]
         self.sim_device = g("sim_device", "cuda")
         self.output_device = g("output_device", "cpu")
         self.frame_source = g("frame_source", None)
@@ -245,7 +247,7 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
                                         replay=[torch.from_numpy(f)[None] for f in fields], **kw)[0]
         else:
             seed = int(np.random.randint(0, 2**31 - 1))          # worker seeding / fixed_seed still govern the noise
-            vox = esim.esim_voxel_batch(frames[None], plist, rng_mode="philox", seed=seed, **kw)[0]
+            vox = esim.esim_voxel_batch(frames[None], plist, rng_mode=self.sim_rng, seed=seed, **kw)[0]
         return params, (vox.cpu().numpy() if is_np else vox)
 
     # ------------------------------------------------------------------ sample assembly
