@@ -1,0 +1,63 @@
+// v2v_args.hpp -- kernel argument structs, shared enums and the launcher entry points of the three translation units
+// (v2v_esim_u8_tu.hip, v2v_esim_f32_tu.hip, v2v_v2e_tu.hip, v2v_capi.hip).  The heavy kernels live in their own TUs so they build in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace v2v {
+
+enum { kInU8 = 0, kInF32 = 1 };
+enum { kRngNone = 0, kRngPhilox = 1, kRngReplay = 2, kRngPhiloxFast = 3 };
+enum { kBinSum = 0, kBinBilinear = 1 };
+constexpr int kBlock = 256;
+
+struct EsimArgs {
+    const void *frames;
+    int64_t clip_stride, frame_stride;     // elements
+    const double *params;
+    int64_t params_stride;
+    void *out;
+    unsigned long long *counts;            // [B,2] or nullptr
+    const double *u_init, *u_hot, *g_hot, *g_base;
+    uint64_t seed, clip_id0;
+    const unsigned long long *clip_keys;   // optional [B,2] per-clip {seed, clip id}: overrides seed / clip_id0 + b
+    int32_t HW, K, Tb, fpb, blocks_per_clip;
+    uint32_t noise_external;
+};
+
+struct V2eParams {            // mirrors v2v_v2e_params (include/v2v_hip.h)
+    double fps;
+    int threshold_model;
+    double thres_mean_mean, thres_mean_std, thres_diff_mean, thres_diff_std;
+    double cutoff_hz, leak_rate_hz, refractory_period_s, shot_noise_rate_hz, leak_jitter_fraction, noise_rate_cov_decades;
+    int uint8_wrap;
+};
+
+struct V2eArgs {
+    const void *frames;
+    int64_t clip_stride, frame_stride;
+    void *out;
+    unsigned long long *counts;
+    long long *shot_sums;                    // [B,K,2] fixed-point sums (native shot noise) or nullptr
+    const double *r_pos_thres, *r_neg_thres; // replay
+    int64_t r_thres_frame_stride;
+    const float *r_noise_rate;
+    const double *r_leak_randn;
+    const long long *r_shot_pos, *r_shot_neg;
+    uint64_t seed, clip_id0;
+    int32_t HW, K, Tb, fpb, blocks_per_clip;
+    V2eParams P;
+};
+
+// defined in v2v_esim_{u8,f32}_tu.hip / v2v_v2e_tu.hip
+hipError_t launch_esim_u8(bool vec4, int bin, int rng, bool noise, bool out64, const EsimArgs &a, dim3 grid, size_t lds, hipStream_t s);
+hipError_t launch_esim_f32(bool vec4, int bin, int rng, bool noise, bool out64, const EsimArgs &a, dim3 grid, size_t lds, hipStream_t s);
+hipError_t launch_v2e(bool in_u8, bool vec4, int bin, int rng, bool out64, bool presum, const V2eArgs &a, dim3 grid, size_t lds,
+                      hipStream_t s);
+// log-intensity tables: which = 0 ESIM float64, 1 ESIM float32 (the esim TUs), 2 v2e float32 (v2e TU).
+// to_device: copy host -> device symbol; else device symbol -> host (falls back to the built-in table without a device).
+hipError_t lut_esim64_copy(void *host, bool to_device);
+hipError_t lut_esim32_copy(void *host, bool to_device);
+hipError_t lut_v2e_copy(void *host, bool to_device);
+
+}  // namespace v2v

@@ -10,11 +10,11 @@
 #include <cstring>
 
 #include "../../include/v2v_hip.h"
-#include "v2v_esim.hpp"
+#include "v2v_args.hpp"
+#include "v2v_rng.hpp"
 #include "v2v_events.hpp"
 #include "v2v_frontend.hpp"
 #include "v2v_postops.hpp"
-#include "v2v_v2e.hpp"
 #include "v2v_synth.hpp"
 
 namespace {
@@ -37,75 +37,6 @@ int hip_fail(hipError_t e, const char *what)
 
 bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
-template <int IN, int VEC, int BIN, int RNG, bool NOISE>
-hipError_t launch_out(bool out64, const v2v::EsimArgs &a, dim3 grid, size_t lds, hipStream_t s)
-{
-    if (out64) hipLaunchKernelGGL((v2v::esim_voxel_kernel<IN, VEC, BIN, RNG, NOISE, true>), grid, dim3(v2v::kBlock), lds, s, a);
-    else hipLaunchKernelGGL((v2v::esim_voxel_kernel<IN, VEC, BIN, RNG, NOISE, false>), grid, dim3(v2v::kBlock), lds, s, a);
-    return hipGetLastError();
-}
-
-template <int IN, int VEC, int BIN>
-hipError_t launch_rng(int rng, bool noise, bool out64, const v2v::EsimArgs &a, dim3 grid, size_t lds, hipStream_t s)
-{
-#ifdef V2V_SWEEP_MINIMAL   // kernel-tuning builds (tools/sweep_variants.sh): only what bench.py's cfg2 workloads launch
-    if constexpr (VEC == 4 && BIN == v2v::kBinBilinear) {
-        if (rng == V2V_RNG_PHILOX_FAST && !out64) {
-            hipLaunchKernelGGL((v2v::esim_voxel_kernel<IN, VEC, BIN, v2v::kRngPhiloxFast, true, false>), grid, dim3(v2v::kBlock), lds, s, a);
-            return hipGetLastError();
-        }
-        if (rng == V2V_RNG_PHILOX && !out64) {
-            if (noise) hipLaunchKernelGGL((v2v::esim_voxel_kernel<IN, VEC, BIN, v2v::kRngPhilox, true, false>), grid, dim3(v2v::kBlock), lds, s, a);
-            else hipLaunchKernelGGL((v2v::esim_voxel_kernel<IN, VEC, BIN, v2v::kRngPhilox, false, false>), grid, dim3(v2v::kBlock), lds, s, a);
-            return hipGetLastError();
-        }
-    }
-    return hipErrorInvalidValue;
-#else
-    switch (rng) {
-    case V2V_RNG_NONE: return launch_out<IN, VEC, BIN, v2v::kRngNone, false>(out64, a, grid, lds, s);
-    case V2V_RNG_PHILOX:
-        return noise ? launch_out<IN, VEC, BIN, v2v::kRngPhilox, true>(out64, a, grid, lds, s)
-                     : launch_out<IN, VEC, BIN, v2v::kRngPhilox, false>(out64, a, grid, lds, s);
-    case V2V_RNG_PHILOX_FAST: return launch_out<IN, VEC, BIN, v2v::kRngPhiloxFast, true>(out64, a, grid, lds, s);
-    default: return launch_out<IN, VEC, BIN, v2v::kRngReplay, true>(out64, a, grid, lds, s);
-    }
-#endif
-}
-
-template <int IN, int VEC>
-hipError_t launch_bin(int bin, int rng, bool noise, bool out64, const v2v::EsimArgs &a, dim3 grid, size_t lds, hipStream_t s)
-{
-    return bin == V2V_BIN_SUM ? launch_rng<IN, VEC, v2v::kBinSum>(rng, noise, out64, a, grid, lds, s)
-                              : launch_rng<IN, VEC, v2v::kBinBilinear>(rng, noise, out64, a, grid, lds, s);
-}
-
-template <int IN, int VEC, int BIN, int RNG>
-hipError_t launch_v2e_out(bool out64, const v2v::V2eArgs &a, dim3 grid, size_t lds, hipStream_t s)
-{
-    if (out64) hipLaunchKernelGGL((v2v::v2e_voxel_kernel<IN, VEC, BIN, RNG, true>), grid, dim3(v2v::kBlock), lds, s, a);
-    else hipLaunchKernelGGL((v2v::v2e_voxel_kernel<IN, VEC, BIN, RNG, false>), grid, dim3(v2v::kBlock), lds, s, a);
-    return hipGetLastError();
-}
-
-template <int IN, int VEC>
-hipError_t launch_v2e(int bin, int rng, bool out64, bool presum, const v2v::V2eArgs &a, dim3 grid, size_t lds, hipStream_t s)
-{
-#ifdef V2V_SWEEP_MINIMAL
-    return hipErrorInvalidValue;
-#endif
-    if (presum) {
-        hipLaunchKernelGGL((v2v::v2e_shot_sum_kernel<IN, VEC>), grid, dim3(v2v::kBlock), 0, s, a);
-        const hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
-    if (bin == V2V_BIN_SUM)
-        return rng == V2V_RNG_PHILOX ? launch_v2e_out<IN, VEC, v2v::kBinSum, v2v::kRngPhilox>(out64, a, grid, lds, s)
-                                     : launch_v2e_out<IN, VEC, v2v::kBinSum, v2v::kRngReplay>(out64, a, grid, lds, s);
-    return rng == V2V_RNG_PHILOX ? launch_v2e_out<IN, VEC, v2v::kBinBilinear, v2v::kRngPhilox>(out64, a, grid, lds, s)
-                                 : launch_v2e_out<IN, VEC, v2v::kBinBilinear, v2v::kRngReplay>(out64, a, grid, lds, s);
-}
-
 }  // namespace
 
 extern "C" {
@@ -124,35 +55,17 @@ int v2v_device_count(void)
 int v2v_lut_get(int which, void *dst)
 {
     if (!dst) return fail(V2V_ERR_NULL, "v2v_lut_get: dst is NULL");
-    hipError_t e;
-    switch (which) {
-    case 0: e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(v2v::g_lut_esim64), sizeof(double) * 256); break;
-    case 1: e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(v2v::g_lut_esim32), sizeof(float) * 256); break;
-    case 2: e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(v2v::g_lut_v2e32), sizeof(float) * 256); break;
-    default: return fail(V2V_ERR_PARAM, "v2v_lut_get: which=%d", which);
-    }
-    if (e != hipSuccess) {
-        // no device: hand back the built-in tables so a host can still inspect what the library ships
-        (void)hipGetLastError();
-        switch (which) {
-        case 0: memcpy(dst, v2v::kLutEsim64, sizeof(double) * 256); break;
-        case 1: memcpy(dst, v2v::kLutEsim32, sizeof(float) * 256); break;
-        default: memcpy(dst, v2v::kLutV2e32, sizeof(float) * 256); break;
-        }
-    }
+    if (which < 0 || which > 2) return fail(V2V_ERR_PARAM, "v2v_lut_get: which=%d", which);
+    if (which == 2) (void)v2v::lut_v2e_copy(dst, false); else if (which == 1) (void)v2v::lut_esim32_copy(dst, false); else (void)v2v::lut_esim64_copy(dst, false);
     return V2V_OK;
 }
 
 int v2v_lut_set(int which, const void *src)
 {
     if (!src) return fail(V2V_ERR_NULL, "v2v_lut_set: src is NULL");
-    hipError_t e;
-    switch (which) {
-    case 0: e = hipMemcpyToSymbol(HIP_SYMBOL(v2v::g_lut_esim64), src, sizeof(double) * 256); break;
-    case 1: e = hipMemcpyToSymbol(HIP_SYMBOL(v2v::g_lut_esim32), src, sizeof(float) * 256); break;
-    case 2: e = hipMemcpyToSymbol(HIP_SYMBOL(v2v::g_lut_v2e32), src, sizeof(float) * 256); break;
-    default: return fail(V2V_ERR_PARAM, "v2v_lut_set: which=%d", which);
-    }
+    if (which < 0 || which > 2) return fail(V2V_ERR_PARAM, "v2v_lut_set: which=%d", which);
+    void *p = const_cast<void *>(src);
+    const hipError_t e = which == 2 ? v2v::lut_v2e_copy(p, true) : which == 1 ? v2v::lut_esim32_copy(p, true) : v2v::lut_esim64_copy(p, true);
     return e == hipSuccess ? V2V_OK : hip_fail(e, "v2v_lut_set");
 }
 
@@ -258,8 +171,8 @@ int v2v_esim_voxel_keyed_hip(const void *frames, int in_dtype, int64_t B, int64_
     hipStream_t s = static_cast<hipStream_t>(stream);
 
     hipError_t e;
-    if (in_dtype == V2V_U8) e = vec4 ? launch_bin<v2v::kInU8, 4>(bin_mode, rng_mode, noise, out64, a, grid, lds, s) : launch_bin<v2v::kInU8, 1>(bin_mode, rng_mode, noise, out64, a, grid, lds, s);
-    else e = vec4 ? launch_bin<v2v::kInF32, 4>(bin_mode, rng_mode, noise, out64, a, grid, lds, s) : launch_bin<v2v::kInF32, 1>(bin_mode, rng_mode, noise, out64, a, grid, lds, s);
+    e = in_dtype == V2V_U8 ? v2v::launch_esim_u8(vec4, bin_mode, rng_mode, noise, out64, a, grid, lds, s)
+                           : v2v::launch_esim_f32(vec4, bin_mode, rng_mode, noise, out64, a, grid, lds, s);
     return e == hipSuccess ? V2V_OK : hip_fail(e, "esim_voxel_kernel launch");
 }
 
@@ -363,8 +276,7 @@ int v2v_v2e_voxel_hip(const void *frames, int in_dtype, int64_t B, int64_t N, in
     }
     const dim3 grid((unsigned)nblocks);
     hipError_t e;
-    if (in_dtype == V2V_U8) e = vec4 ? launch_v2e<v2v::kInU8, 4>(bin_mode, rng_mode, out64, presum, a, grid, lds, s) : launch_v2e<v2v::kInU8, 1>(bin_mode, rng_mode, out64, presum, a, grid, lds, s);
-    else e = vec4 ? launch_v2e<v2v::kInF32, 4>(bin_mode, rng_mode, out64, presum, a, grid, lds, s) : launch_v2e<v2v::kInF32, 1>(bin_mode, rng_mode, out64, presum, a, grid, lds, s);
+    e = v2v::launch_v2e(in_dtype == V2V_U8, vec4, bin_mode, rng_mode, out64, presum, a, grid, lds, s);
     return e == hipSuccess ? V2V_OK : hip_fail(e, "v2e kernel launch");
 }
 

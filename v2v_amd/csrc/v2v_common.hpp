@@ -1,0 +1,75 @@
+// v2v_common.hpp -- build-time tunables and the raw-vector load/store helpers shared by the ESIM and v2e kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "v2v_args.hpp"
+#include "v2v_rng.hpp"
+
+namespace v2v {
+
+// Tunables (overridable at build time for sweeps: make EXTRA="-DV2V_DEPTH=3 -DV2V_MIN_WAVES=4")
+#ifndef V2V_DEPTH
+#define V2V_DEPTH 4
+#endif
+#ifndef V2V_MIN_WAVES
+#define V2V_MIN_WAVES 1
+#endif
+#ifndef V2V_NT_LOADS
+#define V2V_NT_LOADS 1
+#endif
+constexpr int kDepth = V2V_DEPTH;   // frames in flight per work-item (register ring, reloaded right after use)
+
+// ------------------------------------------------------------------------------------------------
+// raw input vectors
+template <int IN, int VEC> struct Raw;
+template <> struct Raw<kInF32, 4> { float4 v; };
+template <> struct Raw<kInF32, 1> { float v; };
+template <> struct Raw<kInU8, 4> { uint32_t v; };
+template <> struct Raw<kInU8, 1> { uint8_t v; };
+
+template <int IN, int VEC>
+__device__ __forceinline__ Raw<IN, VEC> load_raw(const void *base, int64_t elem_off)
+{
+    Raw<IN, VEC> r;
+    if constexpr (IN == kInF32 && VEC == 4) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+#if V2V_NT_LOADS
+        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(static_cast<const float *>(base) + elem_off));
+#else
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(static_cast<const float *>(base) + elem_off);
+#endif
+        r.v = make_float4(t.x, t.y, t.z, t.w);
+    } else if constexpr (IN == kInF32) r.v = static_cast<const float *>(base)[elem_off];
+    else if constexpr (VEC == 4) r.v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(base) + elem_off));
+    else r.v = static_cast<const uint8_t *>(base)[elem_off];
+    return r;
+}
+
+template <int IN> struct LutT { using type = double; };
+template <> struct LutT<kInF32> { using type = float; };
+
+template <int VEC>
+__device__ __forceinline__ float raw_f32(const Raw<kInF32, VEC> &r, int j)
+{
+    if constexpr (VEC == 4) return (j == 0) ? r.v.x : (j == 1) ? r.v.y : (j == 2) ? r.v.z : r.v.w;
+    else return r.v;
+}
+
+template <int VEC, typename T>
+__device__ __forceinline__ void store_vec(void *out, int64_t off, const T (&v)[VEC])
+{
+    T *o = static_cast<T *>(out) + off;
+    if constexpr (VEC == 4 && sizeof(T) == 8) {
+        reinterpret_cast<double2 *>(o)[0] = make_double2(v[0], v[1]);
+        reinterpret_cast<double2 *>(o)[1] = make_double2(v[2], v[3]);
+    } else if constexpr (VEC == 4) {
+        *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        o[0] = v[0];
+    }
+}
+
+}  // namespace v2v

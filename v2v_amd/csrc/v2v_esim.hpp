@@ -22,88 +22,19 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <type_traits>
-
-#include "v2v_rng.hpp"
+#include "v2v_common.hpp"
 
 namespace v2v {
 
-enum { kInU8 = 0, kInF32 = 1 };
-enum { kRngNone = 0, kRngPhilox = 1, kRngReplay = 2, kRngPhiloxFast = 3 };
-enum { kBinSum = 0, kBinBilinear = 1 };
 
-struct EsimArgs {
-    const void *frames;
-    int64_t clip_stride, frame_stride;     // elements
-    const double *params;
-    int64_t params_stride;
-    void *out;
-    unsigned long long *counts;            // [B,2] or nullptr
-    const double *u_init, *u_hot, *g_hot, *g_base;
-    uint64_t seed, clip_id0;
-    const unsigned long long *clip_keys;   // optional [B,2] per-clip {seed, clip id}: overrides seed / clip_id0 + b
-    int32_t HW, K, Tb, fpb, blocks_per_clip;
-    uint32_t noise_external;
-};
 
 // Log-intensity tables in device memory (initialised with NumPy's bits, golden G1; re-pinnable through
 // v2v_lut_set).  Each workgroup copies the one it needs into LDS.
 #include "v2v_luts.inc"
-__device__ double g_lut_esim64[256] = {V2V_LUT_ESIM64_VALUES};
-__device__ float g_lut_esim32[256] = {V2V_LUT_ESIM32_VALUES};
-__device__ float g_lut_v2e32[256] = {V2V_LUT_V2E32_VALUES};
+static __device__ double g_lut_esim64[256] = {V2V_LUT_ESIM64_VALUES};
+static __device__ float g_lut_esim32[256] = {V2V_LUT_ESIM32_VALUES};
 static const double kLutEsim64[256] = {V2V_LUT_ESIM64_VALUES};
 static const float kLutEsim32[256] = {V2V_LUT_ESIM32_VALUES};
-static const float kLutV2e32[256] = {V2V_LUT_V2E32_VALUES};
-
-// Tunables (overridable at build time for sweeps: make EXTRA="-DV2V_DEPTH=3 -DV2V_MIN_WAVES=4")
-#ifndef V2V_DEPTH
-#define V2V_DEPTH 4
-#endif
-#ifndef V2V_MIN_WAVES
-#define V2V_MIN_WAVES 1
-#endif
-#ifndef V2V_NT_LOADS
-#define V2V_NT_LOADS 1
-#endif
-constexpr int kBlock = 256;
-constexpr int kDepth = V2V_DEPTH;   // frames in flight per work-item (register ring, reloaded right after use)
-
-// ------------------------------------------------------------------------------------------------
-// raw input vectors
-template <int IN, int VEC> struct Raw;
-template <> struct Raw<kInF32, 4> { float4 v; };
-template <> struct Raw<kInF32, 1> { float v; };
-template <> struct Raw<kInU8, 4> { uint32_t v; };
-template <> struct Raw<kInU8, 1> { uint8_t v; };
-
-template <int IN, int VEC>
-__device__ __forceinline__ Raw<IN, VEC> load_raw(const void *base, int64_t elem_off)
-{
-    Raw<IN, VEC> r;
-    if constexpr (IN == kInF32 && VEC == 4) {
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-#if V2V_NT_LOADS
-        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(static_cast<const float *>(base) + elem_off));
-#else
-        const f32x4 t = *reinterpret_cast<const f32x4 *>(static_cast<const float *>(base) + elem_off);
-#endif
-        r.v = make_float4(t.x, t.y, t.z, t.w);
-    } else if constexpr (IN == kInF32) r.v = static_cast<const float *>(base)[elem_off];
-    else if constexpr (VEC == 4) r.v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(base) + elem_off));
-    else r.v = static_cast<const uint8_t *>(base)[elem_off];
-    return r;
-}
-
-template <int IN> struct LutT { using type = double; };
-template <> struct LutT<kInF32> { using type = float; };
-
-template <int VEC>
-__device__ __forceinline__ float raw_f32(const Raw<kInF32, VEC> &r, int j)
-{
-    if constexpr (VEC == 4) return (j == 0) ? r.v.x : (j == 1) ? r.v.y : (j == 2) ? r.v.z : r.v.w;
-    else return r.v;
-}
 
 // Log intensity of the VEC pixels of one raw vector.
 //  u8 : one LDS lookup per pixel (float64 table).
@@ -146,19 +77,6 @@ __device__ __forceinline__ void pix_logs(const Raw<IN, VEC> &r, const typename L
     }
 }
 
-template <int VEC, typename T>
-__device__ __forceinline__ void store_vec(void *out, int64_t off, const T (&v)[VEC])
-{
-    T *o = static_cast<T *>(out) + off;
-    if constexpr (VEC == 4 && sizeof(T) == 8) {
-        reinterpret_cast<double2 *>(o)[0] = make_double2(v[0], v[1]);
-        reinterpret_cast<double2 *>(o)[1] = make_double2(v[2], v[3]);
-    } else if constexpr (VEC == 4) {
-        *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-        o[0] = v[0];
-    }
-}
 
 // NOISE  : false -> the caller guarantees base_noise_std == 0 and hot_pixel_fraction == 0 for every clip
 //          (V2V_FLAG_NO_NOISE); the noise adds, their registers and the Gaussian generator disappear.

@@ -18,36 +18,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "v2v_esim.hpp"
+#include "v2v_common.hpp"
+#include "v2v_luts.inc"
 
 namespace v2v {
+
+__device__ float g_lut_v2e32[256] = {V2V_LUT_V2E32_VALUES};
+static const float kLutV2e32[256] = {V2V_LUT_V2E32_VALUES};
 
 enum { kV2ePnRelated = 0, kV2eSpatialIndependent = 1, kV2eSpatialTemporalIndependent = 2 };
 enum : uint32_t { kV2eFThresA = 0, kV2eFThresB = 1, kV2eFNoiseRate = 2, kV2eFFrame0 = 16, kV2eFStride = 8 };
 
-struct V2eParams {            // mirrors v2v_v2e_params (include/v2v_hip.h)
-    double fps;
-    int threshold_model;
-    double thres_mean_mean, thres_mean_std, thres_diff_mean, thres_diff_std;
-    double cutoff_hz, leak_rate_hz, refractory_period_s, shot_noise_rate_hz, leak_jitter_fraction, noise_rate_cov_decades;
-    int uint8_wrap;
-};
 
-struct V2eArgs {
-    const void *frames;
-    int64_t clip_stride, frame_stride;
-    void *out;
-    unsigned long long *counts;
-    long long *shot_sums;                    // [B,K,2] fixed-point sums (native shot noise) or nullptr
-    const double *r_pos_thres, *r_neg_thres; // replay
-    int64_t r_thres_frame_stride;
-    const float *r_noise_rate;
-    const double *r_leak_randn;
-    const long long *r_shot_pos, *r_shot_neg;
-    uint64_t seed, clip_id0;
-    int32_t HW, K, Tb, fpb, blocks_per_clip;
-    V2eParams P;
-};
 
 __device__ __forceinline__ double exp_neg_det(double lam)
 {
