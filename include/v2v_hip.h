@@ -124,6 +124,14 @@ int64_t v2v_esim_voxel_bytes(int in_dtype, int64_t B, int64_t N, int64_t H, int6
 int v2v_synth_clips_hip(void *frames, int dtype, int64_t B, int64_t N, int64_t H, int64_t W, uint64_t seed,
                         uint64_t clip_id0, void *stream);
 
+/* Segmented form: the voxel grids of consecutive image intervals in ONE launch -- what TestH5Dataset.__getitem__
+ * (data/testh5.py:111-119) does with one make_voxel call per image.  seg_offsets = device int64 [n_segments+1]
+ * ascending event offsets (the h5 `event_idx` attributes); grid f is built from events [seg[f], seg[f+1]) with that
+ * interval's own first/last timestamp; out_voxel float64 [n_segments,num_bins,H,W]. */
+int v2v_events_to_voxel_segmented_hip(const double *ts, const int64_t *xs, const int64_t *ys, const double *ps, int64_t n,
+                                      const int64_t *seg_offsets, int64_t n_segments, int mode, int num_bins, int64_t H, int64_t W,
+                                      double *out_voxel, uint64_t *dropped, void *stream);
+
 /* ---- v2e-derived DVS model fused with voxel binning (BASELINE config 3) -----------------------------------
  * Replaces video_to_voxel (data/v2v_core_v2e.py:556-581) around EventEmulator.generate_events (:401-553): lin-log
  * table, intensity-dependent IIR low-pass, leak current, per-pixel random ON/OFF thresholds, Poisson shot noise,

@@ -193,3 +193,25 @@ def test_g12_events_to_voxel_torch(golden):
     np.testing.assert_allclose(bil.cpu().numpy(), g["bilinear"], rtol=1e-5, atol=1e-5)
     disc = voxel.events_to_voxel_torch(*args, 5, sensor_size=(16, 24), temporal_bilinear=False)
     assert np.array_equal(disc.cpu().numpy(), g["discrete"])                      # +-1 sums: exact
+
+
+@pytest.mark.parametrize("interp", [False, True])
+def test_make_voxels_segmented_equals_per_interval_calls(interp):
+    """One launch for all image intervals == one make_voxel per interval (data/testh5.py:111-119), incl. empty ones."""
+    from v2v_amd import voxel
+    g = np.random.default_rng(21)
+    n, h, w = 50_000, 60, 80
+    ts = np.sort(g.uniform(1.0, 1.4, size=n))
+    xs, ys, ps = g.integers(0, w, n), g.integers(0, h, n), g.integers(0, 2, n)
+    idx = np.array([0, 0, 7000, 7001, 20000, 20000, 33333, 50000])           # empty, 1-event and large intervals
+    got = voxel.make_voxels_segmented([ts, xs, ys, ps], idx, h, w, 5, interp)
+    assert got.shape == (7, 5, h, w)
+    for f in range(7):
+        sl = slice(idx[f], idx[f + 1])
+        want = O.make_voxel([ts[sl], xs[sl], ys[sl], ps[sl]], 5, h, w, interp)
+        if interp:
+            np.testing.assert_allclose(got[f], want, rtol=1e-11, atol=1e-11)
+        else:
+            assert np.array_equal(got[f], want)
+    with pytest.raises(ValueError):
+        voxel.make_voxels_segmented([ts, xs, ys, ps], [0, 10, 5], h, w)

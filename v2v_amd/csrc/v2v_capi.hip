@@ -283,19 +283,28 @@ int v2v_v2e_voxel_hip(const void *frames, int in_dtype, int64_t B, int64_t N, in
 int v2v_events_to_voxel_hip(const double *ts, const int64_t *xs, const int64_t *ys, const double *ps, int64_t n, int mode,
                             int num_bins, int64_t H, int64_t W, double *out_voxel, uint64_t *dropped, void *stream)
 {
-    if (!out_voxel || !dropped) return fail(V2V_ERR_NULL, "v2v_events_to_voxel_hip: out_voxel/dropped is NULL");
-    if (n < 0 || H < 1 || W < 1 || num_bins < 1 || num_bins > 255) return fail(V2V_ERR_SHAPE, "need n>=0, H,W>=1, 1<=num_bins<=255");
+    return v2v_events_to_voxel_segmented_hip(ts, xs, ys, ps, n, nullptr, 1, mode, num_bins, H, W, out_voxel, dropped, stream);
+}
+
+int v2v_events_to_voxel_segmented_hip(const double *ts, const int64_t *xs, const int64_t *ys, const double *ps, int64_t n,
+                                      const int64_t *seg_offsets, int64_t n_segments, int mode, int num_bins, int64_t H, int64_t W,
+                                      double *out_voxel, uint64_t *dropped, void *stream)
+{
+    if (!out_voxel || !dropped) return fail(V2V_ERR_NULL, "v2v_events_to_voxel: out_voxel/dropped is NULL");
+    if (n < 0 || H < 1 || W < 1 || num_bins < 1 || num_bins > 255 || n_segments < 1) return fail(V2V_ERR_SHAPE, "need n>=0, H,W>=1, 1<=num_bins<=255, n_segments>=1");
     if (mode < V2V_EV_MAKE_VOXEL_DISCRETE || mode > V2V_EV_BILINEAR) return fail(V2V_ERR_MODE, "unknown event mode %d", mode);
-    if (n > 0 && (!ts || !xs || !ys || !ps)) return fail(V2V_ERR_NULL, "v2v_events_to_voxel_hip: event arrays are NULL");
-    if (!aligned(out_voxel, 8) || !aligned(dropped, 8) || !aligned(ts, 8) || !aligned(xs, 8) || !aligned(ys, 8) || !aligned(ps, 8))
+    if (n > 0 && (!ts || !xs || !ys || !ps)) return fail(V2V_ERR_NULL, "v2v_events_to_voxel: event arrays are NULL");
+    if (!aligned(out_voxel, 8) || !aligned(dropped, 8) || !aligned(ts, 8) || !aligned(xs, 8) || !aligned(ys, 8) || !aligned(ps, 8) ||
+        (seg_offsets && !aligned(seg_offsets, 8)))
         return fail(V2V_ERR_ALIGN, "buffers must be 8-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(out_voxel, 0, sizeof(double) * (size_t)num_bins * H * W, s);   // empty list -> zeros (testh5.py:63-64)
+    hipError_t e = hipMemsetAsync(out_voxel, 0, sizeof(double) * (size_t)n_segments * num_bins * H * W, s);   // empty list -> zeros (testh5.py:63-64)
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(out_voxel)");
     e = hipMemsetAsync(dropped, 0, sizeof(uint64_t), s);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dropped)");
     if (n == 0) return V2V_OK;
     v2v::EventArgs a{};
+    a.seg = seg_offsets; a.n_seg = n_segments;
     a.ts = ts; a.xs = xs; a.ys = ys; a.ps = ps; a.n = n; a.mode = mode; a.Tb = num_bins; a.H = H; a.W = W;
     a.out = out_voxel;
     a.dropped = reinterpret_cast<unsigned long long *>(dropped);

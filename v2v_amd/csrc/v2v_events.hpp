@@ -18,6 +18,8 @@ namespace v2v {
 enum { kEvMakeVoxelDiscrete = 0, kEvMakeVoxelInterp = 1, kEvBilinear = 2 };
 
 struct EventArgs {
+    const int64_t *seg;      // optional [F+1] ascending event offsets: events [seg[f], seg[f+1]) form voxel grid f (nullptr: one grid)
+    int64_t n_seg;
     const double *ts;
     const int64_t *xs, *ys;
     const double *ps;
@@ -34,9 +36,18 @@ __global__ void __launch_bounds__(256) events_to_voxel_kernel(const EventArgs a)
     if (i >= a.n) return;
     const int64_t x = a.xs[i], y = a.ys[i];
     if (x < 0 || x >= a.W || y < 0 || y >= a.H) { atomicAdd(a.dropped, 1ull); return; }
-    const double t0 = a.ts[0], t1 = a.ts[a.n - 1], t = a.ts[i];
-    double *cell = a.out + y * a.W + x;
+    // segmented form (TestH5Dataset.__getitem__, data/testh5.py:111-119: one make_voxel per image interval): the
+    // interval of event i is found by binary search; its first / last timestamps play the role of ts[0] / ts[-1]
+    int64_t lo = 0, hi = a.n, f = 0;
+    if (a.seg) {
+        int64_t l = 0, r = a.n_seg;                                      // seg[l] <= i < seg[r]
+        while (r - l > 1) { const int64_t m = (l + r) >> 1; if (a.seg[m] <= i) l = m; else r = m; }
+        f = l; lo = a.seg[l]; hi = a.seg[l + 1];
+        if (i < lo || i >= hi) return;                                   // event outside every interval
+    }
+    const double t0 = a.ts[lo], t1 = a.ts[hi - 1], t = a.ts[i];
     const int64_t plane = a.H * a.W;
+    double *cell = a.out + f * a.Tb * plane + y * a.W + x;
     if (a.mode == kEvBilinear) {
         // event_utils.py:713-719: dt = ts[-1]-ts[0]; t_norm = (ts-ts[0])/dt*(B-1); w_b = max(0, 1-|t_norm-b|)
         const double dt = t1 - t0;

@@ -103,3 +103,35 @@ def events_to_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(180, 240)
     if n and int(dropped.item()) != 0:
         raise IndexError(f"{int(dropped.item())} event(s) outside the sensor / bin range")
     return out
+
+
+def make_voxels_segmented(evs, event_idx, H, W, num_bins=5, interpolate_bins=False, device="cuda"):
+    """All voxel grids of a sequence in ONE launch: grid f = make_voxel(events[event_idx[f]:event_idx[f+1]]), exactly
+    what TestH5Dataset.__getitem__ (data/testh5.py:111-119) builds with one make_voxel call per image.
+    evs = [ts, xs, ys, ps] for the whole range, event_idx = ascending offsets [F+1].  Returns [F,num_bins,H,W] float64."""
+    _lib.require_gpu()
+    ts, xs, ys, ps = evs
+    is_np = not isinstance(ts, torch.Tensor)
+    if isinstance(ts, torch.Tensor) and ts.is_cuda:
+        device = ts.device
+    ts_d, xs_d, ys_d, ps_d = _dev(ts, torch.float64, device), _dev(xs, torch.int64, device), _dev(ys, torch.int64, device), \
+        _dev(ps, torch.float64, device)
+    n = ts_d.numel()
+    seg_h = np.asarray(event_idx.cpu() if isinstance(event_idx, torch.Tensor) else event_idx, dtype=np.int64).reshape(-1)
+    if seg_h.size < 2 or np.any(np.diff(seg_h) < 0) or seg_h[0] < 0 or seg_h[-1] > n:
+        raise ValueError("event_idx must be ascending offsets within the event arrays")
+    f = seg_h.size - 1
+    seg = torch.as_tensor(seg_h, device=ts_d.device)
+    out = torch.empty((f, num_bins, H, W), dtype=torch.float64, device=ts_d.device)
+    dropped = torch.empty((1,), dtype=torch.int64, device=ts_d.device)
+    mode = _lib.EV_MAKE_VOXEL_INTERP if interpolate_bins else _lib.EV_MAKE_VOXEL_DISCRETE
+    with torch.cuda.device(out.device):
+        rc = _lib.lib().v2v_events_to_voxel_segmented_hip(
+            C.c_void_p(ts_d.data_ptr()) if n else None, C.c_void_p(xs_d.data_ptr()) if n else None,
+            C.c_void_p(ys_d.data_ptr()) if n else None, C.c_void_p(ps_d.data_ptr()) if n else None, n,
+            C.c_void_p(seg.data_ptr()), f, mode, num_bins, H, W, C.c_void_p(out.data_ptr()), C.c_void_p(dropped.data_ptr()),
+            _lib.stream_ptr())
+    _lib.check(rc)
+    if n and int(dropped.item()) != 0:
+        raise IndexError(f"{int(dropped.item())} event(s) outside the {H}x{W} sensor / {num_bins} bins")
+    return out.cpu().numpy() if is_np else out
