@@ -93,3 +93,24 @@ def test_wrappers_fail_loudly_without_gpu(L):
         esim.esim_voxel_batch(torch.zeros((1, 6, 4, 4), dtype=torch.uint8), [0.2, 0.2, 0, 0, 0])
     with pytest.raises(RuntimeError):
         esim.synth_clips(1, 2, 4, 4)
+
+
+def test_binding_constants_match_header(L):
+    """The ctypes binding's enum values are the header's (a maintainer's stub would be generated from the same header)."""
+    hdr = open(os.path.join(ROOT, "include", "v2v_hip.h")).read()
+    vals = {k: int(v, 0) for k, v in re.findall(r"\b(V2V_[A-Z0-9_]+)\s*=\s*(-?\d+|0x[0-9a-fA-F]+)", hdr)}
+    vals.update({k: int(v.rstrip("u"), 0) for k, v in re.findall(r"#define\s+(V2V_[A-Z0-9_]+)\s+(0x[0-9a-fA-F]+u?|\d+)\b", hdr)})
+    pairs = {"V2V_U8": L.U8, "V2V_F32": L.F32, "V2V_F64": L.F64, "V2V_RNG_NONE": L.RNG_NONE, "V2V_RNG_PHILOX": L.RNG_PHILOX,
+             "V2V_RNG_REPLAY": L.RNG_REPLAY, "V2V_RNG_PHILOX_FAST": L.RNG_PHILOX_FAST, "V2V_BIN_SUM": L.BIN_SUM,
+             "V2V_BIN_BILINEAR": L.BIN_BILINEAR, "V2V_FLAG_NOISE_EXTERNAL": L.FLAG_NOISE_EXTERNAL, "V2V_FLAG_NO_NOISE": L.FLAG_NO_NOISE,
+             "V2V_OK": L.OK, "V2V_ERR_NULL": L.ERR_NULL, "V2V_ERR_SHAPE": L.ERR_SHAPE, "V2V_ERR_BINS": L.ERR_BINS,
+             "V2V_ERR_DTYPE": L.ERR_DTYPE, "V2V_ERR_MODE": L.ERR_MODE, "V2V_ERR_ALIGN": L.ERR_ALIGN, "V2V_ERR_HIP": L.ERR_HIP,
+             "V2V_ERR_PARAM": L.ERR_PARAM, "V2V_ABI_VERSION": L.ABI_VERSION, "V2V_EV_MAKE_VOXEL_DISCRETE": L.EV_MAKE_VOXEL_DISCRETE,
+             "V2V_EV_MAKE_VOXEL_INTERP": L.EV_MAKE_VOXEL_INTERP, "V2V_EV_BILINEAR": L.EV_BILINEAR,
+             "V2V_V2E_PN_RELATED": L.V2E_MODELS["pn_related"], "V2V_V2E_SPATIAL_INDEPENDENT": L.V2E_MODELS["spatial_independent"],
+             "V2V_V2E_SPATIAL_TEMPORAL_INDEPENDENT": L.V2E_MODELS["spatial_temporal_independent"]}
+    for name, py in pairs.items():
+        assert name in vals, name
+        assert vals[name] == py, (name, vals[name], py)
+    import ctypes as C
+    assert C.sizeof(L.V2EParams) == 8 * 12 + 8 and C.sizeof(L.EsimReplay) == 32 and C.sizeof(L.V2EReplay) == 56

@@ -70,6 +70,8 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
         pa = np.asarray(params, dtype=np.float64).reshape(-1, 5)
         if validate and not (np.all(pa[:, 0] > 0) and np.all(pa[:, 1] > 0)):
             raise ValueError("pos_thres and neg_thres must be > 0")
+        if validate and (np.any(pa[:, 0] < 1e-9) or np.any(pa[:, 1] < 1e-9)):
+            raise ValueError("thresholds below 1e-9 are outside the exact floor-divide domain (|potential|/C must stay < 2^40)")
         if no_noise is None:
             no_noise = bool(np.all(pa[:, 2] == 0) and np.all(pa[:, 3] <= 0))
     no_noise = bool(no_noise) and not put_noise_external and rng_mode != "replay"
