@@ -44,6 +44,10 @@ WORKLOADS = {
     # 256x256, flip) -> fused sim + sum binning.  41 frames so that (N-1) % 5 == 0 as the reference asserts.
     "cfg4_pipeline_720p_to_256_41f_sum5": dict(model="pipeline", b=24, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1,
                                                params=[0.2, 0.3, 0.05, 5e-4, 1.0], src_hw=(720, 1280)),
+    # BASELINE config 5 (per GPU): config 4's pipeline feeding a random-init E2VID-shaped recurrent UNet (bf16 autocast,
+    # stock PyTorch ops, tools/e2vid_consumer.py) -- end-to-end "dataloader -> model forward" throughput.
+    "cfg5_pipeline_plus_e2vid_bf16": dict(model="pipeline", b=8, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1,
+                                          params=[0.2, 0.3, 0.05, 5e-4, 1.0], src_hw=(720, 1280), consumer=True),
     "train_u8_12x201x128x128_sum5": dict(model="esim", b=12, n=201, h=128, w=128, dtype="uint8", bin="sum", tb=5, fpb=1,
                                          params=[0.2, 0.2, 0.05, 5e-4, 1.0]),
     "cfg1_plumbing_u8_1x8x128x128": dict(model="esim", b=1, n=8, h=128, w=128, dtype="uint8", bin="sum", tb=7, fpb=1,
@@ -155,12 +159,21 @@ def main():
         ptensor = torch.tensor(params, dtype=torch.float64, device=dev)
         kernel_name = "frontend_kernel + esim_voxel_kernel"
         alg_bytes += src_bytes + b * n * h * w                 # source crop regions read once + uint8 clips written once
-        gray_buf = frames
+        consumer = None
+        if wl.get("consumer"):
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from e2vid_consumer import E2VIDShapedConsumer, forward_sequence
+            torch.manual_seed(0)
+            consumer = E2VIDShapedConsumer(num_bins=tb).to(dev).eval()
+            kernel_name += " + E2VID-shaped UNet forward (bf16 autocast, stock PyTorch)"
 
         def step():
             gray = frontend.prepare_clips_batch(raw, table_d, idx_d, h, "gray", validate=False)[1]
             esim.esim_voxel_batch(gray, ptensor, bin_mode=bin_mode, num_bins=tb, frames_per_bin=fpb, rng_mode="philox",
                                   seed=20240001, clip_id0=clip_id0, out=out, validate=False, no_noise=False)
+            if consumer is not None:
+                with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                    forward_sequence(consumer, out)
     elif wl["model"] == "esim":
         ptensor = torch.tensor(params, dtype=torch.float64, device=dev)
         kernel_name = "esim_voxel_kernel"

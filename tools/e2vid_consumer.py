@@ -1,0 +1,74 @@
+"""Load generator for BASELINE config 5: a random-init recurrent UNet with the SHAPE of the reference's E2VIDRecurrent
+(model/model.py:216-223 -> model/unet.py:252-310 with the kwargs of config/train_v2v_e2vid_10k.yaml:21-30: 5 bins,
+3 encoders, base 32 channels, ConvLSTM, 2 residual blocks, sum skips, bilinear-upsample decoders, 1x1 prediction).
+Stock PyTorch-ROCm ops only -- it is NOT part of the accelerated path or of the product package (SURVEY: model families
+are out of scope); bench.py uses it to measure how fast the fused simulator can feed a consumer.
+Parameter count matches the reference model: 10,710,401.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class _ConvLSTM(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.gates = nn.Conv2d(2 * ch, 4 * ch, 3, padding=1)
+
+    def forward(self, x, state):
+        if state is None:
+            state = (torch.zeros_like(x), torch.zeros_like(x))
+        h, c = state
+        i, r, o, g = self.gates(torch.cat([x, h], dim=1)).chunk(4, dim=1)
+        c = torch.sigmoid(r) * c + torch.sigmoid(i) * torch.tanh(g)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        return h, (h, c)
+
+
+class _Res(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.a, self.b = nn.Conv2d(ch, ch, 3, padding=1), nn.Conv2d(ch, ch, 3, padding=1)
+
+    def forward(self, x):
+        return F.relu(self.b(F.relu(self.a(x))) + x)
+
+
+class E2VIDShapedConsumer(nn.Module):
+    def __init__(self, num_bins=5, base=32, num_encoders=3, num_res=2):
+        super().__init__()
+        self.head = nn.Conv2d(num_bins, base, 5, padding=2)
+        chans = [base * 2 ** i for i in range(num_encoders + 1)]
+        self.enc = nn.ModuleList(nn.Conv2d(a, b, 5, stride=2, padding=2) for a, b in zip(chans[:-1], chans[1:]))
+        self.rec = nn.ModuleList(_ConvLSTM(b) for b in chans[1:])
+        self.res = nn.ModuleList(_Res(chans[-1]) for _ in range(num_res))
+        self.dec = nn.ModuleList(nn.Conv2d(b, a, 5, padding=2) for a, b in reversed(list(zip(chans[:-1], chans[1:]))))
+        self.pred = nn.Conv2d(base, 1, 1)
+        self.states = [None] * num_encoders
+
+    def reset_states(self):
+        self.states = [None] * len(self.enc)
+
+    def forward(self, x):
+        x = F.relu(self.head(x))
+        head, blocks = x, []
+        for i, (conv, rec) in enumerate(zip(self.enc, self.rec)):
+            x, self.states[i] = rec(F.relu(conv(x)), self.states[i])
+            blocks.append(x)
+        for r in self.res:
+            x = r(x)
+        for i, conv in enumerate(self.dec):
+            x = x + blocks[len(blocks) - 1 - i]                                        # skip_type: sum
+            x = F.relu(conv(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)))
+        return self.pred(x + head)
+
+
+def forward_sequence(model, events):
+    """events [B,T,C,H,W] -> list of T predictions (the time loop of model/train_utils.py:339-345)."""
+    model.reset_states()
+    return [model(events[:, t]) for t in range(events.shape[1])]
+
+
+if __name__ == "__main__":
+    m = E2VIDShapedConsumer()
+    print(sum(p.numel() for p in m.parameters()))
