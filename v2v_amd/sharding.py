@@ -47,7 +47,11 @@ def env_rank_world():
 
 
 def init_process_group(backend: str | None = None, device: torch.device | None = None):
-    """One process per GPU, launched by torch.distributed.run; returns the module or None for world size 1."""
+    """One process per GPU, launched by torch.distributed.run; returns the module or None for world size 1.
+
+    The data path never communicates, so the process group only serves the barrier and the max-over-ranks of the
+    timing: if RCCL cannot be brought up (driver/IPC problems) the group silently falls back to gloo rather than
+    losing the measurement."""
     _, _, world = env_rank_world()
     if world <= 1:
         return None
@@ -55,18 +59,33 @@ def init_process_group(backend: str | None = None, device: torch.device | None =
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if not dist.is_initialized():
-        if backend == "nccl" and device is not None:
-            dist.init_process_group(backend=backend, device_id=device)
-        else:
-            dist.init_process_group(backend=backend)
+    if dist.is_initialized():
+        return dist
+    if backend == "nccl":
+        try:
+            try:
+                dist.init_process_group(backend="nccl", device_id=device)
+            except TypeError:                      # older torch: no device_id argument
+                dist.init_process_group(backend="nccl")
+            probe = torch.zeros(1, device=device if device is not None else "cuda")
+            dist.all_reduce(probe)                 # forces communicator creation now, not inside the timed region
+            torch.cuda.synchronize()
+            return dist
+        except Exception as exc:                   # noqa: BLE001 - any RCCL bring-up failure
+            print(f"[v2v_amd.sharding] RCCL unavailable ({type(exc).__name__}: {exc}); using gloo for the barrier", flush=True)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+    dist.init_process_group(backend="gloo")
     return dist
 
 
 def barrier(dist, local_rank: int = 0):
     if dist is not None:
         if dist.get_backend() == "nccl":
-            dist.barrier(device_ids=[local_rank])
+            try:
+                dist.barrier(device_ids=[local_rank])
+            except TypeError:
+                dist.barrier()
         else:
             dist.barrier()
     if torch.cuda.is_available():
