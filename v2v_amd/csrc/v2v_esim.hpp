@@ -5,17 +5,22 @@
 //   data/v2v_datasets.py:399-400  reshape(L,Tb,fpb,H,W).sum(2)   (V2V_BIN_SUM)
 //   utils/event_utils.py:692-728  temporal-bilinear voxel bins    (V2V_BIN_BILINEAR, pseudo-events at ts=k)
 //
-// Mapping to the hardware (memory-bound: pointwise in space, sequential scan in time, zero reuse):
+// Mapping to the hardware (HBM-bound on paper: pointwise in space, sequential scan in time, zero reuse; measured
+// VALU-bound at ~21 vector instructions per pixel and frame pair -- see DESIGN.md section 4.1):
 //   * one work-item owns VEC=4 horizontally adjacent pixels of one clip and streams the clip's N frames
 //     through registers: per-pixel state (float64 potential, previous log value, hot-pixel noise, bin
 //     accumulators) never leaves the register file, so HBM traffic is exactly "read every input byte
 //     once, write every voxel byte once".
-//   * a wave reads one contiguous 1 KiB segment per frame (global_load_dwordx4 per lane, fp32 input),
-//     frames are software-prefetched U at a time into a register ping-pong so ~2U KiB per wave are in flight.
+//   * a wave reads one contiguous 1 KiB segment per frame (global_load_dwordx4 per lane, fp32 input); a register
+//     ring of kDepth frames is reloaded right after each slot is consumed (unconditional, clamped loads so the
+//     compiler can count them: s_waitcnt vmcnt(kDepth-1)), keeping ~kDepth KiB per wave in flight.
 //   * the 256-entry log-intensity table (NumPy's bits, golden G1) lives in LDS; integer-valued input
 //     costs one ds_read per sample instead of a float64 pow+log.
-//   * np.floor_divide's exact result for a >= b > 0 is the true floor of the real quotient; it is
-//     obtained without a division: q = floor(a * (1/b)), one exact fma residual, and a +-1 correction.
+//   * np.floor_divide's exact result for a >= 0, b > 0 is the true floor of the real quotient; it is obtained
+//     without a division and without a per-pixel branch: q = floor(a * inv_low(b)), one sign-exact fma residual,
+//     and a rare (wave-level) +1 fix-up; q == 0 exactly when a < b, so the reference's where() masks fall out.
+//   * symmetric thresholds (C+ == C-, wave-uniform per clip) take a loop specialised without the per-lane
+//     threshold selection; noise-free launches (V2V_FLAG_NO_NOISE) take kernels without the noise adds.
 //   * per-clip ON/OFF totals: lane-local counters -> wave reduction -> one 64-bit atomic per wave.
 // No MFMA (nothing here is a contraction), no cross-workgroup communication, no collectives.
 #pragma once
@@ -25,8 +30,6 @@
 #include "v2v_common.hpp"
 
 namespace v2v {
-
-
 
 // Log-intensity tables in device memory (initialised with NumPy's bits, golden G1; re-pinnable through
 // v2v_lut_set).  Each workgroup copies the one it needs into LDS.
