@@ -54,3 +54,50 @@ def test_random_esim_case(oracle_c, luts, case):
         tail = E.esim_voxel_batch(torch.from_numpy(video[cut:]).cuda(), params[cut:], out_dtype=torch.float64,
                                   **dict(kw, clip_id0=cid0 + cut))
         assert torch.equal(tail, got[cut:])
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_random_v2e_case(oracle_c, luts, case):
+    """v2e model, native RNG: HIP vs the scalar C oracle over random shapes / models / parameter combinations."""
+    from v2v_amd import v2e
+    g = np.random.default_rng(5000 + case)
+    b, h, w = int(g.integers(1, 4)), int(g.integers(2, 30)), int(g.integers(2, 50))
+    if g.random() < 0.5:
+        w = (w + 3) // 4 * 4
+    dt = np.uint8 if g.random() < 0.5 else np.float32
+    bilinear = g.random() < 0.4
+    nb = int(g.integers(1, 6))
+    fpb = 1 if bilinear else int(g.integers(1, 3))
+    k = int(g.integers(2, 12)) if bilinear else nb * fpb * int(g.integers(1, 3))
+    video = np.stack([O.synth_clip_s1(k + 1, h, w, seed=int(g.integers(1 << 30)), dtype=dt) for _ in range(b)])
+    model = list(O.V2E_MODELS)[int(g.integers(0, 3))]
+    args = [float(g.choice([24, 30, 29.97])), model, float(g.uniform(0.2, 0.8)), float(g.uniform(0, 0.15)), float(g.uniform(-0.1, 0.1)),
+            float(g.uniform(0, 0.15)), float(g.choice([0, 30, 100])), float(g.choice([0, 0.1, 1.0])), float(g.choice([0, 1 / 240, 1 / 60])),
+            float(g.choice([0, 5.0, 20.0])), float(g.uniform(0, 0.3)), float(g.uniform(0, 0.3))]
+    wrap = bool(g.random() < 0.5)
+    seed, cid0 = int(g.integers(1 << 62)), int(g.integers(1 << 20))
+    bm = oracle_c.BIN_BILINEAR if bilinear else oracle_c.BIN_SUM
+    want, totals = oracle_c.v2e_voxel(video, oracle_c.v2e_params(*args, uint8_wrap=wrap), luts, seed=seed, clip_id0=cid0,
+                                      bin_mode=bm, num_bins=nb, frames_per_bin=fpb)
+    counts = torch.zeros((b, 2), dtype=torch.int64, device="cuda")
+    got = v2e.v2e_voxel_batch(torch.from_numpy(video).cuda(), v2e.make_params(*args, uint8_wrap=wrap),
+                              bin_mode="bilinear" if bilinear else "sum", num_bins=nb, frames_per_bin=fpb, seed=seed, clip_id0=cid0,
+                              out_dtype=torch.float64, counts=counts)
+    assert np.array_equal(got.cpu().numpy(), want), (args, dt, h, w)
+    assert np.array_equal(counts.cpu().numpy(), totals)
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_random_event_lists(case):
+    from v2v_amd import voxel
+    g = np.random.default_rng(9000 + case)
+    n, h, w, nb = int(g.integers(1, 30000)), int(g.integers(1, 100)), int(g.integers(1, 100)), int(g.integers(1, 9))
+    ts = np.sort(g.uniform(0.0, g.uniform(1e-3, 2.0), size=n)) + g.uniform(0, 100)
+    xs, ys, ps = g.integers(0, w, n), g.integers(0, h, n), g.integers(0, 2, n)
+    assert np.array_equal(voxel.make_voxel([ts, xs, ys, ps], h, w, nb, False), O.make_voxel([ts, xs, ys, ps], nb, h, w, False))
+    np.testing.assert_allclose(voxel.make_voxel([ts, xs, ys, ps], h, w, nb, True), O.make_voxel([ts, xs, ys, ps], nb, h, w, True),
+                               rtol=1e-11, atol=1e-11)
+    if n > 1 and ts[-1] > ts[0] and nb > 1:
+        pf = (ps * 2 - 1).astype(np.float64)
+        np.testing.assert_allclose(voxel.events_to_voxel(xs, ys, ts, pf, nb, (h, w)), O.events_to_voxel(xs, ys, ts, pf, nb, (h, w)),
+                                   rtol=1e-11, atol=1e-11)
