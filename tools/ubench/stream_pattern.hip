@@ -1,0 +1,80 @@
+// stream_pattern.hip -- what HBM rate does the fused kernel's ACCESS PATTERN allow, with the arithmetic removed?
+// Same mapping as esim_voxel_kernel (one work-item = 4 adjacent pixels of one clip, N frames streamed at stride H*W,
+// 5 output planes of 16 B per lane), but each sample costs one add.  Compared with a linear read of the same bytes.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+constexpr int B = 256, N = 32, H = 256, W = 256, HW = H * W, TB = 5;
+
+template <int DEPTH, bool NT, int REMAP = 0>
+__global__ void __launch_bounds__(256) pattern_kernel(const float *__restrict__ in, float *__restrict__ out)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int blocks_per_clip = HW / 1024;
+    int bid = blockIdx.x;
+    if (REMAP == 1) {            // blocks b, b+8, b+16.. share an XCD: give each XCD a contiguous range of chunks
+        const int per_xcd = gridDim.x / 8;
+        bid = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    } else if (REMAP == 2) {     // same, but contiguous within a clip only (8 consecutive-chunk streams per clip)
+        const int g = blockIdx.x / blocks_per_clip, r = blockIdx.x % blocks_per_clip;
+        bid = g * blocks_per_clip + (r % 8) * (blocks_per_clip / 8) + r / 8;
+    }
+    const int clip = bid / blocks_per_clip, blk = bid % blocks_per_clip;
+    const int p0 = (blk * 256 + threadIdx.x) * 4;
+    const float *base = in + (size_t)clip * N * HW + p0;
+    f32x4 acc = {0, 0, 0, 0};
+    f32x4 ring[DEPTH];
+    auto ld = [&](int f) { const f32x4 *p = reinterpret_cast<const f32x4 *>(base + (size_t)f * HW); return NT ? __builtin_nontemporal_load(p) : *p; };
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) ring[u] = ld(u);
+    for (int f0 = 0; f0 < N; f0 += DEPTH) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            acc += ring[u];
+            const int fn = f0 + u + DEPTH;
+            ring[u] = ld(fn < N ? fn : N - 1);
+        }
+    }
+    for (int b = 0; b < TB; ++b)
+        *reinterpret_cast<f32x4 *>(out + ((size_t)clip * TB + b) * HW + p0) = acc * (float)(b + 1);
+}
+
+__global__ void __launch_bounds__(256) linear_kernel(const float *__restrict__ in, float *__restrict__ out, size_t n4_in, size_t n4_out)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acc = {0, 0, 0, 0};
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4_in; i += stride) acc += reinterpret_cast<const f32x4 *>(in)[i];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4_out; i += stride) reinterpret_cast<f32x4 *>(out)[i] = acc;
+}
+
+int main()
+{
+    const size_t n_in = (size_t)B * N * HW, n_out = (size_t)B * TB * HW;
+    float *in, *out;
+    hipMalloc(&in, n_in * 4); hipMalloc(&out, n_out * 4);
+    hipMemset(in, 0, n_in * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const double bytes = (double)(n_in + n_out) * 4;
+    auto time = [&](auto launch, const char *name) {
+        for (int i = 0; i < 3; ++i) launch();
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int i = 0; i < 20; ++i) launch();
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 20;
+        printf("%-34s %.4f ms  %.0f GB/s\n", name, ms, bytes / ms / 1e6);
+    };
+    const int grid = B * (HW / 1024);
+    time([&] { pattern_kernel<4, true><<<grid, 256>>>(in, out); }, "esim pattern, depth 4, nt loads");
+    time([&] { pattern_kernel<4, false><<<grid, 256>>>(in, out); }, "esim pattern, depth 4, plain loads");
+    time([&] { pattern_kernel<2, true><<<grid, 256>>>(in, out); }, "esim pattern, depth 2, nt loads");
+    time([&] { pattern_kernel<8, true><<<grid, 256>>>(in, out); }, "esim pattern, depth 8, nt loads");
+    time([&] { pattern_kernel<4, true, 1><<<grid, 256>>>(in, out); }, "esim pattern, XCD-contiguous remap");
+    time([&] { pattern_kernel<4, true, 2><<<grid, 256>>>(in, out); }, "esim pattern, per-clip XCD remap");
+    time([&] { pattern_kernel<8, true, 1><<<grid, 256>>>(in, out); }, "depth 8, XCD-contiguous remap");
+    time([&] { linear_kernel<<<256 * 8, 256>>>(in, out, n_in / 4, n_out / 4); }, "linear read + write, 2048 blocks");
+    time([&] { linear_kernel<<<256 * 32, 256>>>(in, out, n_in / 4, n_out / 4); }, "linear read + write, 8192 blocks");
+    return 0;
+}
