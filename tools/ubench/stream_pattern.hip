@@ -49,6 +49,51 @@ __global__ void __launch_bounds__(256) linear_kernel(const float *__restrict__ i
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4_out; i += stride) reinterpret_cast<f32x4 *>(out)[i] = acc;
 }
 
+// 8 pixels per work-item: each lane reads 32 contiguous bytes per frame (wave = 2 KiB contiguous)
+template <int DEPTH>
+__global__ void __launch_bounds__(256) pattern8_kernel(const float *__restrict__ in, float *__restrict__ out)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int blocks_per_clip = HW / 2048;
+    const int clip = blockIdx.x / blocks_per_clip, blk = blockIdx.x % blocks_per_clip;
+    const int p0 = (blk * 256 + threadIdx.x) * 8;
+    const float *base = in + (size_t)clip * N * HW + p0;
+    f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+    f32x4 r0[DEPTH], r1[DEPTH];
+    auto ld = [&](int f, int h) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + (size_t)f * HW) + h); };
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) { r0[u] = ld(u, 0); r1[u] = ld(u, 1); }
+    for (int f0 = 0; f0 < N; f0 += DEPTH) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            a0 += r0[u]; a1 += r1[u];
+            const int fn = f0 + u + DEPTH < N ? f0 + u + DEPTH : N - 1;
+            r0[u] = ld(fn, 0); r1[u] = ld(fn, 1);
+        }
+    }
+    for (int b = 0; b < TB; ++b) {
+        f32x4 *o = reinterpret_cast<f32x4 *>(out + ((size_t)clip * TB + b) * HW + p0);
+        o[0] = a0 * (float)(b + 1); o[1] = a1 * (float)(b + 1);
+    }
+}
+
+// linear read with 4 independent 16-byte loads in flight per lane
+__global__ void __launch_bounds__(256) linear4_kernel(const float *__restrict__ in, float *__restrict__ out, size_t n4_in, size_t n4_out)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+    const size_t stride = (size_t)gridDim.x * 256;
+    const f32x4 *p = reinterpret_cast<const f32x4 *>(in);
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4_in; i += 4 * stride) {
+        a0 += __builtin_nontemporal_load(p + i); a1 += __builtin_nontemporal_load(p + i + stride);
+        a2 += __builtin_nontemporal_load(p + i + 2 * stride); a3 += __builtin_nontemporal_load(p + i + 3 * stride);
+    }
+    for (; i < n4_in; i += stride) a0 += p[i];
+    a0 += a1 + a2 + a3;
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n4_out; j += stride) reinterpret_cast<f32x4 *>(out)[j] = a0;
+}
+
 int main()
 {
     const size_t n_in = (size_t)B * N * HW, n_out = (size_t)B * TB * HW;
@@ -74,6 +119,12 @@ int main()
     time([&] { pattern_kernel<4, true, 1><<<grid, 256>>>(in, out); }, "esim pattern, XCD-contiguous remap");
     time([&] { pattern_kernel<4, true, 2><<<grid, 256>>>(in, out); }, "esim pattern, per-clip XCD remap");
     time([&] { pattern_kernel<8, true, 1><<<grid, 256>>>(in, out); }, "depth 8, XCD-contiguous remap");
+    time([&] { pattern8_kernel<2><<<B * (HW / 2048), 256>>>(in, out); }, "8 px per item (2 KiB per wave), depth 2");
+    time([&] { pattern8_kernel<4><<<B * (HW / 2048), 256>>>(in, out); }, "8 px per item (2 KiB per wave), depth 4");
+    for (int g : {1024, 2048, 4096}) {
+        char nm[64]; snprintf(nm, sizeof nm, "linear x4 unrolled nt, %d blocks", g);
+        time([&] { linear4_kernel<<<g, 256>>>(in, out, n_in / 4, n_out / 4); }, nm);
+    }
     time([&] { linear_kernel<<<256 * 8, 256>>>(in, out, n_in / 4, n_out / 4); }, "linear read + write, 2048 blocks");
     time([&] { linear_kernel<<<256 * 32, 256>>>(in, out, n_in / 4, n_out / 4); }, "linear read + write, 8192 blocks");
     return 0;
