@@ -94,6 +94,26 @@ __global__ void __launch_bounds__(256) linear4_kernel(const float *__restrict__ 
     for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n4_out; j += stride) reinterpret_cast<f32x4 *>(out)[j] = a0;
 }
 
+// reference ceilings: float4 copy (1:1 read:write, the guide's 6.29 TB/s figure) and a read-only sweep
+__global__ void __launch_bounds__(256) copy_kernel(const float *__restrict__ in, float *__restrict__ out, size_t n4)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(in) + i), reinterpret_cast<f32x4 *>(out) + i);
+}
+__global__ void __launch_bounds__(256) read_kernel(const float *__restrict__ in, float *__restrict__ out, size_t n4)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 a0 = {0, 0, 0, 0}, a1 = a0;
+    const size_t stride = (size_t)gridDim.x * 256;
+    const f32x4 *p = reinterpret_cast<const f32x4 *>(in);
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) { a0 += __builtin_nontemporal_load(p + i); a1 += __builtin_nontemporal_load(p + i + stride); }
+    a0 += a1;
+    if (a0.x == 12345.0f) reinterpret_cast<f32x4 *>(out)[threadIdx.x] = a0;
+}
+
 int main()
 {
     const size_t n_in = (size_t)B * N * HW, n_out = (size_t)B * TB * HW;
@@ -127,5 +147,22 @@ int main()
     }
     time([&] { linear_kernel<<<256 * 8, 256>>>(in, out, n_in / 4, n_out / 4); }, "linear read + write, 2048 blocks");
     time([&] { linear_kernel<<<256 * 32, 256>>>(in, out, n_in / 4, n_out / 4); }, "linear read + write, 8192 blocks");
+    {   // ceilings at other read:write mixes (bytes counted = read + written)
+        const size_t n4 = n_in / 8;                 // half of the input buffer copied into the other half: 1.07 GB each way
+        auto time2 = [&](auto launch, const char *name, double by) {
+            for (int i = 0; i < 3; ++i) launch();
+            hipDeviceSynchronize();
+            hipEventRecord(e0);
+            for (int i = 0; i < 20; ++i) launch();
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 20;
+            printf("%-34s %.4f ms  %.0f GB/s\n", name, ms, by / ms / 1e6);
+        };
+        for (int g : {2048, 8192})
+            time2([&] { copy_kernel<<<g, 256>>>(in, in + n4 * 4, n4); }, g == 2048 ? "float4 copy 1:1, 2048 blocks" : "float4 copy 1:1, 8192 blocks", 2.0 * n4 * 16);
+        time2([&] { hipMemcpyAsync(in + n4 * 4, in, n4 * 16, hipMemcpyDeviceToDevice, 0); }, "hipMemcpy D2D 1:1", 2.0 * n4 * 16);
+        for (int g : {2048, 8192})
+            time2([&] { read_kernel<<<g, 256>>>(in, out, n_in / 4); }, g == 2048 ? "read-only sweep, 2048 blocks" : "read-only sweep, 8192 blocks", (double)n_in * 4);
+    }
     return 0;
 }

@@ -1,5 +1,5 @@
 // v2v_args.hpp -- kernel argument structs, shared enums and the launcher entry points of the three translation units
-// (v2v_esim_u8_tu.hip, v2v_esim_f32_tu.hip, v2v_v2e_tu.hip, v2v_capi.hip).  The heavy kernels live in their own TUs so they build in parallel.
+// (v2v_esim_{u8,f32}_tu.hip, v2v_v2e_tu.hip, v2v_v2e_spec_{u8,f32}_tu.hip, v2v_capi.hip).  The heavy kernels live in their own TUs so they build in parallel.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -39,6 +39,7 @@ struct V2eArgs {
     void *out;
     unsigned long long *counts;
     long long *shot_sums;                    // [B,K,2] fixed-point sums (native shot noise) or nullptr
+    const float *lut;                        // 256-entry lin_log table in device memory (set by launch_v2e)
     const double *r_pos_thres, *r_neg_thres; // replay
     int64_t r_thres_frame_stride;
     const float *r_noise_rate;
@@ -54,6 +55,10 @@ hipError_t launch_esim_u8(bool vec4, int bin, int rng, bool noise, bool out64, c
 hipError_t launch_esim_f32(bool vec4, int bin, int rng, bool noise, bool out64, const EsimArgs &a, dim3 grid, size_t lds, hipStream_t s);
 hipError_t launch_v2e(bool in_u8, bool vec4, int bin, int rng, bool out64, bool presum, const V2eArgs &a, dim3 grid, size_t lds,
                       hipStream_t s);
+// specialised v2e instances (v2v_v2e_spec_{u8,f32}_tu.hip): 4 pixels per work-item, float32 grid, device RNG, static
+// thresholds, no refractory period; `feat` = compile-time feature mask {1 low-pass, 2 leak, 4 shot noise}
+hipError_t launch_v2e_spec_u8(int bin, int feat, const V2eArgs &a, dim3 grid, size_t lds, hipStream_t s);
+hipError_t launch_v2e_spec_f32(int bin, int feat, const V2eArgs &a, dim3 grid, size_t lds, hipStream_t s);
 // log-intensity tables: which = 0 ESIM float64, 1 ESIM float32 (the esim TUs), 2 v2e float32 (v2e TU).
 // to_device: copy host -> device symbol; else device symbol -> host (falls back to the built-in table without a device).
 hipError_t lut_esim64_copy(void *host, bool to_device);

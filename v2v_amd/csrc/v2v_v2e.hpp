@@ -19,12 +19,9 @@
 #include <stdint.h>
 
 #include "v2v_common.hpp"
-#include "v2v_luts.inc"
 
 namespace v2v {
 
-__device__ float g_lut_v2e32[256] = {V2V_LUT_V2E32_VALUES};
-static const float kLutV2e32[256] = {V2V_LUT_V2E32_VALUES};
 
 enum { kV2ePnRelated = 0, kV2eSpatialIndependent = 1, kV2eSpatialTemporalIndependent = 2 };
 enum : uint32_t { kV2eFThresA = 0, kV2eFThresB = 1, kV2eFNoiseRate = 2, kV2eFFrame0 = 16, kV2eFStride = 8 };
@@ -76,6 +73,28 @@ __device__ __forceinline__ float poisson_inv_f32(float lam, float u)
     return x;
 }
 
+// The same inversion split for the kernel: counts 0..2 without a branch or a division (lam/1 and lam/2 are exact as
+// lam and lam*0.5), and a tail loop that a wave enters only when some lane needs a count >= 3 (P ~ lam^3/6).
+struct PoissonHead { float x, p2, s2; bool more; };
+__device__ __forceinline__ PoissonHead poisson_head_f32(float lam, float u)
+{
+    const float p0 = expf_det(-lam);
+    const float p1 = p0 * lam, s1 = p0 + p1;
+    const float p2 = p1 * (lam * 0.5f), s2 = s1 + p2;
+    const bool c1 = (lam > 0.0f) && (u > p0), c2 = c1 && (u > s1);
+    PoissonHead h;
+    h.x = (c1 ? 1.0f : 0.0f) + (c2 ? 1.0f : 0.0f);
+    h.p2 = p2; h.s2 = s2;
+    h.more = c2 && (u > s2);
+    return h;
+}
+__device__ __forceinline__ float poisson_tail_f32(float lam, float u, float p, float s)
+{
+    float x = 2.0f;                                    // entered with count 2 reached and u > s
+    do { x += 1.0f; p = p * (lam / x); s = s + p; } while (u > s && x < 64.0f);
+    return x;
+}
+
 template <int VEC>
 __device__ __forceinline__ void field_uniform24(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream, uint32_t p0,
                                                 float (&u)[VEC])
@@ -96,7 +115,8 @@ __device__ __forceinline__ void field_uniform24(uint64_t seed, uint32_t clip, ui
 
 __device__ __forceinline__ float expf_det(float x)
 {
-    if (x < -87.0f) return 0.0f;
+    const bool under = x < -87.0f;                      // -> 0 (selected at the end: no branch in the callers' loops)
+    x = under ? -87.0f : x;
     if (x > 88.0f) x = 88.0f;
     const float k = __builtin_rintf(x * 1.44269502f);
     float r = __builtin_fmaf(-k, 0.693359375f, x);
@@ -109,7 +129,8 @@ __device__ __forceinline__ float expf_det(float x)
     p = __builtin_fmaf(p, r, 5.0000001201e-1f);
     const float r2 = r * r;
     p = __builtin_fmaf(p, r2, r) + 1.0f;
-    return p * __uint_as_float((uint32_t)(127 + (int)k) << 23);
+    const float e = p * __uint_as_float((uint32_t)(127 + (int)k) << 23);
+    return under ? 0.0f : e;
 }
 
 // ON/OFF thresholds of VEC pixels from two Gaussian fields (normal(loc,scale) = loc + scale*g), clipped at 0.01
@@ -207,12 +228,44 @@ __device__ __forceinline__ float v2e_linlog(float x, const float *lut)
     return (float)log((double)x / 255 + 0.01);          // non-integer content: within 1 ulp of NumPy's float64 log
 }
 
+// Wave-wide float64 sum on the VALU (DPP row shifts + four v_readlane): the LDS-routed __shfl_down version of this
+// reduction made the pre-pass LDS-issue-bound (24 ds_bpermute per frame and wave).  Every lane returns the total.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xF, 0xF, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), lane);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+    v += dpp_mov_f64<0x111>(v);          // row_shr:1 (lanes shifted in from outside the 16-lane row read 0)
+    v += dpp_mov_f64<0x112>(v);          // row_shr:2
+    v += dpp_mov_f64<0x114>(v);          // row_shr:4
+    v += dpp_mov_f64<0x118>(v);          // row_shr:8 -> lane 15 of every row holds the row total
+    return (readlane_f64(v, 15) + readlane_f64(v, 31)) + (readlane_f64(v, 47) + readlane_f64(v, 63));
+}
+
 // ---- pre-pass: per (clip, frame) fixed-point sums of the shot-noise factors (native mode only)
+// Each pixel contributes rint(factor * 2^32) -- an integer, so the total does not depend on summation order, launch
+// geometry or the CPU oracle's loop order.  While every term is below 2^44 a wave's 256 terms sum exactly in float64
+// (< 2^52): the lanes accumulate and reduce in float64 (one v_rndne + one v_add per term instead of a 64-bit integer
+// convert and add-with-carry) and only the wave total is converted; larger terms take the integer path.
 template <int IN, int VEC>
 __global__ void __launch_bounds__(kBlock) v2e_shot_sum_kernel(const V2eArgs a)
 {
     __shared__ __align__(16) unsigned char s_tab[kV2eTableBytes];
+    extern __shared__ __align__(16) unsigned long long s_sum[];          // [K,2] workgroup partial sums
     const V2eIntenTables tb = v2e_build_tables<IN>(s_tab, a.P.uint8_wrap);
+    for (int t = threadIdx.x; t < 2 * a.K; t += kBlock) s_sum[t] = 0ull;
     __syncthreads();
     const int clip = blockIdx.x / a.blocks_per_clip;
     const int blk = blockIdx.x - clip * a.blocks_per_clip;
@@ -223,52 +276,120 @@ __global__ void __launch_bounds__(kBlock) v2e_shot_sum_kernel(const V2eArgs a)
     const double pos_nominal = P.thres_mean_mean + P.thres_diff_mean / 2, neg_nominal = P.thres_mean_mean - P.thres_diff_mean / 2;
     const bool temporal = P.threshold_model == kV2eSpatialTemporalIndependent;
     double pt[VEC], nt[VEC], pre_p[VEC], pre_n[VEC];
-    auto derive = [&]() {
+    auto derive = [&]() {                       // nominal/threshold, pre-scaled by 2^32 (exact: a power of two)
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) { pre_p[j] = pos_nominal / pt[j]; pre_n[j] = neg_nominal / nt[j]; }
+        for (int j = 0; j < VEC; ++j) { pre_p[j] = (pos_nominal / pt[j]) * 4294967296.0; pre_n[j] = (neg_nominal / nt[j]) * 4294967296.0; }
     };
-    if (active) { v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFThresA, p0, pt, nt); derive(); }
-    const int64_t in_base = (int64_t)clip * a.clip_stride + p0;
-    for (int k = 0; k < a.K; ++k) {
-        long long sp = 0, sn = 0;
-        if (active) {
-            const int i = k + 1;
-            if (temporal) { v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i, p0, pt, nt); derive(); }
-            const Raw<IN, VEC> raw = load_raw<IN, VEC>(a.frames, in_base + (int64_t)i * a.frame_stride);
-            float x[VEC];
-            v2e_pixels<IN, VEC>(raw, x);
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                double i64, fac; float i32;
-                v2e_inten<IN>(x[j], P.uint8_wrap, tb, i64, i32, fac);
-                const double fp = fac * pre_p[j], fn = fac * pre_n[j];
-                sp += __double2ll_rn(fp * 4294967296.0);
-                sn += __double2ll_rn(fn * 4294967296.0);
+    for (int j = 0; j < VEC; ++j) { pre_p[j] = 0.0; pre_n[j] = 0.0; }
+    if (active) { v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFThresA, p0, pt, nt); derive(); }
+    const int64_t in_base = (int64_t)clip * a.clip_stride + (active ? p0 : 0u);
+    Raw<IN, VEC> nxt = load_raw<IN, VEC>(a.frames, in_base + a.frame_stride);
+    for (int k = 0; k < a.K; ++k) {
+        const int i = k + 1;
+        const Raw<IN, VEC> raw = nxt;
+        nxt = load_raw<IN, VEC>(a.frames, in_base + (int64_t)(i + 1 <= a.K ? i + 1 : a.K) * a.frame_stride);
+        if (temporal && active) { v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i, p0, pt, nt); derive(); }
+        float x[VEC];
+        double fac[VEC];
+        v2e_pixels<IN, VEC>(raw, x);
+        uint32_t mismatch = 0;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            uint32_t idx;
+            if constexpr (IN == kInU8) idx = VEC == 4 ? (raw.v >> (8 * j)) & 0xFFu : raw.v;
+            else { idx = __float_as_uint(x[j] + 8388608.0f) & 255u; mismatch |= __float_as_uint((float)idx - x[j]); }
+            fac[j] = tb.fac[idx];
+        }
+        if constexpr (IN != kInU8) {
+            if (__builtin_expect(mismatch != 0, 0)) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) { double i64; float i32; v2e_inten<IN>(x[j], P.uint8_wrap, tb, i64, i32, fac[j]); }
             }
         }
+        double fp[VEC], fn[VEC], dsp = 0.0, dsn = 0.0;
+        bool big = false;
 #pragma unroll
-        for (int s = 32; s > 0; s >>= 1) { sp += __shfl_down(sp, s, 64); sn += __shfl_down(sn, s, 64); }
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(reinterpret_cast<unsigned long long *>(&a.shot_sums[((int64_t)clip * a.K + k) * 2]), (unsigned long long)sp);
-            atomicAdd(reinterpret_cast<unsigned long long *>(&a.shot_sums[((int64_t)clip * a.K + k) * 2 + 1]), (unsigned long long)sn);
+        for (int j = 0; j < VEC; ++j) {
+            fp[j] = fac[j] * pre_p[j];
+            fn[j] = fac[j] * pre_n[j];
+            big |= !(__builtin_fabs(fp[j]) < 0x1p44) | !(__builtin_fabs(fn[j]) < 0x1p44);
+            dsp += __builtin_rint(fp[j]);
+            dsn += __builtin_rint(fn[j]);
+        }
+        long long sp, sn;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(big && active) == 0, 1)) {
+            sp = (long long)wave_sum_f64(dsp);                           // exact: an integer below 2^52
+            sn = (long long)wave_sum_f64(dsn);
+        } else {
+            sp = 0; sn = 0;
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) { sp += __double2ll_rn(fp[j]); sn += __double2ll_rn(fn[j]); }
+            }
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) { sp += __shfl_down(sp, s, 64); sn += __shfl_down(sn, s, 64); }
+        }
+        if ((threadIdx.x & 63) == 0) {                                   // LDS atomics: 4 waves per workgroup
+            atomicAdd(&s_sum[2 * k], (unsigned long long)sp);
+            atomicAdd(&s_sum[2 * k + 1], (unsigned long long)sn);
         }
     }
+    // one global atomic per (workgroup, frame, sign): ~256 waves of a clip adding into the same address every frame
+    // serialised at the memory side and cost more than the whole read of the clip
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * a.K; t += kBlock)
+        atomicAdd(reinterpret_cast<unsigned long long *>(&a.shot_sums[(int64_t)clip * a.K * 2 + t]), s_sum[t]);
 }
 
-template <int IN, int VEC, int BIN, int RNG, bool OUT64>
+// Per-frame constants every work-item of a clip shares (time step, low-pass step, shot-noise scale, refractory cap):
+// tabulated once per workgroup in LDS -- they cost float64 divisions, which the time loop must not repeat.
+constexpr int kV2eFrameConsts = 5;   // {dt, dt/tau, scale_pos, scale_neg, refractory cap}
+
+// FEAT < 0: model features are read from the parameters at run time (wave-uniform branches); FEAT >= 0: compile-time
+// bit mask {1 low-pass, 2 leak, 4 shot noise, 8 refractory, 16 per-frame thresholds} for the specialised instances
+enum { kV2eLowpass = 1, kV2eLeak = 2, kV2eShot = 4, kV2eRefr = 8, kV2eTemporal = 16 };
+
+template <int IN, int VEC, int BIN, int RNG, bool OUT64, int FEAT = -1>
 __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
 {
     using acc_t = typename std::conditional<OUT64, double, float>::type;
     extern __shared__ __align__(16) unsigned char s_raw[];
     float *s_lut = reinterpret_cast<float *>(s_raw);
-    acc_t *s_wlo = reinterpret_cast<acc_t *>(s_raw + 256 * sizeof(float));
+    double *s_fc = reinterpret_cast<double *>(s_raw + 256 * sizeof(float));
+    acc_t *s_wlo = reinterpret_cast<acc_t *>(s_fc + (size_t)kV2eFrameConsts * a.K);
     acc_t *s_whi = s_wlo + a.K;
     int *s_seg = reinterpret_cast<int *>(s_whi + a.K);
-    s_lut[threadIdx.x] = g_lut_v2e32[threadIdx.x];
+    s_lut[threadIdx.x] = a.lut[threadIdx.x];
     __shared__ __align__(16) unsigned char s_tab[kV2eTableBytes];
     const V2eIntenTables tb = v2e_build_tables<IN>(s_tab, a.P.uint8_wrap);
-    if constexpr (BIN == kBinBilinear) {
-        for (int k = threadIdx.x; k < a.K; k += kBlock) {
+    const int clip = blockIdx.x / a.blocks_per_clip;
+    const int blk = blockIdx.x - clip * a.blocks_per_clip;
+    const V2eParams &P = a.P;
+    const bool lowpass = FEAT < 0 ? P.cutoff_hz > 0 : (FEAT & kV2eLowpass) != 0;
+    const bool leak = FEAT < 0 ? P.leak_rate_hz > 0 : (FEAT & kV2eLeak) != 0;
+    const bool shot = FEAT < 0 ? P.shot_noise_rate_hz > 0 : (FEAT & kV2eShot) != 0;
+    const bool refractory = FEAT < 0 ? P.refractory_period_s > 0 : (FEAT & kV2eRefr) != 0;
+    const bool temporal = FEAT < 0 ? P.threshold_model == kV2eSpatialTemporalIndependent : (FEAT & kV2eTemporal) != 0;
+    const double tau = lowpass ? 1 / (3.141592653589793 * 2 * P.cutoff_hz) : 0.0;
+    for (int k = threadIdx.x; k < a.K; k += kBlock) {
+        const int i = k + 1;
+        const double dt = (double)i / P.fps - (double)(i - 1) / P.fps;                  // t_frame - t_previous (:440)
+        double *fc = s_fc + (size_t)kV2eFrameConsts * k;
+        fc[0] = dt;
+        fc[1] = lowpass ? dt / tau : 0.0;
+        double scale_p = 0.0, scale_n = 0.0;
+        if (RNG == kRngPhilox && shot) {                                                // generate_shot_noise (:86-100)
+            const double mean_p = ((double)a.shot_sums[((int64_t)clip * a.K + k) * 2] / 4294967296.0) / (double)a.HW;
+            const double mean_n = ((double)a.shot_sums[((int64_t)clip * a.K + k) * 2 + 1] / 4294967296.0) / (double)a.HW;
+            const double f = (P.shot_noise_rate_hz / 2) * dt;
+            scale_p = f / mean_p;
+            scale_n = f / mean_n;
+        }
+        fc[2] = scale_p;
+        fc[3] = scale_n;
+        fc[4] = refractory ? (double)(int)(dt / P.refractory_period_s) : 0.0;
+        if constexpr (BIN == kBinBilinear) {
             const double t_norm = ((double)k - 0.0) / ((double)(a.K - 1) - 0.0) * (double)(a.Tb - 1);
             int b0 = (int)floor(t_norm);
             if (b0 > a.Tb - 2) b0 = a.Tb - 2;
@@ -281,18 +402,12 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
     }
     __syncthreads();
 
-    const int clip = blockIdx.x / a.blocks_per_clip;
-    const int blk = blockIdx.x - clip * a.blocks_per_clip;
     const uint32_t p0 = (uint32_t)(blk * kBlock + threadIdx.x) * VEC;
     if (p0 >= (uint32_t)a.HW) return;
-    const V2eParams &P = a.P;
     const uint32_t clip_id = (uint32_t)(a.clip_id0 + (uint64_t)clip);
-    const bool lp32 = (P.cutoff_hz <= 0) || (IN == kInF32);
-    const bool base32 = lp32 && !(P.leak_rate_hz > 0);
-    const bool temporal = P.threshold_model == kV2eSpatialTemporalIndependent;
-    const bool shot = P.shot_noise_rate_hz > 0;
+    const bool lp32 = !lowpass || (IN == kInF32);
+    const bool base32 = lp32 && !leak;
     const double pos_nominal = P.thres_mean_mean + P.thres_diff_mean / 2, neg_nominal = P.thres_mean_mean - P.thres_diff_mean / 2;
-    const double tau = P.cutoff_hz > 0 ? 1 / (3.141592653589793 * 2 * P.cutoff_hz) : 0.0;
     const int64_t in_base = (int64_t)clip * a.clip_stride + p0;
     const int64_t pix_base = (int64_t)clip * a.HW + p0;
 
@@ -337,6 +452,10 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
     };
     derive_thres();
 
+    double leak_cur[VEC];                                  // float32 product leak_rate_hz * noise_rate_array (:204), widened
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) leak_cur[j] = (double)((float)P.leak_rate_hz * nrate[j]);
+
     acc_t acc_lo[VEC], acc_hi[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { acc_lo[j] = 0; acc_hi[j] = 0; }
@@ -360,8 +479,8 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
                 ++cur_seg;
             }
         }
-        const double dt = (double)i / P.fps - (double)(i - 1) / P.fps;                  // t_frame - t_previous (:440)
-        const double dt_tau = P.cutoff_hz > 0 ? dt / tau : 0.0;                         // wave-uniform
+        const double *fc = s_fc + (size_t)kV2eFrameConsts * k;                          // wave-uniform LDS reads
+        const double dt = fc[0], dt_tau = fc[1], scale_p = fc[2], scale_n = fc[3], cap = fc[4];
         const float dt_tau32 = (float)dt_tau;
         if (temporal) {                                                                 // thresholds redrawn per frame (:417-421)
             if constexpr (RNG == kRngPhilox) v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i, p0, pt, nt);
@@ -373,99 +492,150 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
                     nt[j] = a.r_neg_thres[o];
                 }
             }
+            derive_thres();
         }
         float gleak[VEC];
         float u_sp[VEC], u_sn[VEC];
-        double scale_p = 0.0, scale_n = 0.0;
         if constexpr (RNG == kRngPhilox) {
-            if (P.leak_rate_hz > 0) field_gauss32<VEC>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i + 2u, kStreamV2e, p0, gleak);
+            if (leak) field_gauss32<VEC>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i + 2u, kStreamV2e, p0, gleak);
             if (shot) {
                 field_uniform24<VEC>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i + 3u, kStreamV2e, p0, u_sp);
                 field_uniform24<VEC>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i + 4u, kStreamV2e, p0, u_sn);
-                const double mean_p = ((double)a.shot_sums[((int64_t)clip * a.K + k) * 2] / 4294967296.0) / (double)a.HW;
-                const double mean_n = ((double)a.shot_sums[((int64_t)clip * a.K + k) * 2 + 1] / 4294967296.0) / (double)a.HW;
-                const double f = (P.shot_noise_rate_hz / 2) * dt;
-                scale_p = f / mean_p;                                                // wave-uniform: 2 divisions per frame
-                scale_n = f / mean_n;
             }
         }
-        if (temporal) derive_thres();
-        float x[VEC];
-        v2e_pixels<IN, VEC>(raw, x);
         const acc_t wl = BIN == kBinBilinear ? s_wlo[k] : (acc_t)1, wh = BIN == kBinBilinear ? s_whi[k] : (acc_t)0;
+
+        // ---- lin_log (:445) + intensity terms: table reads by the 8-bit intensity; a wave leaves the table path only
+        // when some float32 pixel is not an integer in 0..255
+        float x[VEC], log_new[VEC], i01_32[VEC];
+        double i01_64[VEC], fac[VEC];
+        v2e_pixels<IN, VEC>(raw, x);
+        uint32_t mismatch = 0;                            // != 0 iff some float32 pixel is not an integer in 0..255 (or NaN)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const float log_new = v2e_linlog(x[j], s_lut);                              // lin_log (:445)
-            double i01_64, fac; float i01_32;
-            v2e_inten<IN>(x[j], P.uint8_wrap, tb, i01_64, i01_32, fac);
-            if (P.cutoff_hz > 0) {                                                      // low_pass_filter (:139-182)
+            uint32_t idx;
+            if constexpr (IN == kInU8) idx = VEC == 4 ? (raw.v >> (8 * j)) & 0xFFu : raw.v;
+            else { idx = __float_as_uint(x[j] + 8388608.0f) & 255u; mismatch |= __float_as_uint((float)idx - x[j]); }
+            log_new[j] = s_lut[idx];
+            if (shot) fac[j] = tb.fac[idx]; else fac[j] = 0.0;
+            if constexpr (IN == kInU8) { i01_64[j] = lowpass ? tb.i01_64[idx] : 0.0; i01_32[j] = 0.0f; }
+            else { i01_32[j] = lowpass ? tb.i01_32[idx] : 0.0f; i01_64[j] = 0.0; }
+        }
+        if constexpr (IN != kInU8) {
+            if (__builtin_expect(mismatch != 0, 0)) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    log_new[j] = v2e_linlog(x[j], s_lut);
+                    v2e_inten<IN>(x[j], P.uint8_wrap, tb, i01_64[j], i01_32[j], fac[j]);
+                }
+            }
+        }
+
+        // ---- low pass, leak, event map: floor_divide(clip(+-diff, 0), thres) as floor(x * low-biased reciprocal) with
+        // the exact fma residual; the correction (quotient one short, or a non-finite operand) is a rare wave-level path
+        double dif[VEC], fpos[VEC], fneg[VEC];
+        bool fix = false;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if (lowpass) {                                                              // low_pass_filter (:139-182)
                 if constexpr (IN == kInF32) {
-                    float eps = i01_32 * dt_tau32;
+                    float eps = i01_32[j] * dt_tau32;
                     eps = eps > 1.0f ? 1.0f : eps;
-                    const float ta = (1.0f - eps) * lp_f[j], tb = eps * log_new;
-                    lp_f[j] = ta + tb;
+                    const float ta = (1.0f - eps) * lp_f[j], tb2 = eps * log_new[j];
+                    lp_f[j] = ta + tb2;
                 } else {
-                    double eps = i01_64 * dt_tau;
+                    double eps = i01_64[j] * dt_tau;
                     eps = eps > 1.0 ? 1.0 : eps;
-                    const double ta = (1 - eps) * lp64[j], tb = eps * (double)log_new;
-                    lp64[j] = ta + tb;
+                    const double ta = (1 - eps) * lp64[j], tb2 = eps * (double)log_new[j];
+                    lp64[j] = ta + tb2;
                 }
             } else {
-                lp_f[j] = log_new;
+                lp_f[j] = log_new[j];
             }
-            if (P.leak_rate_hz > 0) {                                                   // subtract_leak_current (:192-211)
+            if (leak) {                                                                 // subtract_leak_current (:192-211)
                 double g;
                 if constexpr (RNG == kRngPhilox) g = (double)gleak[j];
                 else g = a.r_leak_randn[((int64_t)clip * a.K + k) * a.HW + p0 + j];
-                const float a32 = (float)P.leak_rate_hz * nrate[j];
                 const double jit = P.leak_jitter_fraction * g;
-                const double curr = (double)a32 * (1 - jit);
+                const double curr = leak_cur[j] * (1 - jit);
                 const double dl = dt * curr * pt[j];
                 base64[j] = base64[j] - dl;
             }
             double diff;
             if (lp32 && base32) { const float d = lp_f[j] - base_f[j]; diff = (double)d; }
             else diff = (lp32 ? (double)lp_f[j] : lp64[j]) - base64[j];
-            // compute_event_map (:42-62): floor_divide(clip(+-diff, 0), thres); exact floor via reciprocal + fma residual
-            const double nd = -diff;
-            const double pos_frame = diff > 0 ? diff : (diff == diff ? 0.0 : diff);
-            const double neg_frame = nd > 0 ? nd : (nd == nd ? 0.0 : nd);
-            double fpos = floor(pos_frame * inv_p[j]), fneg = floor(neg_frame * inv_n[j]);
-            { const double r = __builtin_fma(-fpos, pt[j], pos_frame); if (r >= pt[j]) fpos += 1.0; else if (!(r < pt[j])) fpos = pos_frame / pt[j]; }
-            { const double r = __builtin_fma(-fneg, nt[j], neg_frame); if (r >= nt[j]) fneg += 1.0; else if (!(r < nt[j])) fneg = neg_frame / nt[j]; }
-            if (shot) {                                                                 // generate_shot_noise (:65-105)
-                double sp, sn;
-                if constexpr (RNG == kRngPhilox) {
-                    const double lam_p = (fac * pre_p[j]) * scale_p;
-                    const double lam_n = (fac * pre_n[j]) * scale_n;
-                    sp = (double)poisson_inv_f32((float)lam_p, u_sp[j]);
-                    sn = (double)poisson_inv_f32((float)lam_n, u_sn[j]);
-                } else {
-                    const int64_t o = ((int64_t)clip * a.K + k) * a.HW + p0 + j;
-                    sp = (double)a.r_shot_pos[o];
-                    sn = (double)a.r_shot_neg[o];
-                }
-                fpos = fpos + sp;
-                fneg = fneg + sn;
+            // compute_event_map (:42-62).  The residuals are taken against +-diff itself: for the side that is clipped
+            // to zero they are negative (check passes), for a NaN difference they are NaN (check fails -> exact path)
+            dif[j] = diff;
+            fpos[j] = floor(__builtin_fmax(diff, 0.0) * inv_p[j]);
+            fneg[j] = floor(__builtin_fmax(-diff, 0.0) * inv_n[j]);
+            const double rp = __builtin_fma(-fpos[j], pt[j], diff), rn = __builtin_fma(-fneg[j], nt[j], -diff);
+            fix |= !(rp < pt[j]);
+            fix |= !(rn < nt[j]);
+        }
+        if (__builtin_expect(fix, 0)) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const double diff = dif[j], nd = -diff;
+                const double pos_frame = diff > 0 ? diff : (diff == diff ? 0.0 : diff);
+                const double neg_frame = nd > 0 ? nd : (nd == nd ? 0.0 : nd);
+                fpos[j] = floor(pos_frame * inv_p[j]);
+                fneg[j] = floor(neg_frame * inv_n[j]);
+                { const double r = __builtin_fma(-fpos[j], pt[j], pos_frame); if (r >= pt[j]) fpos[j] += 1.0; else if (!(r < pt[j])) fpos[j] = pos_frame / pt[j]; }
+                { const double r = __builtin_fma(-fneg[j], nt[j], neg_frame); if (r >= nt[j]) fneg[j] += 1.0; else if (!(r < nt[j])) fneg[j] = neg_frame / nt[j]; }
             }
-            if (P.refractory_period_s > 0) {                                            // intended semantics of :534-537
-                const double cap = (double)(int)(dt / P.refractory_period_s);
-                fpos = fpos > cap ? cap : fpos;
-                fneg = fneg > cap ? cap : fneg;
+        }
+
+        if (shot) {                                                                     // generate_shot_noise (:65-105)
+            if constexpr (RNG == kRngPhilox) {
+                float lam_p[VEC], lam_n[VEC];
+                PoissonHead hp[VEC], hn[VEC];
+                bool more = false;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    lam_p[j] = (float)((fac[j] * pre_p[j]) * scale_p);
+                    lam_n[j] = (float)((fac[j] * pre_n[j]) * scale_n);
+                    hp[j] = poisson_head_f32(lam_p[j], u_sp[j]);
+                    hn[j] = poisson_head_f32(lam_n[j], u_sn[j]);
+                    more |= hp[j].more | hn[j].more;
+                }
+                if (__builtin_expect(more, 0)) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        if (hp[j].more) hp[j].x = poisson_tail_f32(lam_p[j], u_sp[j], hp[j].p2, hp[j].s2);
+                        if (hn[j].more) hn[j].x = poisson_tail_f32(lam_n[j], u_sn[j], hn[j].p2, hn[j].s2);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) { fpos[j] = fpos[j] + (double)hp[j].x; fneg[j] = fneg[j] + (double)hn[j].x; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const int64_t o = ((int64_t)clip * a.K + k) * a.HW + p0 + j;
+                    fpos[j] = fpos[j] + (double)a.r_shot_pos[o];
+                    fneg[j] = fneg[j] + (double)a.r_shot_neg[o];
+                }
+            }
+        }
+
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if (refractory) {                                                           // intended semantics of :534-537
+                fpos[j] = fpos[j] > cap ? cap : fpos[j];
+                fneg[j] = fneg[j] > cap ? cap : fneg[j];
             }
             if (base32) {                                                               // in-place += on a float32 array (:547-548)
-                const double up = fpos * pt[j];
+                const double up = fpos[j] * pt[j];
                 base_f[j] = (float)((double)base_f[j] + up);
-                const double dn = fneg * nt[j];
+                const double dn = fneg[j] * nt[j];
                 base_f[j] = (float)((double)base_f[j] - dn);
             } else {
-                const double up = fpos * pt[j];
+                const double up = fpos[j] * pt[j];
                 base64[j] = base64[j] + up;
-                const double dn = fneg * nt[j];
+                const double dn = fneg[j] * nt[j];
                 base64[j] = base64[j] - dn;
             }
-            const double vox = fpos - fneg;
-            if (want_counts) { n_on += (uint32_t)fpos; n_off += (uint32_t)fneg; }
+            const double vox = fpos[j] - fneg[j];
             if constexpr (OUT64) {
                 if constexpr (BIN == kBinBilinear) {
                     const double cl = vox * wl, ch = vox * wh;
@@ -483,6 +653,10 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
                     acc_lo[j] = acc_lo[j] + vf;
                 }
             }
+        }
+        if (want_counts) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { n_on += (uint32_t)fpos[j]; n_off += (uint32_t)fneg[j]; }
         }
         if constexpr (BIN == kBinSum) {
             if (++sub == a.fpb) {

@@ -3,8 +3,13 @@
 
 #include "../../include/v2v_hip.h"
 #include "v2v_v2e.hpp"
+#include "v2v_luts.inc"
 
 namespace v2v {
+
+__device__ float g_lut_v2e32[256] = {V2V_LUT_V2E32_VALUES};    // lin_log table (golden G1); replaceable via v2v_lut_set
+static const float kLutV2e32[256] = {V2V_LUT_V2E32_VALUES};
+
 namespace {
 
 template <int IN, int VEC, int BIN, int RNG>
@@ -22,7 +27,7 @@ hipError_t launch_v2e_t(int bin, int rng, bool out64, bool presum, const V2eArgs
     return hipErrorInvalidValue;
 #endif
     if (presum) {
-        hipLaunchKernelGGL((v2e_shot_sum_kernel<IN, VEC>), grid, dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL((v2e_shot_sum_kernel<IN, VEC>), grid, dim3(kBlock), (size_t)a.K * 16, s, a);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -35,9 +40,27 @@ hipError_t launch_v2e_t(int bin, int rng, bool out64, bool presum, const V2eArgs
 
 }  // namespace
 
-hipError_t launch_v2e(bool in_u8, bool vec4, int bin, int rng, bool out64, bool presum, const V2eArgs &a, dim3 grid, size_t lds,
+hipError_t launch_v2e(bool in_u8, bool vec4, int bin, int rng, bool out64, bool presum, const V2eArgs &a_in, dim3 grid, size_t lds,
                       hipStream_t s)
 {
+    V2eArgs a = a_in;
+    void *lut = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&lut, HIP_SYMBOL(g_lut_v2e32));      // address on the current device
+    if (e != hipSuccess) return e;
+    a.lut = static_cast<const float *>(lut);
+    const V2eParams &P = a.P;
+    const bool spec = vec4 && !out64 && rng == V2V_RNG_PHILOX && P.threshold_model != kV2eSpatialTemporalIndependent &&
+                      !(P.refractory_period_s > 0);
+    if (spec) {
+        if (presum) {
+            if (in_u8) hipLaunchKernelGGL((v2e_shot_sum_kernel<kInU8, 4>), grid, dim3(kBlock), (size_t)a.K * 16, s, a);
+            else hipLaunchKernelGGL((v2e_shot_sum_kernel<kInF32, 4>), grid, dim3(kBlock), (size_t)a.K * 16, s, a);
+            const hipError_t e1 = hipGetLastError();
+            if (e1 != hipSuccess) return e1;
+        }
+        const int feat = (P.cutoff_hz > 0 ? kV2eLowpass : 0) | (P.leak_rate_hz > 0 ? kV2eLeak : 0) | (P.shot_noise_rate_hz > 0 ? kV2eShot : 0);
+        return in_u8 ? launch_v2e_spec_u8(bin, feat, a, grid, lds, s) : launch_v2e_spec_f32(bin, feat, a, grid, lds, s);
+    }
     if (in_u8) return vec4 ? launch_v2e_t<kInU8, 4>(bin, rng, out64, presum, a, grid, lds, s) : launch_v2e_t<kInU8, 1>(bin, rng, out64, presum, a, grid, lds, s);
     return vec4 ? launch_v2e_t<kInF32, 4>(bin, rng, out64, presum, a, grid, lds, s) : launch_v2e_t<kInF32, 1>(bin, rng, out64, presum, a, grid, lds, s);
 }
