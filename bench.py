@@ -146,7 +146,7 @@ def main():
         table = np.stack([[g.integers(0, keep_h - c + 1), g.integers(0, sw - c + 1), c, int(g.random() > 0.5)] for c in cb]).astype(np.int32)
         idx = np.tile(np.arange(n, dtype=np.int32), (b, 1))
         table_d, idx_d = torch.as_tensor(table, device=dev), torch.as_tensor(idx, device=dev)
-        frames = frontend.prepare_clips_batch(raw, table_d, idx_d, h, "gray", validate=False)[1]
+        frames = frontend.prepare_clips_batch(raw, table_d, idx_d, h, "gray", validate=False, max_crop_before=int(cb.max()))[1]
         src_bytes = int((cb.astype(np.int64) ** 2).sum()) * 3 * n
     else:
         frames = esim.synth_clips(b, n, h, w, dtype=tdtype, seed=20240001, clip_id0=clip_id0, device=dev)
@@ -168,7 +168,7 @@ def main():
             kernel_name += " + E2VID-shaped UNet forward (bf16 autocast, stock PyTorch)"
 
         def step():
-            gray = frontend.prepare_clips_batch(raw, table_d, idx_d, h, "gray", validate=False)[1]
+            gray = frontend.prepare_clips_batch(raw, table_d, idx_d, h, "gray", validate=False, max_crop_before=int(cb.max()))[1]
             esim.esim_voxel_batch(gray, ptensor, bin_mode=bin_mode, num_bins=tb, frames_per_bin=fpb, rng_mode="philox",
                                   seed=20240001, clip_id0=clip_id0, out=out, validate=False, no_noise=False)
             if consumer is not None:

@@ -76,3 +76,48 @@ def test_hip_frontend_batch_equals_single_clip_calls():
             assert torch.equal(gray[c], g1) and torch.equal(imgs[c], i1)
     with pytest.raises(ValueError):
         frontend.prepare_clips_batch(raw, np.array([[0, 0, 200, 0]] * 3), idx, crop)
+
+
+# ---- LDS-tiled kernel (gray output only, no shake): same bits as the oracle and as the per-pixel gather kernel
+@pytest.mark.gpu
+@pytest.mark.parametrize("flip", [False, True])
+@pytest.mark.parametrize("hs,ws,crop,crop_before,mi,mj", [
+    (120, 160, 32, 100, 11, 23),       # one partial tile, downscale 3.1x
+    (120, 161, 32, 64, 3, 5),          # OpenCV's 2x2 area shortcut (crop_before == 2*crop), odd row pitch
+    (300, 400, 200, 290, 5, 17),       # several tiles, partial last column tile and row tile, scale 1.45
+    (300, 401, 256, 197, 40, 101),     # upscale 0.77 (config-4 lower bound), two column tiles, odd row pitch
+    (300, 400, 130, 131, 0, 0),        # scale ~1: border taps clamp (s1 == s0) at the right/bottom edge
+    (64, 64, 7, 64, 0, 0),             # crop smaller than one 4-pixel group row; whole frame
+    (700, 700, 64, 600, 50, 60),       # rectangle larger than the LDS row budget -> per-pixel fallback inside the tile kernel
+    (700, 700, 64, 70, 500, 600),      # same launch geometry, small rectangle -> staged
+])
+def test_hip_frontend_tiled_equals_oracle(flip, hs, ws, crop, crop_before, mi, mj):
+    import torch
+    from v2v_amd import frontend
+    g = np.random.default_rng(hs + ws + crop + crop_before + flip)
+    t = 3
+    raw = g.integers(0, 256, size=(t, hs, ws, 3), dtype=np.uint8)
+    idxes = [2, 0, 1, 1]
+    _, want_gray = F.frontend(raw, crop_before, mi, mj, flip, crop, idxes, None, None, "gray")
+    raw_d = torch.from_numpy(raw).cuda()
+    none_imgs, gray = frontend.prepare_clip(raw_d, crop_before, mi, mj, flip, crop, idxes, want_imgs=False)     # tiled kernel
+    assert none_imgs is None
+    assert np.array_equal(gray.cpu().numpy(), want_gray)
+    _, gray_gather = frontend.prepare_clip(raw_d, crop_before, mi, mj, flip, crop, idxes, want_imgs=True)       # gather kernel
+    assert torch.equal(gray, gray_gather)
+
+
+@pytest.mark.gpu
+def test_hip_frontend_tiled_batch_mixed_rectangles():
+    """One launch with staged, area-shortcut and over-budget clips; rectangle touching the end of the buffer."""
+    import torch
+    from v2v_amd import frontend
+    g = np.random.default_rng(11)
+    b, t, hs, ws, crop = 4, 2, 700, 700, 64
+    raw = g.integers(0, 256, size=(b, t, hs, ws, 3), dtype=np.uint8)
+    table = np.array([[0, 0, 70, 0], [100, 200, 128, 1], [0, 0, 700, 1], [630, 630, 70, 0]], dtype=np.int32)
+    idx = np.array([[0, 1, 1]] * b, dtype=np.int32)
+    _, gray = frontend.prepare_clips_batch(torch.from_numpy(raw).cuda(), table, idx, crop, "gray", want_imgs=False)
+    for c in range(b):
+        _, want = F.frontend(raw[c], int(table[c, 2]), int(table[c, 0]), int(table[c, 1]), bool(table[c, 3]), crop, idx[c], None, None, "gray")
+        assert np.array_equal(gray[c].cpu().numpy(), want), c

@@ -97,7 +97,7 @@ def lib():
     L.v2v_frontend_hip.argtypes = [C.c_void_p] + [C.c_int64] * 10 + [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.v2v_frontend_batch_hip.restype = C.c_int
-    L.v2v_frontend_batch_hip.argtypes = [C.c_void_p] + [C.c_int64] * 5 + [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
+    L.v2v_frontend_batch_hip.argtypes = [C.c_void_p] + [C.c_int64] * 5 + [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
                                                                            C.c_void_p, C.c_void_p, C.c_void_p]
     L.v2v_postops_workspace_bytes.restype = C.c_int64
     L.v2v_postops_workspace_bytes.argtypes = [C.c_int64]

@@ -315,6 +315,42 @@ int v2v_events_to_voxel_segmented_hip(const double *ts, const int64_t *xs, const
     return e == hipSuccess ? V2V_OK : hip_fail(e, "events_to_voxel_kernel launch");
 }
 
+// Front-end dispatch: the LDS-tiled kernel for the training configuration (BGR source, gray output only, no shake),
+// the per-pixel gather kernel otherwise.  LDS is sized for the largest crop rectangle the frame allows (the batch form
+// keeps the rectangles on the device); tiles that do not fit fall back to global reads inside the kernel.
+static hipError_t launch_frontend(const v2v::FrontendArgs &a, int64_t B, int64_t max_crop_before, hipStream_t s)
+{
+    static const bool force_gather = getenv("V2V_FRONTEND_GATHER") != nullptr;      // tuning/debug: always the gather kernel
+    const bool tiled = !force_gather && a.gray_first && a.Cs == 3 && !a.out_imgs && !a.di && a.need_h == a.crop && a.need_w == a.crop;
+    if (tiled) {
+        const int64_t frame_min = a.Hs < a.Ws ? a.Hs : a.Ws;
+        const int64_t cb_max = (max_crop_before > 0 && max_crop_before < frame_min) ? max_crop_before : frame_min;
+        const double s_max = (double)cb_max / (double)a.crop;
+        const int64_t span_px = (int64_t)(v2v::kTileCols * s_max) + 3;
+        const int64_t pitch = ((span_px * 3 + 12 + 15) / 16) * 16 + 16;
+        int64_t max_rows = (int64_t)(v2v::kTileRows * s_max) + 3;
+        const int64_t budget = 48 * 1024 - v2v::kTileHdrBytes;
+        if (max_rows * pitch > budget) max_rows = budget / pitch;
+        if (max_rows >= 4 && pitch <= budget) {
+            v2v::FrontendTileArgs ta{};
+            ta.f = a;
+            ta.pitch = (int32_t)pitch; ta.max_rows = (int32_t)max_rows;
+            ta.tiles_x = (a.crop + v2v::kTileCols - 1) / v2v::kTileCols;
+            ta.tiles_y = (a.crop + v2v::kTileRows - 1) / v2v::kTileRows;
+            const int64_t nblocks = (int64_t)ta.tiles_x * ta.tiles_y * a.N;
+            if (nblocks <= 0x7FFFFFFF) {
+                hipLaunchKernelGGL(v2v::frontend_tile_kernel, dim3((unsigned)nblocks, (unsigned)B), dim3(256),
+                                   (size_t)(v2v::kTileHdrBytes + max_rows * pitch), s, ta);
+                return hipGetLastError();
+            }
+        }
+    }
+    const int64_t nblocks = ((int64_t)a.N * a.crop * ((a.crop + v2v::kFrontPx - 1) / v2v::kFrontPx) + 255) / 256;
+    if (nblocks > 0x7FFFFFFF) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(v2v::frontend_kernel, dim3((unsigned)nblocks, (unsigned)B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 int v2v_frontend_hip(const uint8_t *src, int64_t T, int64_t Hs, int64_t Ws, int64_t Cs, int64_t min_i, int64_t min_j,
                      int64_t crop_before, int64_t need_h, int64_t need_w, int64_t crop, int flip, int gray_first,
                      const int32_t *frame_idx, int64_t N, const int32_t *shake_di, const int32_t *shake_dj, uint8_t *out_imgs,
@@ -338,16 +374,14 @@ int v2v_frontend_hip(const uint8_t *src, int64_t T, int64_t Hs, int64_t Ws, int6
     a.out_imgs = out_imgs; a.out_gray = out_gray;
     a.src_end = src + T * Hs * Ws * Cs;
     const int64_t total = N * crop * ((crop + v2v::kFrontPx - 1) / v2v::kFrontPx);
-    const int64_t nblocks = (total + 255) / 256;
-    if (nblocks > 0x7FFFFFFF) return fail(V2V_ERR_SHAPE, "grid too large");
-    hipLaunchKernelGGL(v2v::frontend_kernel, dim3((unsigned)nblocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? V2V_OK : hip_fail(e, "frontend_kernel launch");
+    if ((total + 255) / 256 > 0x7FFFFFFF) return fail(V2V_ERR_SHAPE, "grid too large");
+    const hipError_t e = launch_frontend(a, 1, crop_before, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "frontend kernel launch");
 }
 
 int v2v_frontend_batch_hip(const uint8_t *src, int64_t B, int64_t T, int64_t Hs, int64_t Ws, int64_t Cs, const int32_t *clip_table,
-                           int64_t crop, int gray_first, const int32_t *frame_idx, int64_t N, uint8_t *out_imgs, uint8_t *out_gray,
-                           void *stream)
+                           int64_t max_crop_before, int64_t crop, int gray_first, const int32_t *frame_idx, int64_t N,
+                           uint8_t *out_imgs, uint8_t *out_gray, void *stream)
 {
     if (!src || !frame_idx || !out_gray || !clip_table) return fail(V2V_ERR_NULL, "v2v_frontend_batch_hip: src/clip_table/frame_idx/out_gray is NULL");
     if (B < 0 || T < 1 || N < 0 || Hs < 1 || Ws < 1 || (Cs != 1 && Cs != 3) || crop < 1) return fail(V2V_ERR_SHAPE, "need B>=0, T>=1, N>=0, Hs,Ws,crop>=1, Cs in {1,3}");
@@ -364,9 +398,8 @@ int v2v_frontend_batch_hip(const uint8_t *src, int64_t B, int64_t T, int64_t Hs,
     a.clip_table = clip_table;                     // the crop rectangles are validated by the caller (device-resident table)
     const int64_t nblocks = (N * crop * ((crop + v2v::kFrontPx - 1) / v2v::kFrontPx) + 255) / 256;
     if (nblocks > 0x7FFFFFFF || B > 65535) return fail(V2V_ERR_SHAPE, "grid too large");
-    hipLaunchKernelGGL(v2v::frontend_kernel, dim3((unsigned)nblocks, (unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), a);
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? V2V_OK : hip_fail(e, "frontend_kernel (batch) launch");
+    const hipError_t e = launch_frontend(a, B, max_crop_before, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "frontend kernel (batch) launch");
 }
 
 int64_t v2v_postops_workspace_bytes(int64_t B)

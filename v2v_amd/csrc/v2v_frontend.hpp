@@ -48,6 +48,16 @@ __device__ __forceinline__ Coef resize_coef(int d, int ssize, double scale)
     return c;
 }
 
+// index part of resize_coef only: the clamped left/top tap of destination index d (its right/bottom tap is min(+1, ssize-1))
+__device__ __forceinline__ int resize_src_lo(int d, int ssize, double scale)
+{
+    const float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    if (s < 0) s = 0;
+    if (s >= ssize - 1) s = ssize - 1;
+    return s;
+}
+
 __device__ __forceinline__ int bgr2gray_cv(const uint8_t *p)
 {
     return ((int)p[0] * 1868 + (int)p[1] * 9617 + (int)p[2] * 4899 + (1 << 13)) >> 14;
@@ -142,6 +152,150 @@ __global__ void __launch_bounds__(256) frontend_kernel(const FrontendArgs a_in)
     } else {
         for (int j = 0; j < kFrontPx && x0 + j < a.crop; ++j) a.out_gray[obase + j] = (uint8_t)(packed >> (8 * j));
     }
+}
+
+// ---- LDS-tiled variant for the training configuration (BGR source, color_mode 'gray', no shake, gray output only) ---
+// The gather kernel above issues eight unaligned 8-byte loads and ~350 VALU instructions (float64 coordinate maths)
+// per four output pixels and runs at a fifth of the source bytes' streaming time.  Here a workgroup owns a tile of
+// kTileRows x kTileCols output pixels of one frame: (1) 128+8 lanes compute the OpenCV column/row coefficients of the
+// tile once into LDS, (2) the source rectangle the tile touches is copied with 16-byte loads into LDS, (3) every lane
+// blends its 4 adjacent outputs from LDS (three aligned dword reads + v_alignbyte per tap row) and stores one dword.
+// Same fixed-point arithmetic, bit for bit; clips whose rectangle does not fit the LDS budget (or that take OpenCV's
+// 2x2 area shortcut) fall back to per-pixel global reads inside the same kernel.
+constexpr int kTileRows = 8, kTileCols = 128;
+struct ColC { uint16_t s0, single; int16_t a0, a1; };   // source column of the left tap, s1 == s0 (border clamp), weights
+struct RowC { int16_t s0, s1, a0, a1; };
+constexpr int kTileHdrBytes = kTileCols * 8 + kTileRows * 8;
+
+struct FrontendTileArgs {
+    FrontendArgs f;
+    int32_t pitch, max_rows;      // LDS row pitch (bytes, multiple of 16) and row capacity
+    int32_t tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ int blend_cv(int g00, int g01, int g10, int g11, int xa0, int xa1, int ya0, int ya1)
+{
+    const int r0 = g00 * xa0 + g01 * xa1;
+    const int r1 = g10 * xa0 + g11 * xa1;
+    const int v = (((ya0 * (r0 >> 4)) >> 16) + ((ya1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+// bytes [o, o+6) of an LDS row (o = byte offset from the 4-byte-aligned row start) -> gray of the two BGR pixels
+__device__ __forceinline__ void lds_gray_pair(const unsigned char *row, uint32_t o, int &g0, int &g1)
+{
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(row + (o & ~3u));
+    const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+    const uint32_t sh = o & 3u;
+    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);       // bytes o .. o+3
+    const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);       // bytes o+4 .. o+7
+    g0 = ((int)(lo & 255u) * 1868 + (int)((lo >> 8) & 255u) * 9617 + (int)((lo >> 16) & 255u) * 4899 + (1 << 13)) >> 14;
+    g1 = ((int)(lo >> 24) * 1868 + (int)(hi & 255u) * 9617 + (int)((hi >> 8) & 255u) * 4899 + (1 << 13)) >> 14;
+}
+
+__global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileArgs ta)
+{
+    extern __shared__ __align__(16) unsigned char s_mem[];
+    ColC *s_col = reinterpret_cast<ColC *>(s_mem);
+    RowC *s_row = reinterpret_cast<RowC *>(s_mem + kTileCols * 8);
+    unsigned char *s_rows = s_mem + kTileHdrBytes;
+    const FrontendArgs &a = ta.f;
+    const int clip = blockIdx.y;
+    const int tiles = ta.tiles_x * ta.tiles_y;
+    const int n = blockIdx.x / tiles;
+    const int tile = blockIdx.x - n * tiles;
+    const int ty = tile / ta.tiles_x, tx = tile - ty * ta.tiles_x;
+    const int y0 = ty * kTileRows, x0 = tx * kTileCols;
+    const int ncol = min(kTileCols, a.crop - x0), nrow = min(kTileRows, a.crop - y0);
+    int min_i = a.min_i, min_j = a.min_j, cb = a.crop_before, flip = a.flip;
+    if (a.clip_table) { const int32_t *t4 = a.clip_table + (int64_t)clip * 4; min_i = t4[0]; min_j = t4[1]; cb = t4[2]; flip = t4[3]; }
+    const int t = a.frame_idx[(int64_t)clip * a.N + n];
+    const uint8_t *frame = a.src + (((int64_t)clip * a.T + t) * a.Hs * a.Ws + (int64_t)min_i * a.Ws + min_j) * 3;
+    uint8_t *out = a.out_gray + ((int64_t)clip * a.N + n) * a.crop * a.crop;
+    const bool area2 = cb == 2 * a.crop;
+    const double scale = 1.0 / ((double)a.crop / (double)cb);
+    const int tid = threadIdx.x;
+
+    // (1) extent of the source rectangle: every lane evaluates the four corner coordinates itself (index part only), so
+    //     the copy below can be issued before any LDS traffic or barrier
+    const int Xa = flip ? a.crop - 1 - (x0 + ncol - 1) : x0, Xb = flip ? a.crop - 1 - x0 : x0 + ncol - 1;
+    const int sx_lo = resize_src_lo(Xa, cb, scale), sy_lo = resize_src_lo(y0, cb, scale);
+    const int sx_hi = min(resize_src_lo(Xb, cb, scale) + 1, cb - 1), sy_hi = min(resize_src_lo(y0 + nrow - 1, cb, scale) + 1, cb - 1);
+    const int rows = sy_hi - sy_lo + 1;
+    const int span = (sx_hi - sx_lo + 1) * 3;
+    const int nch = (span + 12 + 15) >> 4;               // 16-byte chunks per row: misalignment (<= 3) + span + the 12-byte tap reads
+    const bool staged = !area2 && rows <= ta.max_rows && nch * 16 <= ta.pitch && cb <= 32767;
+
+    // (2) source rectangle -> LDS (row r at s_rows + r*pitch, starting at the 4-byte-aligned address below its first
+    //     byte); the tile's column / row coefficients are computed while those loads are in flight
+    if (staged) {
+        for (int idx = tid; idx < rows * nch; idx += 256) {
+            const int r = idx / nch, c = idx - r * nch;
+            const uint8_t *g = frame + ((int64_t)(sy_lo + r) * a.Ws + sx_lo) * 3;
+            g -= reinterpret_cast<uintptr_t>(g) & 3u;
+            g += c * 16;
+            uint32_t v[4] = {0u, 0u, 0u, 0u};
+            if (g + 16 <= a.src_end) __builtin_memcpy(v, g, 16);
+            else for (int b = 0; b < 16 && g + b < a.src_end; ++b) reinterpret_cast<unsigned char *>(v)[b] = g[b];
+            uint32_t *d = reinterpret_cast<uint32_t *>(s_rows + (size_t)r * ta.pitch + c * 16);
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        }
+    }
+    if (tid < ncol) {
+        int X = x0 + tid;
+        if (flip) X = a.crop - 1 - X;
+        const Coef c = resize_coef(X, cb, scale);
+        s_col[tid] = ColC{(uint16_t)c.s0, (uint16_t)(c.s1 == c.s0), (int16_t)c.a0, (int16_t)c.a1};
+    } else if (tid >= kTileCols && tid < kTileCols + nrow) {
+        const Coef c = resize_coef(y0 + tid - kTileCols, cb, scale);
+        s_row[tid - kTileCols] = RowC{(int16_t)c.s0, (int16_t)c.s1, (int16_t)c.a0, (int16_t)c.a1};
+    }
+    __syncthreads();
+
+    // (3) blend: lane -> one row, 4 adjacent columns
+    const int r = tid >> 5, cg = (tid & 31) * 4;
+    if (r >= nrow || cg >= ncol) return;
+    const RowC rc = s_row[r];
+    const int y = y0 + r;
+    uint32_t packed = 0;
+    if (staged) {
+        const uint8_t *g0p = frame + ((int64_t)rc.s0 * a.Ws + sx_lo) * 3, *g1p = frame + ((int64_t)rc.s1 * a.Ws + sx_lo) * 3;
+        const uint32_t m0 = (uint32_t)(reinterpret_cast<uintptr_t>(g0p) & 3u), m1 = (uint32_t)(reinterpret_cast<uintptr_t>(g1p) & 3u);
+        const unsigned char *l0 = s_rows + (size_t)(rc.s0 - sy_lo) * ta.pitch, *l1 = s_rows + (size_t)(rc.s1 - sy_lo) * ta.pitch;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (cg + j >= ncol) break;
+            const ColC cc = s_col[cg + j];
+            const uint32_t off = (uint32_t)(cc.s0 - sx_lo) * 3u;
+            int g00, g01, g10, g11;
+            lds_gray_pair(l0, off + m0, g00, g01);
+            lds_gray_pair(l1, off + m1, g10, g11);
+            if (cc.single) { g01 = g00; g11 = g10; }
+            packed |= (uint32_t)blend_cv(g00, g01, g10, g11, cc.a0, cc.a1, rc.a0, rc.a1) << (8 * j);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (cg + j >= ncol) break;
+            int X = x0 + cg + j;
+            if (flip) X = a.crop - 1 - X;
+            int v;
+            if (area2) {
+                const uint8_t *p0 = frame + ((int64_t)(2 * y) * a.Ws + 2 * X) * 3, *p1 = p0 + (int64_t)a.Ws * 3;
+                v = (bgr2gray_cv(p0) + bgr2gray_cv(p0 + 3) + bgr2gray_cv(p1) + bgr2gray_cv(p1 + 3) + 2) >> 2;
+            } else {
+                const ColC cc = s_col[cg + j];
+                const int s1 = cc.single ? cc.s0 : cc.s0 + 1;
+                const uint8_t *p0 = frame + (int64_t)rc.s0 * a.Ws * 3, *p1 = frame + (int64_t)rc.s1 * a.Ws * 3;
+                v = blend_cv(bgr2gray_cv(p0 + cc.s0 * 3), bgr2gray_cv(p0 + s1 * 3), bgr2gray_cv(p1 + cc.s0 * 3), bgr2gray_cv(p1 + s1 * 3),
+                             cc.a0, cc.a1, rc.a0, rc.a1);
+            }
+            packed |= (uint32_t)v << (8 * j);
+        }
+    }
+    uint8_t *o = out + (int64_t)y * a.crop + x0 + cg;
+    if (cg + 4 <= ncol && (reinterpret_cast<uintptr_t>(o) & 3u) == 0) *reinterpret_cast<uint32_t *>(o) = packed;
+    else for (int j = 0; j < 4 && cg + j < ncol; ++j) o[j] = (uint8_t)(packed >> (8 * j));
 }
 
 }  // namespace v2v

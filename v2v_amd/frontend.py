@@ -53,9 +53,11 @@ def prepare_clip(raw: torch.Tensor, crop_before: int, min_i: int, min_j: int, fl
 
 
 def prepare_clips_batch(raw: torch.Tensor, clip_table, img_idxes, crop_size: int, color_mode: str = "gray",
-                        want_imgs: bool = False, validate: bool = True):
+                        want_imgs: bool = False, validate: bool = True, max_crop_before: int = 0):
     """Batch form of prepare_clip (no shake): raw [B,T,Hs,Ws,C] uint8 CUDA; clip_table [B,4] int = {min_i, min_j,
-    crop_before, flip}; img_idxes [B,N].  Returns (imgs [B,N,crop,crop,Cout] or None, gray [B,N,crop,crop]) -- ONE launch."""
+    crop_before, flip}; img_idxes [B,N].  Returns (imgs [B,N,crop,crop,Cout] or None, gray [B,N,crop,crop]) -- ONE launch.
+    max_crop_before: optional upper bound of crop_before for device-resident tables (taken from the table when it is on
+    the host); it only sizes the kernel's LDS tile."""
     _lib.require_gpu()
     if raw.ndim != 5 or raw.dtype != torch.uint8 or not raw.is_cuda:
         raise ValueError("raw must be a [B,T,Hs,Ws,C] uint8 CUDA tensor")
@@ -63,23 +65,31 @@ def prepare_clips_batch(raw: torch.Tensor, clip_table, img_idxes, crop_size: int
     raw = raw.contiguous()
     b, t, hs, ws, cs = raw.shape
     dev = raw.device
-    tab_h = np.asarray(clip_table.cpu() if isinstance(clip_table, torch.Tensor) else clip_table, dtype=np.int32).reshape(b, 4)
-    idx_h = np.asarray(img_idxes.cpu() if isinstance(img_idxes, torch.Tensor) else img_idxes, dtype=np.int32).reshape(b, -1)
-    if validate:
-        if (tab_h[:, 0] < 0).any() or (tab_h[:, 1] < 0).any() or (tab_h[:, 2] < 1).any() or \
-                (tab_h[:, 0] + tab_h[:, 2] > hs).any() or (tab_h[:, 1] + tab_h[:, 2] > ws).any():
-            raise ValueError("crop rectangle outside the frame")
-        if idx_h.size and (idx_h.min() < 0 or idx_h.max() >= t):
-            raise IndexError("img_idxes outside the decoded frames")
-    tab = torch.as_tensor(tab_h, device=dev)
-    idx = torch.as_tensor(idx_h, device=dev)
+    def on_device(x):
+        return isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.int32 and x.is_contiguous()
+    if not validate and on_device(clip_table) and on_device(img_idxes):
+        # device-resident tables are used as they are: no host round trip (and no synchronisation) per batch
+        tab, idx = clip_table.reshape(b, 4), img_idxes.reshape(b, -1)
+    else:
+        tab_h = np.asarray(clip_table.cpu() if isinstance(clip_table, torch.Tensor) else clip_table, dtype=np.int32).reshape(b, 4)
+        idx_h = np.asarray(img_idxes.cpu() if isinstance(img_idxes, torch.Tensor) else img_idxes, dtype=np.int32).reshape(b, -1)
+        if validate:
+            if (tab_h[:, 0] < 0).any() or (tab_h[:, 1] < 0).any() or (tab_h[:, 2] < 1).any() or \
+                    (tab_h[:, 0] + tab_h[:, 2] > hs).any() or (tab_h[:, 1] + tab_h[:, 2] > ws).any():
+                raise ValueError("crop rectangle outside the frame")
+            if idx_h.size and (idx_h.min() < 0 or idx_h.max() >= t):
+                raise IndexError("img_idxes outside the decoded frames")
+        tab = torch.as_tensor(tab_h, device=dev)
+        idx = torch.as_tensor(idx_h, device=dev)
+        if b:
+            max_crop_before = int(tab_h[:, 2].max())
     n = idx.shape[1]
     gray_first = color_mode == "gray"
     cout = 1 if (gray_first or cs == 1) else 3
     imgs = torch.empty((b, n, crop_size, crop_size, cout), dtype=torch.uint8, device=dev) if want_imgs else None
     gray = torch.empty((b, n, crop_size, crop_size), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        rc = _lib.lib().v2v_frontend_batch_hip(C.c_void_p(raw.data_ptr()), b, t, hs, ws, cs, C.c_void_p(tab.data_ptr()), crop_size,
+        rc = _lib.lib().v2v_frontend_batch_hip(C.c_void_p(raw.data_ptr()), b, t, hs, ws, cs, C.c_void_p(tab.data_ptr()), int(max_crop_before), crop_size,
                                                int(gray_first), C.c_void_p(idx.data_ptr()), n,
                                                C.c_void_p(imgs.data_ptr()) if imgs is not None else None,
                                                C.c_void_p(gray.data_ptr()), _lib.stream_ptr())
