@@ -167,7 +167,7 @@ int v2v_esim_voxel_keyed_hip(const void *frames, int in_dtype, int64_t B, int64_
     if (!noise && rng_mode == V2V_RNG_REPLAY) return fail(V2V_ERR_PARAM, "V2V_FLAG_NO_NOISE is not available in replay mode");
     const size_t lds = 256 * (in_dtype == V2V_U8 ? sizeof(double) : sizeof(float)) +
                        (bin_mode == V2V_BIN_BILINEAR ? (size_t)K * 2 * (out64 ? sizeof(double) : sizeof(float)) + (size_t)num_bins * sizeof(int) : 0);
-    if (lds > 160 * 1024) return fail(V2V_ERR_SHAPE, "too many frame pairs for the LDS weight table");
+    if (lds > 64 * 1024) return fail(V2V_ERR_SHAPE, "too many frame pairs for the LDS tables (%zu bytes > 64 KiB): split the clip", lds);
     hipStream_t s = static_cast<hipStream_t>(stream);
 
     hipError_t e;
@@ -268,7 +268,7 @@ int v2v_v2e_voxel_hip(const void *frames, int in_dtype, int64_t B, int64_t N, in
     if (nblocks > 0x7FFFFFFF) return fail(V2V_ERR_SHAPE, "grid too large");
     const bool out64 = out_dtype == V2V_F64;
     const size_t lds = 256 * sizeof(float) + (size_t)K * 5 * sizeof(double) /* per-frame constants */ + (bin_mode == V2V_BIN_BILINEAR ? (size_t)K * (2 * (out64 ? sizeof(double) : sizeof(float)) + sizeof(int)) : 0);
-    if (lds > 160 * 1024) return fail(V2V_ERR_SHAPE, "too many frame pairs for the LDS weight table");
+    if (lds > 64 * 1024) return fail(V2V_ERR_SHAPE, "too many frame pairs for the LDS tables (%zu bytes > 64 KiB): split the clip", lds);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (presum) {
         const hipError_t e0 = hipMemsetAsync(workspace, 0, (size_t)v2v_v2e_workspace_bytes(B, N), s);
@@ -326,21 +326,26 @@ static hipError_t launch_frontend(const v2v::FrontendArgs &a, int64_t B, int64_t
         const int64_t frame_min = a.Hs < a.Ws ? a.Hs : a.Ws;
         const int64_t cb_max = (max_crop_before > 0 && max_crop_before < frame_min) ? max_crop_before : frame_min;
         const double s_max = (double)cb_max / (double)a.crop;
-        const int64_t span_px = (int64_t)(v2v::kTileCols * s_max) + 3;
-        const int64_t pitch = ((span_px * 3 + 12 + 15) / 16) * 16 + 16;
-        int64_t max_rows = (int64_t)(v2v::kTileRows * s_max) + 3;
-        const int64_t budget = 48 * 1024 - v2v::kTileHdrBytes;
-        if (max_rows * pitch > budget) max_rows = budget / pitch;
-        if (max_rows >= 4 && pitch <= budget) {
-            v2v::FrontendTileArgs ta{};
-            ta.f = a;
-            ta.pitch = (int32_t)pitch; ta.max_rows = (int32_t)max_rows;
-            ta.tiles_x = (a.crop + v2v::kTileCols - 1) / v2v::kTileCols;
-            ta.tiles_y = (a.crop + v2v::kTileRows - 1) / v2v::kTileRows;
-            const int64_t nblocks = (int64_t)ta.tiles_x * ta.tiles_y * a.N;
-            if (nblocks <= 0x7FFFFFFF) {
-                hipLaunchKernelGGL(v2v::frontend_tile_kernel, dim3((unsigned)nblocks, (unsigned)B), dim3(256),
-                                   (size_t)(v2v::kTileHdrBytes + max_rows * pitch), s, ta);
+        // tile = (4 waves x rows_per_wave) rows x (64 lanes x cpl) columns; shrink until the worst-case source rectangle fits
+        for (int cpl = a.crop > 128 ? 4 : 2; cpl >= 2; cpl -= 2) {
+            const int64_t span_px = (int64_t)(64 * cpl * s_max) + 3;
+            const int64_t pitch = ((span_px * 3 + 12 + 15) / 16) * 16 + 16;
+            const int64_t budget = 48 * 1024 - v2v::tile_hdr_bytes(cpl);
+            int rpw_cap = (int)((a.crop + 3) / 4);                        // no point in more rows per wave than the image has
+            if (rpw_cap > 4) rpw_cap = 4;
+            for (int rpw = rpw_cap; rpw >= 1; rpw >>= 1) {
+                const int64_t max_rows = (int64_t)(4 * rpw * s_max) + 3;
+                if (max_rows * pitch > budget) continue;
+                v2v::FrontendTileArgs ta{};
+                ta.f = a;
+                ta.pitch = (int32_t)pitch; ta.max_rows = (int32_t)max_rows; ta.rows_per_wave = rpw;
+                ta.tiles_x = (a.crop + 64 * cpl - 1) / (64 * cpl);
+                ta.tiles_y = (a.crop + 4 * rpw - 1) / (4 * rpw);
+                const int64_t nblocks = (int64_t)ta.tiles_x * ta.tiles_y * a.N;
+                if (nblocks > 0x7FFFFFFF) break;
+                const size_t lds = (size_t)(v2v::tile_hdr_bytes(cpl) + max_rows * pitch);
+                if (cpl == 4) hipLaunchKernelGGL(v2v::frontend_tile_kernel<4>, dim3((unsigned)nblocks, (unsigned)B), dim3(256), lds, s, ta);
+                else hipLaunchKernelGGL(v2v::frontend_tile_kernel<2>, dim3((unsigned)nblocks, (unsigned)B), dim3(256), lds, s, ta);
                 return hipGetLastError();
             }
         }

@@ -155,29 +155,46 @@ __global__ void __launch_bounds__(256) frontend_kernel(const FrontendArgs a_in)
 }
 
 // ---- LDS-tiled variant for the training configuration (BGR source, color_mode 'gray', no shake, gray output only) ---
-// The gather kernel above issues eight unaligned 8-byte loads and ~350 VALU instructions (float64 coordinate maths)
-// per four output pixels and runs at a fifth of the source bytes' streaming time.  Here a workgroup owns a tile of
-// kTileRows x kTileCols output pixels of one frame: (1) 128+8 lanes compute the OpenCV column/row coefficients of the
-// tile once into LDS, (2) the source rectangle the tile touches is copied with 16-byte loads into LDS, (3) every lane
-// blends its 4 adjacent outputs from LDS (three aligned dword reads + v_alignbyte per tap row) and stores one dword.
+// The gather kernel above spends ~350 VALU instructions (float64 coordinate maths, four gray conversions) and eight
+// unaligned 8-byte loads per four output pixels.  Here a workgroup owns a tile of (4 x rows_per_wave) x (64 x CPL) output
+// pixels of one frame:
+//  (1) every lane evaluates the four corner source coordinates (index part only), so that
+//  (2) the copy of the source rectangle into LDS (16-byte loads, one wave per source row) is issued before any barrier;
+//      the tile's column / row coefficients (OpenCV's fixed-point weights) are computed into LDS while the loads fly;
+//  (3) a wave owns rows_per_wave adjacent output rows, a lane CPL adjacent columns.  The wave walks the SOURCE rows it
+//      needs once, in order: the horizontal pass of a source row (BGR->gray of both taps from LDS -- three aligned
+//      dword reads + v_alignbyte -- and the 11-bit blend) is computed once and reused by every output row that taps it
+//      (OpenCV's own hresize/vresize order: ~scale horizontal passes per output row instead of 2); row bookkeeping is
+//      wave-uniform (scalar branches).
 // Same fixed-point arithmetic, bit for bit; clips whose rectangle does not fit the LDS budget (or that take OpenCV's
 // 2x2 area shortcut) fall back to per-pixel global reads inside the same kernel.
-constexpr int kTileRows = 8, kTileCols = 128;
+constexpr int kTileMaxRows = 64;                          // output rows per tile <= 4 waves x 16
 struct ColC { uint16_t s0, single; int16_t a0, a1; };   // source column of the left tap, s1 == s0 (border clamp), weights
 struct RowC { int16_t s0, s1, a0, a1; };
-constexpr int kTileHdrBytes = kTileCols * 8 + kTileRows * 8;
+__host__ __device__ constexpr int tile_hdr_bytes(int cpl) { return 64 * cpl * 8 + kTileMaxRows * 8; }
 
 struct FrontendTileArgs {
     FrontendArgs f;
     int32_t pitch, max_rows;      // LDS row pitch (bytes, multiple of 16) and row capacity
+    int32_t rows_per_wave;        // output rows per wave (tile = 4 x rows_per_wave rows)
     int32_t tiles_x, tiles_y;
 };
 
-__device__ __forceinline__ int blend_cv(int g00, int g01, int g10, int g11, int xa0, int xa1, int ya0, int ya1)
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+
+// 16 bytes starting at g, zero beyond `end` (never inlined: it would bloat the copy loop it is the rare exit of)
+__device__ __noinline__ u32x4v load16_clipped(const uint8_t *g, const uint8_t *end)
 {
-    const int r0 = g00 * xa0 + g01 * xa1;
-    const int r1 = g10 * xa0 + g11 * xa1;
-    const int v = (((ya0 * (r0 >> 4)) >> 16) + ((ya1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    unsigned char b[16];
+    for (int i = 0; i < 16; ++i) b[i] = (g + i < end) ? g[i] : (unsigned char)0;
+    u32x4v v;
+    __builtin_memcpy(&v, b, 16);
+    return v;
+}
+
+__device__ __forceinline__ int vblend_cv(int h0, int h1, int ya0, int ya1)
+{
+    const int v = (((ya0 * h0) >> 16) + ((ya1 * h1) >> 16) + 2) >> 2;
     return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
@@ -193,20 +210,23 @@ __device__ __forceinline__ void lds_gray_pair(const unsigned char *row, uint32_t
     g1 = ((int)(lo >> 24) * 1868 + (int)(hi & 255u) * 9617 + (int)((hi >> 8) & 255u) * 4899 + (1 << 13)) >> 14;
 }
 
+template <int CPL>
 __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileArgs ta)
 {
+    constexpr int kCols = 64 * CPL;
     extern __shared__ __align__(16) unsigned char s_mem[];
     ColC *s_col = reinterpret_cast<ColC *>(s_mem);
-    RowC *s_row = reinterpret_cast<RowC *>(s_mem + kTileCols * 8);
-    unsigned char *s_rows = s_mem + kTileHdrBytes;
+    RowC *s_row = reinterpret_cast<RowC *>(s_mem + kCols * 8);
+    unsigned char *s_rows = s_mem + tile_hdr_bytes(CPL);
     const FrontendArgs &a = ta.f;
     const int clip = blockIdx.y;
     const int tiles = ta.tiles_x * ta.tiles_y;
     const int n = blockIdx.x / tiles;
     const int tile = blockIdx.x - n * tiles;
     const int ty = tile / ta.tiles_x, tx = tile - ty * ta.tiles_x;
-    const int y0 = ty * kTileRows, x0 = tx * kTileCols;
-    const int ncol = min(kTileCols, a.crop - x0), nrow = min(kTileRows, a.crop - y0);
+    const int tile_rows = 4 * ta.rows_per_wave;
+    const int y0 = ty * tile_rows, x0 = tx * kCols;
+    const int ncol = min(kCols, a.crop - x0), nrow = min(tile_rows, a.crop - y0);
     int min_i = a.min_i, min_j = a.min_j, cb = a.crop_before, flip = a.flip;
     if (a.clip_table) { const int32_t *t4 = a.clip_table + (int64_t)clip * 4; min_i = t4[0]; min_j = t4[1]; cb = t4[2]; flip = t4[3]; }
     const int t = a.frame_idx[(int64_t)clip * a.N + n];
@@ -216,8 +236,7 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
     const double scale = 1.0 / ((double)a.crop / (double)cb);
     const int tid = threadIdx.x;
 
-    // (1) extent of the source rectangle: every lane evaluates the four corner coordinates itself (index part only), so
-    //     the copy below can be issued before any LDS traffic or barrier
+    // (1) extent of the source rectangle
     const int Xa = flip ? a.crop - 1 - (x0 + ncol - 1) : x0, Xb = flip ? a.crop - 1 - x0 : x0 + ncol - 1;
     const int sx_lo = resize_src_lo(Xa, cb, scale), sy_lo = resize_src_lo(y0, cb, scale);
     const int sx_hi = min(resize_src_lo(Xb, cb, scale) + 1, cb - 1), sy_hi = min(resize_src_lo(y0 + nrow - 1, cb, scale) + 1, cb - 1);
@@ -226,76 +245,118 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
     const int nch = (span + 12 + 15) >> 4;               // 16-byte chunks per row: misalignment (<= 3) + span + the 12-byte tap reads
     const bool staged = !area2 && rows <= ta.max_rows && nch * 16 <= ta.pitch && cb <= 32767;
 
-    // (2) source rectangle -> LDS (row r at s_rows + r*pitch, starting at the 4-byte-aligned address below its first
-    //     byte); the tile's column / row coefficients are computed while those loads are in flight
+    // (2) source rectangle -> LDS (row r at s_rows + r*pitch, starting at the 4-byte-aligned address below its first byte)
+    const int lane = tid & 63, wave = tid >> 6;
     if (staged) {
-        for (int idx = tid; idx < rows * nch; idx += 256) {
-            const int r = idx / nch, c = idx - r * nch;
-            const uint8_t *g = frame + ((int64_t)(sy_lo + r) * a.Ws + sx_lo) * 3;
-            g -= reinterpret_cast<uintptr_t>(g) & 3u;
-            g += c * 16;
-            uint32_t v[4] = {0u, 0u, 0u, 0u};
-            if (g + 16 <= a.src_end) __builtin_memcpy(v, g, 16);
-            else for (int b = 0; b < 16 && g + b < a.src_end; ++b) reinterpret_cast<unsigned char *>(v)[b] = g[b];
-            uint32_t *d = reinterpret_cast<uint32_t *>(s_rows + (size_t)r * ta.pitch + c * 16);
-            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        for (int r = wave; r < rows; r += 4) {                           // one wave per source row: wave-uniform row address
+            const uint8_t *grow = frame + ((int64_t)(sy_lo + r) * a.Ws + sx_lo) * 3;
+            grow -= reinterpret_cast<uintptr_t>(grow) & 3u;
+            unsigned char *lrow = s_rows + (size_t)r * ta.pitch;
+            for (int c = lane; c < nch; c += 64) {
+                const uint8_t *g = grow + c * 16;
+                u32x4v v;
+                if (__builtin_expect(g + 16 <= a.src_end, 1)) __builtin_memcpy(&v, g, 16);
+                else v = load16_clipped(g, a.src_end);                   // last bytes of the whole source buffer
+                *reinterpret_cast<u32x4v *>(lrow + c * 16) = v;
+            }
         }
     }
     if (tid < ncol) {
         int X = x0 + tid;
         if (flip) X = a.crop - 1 - X;
         const Coef c = resize_coef(X, cb, scale);
-        s_col[tid] = ColC{(uint16_t)c.s0, (uint16_t)(c.s1 == c.s0), (int16_t)c.a0, (int16_t)c.a1};
-    } else if (tid >= kTileCols && tid < kTileCols + nrow) {
-        const Coef c = resize_coef(y0 + tid - kTileCols, cb, scale);
-        s_row[tid - kTileCols] = RowC{(int16_t)c.s0, (int16_t)c.s1, (int16_t)c.a0, (int16_t)c.a1};
+        // right tap clamped onto the left one (last source column): g*a0 + g*a1 == g*(a0+a1) + anything*0, so the
+        // blend needs no special case
+        const bool single = c.s1 == c.s0;
+        s_col[tid] = ColC{(uint16_t)c.s0, (uint16_t)single, (int16_t)(single ? c.a0 + c.a1 : c.a0), (int16_t)(single ? 0 : c.a1)};
+    }
+    if (tid < nrow) {
+        const Coef c = resize_coef(y0 + tid, cb, scale);
+        s_row[tid] = RowC{(int16_t)c.s0, (int16_t)c.s1, (int16_t)c.a0, (int16_t)c.a1};
     }
     __syncthreads();
 
-    // (3) blend: lane -> one row, 4 adjacent columns
-    const int r = tid >> 5, cg = (tid & 31) * 4;
-    if (r >= nrow || cg >= ncol) return;
-    const RowC rc = s_row[r];
-    const int y = y0 + r;
-    uint32_t packed = 0;
+    // (3) a wave: rows_per_wave adjacent output rows; a lane: CPL adjacent columns
+    const int yw0 = wave * ta.rows_per_wave, yw1 = min(yw0 + ta.rows_per_wave, nrow) - 1;      // tile-relative, inclusive
+    const int cg = lane * CPL;
+    if (yw0 > yw1 || cg >= ncol) return;
+    auto store_row = [&](int y, uint32_t packed) {
+        uint8_t *o = out + (int64_t)(y0 + y) * a.crop + x0 + cg;
+        if (cg + CPL <= ncol && (reinterpret_cast<uintptr_t>(o) & (CPL - 1)) == 0) {
+            if constexpr (CPL == 4) *reinterpret_cast<uint32_t *>(o) = packed;
+            else *reinterpret_cast<uint16_t *>(o) = (uint16_t)packed;
+        } else {
+            for (int j = 0; j < CPL && cg + j < ncol; ++j) o[j] = (uint8_t)(packed >> (8 * j));
+        }
+    };
     if (staged) {
-        const uint8_t *g0p = frame + ((int64_t)rc.s0 * a.Ws + sx_lo) * 3, *g1p = frame + ((int64_t)rc.s1 * a.Ws + sx_lo) * 3;
-        const uint32_t m0 = (uint32_t)(reinterpret_cast<uintptr_t>(g0p) & 3u), m1 = (uint32_t)(reinterpret_cast<uintptr_t>(g1p) & 3u);
-        const unsigned char *l0 = s_rows + (size_t)(rc.s0 - sy_lo) * ta.pitch, *l1 = s_rows + (size_t)(rc.s1 - sy_lo) * ta.pitch;
+        ColC cc[CPL];
+        uint32_t off[CPL];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (cg + j >= ncol) break;
-            const ColC cc = s_col[cg + j];
-            const uint32_t off = (uint32_t)(cc.s0 - sx_lo) * 3u;
-            int g00, g01, g10, g11;
-            lds_gray_pair(l0, off + m0, g00, g01);
-            lds_gray_pair(l1, off + m1, g10, g11);
-            if (cc.single) { g01 = g00; g11 = g10; }
-            packed |= (uint32_t)blend_cv(g00, g01, g10, g11, cc.a0, cc.a1, rc.a0, rc.a1) << (8 * j);
+        for (int j = 0; j < CPL; ++j) {
+            cc[j] = s_col[min(cg + j, ncol - 1)];
+            off[j] = (uint32_t)(cc[j].s0 - sx_lo) * 3u;
+        }
+        const uint32_t frame_lo = (uint32_t)reinterpret_cast<uintptr_t>(frame);
+        int y = yw0;
+        const int sr_first = __builtin_amdgcn_readfirstlane((int)s_row[yw0].s0);
+        const int sr_last = __builtin_amdgcn_readfirstlane((int)s_row[yw1].s1);
+        int h_prev[CPL], h_cur[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) h_prev[j] = 0;
+        for (int sr = sr_first; sr <= sr_last && y <= yw1; ++sr) {
+            // rows between two output rows' taps (down-scaling by more than 2) are not needed by anyone
+            if (__builtin_amdgcn_readfirstlane((int)s_row[y].s0) > sr) continue;
+            // horizontal pass of source row sr
+            const unsigned char *lrow = s_rows + (size_t)(sr - sy_lo) * ta.pitch;
+            const uint32_t mis = (frame_lo + (uint32_t)((sr * a.Ws + sx_lo) * 3)) & 3u;          // low address bits: wrap-safe
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                int g0, g1;
+                lds_gray_pair(lrow, off[j] + mis, g0, g1);
+                h_cur[j] = (g0 * cc[j].a0 + g1 * cc[j].a1) >> 4;
+            }
+            // vertical pass of every output row whose lower tap is sr
+            while (y <= yw1) {
+                const RowC rc = s_row[y];
+                const int rs0 = __builtin_amdgcn_readfirstlane((int)rc.s0), rs1 = __builtin_amdgcn_readfirstlane((int)rc.s1);
+                if (rs1 != sr) break;
+                const int ya0 = __builtin_amdgcn_readfirstlane((int)rc.a0), ya1 = __builtin_amdgcn_readfirstlane((int)rc.a1);
+                uint32_t packed = 0;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j)
+                    packed |= (uint32_t)vblend_cv(rs0 == sr ? h_cur[j] : h_prev[j], h_cur[j], ya0, ya1) << (8 * j);
+                store_row(y, packed);
+                ++y;
+            }
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) h_prev[j] = h_cur[j];
         }
     } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (cg + j >= ncol) break;
-            int X = x0 + cg + j;
-            if (flip) X = a.crop - 1 - X;
-            int v;
-            if (area2) {
-                const uint8_t *p0 = frame + ((int64_t)(2 * y) * a.Ws + 2 * X) * 3, *p1 = p0 + (int64_t)a.Ws * 3;
-                v = (bgr2gray_cv(p0) + bgr2gray_cv(p0 + 3) + bgr2gray_cv(p1) + bgr2gray_cv(p1 + 3) + 2) >> 2;
-            } else {
-                const ColC cc = s_col[cg + j];
-                const int s1 = cc.single ? cc.s0 : cc.s0 + 1;
-                const uint8_t *p0 = frame + (int64_t)rc.s0 * a.Ws * 3, *p1 = frame + (int64_t)rc.s1 * a.Ws * 3;
-                v = blend_cv(bgr2gray_cv(p0 + cc.s0 * 3), bgr2gray_cv(p0 + s1 * 3), bgr2gray_cv(p1 + cc.s0 * 3), bgr2gray_cv(p1 + s1 * 3),
-                             cc.a0, cc.a1, rc.a0, rc.a1);
+        for (int y = yw0; y <= yw1; ++y) {
+            const RowC rc = s_row[y];
+            uint32_t packed = 0;
+            for (int j = 0; j < CPL; ++j) {
+                if (cg + j >= ncol) break;
+                int X = x0 + cg + j;
+                if (flip) X = a.crop - 1 - X;
+                int v;
+                if (area2) {
+                    const uint8_t *p0 = frame + ((int64_t)(2 * (y0 + y)) * a.Ws + 2 * X) * 3, *p1 = p0 + (int64_t)a.Ws * 3;
+                    v = (bgr2gray_cv(p0) + bgr2gray_cv(p0 + 3) + bgr2gray_cv(p1) + bgr2gray_cv(p1 + 3) + 2) >> 2;
+                } else {
+                    const ColC c1 = s_col[cg + j];
+                    const int s1 = c1.single ? c1.s0 : c1.s0 + 1;      // (a1 is 0 for a clamped tap: either pixel gives the same sum)
+                    const uint8_t *p0 = frame + (int64_t)rc.s0 * a.Ws * 3, *p1 = frame + (int64_t)rc.s1 * a.Ws * 3;
+                    const int h0 = (bgr2gray_cv(p0 + c1.s0 * 3) * c1.a0 + bgr2gray_cv(p0 + s1 * 3) * c1.a1) >> 4;
+                    const int h1 = (bgr2gray_cv(p1 + c1.s0 * 3) * c1.a0 + bgr2gray_cv(p1 + s1 * 3) * c1.a1) >> 4;
+                    v = vblend_cv(h0, h1, rc.a0, rc.a1);
+                }
+                packed |= (uint32_t)v << (8 * j);
             }
-            packed |= (uint32_t)v << (8 * j);
+            store_row(y, packed);
         }
     }
-    uint8_t *o = out + (int64_t)y * a.crop + x0 + cg;
-    if (cg + 4 <= ncol && (reinterpret_cast<uintptr_t>(o) & 3u) == 0) *reinterpret_cast<uint32_t *>(o) = packed;
-    else for (int j = 0; j < 4 && cg + j < ncol; ++j) o[j] = (uint8_t)(packed >> (8 * j));
 }
 
 }  // namespace v2v
