@@ -101,3 +101,28 @@ def test_random_event_lists(case):
         pf = (ps * 2 - 1).astype(np.float64)
         np.testing.assert_allclose(voxel.events_to_voxel(xs, ys, ts, pf, nb, (h, w)), O.events_to_voxel(xs, ys, ts, pf, nb, (h, w)),
                                    rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize("case", range(20))
+def test_random_frontend_tiles(case):
+    """LDS-tiled front-end vs the OpenCV-algorithm restatement (and the gather kernel) on random frames, rectangles,
+    crop sizes (both tile widths), flips; includes up-scaling, >2x down-scaling (skipped source rows) and 1-pixel crops."""
+    from oracle import frontend_oracle as F
+    from v2v_amd import frontend
+    g = np.random.default_rng(7000 + case)
+    hs, ws = int(g.integers(8, 260)), int(g.integers(8, 300))
+    crop = int(g.integers(1, 200)) if case % 4 else int(g.integers(129, 300))          # every 4th case: the 256-wide tile
+    cb = int(g.integers(1, min(hs, ws) + 1))
+    if case % 5 == 0 and 2 * crop <= min(hs, ws):
+        cb = 2 * crop                                                                    # OpenCV's area shortcut
+    mi, mj = int(g.integers(0, hs - cb + 1)), int(g.integers(0, ws - cb + 1))
+    flip = bool(g.integers(0, 2))
+    t = 2
+    raw = g.integers(0, 256, size=(t, hs, ws, 3), dtype=np.uint8)
+    idxes = [1, 0, 1]
+    _, want = F.frontend(raw, cb, mi, mj, flip, crop, idxes, None, None, "gray")
+    raw_d = torch.from_numpy(raw).cuda()
+    _, gray = frontend.prepare_clip(raw_d, cb, mi, mj, flip, crop, idxes, want_imgs=False)
+    assert np.array_equal(gray.cpu().numpy(), want), (hs, ws, crop, cb, mi, mj, flip)
+    _, gather = frontend.prepare_clip(raw_d, cb, mi, mj, flip, crop, idxes, want_imgs=True)
+    assert torch.equal(gray, gather)
