@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses cuda:0 (tests the N>1 code path on a 1-GPU box)")
+    ap.add_argument("--hip-graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the step from a captured hipGraph (auto: multi-launch pipeline workloads only)")
     args = ap.parse_args()
 
     import torch
@@ -193,6 +195,27 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # Multi-launch steps (front-end + simulator [+ consumer]) are replayed from one captured hipGraph: the C-ABI entry
+    # points only enqueue kernels on the caller's stream (no allocation, no synchronisation), so they capture as they are.
+    use_graph = args.hip_graph == "on" or (args.hip_graph == "auto" and wl["model"] == "pipeline")
+    if use_graph:
+        try:
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            step = graph.replay
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+        except Exception as exc:  # noqa: BLE001 - capture is an optimisation; fall back to eager launches
+            print(f"[bench] hipGraph capture unavailable ({type(exc).__name__}: {exc}); eager launches", file=sys.stderr, flush=True)
+            use_graph = False
     sharding.barrier(dist, local_rank)
     # per-launch HIP events on the stream the kernel is launched on (torch's current stream)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -286,7 +309,8 @@ def main():
             "config": {"workload": args.workload, "model": wl["model"], "clips_per_gpu": b, "frames": n, "height": h, "width": w,
                        "input_dtype": wl["dtype"], "bin_mode": bin_mode, "num_bins": tb, "frames_per_bin": fpb,
                        "sim_params": params, "rng": "philox4x32-10 on device",
-                       "sharding": f"batch over {world} GPU(s), no collective", "grid": [tb, h, w]},
+                       "sharding": f"batch over {world} GPU(s), no collective", "grid": [tb, h, w],
+                       "launch": "hipGraph replay" if use_graph else "eager"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": alg_bytes,

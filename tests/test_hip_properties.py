@@ -92,3 +92,44 @@ def test_shapes_at_the_edges_vs_oracle(oracle_c, luts):
     c = torch.zeros((300, 2), dtype=torch.int64, device="cuda")
     got = E.esim_voxel_batch(torch.from_numpy(tiny).cuda(), params, num_bins=5, seed=9, clip_id0=1000, counts=c)
     assert np.array_equal(got.cpu().numpy(), want) and np.array_equal(c.cpu().numpy(), tot)
+
+
+@pytest.mark.gpu
+def test_entry_points_capture_into_a_hip_graph():
+    """The C-ABI launches only enqueue work on the caller's stream (no allocation, no synchronisation): a front-end +
+    simulator + v2e step captured in a hipGraph replays to the same bytes as eager launches."""
+    import torch
+    from v2v_amd import esim, frontend, v2e
+    dev = torch.device("cuda")
+    raw = torch.randint(0, 256, (2, 6, 96, 128, 3), dtype=torch.uint8, device=dev)
+    table = torch.tensor([[3, 5, 80, 0], [10, 20, 70, 1]], dtype=torch.int32, device=dev)
+    idx = torch.tensor([[0, 1, 2, 3, 4, 5]] * 2, dtype=torch.int32, device=dev)
+    params = torch.tensor([0.2, 0.25, 0.05, 1e-3, 0.5], dtype=torch.float64, device=dev)
+    vp = v2e.make_params(24, "pn_related", 0.5, 0.1, 0.0, 0.1, 30, 0.1, 0, 5.0, 0.1, 0.1)
+    out_e = torch.empty((2, 1, 5, 64, 64), dtype=torch.float32, device=dev)
+    out_v = torch.empty((2, 1, 5, 64, 64), dtype=torch.float32, device=dev)
+    gray_keep = torch.empty((2, 6, 64, 64), dtype=torch.uint8, device=dev)
+
+    def step():
+        gray = frontend.prepare_clips_batch(raw, table, idx, 64, "gray", validate=False, max_crop_before=80)[1]
+        gray_keep.copy_(gray)
+        esim.esim_voxel_batch(gray, params, bin_mode="sum", num_bins=5, frames_per_bin=1, seed=9, out=out_e, validate=False)
+        v2e.v2e_voxel_batch(gray, vp, bin_mode="sum", num_bins=5, frames_per_bin=1, seed=9, out=out_v)
+
+    step()
+    torch.cuda.synchronize()
+    want = (gray_keep.clone(), out_e.clone(), out_v.clone())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for t in (gray_keep, out_e, out_v):
+        t.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(gray_keep, want[0]) and torch.equal(out_e, want[1]) and torch.equal(out_v, want[2])
+    assert out_e.abs().sum() > 0 and out_v.abs().sum() > 0
