@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
         // Phase A: new potential, polarity, reciprocal quotient estimate and its sign-exact fma residual.
         double mag[VEC], thr[VEC], q[VEC], r[VEC];
         uint32_t sgn[VEC];
-        bool fix = false;
+        unsigned long long fix = 0;                                    // wave-level mask in an SGPR pair (no per-lane bool)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const lut_t d = ln[j] - lprev[j];                          // difference in the input's precision (:42)
@@ -264,9 +264,9 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
             // |p|/C sits within ~1e-15 above an integer -- and then (or for a NaN potential) r < C fails
             q[j] = floor(mag[j] * inv);
             r[j] = __builtin_fma(-q[j], thr[j], mag[j]);
-            fix |= !(r[j] < thr[j]);
+            fix |= __ballot(!(r[j] < thr[j]));
         }
-        if (__builtin_expect(fix, 0)) {                                // rare: exact multiples, NaN
+        if (__builtin_expect(fix != 0, 0)) {                                // rare: exact multiples, NaN
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 if (r[j] >= thr[j]) q[j] += 1.0;

@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
         // ---- low pass, leak, event map: floor_divide(clip(+-diff, 0), thres) as floor(x * low-biased reciprocal) with
         // the exact fma residual; the correction (quotient one short, or a non-finite operand) is a rare wave-level path
         double dif[VEC], fpos[VEC], fneg[VEC];
-        bool fix = false;
+        unsigned long long fix = 0;                       // wave-level masks (SGPR pairs): no per-lane bool materialised
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             if (lowpass) {                                                              // low_pass_filter (:139-182)
@@ -570,10 +570,10 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
             fpos[j] = floor(__builtin_fmax(diff, 0.0) * inv_p[j]);
             fneg[j] = floor(__builtin_fmax(-diff, 0.0) * inv_n[j]);
             const double rp = __builtin_fma(-fpos[j], pt[j], diff), rn = __builtin_fma(-fneg[j], nt[j], -diff);
-            fix |= !(rp < pt[j]);
-            fix |= !(rn < nt[j]);
+            fix |= __ballot(!(rp < pt[j]));
+            fix |= __ballot(!(rn < nt[j]));
         }
-        if (__builtin_expect(fix, 0)) {
+        if (__builtin_expect(fix != 0, 0)) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const double diff = dif[j], nd = -diff;
@@ -590,16 +590,16 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
             if constexpr (RNG == kRngPhilox) {
                 float lam_p[VEC], lam_n[VEC];
                 PoissonHead hp[VEC], hn[VEC];
-                bool more = false;
+                unsigned long long more = 0;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     lam_p[j] = (float)((fac[j] * pre_p[j]) * scale_p);
                     lam_n[j] = (float)((fac[j] * pre_n[j]) * scale_n);
                     hp[j] = poisson_head_f32(lam_p[j], u_sp[j]);
                     hn[j] = poisson_head_f32(lam_n[j], u_sn[j]);
-                    more |= hp[j].more | hn[j].more;
+                    more |= __ballot(hp[j].more) | __ballot(hn[j].more);
                 }
-                if (__builtin_expect(more, 0)) {
+                if (__builtin_expect(more != 0, 0)) {
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) {
                         if (hp[j].more) hp[j].x = poisson_tail_f32(lam_p[j], u_sp[j], hp[j].p2, hp[j].s2);
