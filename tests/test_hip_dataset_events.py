@@ -215,3 +215,52 @@ def test_make_voxels_segmented_equals_per_interval_calls(interp):
             assert np.array_equal(got[f], want)
     with pytest.raises(ValueError):
         voxel.make_voxels_segmented([ts, xs, ys, ps], [0, 10, 5], h, w)
+
+
+# ------------------------------------------------------------------ dataset with the GPU front-end (SURVEY §8f-1 wired in)
+def _raw_video(ds, sample_idx, start, end):
+    g = np.random.default_rng(5000 + start)                                   # decoded BGR frames [T,Hs,Ws,3]
+    base = g.uniform(0, 255, size=(90, 160, 3))
+    out = []
+    for _ in range(end - start):
+        base = np.clip(base + g.normal(0, 5, size=base.shape), 0, 255)
+        out.append(base.astype(np.uint8))
+    return np.stack(out)
+
+
+def _host_frames_via_restatement(ds, sample_idx, start, end, crop_before, min_i, min_j, flip, need_h, need_w):
+    """The reference's per-frame host loop (v2v_datasets.py:191-224) on the same decoded frames, with OpenCV's
+    cvtColor / resize replaced by their restatement (cv2 is absent here): what read_video's opencv branch returns."""
+    from oracle import frontend_oracle as F
+    raw = _raw_video(ds, sample_idx, start, end)
+    out = []
+    for f in raw:
+        if ds.color_mode == "gray":
+            f = F.cv_bgr2gray_u8(f)[..., None]
+        f = f[min_i:min_i + crop_before, min_j:min_j + crop_before]
+        f = F.cv_resize_linear_u8(f, need_w, need_h)
+        if flip:
+            f = f[:, ::-1]
+        out.append(np.ascontiguousarray(f).reshape(need_h, need_w, -1))
+    return out
+
+
+@pytest.mark.parametrize("cfg", [{}, {"shake_frames": 6, "shake_std": 1.5}, {"color_mode": "gray_in_bgr_out"}])
+def test_dataset_gpu_frontend_equals_host_path(tmp_path, cfg):
+    """gpu_frontend: decode on the host, cvtColor/crop/resize/flip/shake/gather on the GPU, then the simulator --
+    same sample (frames and events) as the host path for the same np.random stream."""
+    common = dict(video_size=(160, 90), keep_top_percentile=1.0, sim_rng="philox", **cfg)
+    ds_host = _make_ds(tmp_path, frame_source=_host_frames_via_restatement, **common)
+    ds_gpu = _make_ds(tmp_path, frame_source=None, raw_frame_source=_raw_video, gpu_frontend=True, **common)
+    for idx in (0, 1):
+        np.random.seed(123 + idx)
+        a = ds_host[idx]
+        np.random.seed(123 + idx)
+        b = ds_gpu[idx]
+        assert a["v2e_params"] == b["v2e_params"]
+        if cfg.get("color_mode") == "gray_in_bgr_out":
+            # bgr_to_gray is the reference's np.dot: tolerance parity on the gray conversion (see DESIGN §4.4b)
+            assert (a["frame"] != b["frame"]).float().mean() == 0
+            assert (a["events"] != b["events"]).float().mean() < 5e-3
+        else:
+            assert torch.equal(a["frame"], b["frame"]) and torch.equal(a["events"], b["events"])

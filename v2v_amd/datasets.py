@@ -135,6 +135,13 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
         # SimulatingCollator then simulates the whole batch in ONE launch in the main process, so DataLoader workers
         # may be fork()ed (they never touch HIP).  Results are identical to the per-sample path.
         self.defer_sim = g("defer_sim", False)
+        # gpu_frontend: the host only decodes (and slices the crop rectangle out of each frame); cvtColor / resize /
+        # flip / shake crop / pause-index gather run on the GPU (v2v_amd.frontend) and the clip never
+        # returns to the host before the simulator.  `raw_frame_source(dataset, sample_idx, start, end)` may supply the
+        # decoded [T,Hs,Ws,3] uint8 frames instead of OpenCV.  Parity of the resize itself is unpinned (no cv2 here).
+        self.gpu_frontend = g("gpu_frontend", False)
+        self.raw_frame_source = g("raw_frame_source", None)
+        assert not (self.gpu_frontend and self.defer_sim), "gpu_frontend runs in the process that owns the GPU; defer_sim is for fork()ed workers"
 
     def __init__(self, dataset_path, configs):
         self.load_configs(configs)
@@ -172,9 +179,9 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
 
     # ------------------------------------------------------------------ decode (host; "next" row of SURVEY §8f)
     def _probe_size(self, video_path):
-        if self.frame_source is not None:
+        if self.frame_source is not None or self.raw_frame_source is not None:
             if self.video_size is None:
-                raise ValueError("frame_source needs video_size=(width, height)")
+                raise ValueError("frame_source / raw_frame_source need video_size=(width, height)")
             return int(self.video_size[0]), int(self.video_size[1])
         import cv2  # the reference's opencv branch, v2v_datasets.py:252-256
         cap = cv2.VideoCapture(video_path)
@@ -222,6 +229,44 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
         off_i = np.array(all_di) - min(all_di)
         off_j = np.array(all_dj) - min(all_dj)
         return [img[off_i[i]:off_i[i] + self.crop_size, off_j[i]:off_j[i] + self.crop_size, :] for i, img in enumerate(imgs)]
+
+    def read_video_gpu(self, video_path, start_frame, end_frame, crop_size_before_resize, min_i, min_j, flip, img_idxes,
+                       sample_idx=None):
+        """GPU form of read_video + the pause-index gather (:145-225, :311-316): returns device tensors
+        (all_imgs [N,crop,crop,C] uint8, gray [N,crop,crop] uint8).  Same np.random draw order as read_video."""
+        from . import frontend
+        n = end_frame - start_frame
+        all_di, all_dj = [0] * n, [0] * n
+        if self.shake_frames > 0:
+            vi = vj = di = dj = 0
+            for i in range(min(self.shake_frames, n) - 1, -1, -1):
+                vi += int(np.random.normal(0, self.shake_std))
+                vj += int(np.random.normal(0, self.shake_std))
+                di += vi
+                dj += vj
+                all_di[i], all_dj[i] = di, dj
+        if self.raw_frame_source is not None:
+            raw = np.asarray(self.raw_frame_source(self, sample_idx, start_frame, end_frame))
+        else:
+            assert self.video_reader == "opencv", "FFMPEG hasn't been updated to support color."
+            import cv2
+            cap = cv2.VideoCapture(video_path)
+            cap.set(cv2.CAP_PROP_POS_FRAMES, start_frame)
+            frames = []
+            for _ in range(start_frame, end_frame):
+                ok, frame = cap.read()
+                if not ok:
+                    break
+                frames.append(frame)
+            cap.release()
+            raw = np.stack(frames)
+        cb = crop_size_before_resize
+        # only the crop rectangle travels over PCIe (cb x cb x 3 per frame instead of the whole frame)
+        rect = np.ascontiguousarray(raw[:, min_i:min_i + cb, min_j:min_j + cb, :])
+        rect_d = torch.from_numpy(rect).to(self.sim_device)
+        shake = self.shake_frames > 0
+        return frontend.prepare_clip(rect_d, cb, 0, 0, flip, self.crop_size, img_idxes, all_di if shake else None,
+                                     all_dj if shake else None, self.color_mode, want_imgs=self.color_mode != "gray")
 
     # ------------------------------------------------------------------ the hot path
     def imgs_to_voxels(self, imgs, num_bins, frames_per_bin, FPS, pos_thres=None, neg_thres=None):
@@ -288,11 +333,17 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
             if not paused:
                 idx += 1
         end_frame = start_frame + idx + 1
-        raw_imgs = self.read_video(video_path, start_frame, end_frame, crop_before, min_i, min_j, flip, sample_idx)
+        if self.gpu_frontend:
+            imgs_d, gray = self.read_video_gpu(video_path, start_frame, end_frame, crop_before, min_i, min_j, flip, img_idxes,
+                                               sample_idx)
+            all_imgs = gray.unsqueeze(-1) if imgs_d is None else imgs_d                                  # device [N,H,W,C] uint8
+        else:
+            raw_imgs = self.read_video(video_path, start_frame, end_frame, crop_before, min_i, min_j, flip, sample_idx)
         if self.video_degrade is not None and np.random.rand() < self.degrade_ratio:
             raise NotImplementedError("video_degrade ablations are outside the accelerated path")
-        all_imgs = np.stack([raw_imgs[i] for i in img_idxes])                                           # [N,H,W,C] uint8
-        gray = all_imgs[..., 0] if self.color_mode == "gray" else bgr_to_gray(all_imgs)
+        if not self.gpu_frontend:
+            all_imgs = np.stack([raw_imgs[i] for i in img_idxes])                                       # [N,H,W,C] uint8
+            gray = all_imgs[..., 0] if self.color_mode == "gray" else bgr_to_gray(all_imgs)
 
         pos = self.sample_pos_thres[sample_idx] if self.use_fixed_thresholds else None
         neg = self.sample_neg_thres[sample_idx] if self.use_fixed_thresholds else None
@@ -305,15 +356,21 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
             voxels = None
         else:
             dev = torch.device(self.sim_device)
-            v2e_params, voxels = self.imgs_to_voxels(torch.from_numpy(np.ascontiguousarray(gray)).to(dev), self.num_bins,
-                                                     self.frames_per_bin, 24, pos, neg)                # [L(+1),Tb,H,W] f32
+            gray_d = gray if isinstance(gray, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(gray)).to(dev)
+            v2e_params, voxels = self.imgs_to_voxels(gray_d, self.num_bins, self.frames_per_bin, 24, pos, neg)   # [L(+1),Tb,H,W] f32
         if self.output_additional_evs:
             all_imgs = all_imgs[self.frames_per_img:]
         if not self.output_additional_frame:
             pick = [(i + 1) * self.frames_per_img for i in range(img_cnt)]                              # :329-333
         else:
             pick = [i * self.frames_per_img for i in range(img_cnt + 1)]                                # :334-338
-        frames = torch.from_numpy(all_imgs[pick]).to(torch.float32).permute(0, 3, 1, 2) / 255           # [L,C,H,W] in [0,1]
+        if isinstance(all_imgs, torch.Tensor):
+            # device frames: v/255 through a table computed on the host, so the float32 values are the reference's
+            # (CPU division) bit for bit whatever division the device's elementwise kernels use
+            table = (torch.arange(256, dtype=torch.float32) / 255).to(all_imgs.device)
+            frames = table[all_imgs[pick].long()].permute(0, 3, 1, 2)                                   # [L,C,H,W] in [0,1]
+        else:
+            frames = torch.from_numpy(all_imgs[pick]).to(torch.float32).permute(0, 3, 1, 2) / 255
         n_ev = img_cnt + 1 if self.output_additional_evs else img_cnt
         out_dev = torch.device(self.output_device)
         if self.defer_sim:
