@@ -81,6 +81,42 @@ def cpu_baseline(frames_host, wl, budget_s=12.0):
                       f"oracle/v2v_oracle.py NumPy port of the reference's op sequence (float64 state), single thread, {dt:.1f} s"}
 
 
+def _pool_clip(job):
+    """Worker of cpu_baseline_pool (top level: picklable under the 'spawn' start method)."""
+    clip, wl, seed = job
+    import numpy as np
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    sys.path.insert(0, ROOT)
+    from oracle import v2v_oracle as O
+    np.random.seed(seed)
+    if wl["model"] in ("esim", "pipeline"):
+        counts = O.esim_video_to_voxel(clip, *wl["params"], put_noise_external=False, rng=O.GlobalNumpyRNG, use_lut=False)
+    else:
+        counts = O.v2e_video_to_voxel(clip, *wl["params"], seed=None)
+    _ = O.bin_bilinear(counts, wl["tb"]) if wl["bin"] == "bilinear" else O.bin_sum(counts, wl["tb"], wl["fpb"])
+    return 1
+
+
+def cpu_baseline_pool(frames_host, wl, max_workers=64, clips_per_worker=2):
+    """The same NumPy port in a process pool over the host cores: how the reference itself scales, one
+    single-threaded simulator per DataLoader worker.  'spawn' start method: the parent owns a HIP context."""
+    import multiprocessing as mp
+    workers = max(1, min(os.cpu_count() or 1, max_workers, frames_host.shape[0]))
+    n_jobs = min(frames_host.shape[0], workers * clips_per_worker)
+    wl_small = {k: wl[k] for k in ("model", "params", "tb", "bin", "fpb")}
+    jobs = [(frames_host[i], wl_small, i) for i in range(n_jobs)]
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(workers) as pool:
+        pool.map(_pool_clip, jobs[:workers])                      # start-up and imports outside the timed part
+        t0 = time.perf_counter()
+        done = sum(pool.map(_pool_clip, jobs, chunksize=1))
+        dt = time.perf_counter() - t0
+    grids = done * (1 if wl["bin"] == "bilinear" else (frames_host.shape[1] - 1) // (wl["tb"] * wl["fpb"]))
+    return {"value": grids / dt, "unit": "voxel grids/s", "cores": workers, "kind": "port",
+            "sample": f"{done} clips over {workers} single-threaded worker processes (of {os.cpu_count()} host cores), "
+                      f"oracle/v2v_oracle.py NumPy port, {dt:.1f} s"}
+
+
 def cpu_baseline_c(frames_host, wl):
     """Secondary: the scalar C twin (table-driven) over all host cores with OpenMP over clips."""
     from oracle import clib, v2v_oracle as O
@@ -231,7 +267,7 @@ def main():
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
 
     # light parity guard outside the timed region (clip 0 of rank 0 against the C oracle) + the CPU baseline
-    parity = cpu = cpu_c = None
+    parity = cpu = cpu_c = cpu_pool = None
     if rank == 0:
         try:
             import numpy as np
@@ -254,6 +290,10 @@ def main():
                 sample = frames[: min(b, 256)].cpu().numpy()
                 cpu = cpu_baseline(sample, wl, budget_s=args.cpu_budget)
                 cpu_c = cpu_baseline_c(sample, wl)
+                try:
+                    cpu_pool = cpu_baseline_pool(sample, wl)
+                except Exception as exc:  # noqa: BLE001 - secondary figure
+                    cpu_pool = {"error": f"{type(exc).__name__}: {exc}"}
         except Exception as exc:  # the oracle is a checker; never let it take the measurement down
             parity = f"unchecked ({type(exc).__name__}: {exc})"
 
@@ -317,6 +357,7 @@ def main():
                          "kernel_ms_avg": kern_avg_ms, "kernel_ms_p10": kern_ms[len(kern_ms) // 10],
                          "kernel_ms_p50": kern_ms[len(kern_ms) // 2], "kernel_ms_p90": kern_ms[(len(kern_ms) * 9) // 10]},
             "cpu_baseline": cpu,
+            "cpu_baseline_numpy_pool": cpu_pool,
             "cpu_baseline_c_omp": cpu_c,
             "parity_check": parity,
             "also_measured": also,
