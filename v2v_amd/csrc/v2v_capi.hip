@@ -321,7 +321,8 @@ int v2v_events_to_voxel_segmented_hip(const double *ts, const int64_t *xs, const
 static hipError_t launch_frontend(const v2v::FrontendArgs &a, int64_t B, int64_t max_crop_before, hipStream_t s)
 {
     static const bool force_gather = getenv("V2V_FRONTEND_GATHER") != nullptr;      // tuning/debug: always the gather kernel
-    const bool tiled = !force_gather && a.gray_first && a.Cs == 3 && !a.out_imgs && !a.di && a.need_h == a.crop && a.need_w == a.crop;
+    const bool tiled = !force_gather && a.gray_first && a.Cs == 3 && !a.out_imgs && !a.di && a.need_h == a.crop && a.need_w == a.crop &&
+                       a.Hs <= 32767 && a.Ws <= 32767;                        // 16-bit source coordinates in the LDS coefficient tables
     if (tiled) {
         const int64_t frame_min = a.Hs < a.Ws ? a.Hs : a.Ws;
         const int64_t cb_max = (max_crop_before > 0 && max_crop_before < frame_min) ? max_crop_before : frame_min;
