@@ -93,7 +93,8 @@ def test_random_v2e_case(oracle_c, luts, case):
     # float32 grid: the production dtype (feature-specialised kernel instances when the launch qualifies)
     got32 = v2e.v2e_voxel_batch(torch.from_numpy(video).cuda(), v2e.make_params(*args, uint8_wrap=wrap),
                                 bin_mode="bilinear" if bilinear else "sum", num_bins=nb, frames_per_bin=fpb, seed=seed, clip_id0=cid0,
-                                out_dtype=torch.float32).cpu().numpy()
+                                out_dtype=torch.float32, counts=counts.zero_()).cpu().numpy()
+    assert np.array_equal(counts.cpu().numpy(), totals)
     if bilinear:
         np.testing.assert_allclose(got32, want, rtol=1e-5, atol=1e-5)
     else:
