@@ -36,3 +36,14 @@ def test_integration_md_stubs_run_and_match_the_wrappers():
     torch.testing.assert_close(ns["make_voxel"](ev[0], ev[1], ev[2], ev[3], 5, 32, 64), voxel.make_voxel(ev, 32, 64, 5, True),
                                rtol=1e-12, atol=1e-12)
     assert torch.equal(ns["make_voxel"](ev[0], ev[1], ev[2], ev[3], 5, 32, 64, False), voxel.make_voxel(ev, 32, 64, 5, False))
+
+
+@pytest.mark.gpu
+def test_readme_usage_snippet_runs():
+    src = open(os.path.join(ROOT, "README.md")).read()
+    block = re.search(r"## Using it\n\n```python\n(.*?)```", src, re.S).group(1)
+    ns = {}
+    exec(block, ns)
+    assert ns["voxels"].shape == (256, 5, 256, 256) and ns["voxels"].dtype == torch.float32
+    assert ns["counts"].shape == (31, 256, 256) and ns["counts"].dtype == np.float64
+    assert ns["dvs"].shape == (256, 5, 256, 256)
