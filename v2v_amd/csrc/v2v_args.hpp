@@ -56,7 +56,7 @@ hipError_t launch_esim_f32(bool vec4, int bin, int rng, bool noise, bool out64, 
 hipError_t launch_v2e(bool in_u8, bool vec4, int bin, int rng, bool out64, bool presum, const V2eArgs &a, dim3 grid, size_t lds,
                       hipStream_t s);
 // specialised v2e instances (v2v_v2e_spec_{u8,f32}_tu.hip): 4 pixels per work-item, float32 grid, device RNG, static
-// thresholds, no refractory period; `feat` = compile-time feature mask {1 low-pass, 2 leak, 4 shot noise}
+// thresholds; `feat` = compile-time feature mask {1 low-pass, 2 leak, 4 shot noise}
 hipError_t launch_v2e_spec_u8(int bin, int feat, const V2eArgs &a, dim3 grid, size_t lds, hipStream_t s);
 hipError_t launch_v2e_spec_f32(int bin, int feat, const V2eArgs &a, dim3 grid, size_t lds, hipStream_t s);
 // log-intensity tables: which = 0 ESIM float64, 1 ESIM float32 (the esim TUs), 2 v2e float32 (v2e TU).

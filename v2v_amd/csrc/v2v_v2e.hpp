@@ -347,8 +347,9 @@ __global__ void __launch_bounds__(kBlock) v2e_shot_sum_kernel(const V2eArgs a)
 constexpr int kV2eFrameConsts = 5;   // {dt, dt/tau, scale_pos, scale_neg, refractory cap}
 
 // FEAT < 0: model features are read from the parameters at run time (wave-uniform branches); FEAT >= 0: compile-time
-// bit mask {1 low-pass, 2 leak, 4 shot noise, 8 refractory, 16 per-frame thresholds} for the specialised instances
-enum { kV2eLowpass = 1, kV2eLeak = 2, kV2eShot = 4, kV2eRefr = 8, kV2eTemporal = 16 };
+// bit mask {1 low-pass, 2 leak, 4 shot noise, 16 per-frame thresholds} for the specialised instances (the refractory
+// cap stays a run-time switch in every instance)
+enum { kV2eLowpass = 1, kV2eLeak = 2, kV2eShot = 4, kV2eTemporal = 16 };
 
 template <int IN, int VEC, int BIN, int RNG, bool OUT64, int FEAT = -1>
 __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
@@ -369,7 +370,7 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
     const bool lowpass = FEAT < 0 ? P.cutoff_hz > 0 : (FEAT & kV2eLowpass) != 0;
     const bool leak = FEAT < 0 ? P.leak_rate_hz > 0 : (FEAT & kV2eLeak) != 0;
     const bool shot = FEAT < 0 ? P.shot_noise_rate_hz > 0 : (FEAT & kV2eShot) != 0;
-    const bool refractory = FEAT < 0 ? P.refractory_period_s > 0 : (FEAT & kV2eRefr) != 0;
+    const bool refractory = P.refractory_period_s > 0;   // always a run-time (wave-uniform) switch: two v_min per pixel
     const bool temporal = FEAT < 0 ? P.threshold_model == kV2eSpatialTemporalIndependent : (FEAT & kV2eTemporal) != 0;
     const double tau = lowpass ? 1 / (3.141592653589793 * 2 * P.cutoff_hz) : 0.0;
     for (int k = threadIdx.x; k < a.K; k += kBlock) {

@@ -49,8 +49,7 @@ hipError_t launch_v2e(bool in_u8, bool vec4, int bin, int rng, bool out64, bool 
     if (e != hipSuccess) return e;
     a.lut = static_cast<const float *>(lut);
     const V2eParams &P = a.P;
-    const bool spec = vec4 && !out64 && rng == V2V_RNG_PHILOX && P.threshold_model != kV2eSpatialTemporalIndependent &&
-                      !(P.refractory_period_s > 0);
+    const bool spec = vec4 && !out64 && rng == V2V_RNG_PHILOX && P.threshold_model != kV2eSpatialTemporalIndependent;
     if (spec) {
         if (presum) {
             if (in_u8) hipLaunchKernelGGL((v2e_shot_sum_kernel<kInU8, 4>), grid, dim3(kBlock), (size_t)a.K * 16, s, a);
