@@ -7,7 +7,7 @@
 
 constexpr int B = 256, N = 32, H = 256, W = 256, HW = H * W, TB = 5;
 
-template <int DEPTH, bool NT, int REMAP = 0>
+template <int DEPTH, bool NT, int REMAP = 0, bool NTS = false, bool SPREAD = false>
 __global__ void __launch_bounds__(256) pattern_kernel(const float *__restrict__ in, float *__restrict__ out)
 {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -28,6 +28,11 @@ __global__ void __launch_bounds__(256) pattern_kernel(const float *__restrict__ 
     auto ld = [&](int f) { const f32x4 *p = reinterpret_cast<const f32x4 *>(base + (size_t)f * HW); return NT ? __builtin_nontemporal_load(p) : *p; };
 #pragma unroll
     for (int u = 0; u < DEPTH; ++u) ring[u] = ld(u);
+    auto st = [&](int b) {
+        f32x4 *o = reinterpret_cast<f32x4 *>(out + ((size_t)clip * TB + b) * HW + p0);
+        if (NTS) __builtin_nontemporal_store(acc * (float)(b + 1), o); else *o = acc * (float)(b + 1);
+    };
+    int nb = 0;
     for (int f0 = 0; f0 < N; f0 += DEPTH) {
 #pragma unroll
         for (int u = 0; u < DEPTH; ++u) {
@@ -35,9 +40,9 @@ __global__ void __launch_bounds__(256) pattern_kernel(const float *__restrict__ 
             const int fn = f0 + u + DEPTH;
             ring[u] = ld(fn < N ? fn : N - 1);
         }
+        if (SPREAD && (f0 + DEPTH) % 8 == 0 && nb < TB - 1) st(nb++);   // planes leave as the scan passes their segment, like the fused kernel
     }
-    for (int b = 0; b < TB; ++b)
-        *reinterpret_cast<f32x4 *>(out + ((size_t)clip * TB + b) * HW + p0) = acc * (float)(b + 1);
+    for (int b = nb; b < TB; ++b) st(b);
 }
 
 __global__ void __launch_bounds__(256) linear_kernel(const float *__restrict__ in, float *__restrict__ out, size_t n4_in, size_t n4_out)
@@ -134,6 +139,13 @@ int main()
     const int grid = B * (HW / 1024);
     time([&] { pattern_kernel<4, true><<<grid, 256>>>(in, out); }, "esim pattern, depth 4, nt loads");
     time([&] { pattern_kernel<4, false><<<grid, 256>>>(in, out); }, "esim pattern, depth 4, plain loads");
+    time([&] { pattern_kernel<4, true, 0, true><<<grid, 256>>>(in, out); }, "depth 4, nt loads + nt stores");
+    time([&] { pattern_kernel<4, true, 0, false, true><<<grid, 256>>>(in, out); }, "depth 4, nt loads, stores spread");
+    time([&] { pattern_kernel<4, true, 0, true, true><<<grid, 256>>>(in, out); }, "depth 4, nt, nt stores spread");
+    time([&] { pattern_kernel<4, true, 1, true, true><<<grid, 256>>>(in, out); }, "same + XCD-contiguous remap");
+    time([&] { pattern_kernel<4, true, 2, true, true><<<grid, 256>>>(in, out); }, "same + per-clip XCD remap");
+    time([&] { pattern_kernel<8, true, 0, true, true><<<grid, 256>>>(in, out); }, "depth 8, nt, nt stores spread");
+    time([&] { pattern_kernel<4, true, 0, true, true><<<grid, 256>>>(in, out); }, "depth 4, nt, nt stores spread (again)");
     time([&] { pattern_kernel<2, true><<<grid, 256>>>(in, out); }, "esim pattern, depth 2, nt loads");
     time([&] { pattern_kernel<8, true><<<grid, 256>>>(in, out); }, "esim pattern, depth 8, nt loads");
     time([&] { pattern_kernel<4, true, 1><<<grid, 256>>>(in, out); }, "esim pattern, XCD-contiguous remap");

@@ -20,6 +20,9 @@ namespace v2v {
 #ifndef V2V_NT_LOADS
 #define V2V_NT_LOADS 1
 #endif
+#ifndef V2V_NT_STORES
+#define V2V_NT_STORES 1     // voxel planes are written once and never re-read by the kernel: keep them out of the caches
+#endif
 constexpr int kDepth = V2V_DEPTH;   // frames in flight per work-item (register ring, reloaded right after use)
 
 // ------------------------------------------------------------------------------------------------
@@ -62,6 +65,18 @@ template <int VEC, typename T>
 __device__ __forceinline__ void store_vec(void *out, int64_t off, const T (&v)[VEC])
 {
     T *o = static_cast<T *>(out) + off;
+#if V2V_NT_STORES
+    if constexpr (VEC == 4 && sizeof(T) == 8) {
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(f64x2{v[0], v[1]}, reinterpret_cast<f64x2 *>(o));
+        __builtin_nontemporal_store(f64x2{v[2], v[3]}, reinterpret_cast<f64x2 *>(o) + 1);
+    } else if constexpr (VEC == 4) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4 *>(o));
+    } else {
+        __builtin_nontemporal_store(v[0], o);
+    }
+#else
     if constexpr (VEC == 4 && sizeof(T) == 8) {
         reinterpret_cast<double2 *>(o)[0] = make_double2(v[0], v[1]);
         reinterpret_cast<double2 *>(o)[1] = make_double2(v[2], v[3]);
@@ -70,6 +85,7 @@ __device__ __forceinline__ void store_vec(void *out, int64_t off, const T (&v)[V
     } else {
         o[0] = v[0];
     }
+#endif
 }
 
 }  // namespace v2v
