@@ -25,7 +25,7 @@ if ROOT not in sys.path:
 # Streaming ceilings measured on this pool with tools/ubench/stream_pattern.hip (profiles/stream_pattern_*.txt): context
 # for roofline.frac, which is always quoted against the 8 TB/s datasheet peak.
 MEASURED_CEILINGS_GBPS = {"read_only_sweep": 6100.0, "float4_copy": 5200.0,
-                          "cfg2_access_pattern_without_arithmetic": 5790.0}
+                          "cfg2_access_pattern_without_arithmetic": 6170.0}
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (measured copy ceiling ~6290)
 
 V2E_NOISY = [24, "pn_related", 0.5, 0.1, 0.0, 0.1, 30, 0.1, 0, 5.0, 0.1, 0.1]     # SURVEY §8d S3 (v2v_core_v2e.py:365-375,600)
