@@ -264,3 +264,26 @@ def test_dataset_gpu_frontend_equals_host_path(tmp_path, cfg):
             assert (a["events"] != b["events"]).float().mean() < 5e-3
         else:
             assert torch.equal(a["frame"], b["frame"]) and torch.equal(a["events"], b["events"])
+
+
+@pytest.mark.gpu
+def test_neg_pos_voxel_wrappers_compose_like_the_reference():
+    """events_to_neg_pos_voxel(_torch) (utils/event_utils.py:730-759, :509-541): the two grids are the bilinear voxeliser
+    run on 0/1 weights; pos - neg equals the signed grid for +-1 polarities."""
+    from v2v_amd import voxel
+    g = np.random.default_rng(4)
+    n, h, w, nb = 3000, 24, 40, 5
+    ts, xs, ys = np.sort(g.uniform(0, 0.1, n)), g.integers(0, w, n), g.integers(0, h, n)
+    ps01 = g.integers(0, 2, n)
+    pos, neg = voxel.events_to_neg_pos_voxel(xs, ys, ts, ps01, nb, (h, w))
+    want_pos = O.events_to_voxel(xs, ys, ts, np.where(ps01, 1, 0), nb, (h, w))
+    want_neg = O.events_to_voxel(xs, ys, ts, np.where(ps01, 0, 1), nb, (h, w))
+    np.testing.assert_allclose(pos, want_pos, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(neg, want_neg, rtol=1e-12, atol=1e-12)
+    tp = torch.from_numpy(ps01 * 2.0 - 1.0).float()
+    tpos, tneg = voxel.events_to_neg_pos_voxel_torch(torch.from_numpy(xs), torch.from_numpy(ys), torch.from_numpy(ts).float(), tp, nb,
+                                                      sensor_size=(h, w))
+    signed = voxel.events_to_voxel_torch(torch.from_numpy(xs), torch.from_numpy(ys), torch.from_numpy(ts).float(), tp, nb,
+                                         sensor_size=(h, w))
+    torch.testing.assert_close(tpos - tneg, signed, rtol=1e-5, atol=1e-5)
+    assert float(tpos.min()) >= 0 and float(tneg.min()) >= 0

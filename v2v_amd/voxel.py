@@ -105,6 +105,23 @@ def events_to_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(180, 240)
     return out
 
 
+def events_to_neg_pos_voxel(xs, ys, ts, ps, B, sensor_size=(180, 240), temporal_bilinear=True, device="cuda"):
+    """utils/event_utils.py:730-759: separate grids for positive (`ps` truthy) and negative events -> (voxel_pos, voxel_neg)."""
+    is_t = isinstance(ps, torch.Tensor)
+    pos_w = torch.where(ps != 0, 1, 0) if is_t else np.where(ps, 1, 0)
+    neg_w = torch.where(ps != 0, 0, 1) if is_t else np.where(ps, 0, 1)
+    return (events_to_voxel(xs, ys, ts, pos_w, B, sensor_size, temporal_bilinear, device),
+            events_to_voxel(xs, ys, ts, neg_w, B, sensor_size, temporal_bilinear, device))
+
+
+def events_to_neg_pos_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(180, 240), temporal_bilinear=True):
+    """utils/event_utils.py:509-541 (float32 torch twin): weights 1 where ps > 0 / where ps <= 0."""
+    one, zero = torch.ones((), dtype=torch.float32, device=ps.device), torch.zeros((), dtype=torch.float32, device=ps.device)
+    pos_w, neg_w = torch.where(ps > 0, one, zero), torch.where(ps <= 0, one, zero)
+    return (events_to_voxel_torch(xs, ys, ts, pos_w, B, device, sensor_size, temporal_bilinear),
+            events_to_voxel_torch(xs, ys, ts, neg_w, B, device, sensor_size, temporal_bilinear))
+
+
 def make_voxels_segmented(evs, event_idx, H, W, num_bins=5, interpolate_bins=False, device="cuda"):
     """All voxel grids of a sequence in ONE launch: grid f = make_voxel(events[event_idx[f]:event_idx[f+1]]), exactly
     what TestH5Dataset.__getitem__ (data/testh5.py:111-119) builds with one make_voxel call per image.
