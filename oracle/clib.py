@@ -57,10 +57,18 @@ def philox4x32(ctr, key):
     return list(o)
 
 
-def bm_pair(a, b):
+def gauss16(w):
+    """(g0, g1) of one 32-bit word through the native 16+16-bit Box-Muller."""
     o = (C.c_float * 2)()
-    lib().oracle_bm_pair(C.c_uint32(a), C.c_uint32(b), o)
+    lib().oracle_gauss16(C.c_uint32(w), o)
     return np.float32(o[0]), np.float32(o[1])
+
+
+def gauss16_many(words):
+    w = np.ascontiguousarray(words, dtype=np.uint32)
+    g0, g1 = np.empty(w.size, dtype=np.float32), np.empty(w.size, dtype=np.float32)
+    lib().oracle_gauss16_many(_p(w), C.c_int64(w.size), _p(g0), _p(g1))
+    return g0, g1
 
 
 def philox_uniform_field(seed, clip_id, field, n_pix, stream=0):
@@ -70,10 +78,11 @@ def philox_uniform_field(seed, clip_id, field, n_pix, stream=0):
     return out
 
 
-def philox_gauss_field(seed, clip_id, field, n_pix, stream=0):
+def philox_gauss_field(seed, clip_id, field, n_pix, stream=0, comp=0):
+    """Normal `comp` (0: first, 1: second) of every pixel's Box-Muller pair in Philox block `field`."""
     out = np.empty(n_pix, dtype=np.float32)
     lib().oracle_philox_gauss_field(C.c_uint64(seed), C.c_uint32(clip_id & 0xFFFFFFFF), C.c_uint32(field),
-                                    C.c_uint32(stream), C.c_int64(n_pix), _p(out))
+                                    C.c_uint32(stream), C.c_int64(n_pix), C.c_int(comp), _p(out))
     return out
 
 

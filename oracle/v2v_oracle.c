@@ -81,65 +81,65 @@ static float u32_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static uint32_t float_as_u32(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
 /*
- * fp32 Box-Muller written with IEEE-exact primitives only (+ - * fmaf sqrtf and integer ops) so that
- * gcc on the host and hipcc on gfx950 produce the same bits.  Not taken from the reference (which uses
- * numpy's MT19937 polar method, impossible to replay at bandwidth on a GPU); this is the definition
- * of the device-native noise fields.  log polynomial: Cephes logf; sin/cos: Cephes sinf/cosf kernels
- * on [-pi/4, pi/4], then an exact-sign rotation by (q+1/2)*pi/2.
+ * Device-native normals: float32 Box-Muller on ONE 32-bit Philox word per pair (16-bit radius x 16-bit angle, both on
+ * midpoint grids), written with IEEE-exact primitives only (+ - * fmaf and integer ops: no division, no sqrt, no libm)
+ * so that gcc on the host and hipcc on gfx950 produce the same bits.  Not taken from the reference (which uses numpy's
+ * MT19937 polar method, impossible to replay at bandwidth on a GPU); this is the definition of the device-native
+ * noise fields, restated here independently of v2v_amd/csrc/v2v_rng.hpp (scalar fmaf chain vs packed v_pk_fma_f32).
+ *   n = w >> 16:  u = (n + 1/2)/2^16,  t = -2 ln u = (16 - e) 2ln2 + L(f) for n + 1/2 = 2^e (1 + f), L a degree-7 minimax
+ *                 polynomial; r = sqrt(t) by the integer seed + two tuned Newton steps on 1/sqrt (5.7e-7 relative)
+ *   a = w & 0xFFFF: x = pi (a + 1/2)/2^16 - pi/2;  S = sqrt2 sin x, C = sqrt2 cos x (minimax in x^2)
+ *   g0 = r cos 2x = r - (r S) S,   g1 = r sin 2x = (r S) C
+ * Coefficients from tools/fit_gauss16.py.
  */
-static void bm_pair(uint32_t a, uint32_t b, float *g0, float *g1)
+static void gauss16_pair(uint32_t w, float *g0, float *g1)
 {
-    /* radius: u1 in (0,1] on a 2^-24 grid */
-    float u1 = (float)((a >> 8) + 1u) * 5.9604644775390625e-08f;
-    uint32_t bits = float_as_u32(u1);
-    int e = (int)(bits >> 23) - 127;
-    float m = u32_as_float((bits & 0x007FFFFFu) | 0x3F800000u);
-    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
-    float f = m - 1.0f;
-    float z = f * f;
-    float p = 7.0376836292e-2f;
-    p = fmaf(p, f, -1.1514610310e-1f);
-    p = fmaf(p, f, 1.1676998740e-1f);
-    p = fmaf(p, f, -1.2420140846e-1f);
-    p = fmaf(p, f, 1.4249322787e-1f);
-    p = fmaf(p, f, -1.6668057665e-1f);
-    p = fmaf(p, f, 2.0000714765e-1f);
-    p = fmaf(p, f, -2.4999993993e-1f);
-    p = fmaf(p, f, 3.3333331174e-1f);
-    float y = (p * f) * z;
-    y = fmaf(-0.5f, z, y);
-    float ln_m = f + y;
-    float ln_u = fmaf((float)e, 0.693147182f, ln_m);
-    float t = -2.0f * ln_u;
-    float r = sqrtf(t) * 0.707106769f;
+    const float xh = (float)(w >> 16) + 0.5f;
+    const uint32_t xb = float_as_u32(xh);
+    const float ef = (float)((int)(xb >> 23) - 143);
+    const float f = u32_as_float((xb & 0x007FFFFFu) | 0x3F800000u) - 1.0f;
+    float L = -0x1.57869cp-6f;
+    L = fmaf(L, f, 0x1.bb3e08p-4f);
+    L = fmaf(L, f, -0x1.10adbap-2f);
+    L = fmaf(L, f, 0x1.cc4bd8p-2f);
+    L = fmaf(L, f, -0x1.4fa778p-1f);
+    L = fmaf(L, f, 0x1.ff5d72p-1f);
+    L = fmaf(L, f, -0x1.fffc7ap+0f);
+    L = fmaf(L, f, -0x1.9cde6p-22f);
+    const float t = fmaf(ef, -0x1.62e43p+0f, L);
+    const float th = t * 0x1.007aa6p-1f;
+    float y = u32_as_float(0x5f374000u - (float_as_u32(t) >> 1));
+    float p = y * y;
+    float q = fmaf(-th, p, 0x1.804d8ep+0f);
+    y = y * q;
+    p = y * y;
+    q = fmaf(-th, p, 0x1.803d52p+0f);
+    const float r = (y * q) * t;
 
-    /* angle: quadrant from the top 2 bits, 24 further bits inside the quadrant */
-    uint32_t q = b >> 30;
-    float yy = (float)((b >> 6) & 0x00FFFFFFu) * 5.9604644775390625e-08f - 0.5f;
-    float x = yy * 1.57079637f;
-    float zz = x * x;
-    float s = -1.9515295891e-4f;
-    s = fmaf(s, zz, 8.3321608736e-3f);
-    s = fmaf(s, zz, -1.6666654611e-1f);
-    s = fmaf(s * zz, x, x);
-    float c = 2.443315711809948e-5f;
-    c = fmaf(c, zz, -1.388731625493765e-3f);
-    c = fmaf(c, zz, 4.166664568298827e-2f);
-    c = fmaf(c * zz, zz, fmaf(-0.5f, zz, 1.0f));
-    /* cosA = sc*h, sinA = ss*h with (sc,ss) = (+,+),(-,+),(-,-),(+,-) for q = 0..3 */
-    uint32_t sc = ((q == 1u) || (q == 2u)) ? 0x80000000u : 0u;
-    uint32_t ss = (q >= 2u) ? 0x80000000u : 0u;
-    float cc = u32_as_float(float_as_u32(c) ^ sc);   /* sc*c */
-    float cs = u32_as_float(float_as_u32(c) ^ ss);   /* ss*c */
-    float sc_s = u32_as_float(float_as_u32(s) ^ sc); /* sc*s */
-    float ss_s = u32_as_float(float_as_u32(s) ^ ss); /* ss*s */
-    float ct = cc - ss_s;
-    float st = cs + sc_s;
-    *g0 = r * ct;
-    *g1 = r * st;
+    const float x = fmaf((float)(w & 0xFFFFu), 0x1.921fb6p-15f, -0x1.921e24p+0f);
+    const float z = x * x;
+    float S = -0x1.12b318p-12f;
+    S = fmaf(S, z, 0x1.813e8ap-7f);
+    S = fmaf(S, z, -0x1.e2b092p-3f);
+    S = fmaf(S, z, 0x1.6a09d4p+0f);
+    const float sn = x * S;
+    float c = 0x1.12ae8p-15f;
+    c = fmaf(c, z, -0x1.00cc2ap-9f);
+    c = fmaf(c, z, 0x1.e2aebap-5f);
+    c = fmaf(c, z, -0x1.6a09bap-1f);
+    c = fmaf(c, z, 0x1.6a09e6p+0f);
+    const float t1 = r * sn;
+    *g0 = fmaf(-t1, sn, r);
+    *g1 = t1 * c;
 }
 
-void oracle_bm_pair(uint32_t a, uint32_t b, float out[2]) { bm_pair(a, b, &out[0], &out[1]); }
+void oracle_gauss16(uint32_t w, float out[2]) { gauss16_pair(w, &out[0], &out[1]); }
+
+/* all 2^16 radii (angle word 0x4000 -> ... ) / all components: exhaustive accuracy checks in the tests */
+void oracle_gauss16_many(const uint32_t *w, int64_t n, float *g0, float *g1)
+{
+    for (int64_t i = 0; i < n; ++i) gauss16_pair(w[i], &g0[i], &g1[i]);
+}
 
 static double px_uniform53(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream, uint32_t p)
 {
@@ -148,13 +148,14 @@ static double px_uniform53(uint64_t seed, uint32_t clip, uint32_t field, uint32_
     return (p & 1u) ? uniform53(c[2], c[3]) : uniform53(c[0], c[1]);
 }
 
-static float px_gauss32(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream, uint32_t p)
+/* normal `comp` (0/1) of pixel p's Box-Muller pair in block `field`: word p&3 of Philox block (p>>2, field, clip, stream) */
+static float px_gauss(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream, uint32_t p, int comp)
 {
     uint32_t c[4] = {p >> 2, field, clip, stream};
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
     float g0, g1;
-    if ((p >> 1) & 1u) bm_pair(c[2], c[3], &g0, &g1); else bm_pair(c[0], c[1], &g0, &g1);
-    return (p & 1u) ? g1 : g0;
+    gauss16_pair(c[p & 3u], &g0, &g1);
+    return comp ? g1 : g0;
 }
 
 void oracle_philox_uniform_field(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream,
@@ -164,9 +165,9 @@ void oracle_philox_uniform_field(uint64_t seed, uint32_t clip, uint32_t field, u
 }
 
 void oracle_philox_gauss_field(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream,
-                               int64_t n_pix, float *out)
+                               int64_t n_pix, int comp, float *out)
 {
-    for (int64_t p = 0; p < n_pix; ++p) out[p] = px_gauss32(seed, clip, field, stream, (uint32_t)p);
+    for (int64_t p = 0; p < n_pix; ++p) out[p] = px_gauss(seed, clip, field, stream, (uint32_t)p, comp);
 }
 
 /* ------------------------------------------------------------------ ESIM + binning, one clip */
@@ -217,7 +218,7 @@ int oracle_esim_voxel_clip(const void *frames, int in_dtype, int64_t N, int64_t 
             u0 = px_uniform53(seed, clip_id, 0, 0, (uint32_t)p);
             if (hot_frac > 0.0) {          /* u >= 0: no hot pixel can exist otherwise */
                 u1 = px_uniform53(seed, clip_id, 1, 0, (uint32_t)p);
-                gh = (double)px_gauss32(seed, clip_id, 2, 0, (uint32_t)p);
+                gh = (double)px_gauss(seed, clip_id, 2, 0, (uint32_t)p, 0);
             }
         } else if (rng_mode == ORACLE_RNG_REPLAY) {
             u0 = rp->u_init[p]; u1 = rp->u_hot[p]; gh = rp->g_hot[p];
@@ -236,7 +237,7 @@ int oracle_esim_voxel_clip(const void *frames, int in_dtype, int64_t N, int64_t 
                 pot += (double)d;
             }
             double g = 0.0;
-            if (rng_mode == ORACLE_RNG_PHILOX) { if (base_std != 0.0) g = (double)px_gauss32(seed, clip_id, 3u + (uint32_t)k, 0, (uint32_t)p); }   /* 0*g adds nothing */
+            if (rng_mode == ORACLE_RNG_PHILOX) { if (base_std != 0.0) g = (double)px_gauss(seed, clip_id, 3u + (uint32_t)(k >> 1), 0, (uint32_t)p, (int)(k & 1)); }   /* 0*g adds nothing; block 3+m serves pairs 2m, 2m+1 */
             else if (rng_mode == ORACLE_RNG_REPLAY) g = rp->g_base[k * HW + p];
             double base = base_std * g;                            /* :44 */
             if (!noise_external) { pot += base; pot += hot; }      /* :48-49 */
@@ -353,12 +354,14 @@ static float expf_det(float x)
 }
 float oracle_expf_det(float x) { return expf_det(x); }
 
-/* Native shot-noise sampler: float32 inversion from one 24-bit uniform (word p&3 of Philox block p>>2). */
-static float px_uniform24(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream, uint32_t p)
+/* Native shot-noise uniforms: word p&3 of Philox block (p>>2, field) -> ON uniform from its high, OFF uniform from its
+ * low 16 bits, midpoint grid (n + 1/2)/2^16. */
+static float px_uniform16(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream, uint32_t p, int low)
 {
     uint32_t c[4] = {p >> 2, field, clip, stream};
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    return (float)(c[p & 3u] >> 8) * 5.9604644775390625e-08f;
+    const uint32_t w = c[p & 3u];
+    return ((float)(low ? (w & 0xFFFFu) : (w >> 16)) + 0.5f) * 1.52587890625e-05f;
 }
 
 static float poisson_inv_f32(float lam, float u)
@@ -371,7 +374,7 @@ static float poisson_inv_f32(float lam, float u)
 float oracle_poisson_inv_f32(float lam, float u) { return poisson_inv_f32(lam, u); }
 
 enum { V2E_PN_RELATED = 0, V2E_SPATIAL_INDEPENDENT = 1, V2E_SPATIAL_TEMPORAL_INDEPENDENT = 2 };
-enum { V2E_F_THRES_A = 0, V2E_F_THRES_B = 1, V2E_F_NOISE_RATE = 2, V2E_F_FRAME0 = 16, V2E_F_STRIDE = 8 };
+enum { V2E_F_THRES_A = 0, V2E_F_NOISE_RATE = 2, V2E_F_FRAME0 = 16, V2E_F_STRIDE = 8 };
 #define V2E_STREAM 1u
 
 typedef struct {
@@ -396,8 +399,8 @@ static double v2e_floor_divide(double a, double b) { return oracle_floor_divide(
 static void v2e_native_thres(const oracle_v2e_params *P, uint64_t seed, uint32_t clip, uint32_t fa, uint32_t p,
                              double *pt, double *nt)
 {
-    const double ga = (double)px_gauss32(seed, clip, fa, V2E_STREAM, p);
-    const double gb = (double)px_gauss32(seed, clip, fa + 1u, V2E_STREAM, p);
+    const double ga = (double)px_gauss(seed, clip, fa, V2E_STREAM, p, 0);   /* the two normals of one Box-Muller pair */
+    const double gb = (double)px_gauss(seed, clip, fa, V2E_STREAM, p, 1);
     double a, b;
     if (P->threshold_model == V2E_PN_RELATED) {
         const double mean = P->thres_mean_mean + P->thres_mean_std * ga;   /* normal(loc,scale) = loc + scale*g */
@@ -473,7 +476,7 @@ int oracle_v2e_voxel_clip(const void *frames, int in_dtype, int64_t N, int64_t H
         float nrate;
         if (rng_mode == ORACLE_RNG_PHILOX) {
             v2e_native_thres(P, seed, clip_id, V2E_F_THRES_A, (uint32_t)p, &pt, &nt);
-            const float g = px_gauss32(seed, clip_id, V2E_F_NOISE_RATE, V2E_STREAM, (uint32_t)p);
+            const float g = px_gauss(seed, clip_id, V2E_F_NOISE_RATE, V2E_STREAM, (uint32_t)p, 0);
             nrate = expf_det((float)(2.302585092994046 * P->noise_rate_cov_decades) * g);
         } else {
             pt = rp->pos_thres[p]; nt = rp->neg_thres[p]; nrate = rp->noise_rate[p];
@@ -506,7 +509,7 @@ int oracle_v2e_voxel_clip(const void *frames, int in_dtype, int64_t N, int64_t H
             }
             if (P->leak_rate_hz > 0) {                                            /* subtract_leak_current */
                 double g;
-                if (rng_mode == ORACLE_RNG_PHILOX) g = (double)px_gauss32(seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * i + 2), V2E_STREAM, (uint32_t)p);
+                if (rng_mode == ORACLE_RNG_PHILOX) g = (double)px_gauss(seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * (k >> 1) + 2), V2E_STREAM, (uint32_t)p, (int)(k & 1));
                 else g = rp->leak_randn[k * HW + p];
                 const float a32 = (float)P->leak_rate_hz * nrate;
                 const double curr = (double)a32 * (1 - P->leak_jitter_fraction * g);
@@ -533,8 +536,8 @@ int oracle_v2e_voxel_clip(const void *frames, int in_dtype, int64_t N, int64_t H
                     const double scale_p = f / mean_p, scale_n = f / mean_n;
                     const double lam_p = (fac * (pos_nominal / pt)) * scale_p;
                     const double lam_n = (fac * (neg_nominal / nt)) * scale_n;
-                    sp = (double)poisson_inv_f32((float)lam_p, px_uniform24(seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * i + 3), V2E_STREAM, (uint32_t)p));
-                    sn = (double)poisson_inv_f32((float)lam_n, px_uniform24(seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * i + 4), V2E_STREAM, (uint32_t)p));
+                    sp = (double)poisson_inv_f32((float)lam_p, px_uniform16(seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * i + 3), V2E_STREAM, (uint32_t)p, 0));
+                    sn = (double)poisson_inv_f32((float)lam_n, px_uniform16(seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * i + 3), V2E_STREAM, (uint32_t)p, 1));
                 } else {
                     sp = (double)rp->shot_pos[k * HW + p]; sn = (double)rp->shot_neg[k * HW + p];
                 }

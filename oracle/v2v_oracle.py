@@ -168,12 +168,12 @@ def philox_uniform53(seed: int, clip_id: int, field: int, n_pix: int, stream: in
     return (a * 67108864.0 + b) / 9007199254740992.0
 
 
-def philox_gauss32(seed: int, clip_id: int, field: int, n_pix: int, stream: int = STREAM_ESIM):
-    """float32 standard normals from Philox words through the fp32 Box-Muller of oracle/v2v_oracle.c
+def philox_gauss32(seed: int, clip_id: int, field: int, n_pix: int, stream: int = STREAM_ESIM, comp: int = 0):
+    """float32 standard normals from Philox words through the 16+16-bit fp32 Box-Muller of oracle/v2v_oracle.c
     (bit-identical op sequence to the device's; needs the built C oracle because NumPy has no fma).
-    Pixel p: block counter (p>>2, field, clip_id, stream), word pair j=(p>>1)&1, member p&1."""
+    Pixel p: word p&3 of block (p>>2, field, clip_id, stream) -> one Box-Muller pair; comp picks its member."""
     from oracle import clib  # local import: the C twin is optional for everything else
-    return clib.philox_gauss_field(seed, clip_id, field, n_pix, stream)
+    return clib.philox_gauss_field(seed, clip_id, field, n_pix, stream, comp)
 
 
 class PhiloxFieldRNG:
@@ -191,9 +191,15 @@ class PhiloxFieldRNG:
         return philox_uniform53(self.seed, self.clip_id, field, h * w).reshape(h, w)
 
     def randn(self, h, w):
-        field = FIELD_HOT_GAUSS if self._n_randn == 0 else FIELD_BASE0 + self._n_randn - 1
+        # draw 0: hot-pixel normals (first member of block 2); draw 1+k: base noise of frame pair k = member k&1 of
+        # block 3 + (k>>1) -- one Philox block and one Box-Muller pair per pixel serve two consecutive pairs
+        if self._n_randn == 0:
+            field, comp = FIELD_HOT_GAUSS, 0
+        else:
+            k = self._n_randn - 1
+            field, comp = FIELD_BASE0 + (k >> 1), k & 1
         self._n_randn += 1
-        return philox_gauss32(self.seed, self.clip_id, field, h * w).astype(np.float64).reshape(h, w)
+        return philox_gauss32(self.seed, self.clip_id, field, h * w, comp=comp).astype(np.float64).reshape(h, w)
 
 
 # ----------------------------------------------------------------------------------------

@@ -224,6 +224,7 @@ def g11_philox_fed():
                 np.random.rand, np.random.randn = real_rand, real_randn
             out[f"ext{int(ext)}_{dt_tag}"] = v
     out["gauss_field3"] = clib.philox_gauss_field(seed, clip_id, 3, 1024)
+    out["gauss_field3b"] = clib.philox_gauss_field(seed, clip_id, 3, 1024, comp=1)
     out["uniform_field0"] = clib.philox_uniform_field(seed, clip_id, 0, 1024)
     save("g11_philox_fed.npz", **out)
 

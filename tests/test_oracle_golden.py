@@ -133,8 +133,9 @@ def test_philox_known_answers(oracle_c):
 
 
 def test_box_muller_exact_fma_semantics(oracle_c):
-    """The fp32 Box-Muller is defined with single-rounded fmaf; re-derive a few values in exact
-    rational arithmetic to prove the C build really single-rounds (i.e. host == device definition)."""
+    """The 16+16-bit fp32 Box-Muller (gauss16) is defined with single-rounded fmaf; re-derive values in exact
+    rational arithmetic (a third, independent statement of the sequence) to prove the C build really single-rounds
+    (i.e. host == device definition)."""
     from fractions import Fraction as Fr
 
     def rnd(x):          # round a Fraction to nearest-even float32
@@ -170,65 +171,90 @@ def test_box_muller_exact_fma_semantics(oracle_c):
 
     F = np.float32
 
-    def bm_ref(a, b):
-        u1 = F(((a >> 8) + 1)) * F(5.9604644775390625e-08)
-        bits = int(np.array(u1, dtype=np.float32).view(np.uint32))
-        e = (bits >> 23) - 127
-        m = np.array((bits & 0x7FFFFF) | 0x3F800000, dtype=np.uint32).view(np.float32)[()]
-        if m > F(1.41421354):
-            m = mul(m, F(0.5)); e += 1
-        f = add(m, F(-1.0)); z = mul(f, f)
-        p = F(7.0376836292e-2)
-        for c in (-1.1514610310e-1, 1.1676998740e-1, -1.2420140846e-1, 1.4249322787e-1, -1.6668057665e-1,
-                  2.0000714765e-1, -2.4999993993e-1, 3.3333331174e-1):
-            p = fma(p, f, F(c))
-        y = mul(mul(p, f), z); y = fma(F(-0.5), z, y)
-        ln_u = fma(F(e), F(0.693147182), add(f, y))
-        t = mul(F(-2.0), ln_u)
-        r = mul(np.sqrt(t, dtype=np.float32), F(0.707106769))
-        q = b >> 30
-        yy = add(mul(F((b >> 6) & 0xFFFFFF), F(5.9604644775390625e-08)), F(-0.5))
-        x = mul(yy, F(1.57079637)); zz = mul(x, x)
-        s = F(-1.9515295891e-4); s = fma(s, zz, F(8.3321608736e-3)); s = fma(s, zz, F(-1.6666654611e-1))
-        s = fma(mul(s, zz), x, x)
-        c = F(2.443315711809948e-5); c = fma(c, zz, F(-1.388731625493765e-3)); c = fma(c, zz, F(4.166664568298827e-2))
-        c = fma(mul(c, zz), zz, fma(F(-0.5), zz, F(1.0)))
-        sc = -1.0 if q in (1, 2) else 1.0
-        ss = -1.0 if q >= 2 else 1.0
-        ct = add(F(sc) * c, -(F(ss) * s)); st = add(F(ss) * c, F(sc) * s)
-        return mul(r, ct), mul(r, st)
+    def as_u32(x):
+        return int(np.array(x, dtype=np.float32).view(np.uint32))
+
+    def as_f32(u):
+        return np.array(u & 0xFFFFFFFF, dtype=np.uint32).view(np.float32)[()]
+
+    def horner(coefs, v):          # coefs highest degree first
+        p = F(float.fromhex(coefs[0]))
+        for c in coefs[1:]:
+            p = fma(p, v, F(float.fromhex(c)))
+        return p
+
+    def gauss16_ref(w):
+        xh = add(F(w >> 16), F(0.5))
+        xb = as_u32(xh)
+        ef = F((xb >> 23) - 143)
+        f = add(as_f32((xb & 0x7FFFFF) | 0x3F800000), F(-1.0))
+        L = horner(["-0x1.57869cp-6", "0x1.bb3e08p-4", "-0x1.10adbap-2", "0x1.cc4bd8p-2", "-0x1.4fa778p-1", "0x1.ff5d72p-1",
+                    "-0x1.fffc7ap+0", "-0x1.9cde6p-22"], f)
+        t = fma(ef, F(float.fromhex("-0x1.62e43p+0")), L)
+        th = mul(t, F(float.fromhex("0x1.007aa6p-1")))
+        y = as_f32(0x5f374000 - (as_u32(t) >> 1))
+        q = fma(-th, mul(y, y), F(float.fromhex("0x1.804d8ep+0")))
+        y = mul(y, q)
+        q = fma(-th, mul(y, y), F(float.fromhex("0x1.803d52p+0")))
+        r = mul(mul(y, q), t)
+        x = fma(F(w & 0xFFFF), F(float.fromhex("0x1.921fb6p-15")), F(float.fromhex("-0x1.921e24p+0")))
+        z = mul(x, x)
+        sn = mul(x, horner(["-0x1.12b318p-12", "0x1.813e8ap-7", "-0x1.e2b092p-3", "0x1.6a09d4p+0"], z))
+        c = horner(["0x1.12ae8p-15", "-0x1.00cc2ap-9", "0x1.e2aebap-5", "-0x1.6a09bap-1", "0x1.6a09e6p+0"], z)
+        t1 = mul(r, sn)
+        return fma(-t1, sn, r), mul(t1, c)
 
     g = np.random.default_rng(3)
-    for a, b in [(0, 0), (0xFFFFFFFF, 0xFFFFFFFF), (0xFFFFFF00, 0x40000000)] + \
-            [tuple(int(v) for v in g.integers(0, 2**32, size=2)) for _ in range(40)]:
-        want = bm_ref(a, b)
-        got = oracle_c.bm_pair(a, b)
+    for w in [0, 0xFFFFFFFF, 0xFFFF0000, 0x0000FFFF, 0x80008000, 0x7FFF7FFF] + [int(v) for v in g.integers(0, 2**32, size=40)]:
+        want = gauss16_ref(w)
+        got = oracle_c.gauss16(w)
         # value equality (the rational emulation does not track the sign of a zero result)
-        assert got[0] == np.float32(want[0]) and got[1] == np.float32(want[1]), (a, b, got, want)
+        assert got[0] == np.float32(want[0]) and got[1] == np.float32(want[1]), (hex(w), got, want)
 
 
 def test_native_fields_statistics(oracle_c):
     g = oracle_c.philox_gauss_field(2024, 3, 5, 1 << 18)
     assert abs(g.mean()) < 0.01 and abs(g.std() - 1) < 0.01
     assert abs(((g - g.mean()) ** 3).mean()) < 0.03 and abs((g ** 4).mean() - 3) < 0.08
-    # accuracy of the hand-written log/sincos: compare with float64 Box-Muller on the same words
+    gb = oracle_c.philox_gauss_field(2024, 3, 5, 1 << 18, comp=1)                   # second normal of every pair
+    assert abs(gb.mean()) < 0.01 and abs(gb.std() - 1) < 0.01 and abs(np.corrcoef(g, gb)[0, 1]) < 0.01
+    assert abs(np.corrcoef(g * g, gb * gb)[0, 1]) < 0.01                            # radius shared, yet independent (Box-Muller)
     u = oracle_c.philox_uniform_field(2024, 3, 0, 1 << 16)
     assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.01
     assert np.array_equal(u, O.philox_uniform53(2024, 3, 0, 1 << 16))
     # independence across clips / fields / pixels: no duplicated blocks
     g2 = oracle_c.philox_gauss_field(2024, 4, 5, 1 << 12)
     assert abs(np.corrcoef(g[:1 << 12], g2)[0, 1]) < 0.06
+    from scipy import stats
+    assert stats.kstest(g.astype(np.float64), "norm").pvalue > 1e-3
+    assert stats.kstest(gb.astype(np.float64), "norm").pvalue > 1e-3
 
 
-def test_box_muller_accuracy(oracle_c):
-    g = np.random.default_rng(11)
-    for a, b in g.integers(0, 2**32, size=(200, 2)):
-        a, b = int(a), int(b)
-        u1 = ((a >> 8) + 1) * 2.0 ** -24
-        th = ((b >> 30) + ((b >> 6) & 0xFFFFFF) * 2.0 ** -24) * (np.pi / 2)
-        r = np.sqrt(-2 * np.log(u1))
-        got = oracle_c.bm_pair(a, b)
-        assert abs(got[0] - r * np.cos(th)) < 2e-6 * max(1, r) and abs(got[1] - r * np.sin(th)) < 2e-6 * max(1, r)
+def test_gauss16_exhaustive_accuracy(oracle_c):
+    """Every one of the 2^16 radii and 2^16 angles of the 16+16-bit Box-Muller against float64 math, and the exact moments of
+    the discrete generator (it is separable: g0 = r[n] * cos2x[a], g1 = r[n] * sin2x[a])."""
+    n = np.arange(1 << 16, dtype=np.uint32)
+    # radius: angle word a such that cos 2x ~ 1: a = 32768 -> x = pi/131072 -> g0 = r cos(2x) ~ r (1 - 1.2e-9)
+    g0, _ = oracle_c.gauss16_many((n << np.uint32(16)) | np.uint32(32768))
+    r_true = np.sqrt(-2.0 * np.log((n.astype(np.float64) + 0.5) / 65536.0))
+    rel = np.abs(g0 / r_true - 1.0)
+    assert rel[:65000].max() < 1e-5, rel[:65000].max()             # r > 0.128 (99.2 % of the radii): 1e-5 relative
+    # the rest: -2 ln u = 2ln2 + L(f) cancels towards u -> 1, the absolute error of L (4e-7) shows: |dr| <= 5e-5 on
+    # radii below 0.13, never negative
+    assert np.abs(g0 - r_true).max() < 5e-5 and np.abs(g0 - r_true)[:65500].max() < 5e-6 and g0.min() > 0
+    # angle: fixed radius word n = 0x8000 (r ~ 1.1774)
+    a = np.arange(1 << 16, dtype=np.uint32)
+    c0, s0 = oracle_c.gauss16_many(np.uint32(0x8000 << 16) | a)
+    r0 = np.sqrt(-2.0 * np.log((0x8000 + 0.5) / 65536.0))
+    th = 2.0 * (np.pi * (a.astype(np.float64) + 0.5) / 65536.0 - np.pi / 2)
+    assert np.abs(c0 / r0 - np.cos(th)).max() < 8e-6 and np.abs(s0 / r0 - np.sin(th)).max() < 8e-6   # angular grid step: 9.6e-5
+    # exact moments of the discrete distribution (float64 sums over the separable grids)
+    r = g0.astype(np.float64) / np.cos(2 * np.pi / 131072)
+    c, s = c0.astype(np.float64) / r0, s0.astype(np.float64) / r0
+    for trig in (c, s):
+        m1, m2, m4 = trig.mean() * r.mean(), (trig ** 2).mean() * (r ** 2).mean(), (trig ** 4).mean() * (r ** 4).mean()
+        assert abs(m1) < 1e-6 and abs(m2 - 1.0) < 2e-4 and abs(m4 - 3.0) < 3e-3, (m1, m2, m4)
+    assert abs((c * s).mean()) < 1e-7                                # the two normals of a pair are uncorrelated
 
 
 # ---------------------------------------------------------------- G11: reference run on the native fields
@@ -240,6 +266,7 @@ def test_g11_philox_fed(golden, oracle_c, luts, ext, dt_tag, dt):
     video = g["video"].astype(dt)
     want = g[f"ext{int(ext)}_{dt_tag}"]
     assert np.array_equal(oracle_c.philox_gauss_field(seed, clip, 3, 1024), g["gauss_field3"])
+    assert np.array_equal(oracle_c.philox_gauss_field(seed, clip, 3, 1024, comp=1), g["gauss_field3b"])
     assert np.array_equal(oracle_c.philox_uniform_field(seed, clip, 0, 1024), g["uniform_field0"])
     got = O.esim_video_to_voxel(video, *g["params"], put_noise_external=ext,
                                 rng=O.PhiloxFieldRNG(seed, clip), use_lut=True)

@@ -95,6 +95,51 @@ DEF_KERNEL_F32(k_mul_hi_u32, A_MULHI)
 DEF_KERNEL_F32(k_sqrt_f32, A_SQRT32)
 DEF_KERNEL_F32(k_max_f32, A_MAX32)
 
+
+#define A_ANDOR(n) "v_and_or_b32 %" #n ", %" #n ", %8, %8\n"
+#define A_ALIGNBIT(n) "v_alignbit_b32 %" #n ", %" #n ", %8, 7\n"
+#define A_FFBH(n) "v_ffbh_u32 %" #n ", %" #n "\n"
+#define A_FREXPM(n) "v_frexp_mant_f32 %" #n ", %" #n "\n"
+#define A_FREXPE(n) "v_frexp_exp_i32_f32 %" #n ", %" #n "\n"
+#define A_CVTF32U32(n) "v_cvt_f32_u32 %" #n ", %" #n "\n"
+#define A_CVTSDWA(n) "v_cvt_f32_u32_sdwa %" #n ", %" #n " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+#define A_EXP32(n) "v_exp_f32 %" #n ", %" #n "\n"
+#define A_LOG32(n) "v_log_f32 %" #n ", %" #n "\n"
+#define A_RNDNE32(n) "v_rndne_f32 %" #n ", %" #n "\n"
+#define A_MULU24(n) "v_mul_u32_u24 %" #n ", %" #n ", %8\n"
+#define A_MULHIU24(n) "v_mul_hi_u32_u24 %" #n ", %" #n ", %8\n"
+#define A_LSHRREV(n) "v_lshrrev_b32 %" #n ", 3, %" #n "\n"
+#define A_OR(n) "v_or_b32 %" #n ", %" #n ", %8\n"
+#define A_FMAC(n) "v_fmac_f32 %" #n ", %8, %8\n"
+#define A_FMAAK(n) "v_fmaak_f32 %" #n ", %" #n ", %8, 0x3f800001\n"
+DEF_KERNEL_F32(k_and_or, A_ANDOR)
+DEF_KERNEL_F32(k_alignbit, A_ALIGNBIT)
+DEF_KERNEL_F32(k_ffbh, A_FFBH)
+DEF_KERNEL_F32(k_frexp_mant, A_FREXPM)
+DEF_KERNEL_F32(k_frexp_exp, A_FREXPE)
+DEF_KERNEL_F32(k_cvt_f32_u32, A_CVTF32U32)
+DEF_KERNEL_F32(k_cvt_sdwa, A_CVTSDWA)
+DEF_KERNEL_F32(k_exp32, A_EXP32)
+DEF_KERNEL_F32(k_log32, A_LOG32)
+DEF_KERNEL_F32(k_rndne32, A_RNDNE32)
+DEF_KERNEL_F32(k_mul_u24, A_MULU24)
+DEF_KERNEL_F32(k_mulhi_u24, A_MULHIU24)
+DEF_KERNEL_F32(k_lshrrev, A_LSHRREV)
+DEF_KERNEL_F32(k_or_b32, A_OR)
+DEF_KERNEL_F32(k_fmac, A_FMAC)
+DEF_KERNEL_F32(k_fmaak, A_FMAAK)
+// 32x32 -> 64 multiply-add (Philox): destination is a register pair
+__global__ void __launch_bounds__(256) k_mad_u64_u32(double *out, double seed) {
+    unsigned long long d0 = threadIdx.x, d1 = d0 + 1, d2 = d0 + 2, d3 = d0 + 3, d4 = d0 + 4, d5 = d0 + 5, d6 = d0 + 6, d7 = d0 + 7;
+    unsigned b = (unsigned)seed * 2654435761u + 12345u;
+    for (int i = 0; i < kIters; ++i) {
+#define MAD(n) "v_mad_u64_u32 %" #n ", vcc, %8, %8, %" #n "\n"
+        asm volatile(MAD(0) MAD(1) MAD(2) MAD(3) MAD(4) MAD(5) MAD(6) MAD(7) MAD(0) MAD(1) MAD(2) MAD(3) MAD(4) MAD(5) MAD(6) MAD(7)
+                     : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(b) : "vcc");
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = (double)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
+}
+
 // mixed-width conversions: f64 <-> f32 (source and destination differ in size, so separate chains)
 __global__ void __launch_bounds__(256) k_cvt_f64_f32(double *out, double seed) {
     float s0 = (float)seed + threadIdx.x, s1 = s0 + 1, s2 = s0 + 2, s3 = s0 + 3;
@@ -174,6 +219,28 @@ __global__ void __launch_bounds__(256) k_pk_fma(double *out, double seed) {
     f32x2 t = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
     out[blockIdx.x * 256 + threadIdx.x] = t.x + t.y;
 }
+__global__ void __launch_bounds__(256) k_pk_mul(double *out, double seed) {
+    f32x2 a0 = {(float)seed + threadIdx.x, 1.f}, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    f32x2 b = {(float)seed * 1.0000001f, 0.5f};
+    for (int i = 0; i < kIters; ++i) {
+#define PKM(n) "v_pk_mul_f32 %" #n ", %" #n ", %8\n"
+        asm volatile(PKM(0) PKM(1) PKM(2) PKM(3) PKM(4) PKM(5) PKM(6) PKM(7) PKM(0) PKM(1) PKM(2) PKM(3) PKM(4) PKM(5) PKM(6) PKM(7)
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+    }
+    f32x2 t = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    out[blockIdx.x * 256 + threadIdx.x] = t.x + t.y;
+}
+__global__ void __launch_bounds__(256) k_pk_add(double *out, double seed) {
+    f32x2 a0 = {(float)seed + threadIdx.x, 1.f}, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    f32x2 b = {(float)seed * 1.0000001f, 0.5f};
+    for (int i = 0; i < kIters; ++i) {
+#define PKA(n) "v_pk_add_f32 %" #n ", %" #n ", %8\n"
+        asm volatile(PKA(0) PKA(1) PKA(2) PKA(3) PKA(4) PKA(5) PKA(6) PKA(7) PKA(0) PKA(1) PKA(2) PKA(3) PKA(4) PKA(5) PKA(6) PKA(7)
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+    }
+    f32x2 t = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    out[blockIdx.x * 256 + threadIdx.x] = t.x + t.y;
+}
 // independent LDS lookups (throughput, not a dependent chain): 8 reads in flight per lane
 __global__ void __launch_bounds__(256) k_lds_tp(double *out, double seed, int mode) {
     __shared__ float lut[256];
@@ -208,6 +275,11 @@ int main() {
         {"v_floor_f64", k_floor_f64, 16}, {"v_trunc_f64", k_trunc_f64, 16}, {"v_cmp_ge_f64", k_cmp_ge_f64, 16}, {"v_rcp_f64", k_rcp_f64, 16},
         {"v_cvt_f64_f32", k_cvt_f64_f32, 16}, {"v_cvt_f32_f64", k_cvt_f32_f64, 16}, {"v_cvt_i32_f64", k_cvt_i32_f64, 16},
         {"v_cvt_f64_i32", k_cvt_f64_i32, 16}, {"v_pk_fma_f32", k_pk_fma, 16},
+        {"v_pk_mul_f32", k_pk_mul, 16}, {"v_pk_add_f32", k_pk_add, 16}, {"v_mad_u64_u32", k_mad_u64_u32, 16}, {"v_and_or_b32", k_and_or, 16},
+        {"v_alignbit_b32", k_alignbit, 16}, {"v_ffbh_u32", k_ffbh, 16}, {"v_frexp_mant_f32", k_frexp_mant, 16}, {"v_frexp_exp_i32_f32", k_frexp_exp, 16},
+        {"v_cvt_f32_u32", k_cvt_f32_u32, 16}, {"v_cvt_f32_u32_sdwa", k_cvt_sdwa, 16}, {"v_exp_f32", k_exp32, 16}, {"v_log_f32", k_log32, 16},
+        {"v_rndne_f32", k_rndne32, 16}, {"v_mul_u32_u24", k_mul_u24, 16}, {"v_mul_hi_u32_u24", k_mulhi_u24, 16}, {"v_lshrrev_b32", k_lshrrev, 16},
+        {"v_or_b32", k_or_b32, 16}, {"v_fmac_f32", k_fmac, 16}, {"v_fmaak_f32", k_fmaak, 16},
     };
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "v2v_args.hpp"
 #include "v2v_rng.hpp"
@@ -24,6 +25,10 @@ namespace v2v {
 #define V2V_NT_STORES 1     // voxel planes are written once and never re-read by the kernel: keep them out of the caches
 #endif
 constexpr int kDepth = V2V_DEPTH;   // frames in flight per work-item (register ring, reloaded right after use)
+
+// compile-time unrolled loop: f(std::integral_constant<int, 0>{}), f(<1>), ...
+template <int... U, typename F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, U...>, F &&f) { (f(std::integral_constant<int, U>{}), ...); }
 
 // ------------------------------------------------------------------------------------------------
 // raw input vectors

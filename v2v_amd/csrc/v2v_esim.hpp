@@ -87,11 +87,17 @@ __device__ __forceinline__ void pix_logs(const Raw<IN, VEC> &r, const typename L
 //                   added): bit-exact against the reference's float64 result.
 //          false -> float32 output.  Integer counts (SUM mode) stay exact; weighted/noisy values are
 //                   accumulated with float32 fma and agree with the float64 result to ~1e-6 relative.
-template <int IN, int VEC, int BIN, int RNG, bool NOISE, bool OUT64>
+// EXT    : put_noise_external (v2v_core_esim.py:46-49 vs :60-65): the noise goes into the voxel, not into the potential.
+//          Compile-time: as a run-time flag the compiler turned both uses into selects over speculated float64 adds and
+//          converts (~28 of 213 VALU instructions per 4-pixel step of the noise-on launch, SQ_INSTS_VALU).
+template <int IN, int VEC, int BIN, int RNG, bool NOISE, bool OUT64, bool EXT = false>
 __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const EsimArgs a)
 {
+    static_assert(NOISE || !EXT, "external noise needs the noise path");
     using lut_t = typename LutT<IN>::type;
     using acc_t = typename std::conditional<OUT64, double, float>::type;
+    // float32 bilinear accumulators are kept as {lower bin, upper bin} pairs: one v_pk_fma_f32 per pixel and pair
+    constexpr bool PK = !OUT64 && BIN == kBinBilinear;
     extern __shared__ __align__(16) unsigned char s_raw[];
     lut_t *s_lut = reinterpret_cast<lut_t *>(s_raw);
     acc_t *s_wlo = reinterpret_cast<acc_t *>(s_raw + 256 * sizeof(lut_t));
@@ -140,7 +146,6 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
     if constexpr (NOISE) { base_std = pp[2]; hot_frac = pp[3]; hot_std = pp[4]; }
     const uint64_t seed_ = a.clip_keys ? a.clip_keys[2 * clip] : a.seed;
     const uint32_t clip_id = a.clip_keys ? (uint32_t)a.clip_keys[2 * clip + 1] : (uint32_t)(a.clip_id0 + (uint64_t)clip);
-    const bool ext = NOISE && a.noise_external != 0;
     const int64_t in_base = (int64_t)clip * a.clip_stride + p0;
 
     // ---- per-pixel state
@@ -168,9 +173,9 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
             if constexpr (RNG == kRngPhilox || RNG == kRngPhiloxFast) {
                 if (hot_frac > 0.0) {                                  // uniform: skipping is exact (u >= 0)
                     double u1[VEC];
-                    float gh[VEC];
+                    float gh[VEC], gh_unused[VEC];
                     field_uniform53<VEC>(seed_, clip_id, kFieldHotMask, kStreamEsim, p0, u1);
-                    field_gauss32<VEC>(seed_, clip_id, kFieldHotGauss, kStreamEsim, p0, gh);
+                    field_gauss_pairs<VEC>(seed_, clip_id, kFieldHotGauss, kStreamEsim, p0, gh, gh_unused);
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) hot[j] = (u1[j] < hot_frac) ? hot_std * (double)gh[j] : 0.0;   // :37-39
                 }
@@ -192,8 +197,24 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
 
     // ---- binning state
     acc_t acc_lo[VEC], acc_hi[VEC];
+    f32x2 acc2[PK ? VEC : 1];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { acc_lo[j] = 0; acc_hi[j] = 0; }
+#pragma unroll
+    for (int j = 0; j < (PK ? VEC : 1); ++j) acc2[j] = f32x2{0.0f, 0.0f};
+    // plane of the lower bin leaves the accumulators, the upper bin becomes the lower one
+    auto flush_lower = [&](int seg) {
+        if constexpr (PK) {
+            float lo[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { lo[j] = acc2[j].x; acc2[j] = f32x2{acc2[j].y, 0.0f}; }
+            store_vec<VEC, float>(a.out, (int64_t)clip * a.Tb * a.HW + p0 + (int64_t)seg * a.HW, lo);
+        } else {
+            store_vec<VEC, acc_t>(a.out, (int64_t)clip * a.Tb * a.HW + p0 + (int64_t)seg * a.HW, acc_lo);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { acc_lo[j] = acc_hi[j]; acc_hi[j] = 0; }
+        }
+    };
     int cur_seg = 0;          // BILINEAR: bin index acc_lo belongs to (wave-uniform)
     int next_k = 0x7FFFFFFF;  // BILINEAR: first pair of segment cur_seg+1 (wave-uniform, kept scalar)
     if constexpr (BIN == kBinBilinear) {
@@ -205,14 +226,21 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
     uint32_t n_all = 0, n_off = 0;
     const bool want_counts = a.counts != nullptr;
 
+    const bool has_base = __builtin_amdgcn_readfirstlane((int)(base_std != 0.0)) != 0;   // per clip: a scalar branch
+    // base-noise normals of the odd pair of each (even, odd) couple of time steps: one Philox block and four
+    // Box-Muller pairs feed 4 pixels x 2 steps (v2v_rng.hpp); drawn at the even step, consumed at the odd one
+    float g_pend[NOISE ? VEC : 1];
+#pragma unroll
+    for (int j = 0; j < (NOISE ? VEC : 1); ++j) g_pend[j] = 0.0f;
+
     // SYM (compile-time tag): C+ == C- for this clip (wave-uniform), so no per-lane threshold selection.
-    auto step = [&](auto sym_tag, int k, const Raw<IN, VEC> &raw) {
+    // PAR (compile-time tag): k & 1 -- the time loop is unrolled by an even factor from an even k.
+    auto step = [&](auto sym_tag, auto par_tag, int k, const Raw<IN, VEC> &raw) {
         constexpr bool SYM = decltype(sym_tag)::value;
+        constexpr int PAR = decltype(par_tag)::value;
         if constexpr (BIN == kBinBilinear) {
             while (k >= next_k) {                                      // scalar compare; rarely taken
-                store_vec<VEC, acc_t>(a.out, out_base + (int64_t)cur_seg * a.HW, acc_lo);
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) { acc_lo[j] = acc_hi[j]; acc_hi[j] = 0; }
+                flush_lower(cur_seg);
                 ++cur_seg;
                 next_k = (cur_seg + 1 <= a.Tb - 2) ? __builtin_amdgcn_readfirstlane(s_kb[cur_seg + 1]) : 0x7FFFFFFF;
             }
@@ -222,10 +250,15 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
 #pragma unroll
             for (int j = 0; j < VEC; ++j) base[j] = 0.0;
             if constexpr (RNG == kRngPhilox || RNG == kRngPhiloxFast) {
-                if (base_std != 0.0) {                                 // uniform; 0*g adds nothing
+                if (has_base) {                                        // uniform (scalar); 0*g adds nothing
                     float g[VEC];
-                    if constexpr (RNG == kRngPhiloxFast) field_gauss32_fast<VEC>(seed_, clip_id, kFieldBase0 + (uint32_t)k, kStreamEsim, p0, g);
-                    else field_gauss32<VEC>(seed_, clip_id, kFieldBase0 + (uint32_t)k, kStreamEsim, p0, g);
+                    if constexpr (PAR == 0) {
+                        if constexpr (RNG == kRngPhiloxFast) field_gauss_pairs_fast<VEC>(seed_, clip_id, kFieldBase0 + (uint32_t)(k >> 1), kStreamEsim, p0, g, g_pend);
+                        else field_gauss_pairs<VEC, kNoiseRounds>(seed_, clip_id, kFieldBase0 + (uint32_t)(k >> 1), kStreamEsim, p0, g, g_pend);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) g[j] = g_pend[j];
+                    }
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) base[j] = base_std * (double)g[j];   // :44
                 }
@@ -237,6 +270,8 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
         }
         acc_t wl = 1, wh = 0;
         if constexpr (BIN == kBinBilinear) { wl = s_wlo[k]; wh = s_whi[k]; }
+        f32x2 w2 = f32x2{0.0f, 0.0f};
+        if constexpr (PK) w2 = f32x2{(float)wl, (float)wh};
         lut_t ln[VEC];
         pix_logs<IN, VEC>(raw, s_lut, ln);
 
@@ -252,9 +287,7 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
             const lut_t d = ln[j] - lprev[j];                          // difference in the input's precision (:42)
             lprev[j] = ln[j];
             double p = pot[j] + (double)d;                             // :43
-            if constexpr (NOISE) {
-                if (!ext) { p = p + base[j]; p = p + hot[j]; }         // :48-49
-            }
+            if constexpr (NOISE && !EXT) { p = p + base[j]; p = p + hot[j]; }   // :48-49
             sgn[j] = (uint32_t)__double2hiint(p) & 0x80000000u;
             mag[j] = fabs(p);
             double inv;
@@ -283,9 +316,7 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
             if constexpr (OUT64) {
                 double vox = __hiloint2double((int)((uint32_t)__double2hiint(q[j]) ^ sgn[j]), __double2loint(q[j]));
                 qabs[j] = (float)q[j];
-                if constexpr (NOISE) {
-                    if (ext) { vox = vox + base[j]; vox = vox + hot[j]; }   // :64-65
-                }
+                if constexpr (EXT) { vox = vox + base[j]; vox = vox + hot[j]; }   // :64-65
                 if constexpr (BIN == kBinBilinear) {
                     const double cl = vox * wl, ch = vox * wh;         // bincount adds ps*w (no fma)
                     acc_lo[j] = acc_lo[j] + cl;
@@ -297,12 +328,9 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
                 const float qf = (float)q[j];
                 qabs[j] = qf;
                 float vf = __uint_as_float(__float_as_uint(qf) ^ sgn[j]);
-                if constexpr (NOISE) {
-                    if (ext) { double vox = (double)vf; vox = vox + base[j]; vox = vox + hot[j]; vf = (float)vox; }
-                }
+                if constexpr (EXT) { double vox = (double)vf; vox = vox + base[j]; vox = vox + hot[j]; vf = (float)vox; }
                 if constexpr (BIN == kBinBilinear) {
-                    acc_lo[j] = __builtin_fmaf(vf, wl, acc_lo[j]);
-                    acc_hi[j] = __builtin_fmaf(vf, wh, acc_hi[j]);
+                    acc2[j] = pk_fma(f32x2{vf, vf}, w2, acc2[j]);
                 } else {
                     acc_lo[j] = acc_lo[j] + vf;
                 }
@@ -331,7 +359,15 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
     //      kDepth-1 loads (x 1 KiB per wave for fp32 input) stay in flight behind the arithmetic.  Loads are
     //      UNCONDITIONAL (frame index clamped to the last frame) so the compiler can count them and wait with
     //      vmcnt(kDepth-1) instead of vmcnt(0); the kDepth clamped re-reads at the end of a clip hit in cache.
+    auto tail = [&](auto sym_tag, int k0, const Raw<IN, VEC> (&ring)[kDepth]) {
+        // up to kDepth-1 remaining steps, with compile-time slot index (and parity)
+        static_for(std::make_integer_sequence<int, kDepth - 1>{}, [&](auto u_tag) {
+            constexpr int u = decltype(u_tag)::value;
+            if (k0 + u < a.K) step(sym_tag, std::integral_constant<int, (u & 1)>{}, k0 + u, ring[u]);
+        });
+    };
     auto run = [&](auto sym_tag) {
+        static_assert(kDepth % 2 == 0, "the time loop must be unrolled by an even factor (noise pairs)");
         Raw<IN, VEC> ring[kDepth];
 #pragma unroll
         for (int u = 0; u < kDepth; ++u) {
@@ -340,28 +376,24 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
         }
         int k0 = 0;
         for (; k0 + kDepth <= a.K; k0 += kDepth) {
-#pragma unroll
-            for (int u = 0; u < kDepth; ++u) {
+            static_for(std::make_integer_sequence<int, kDepth>{}, [&](auto u_tag) {
+                constexpr int u = decltype(u_tag)::value;
                 const int k = k0 + u;
-                step(sym_tag, k, ring[u]);
+                step(sym_tag, std::integral_constant<int, (u & 1)>{}, k, ring[u]);
                 const int fn = k + 1 + kDepth;
                 ring[u] = load_raw<IN, VEC>(a.frames, in_base + (int64_t)(fn <= a.K ? fn : a.K) * a.frame_stride);
-            }
+            });
         }
-#pragma unroll
-        for (int u = 0; u < kDepth - 1; ++u)
-            if (k0 + u < a.K) step(sym_tag, k0 + u, ring[u]);
+        tail(sym_tag, k0, ring);
     };
     if (pp[0] == pp[1]) run(std::true_type{});                         // wave-uniform (per clip)
     else run(std::false_type{});
 
     // ---- epilogue
     if constexpr (BIN == kBinBilinear) {
-        store_vec<VEC, acc_t>(a.out, out_base + (int64_t)cur_seg * a.HW, acc_lo);
-        if (cur_seg + 1 < a.Tb) store_vec<VEC, acc_t>(a.out, out_base + (int64_t)(cur_seg + 1) * a.HW, acc_hi);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) acc_lo[j] = 0;
-        for (int b = cur_seg + 2; b < a.Tb; ++b) store_vec<VEC, acc_t>(a.out, out_base + (int64_t)b * a.HW, acc_lo);
+        flush_lower(cur_seg);
+        if (cur_seg + 1 < a.Tb) flush_lower(cur_seg + 1);
+        for (int b = cur_seg + 2; b < a.Tb; ++b) flush_lower(b);       // zeros by now
     }
     const uint32_t n_on = n_all - n_off;
     if (want_counts) {

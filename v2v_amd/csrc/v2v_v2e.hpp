@@ -24,7 +24,9 @@ namespace v2v {
 
 
 enum { kV2ePnRelated = 0, kV2eSpatialIndependent = 1, kV2eSpatialTemporalIndependent = 2 };
-enum : uint32_t { kV2eFThresA = 0, kV2eFThresB = 1, kV2eFNoiseRate = 2, kV2eFFrame0 = 16, kV2eFStride = 8 };
+// Philox blocks of the native fields: 0 static thresholds (pair = ON/OFF normals), 2 leak-rate normal; per frame i:
+// kV2eFFrame0 + 8 i + {0 thresholds redrawn (temporal model), 3 shot uniforms}; per couple m of frame pairs: + 8 m + 2 leak jitter
+enum : uint32_t { kV2eFThresA = 0, kV2eFNoiseRate = 2, kV2eFFrame0 = 16, kV2eFStride = 8 };
 
 
 
@@ -95,21 +97,26 @@ __device__ __forceinline__ float poisson_tail_f32(float lam, float u, float p, f
     return x;
 }
 
+// shot-noise uniforms of VEC pixels: ONE Philox block per 4 pixels and frame; word j -> pixel j, its high half the ON and
+// its low half the OFF uniform, both on the midpoint grid (n + 1/2) / 2^16 in (0,1)
 template <int VEC>
-__device__ __forceinline__ void field_uniform24(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream, uint32_t p0,
-                                                float (&u)[VEC])
+__device__ __forceinline__ void field_uniform16x2(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream, uint32_t p0,
+                                                  float (&ua)[VEC], float (&ub)[VEC])
 {
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const u32x4 w = philox4x32_10(p0 >> 2, field, clip, stream, k0, k1);
     if constexpr (VEC == 1) {
-        const u32x4 w = philox4x32_10(p0 >> 2, field, clip, stream, k0, k1);
         const uint32_t j = p0 & 3u;
-        u[0] = (float)((j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w) >> 8) * 5.9604644775390625e-08f;
+        const uint32_t x = j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w;
+        ua[0] = ((float)(x >> 16) + 0.5f) * 1.52587890625e-05f;
+        ub[0] = ((float)(x & 0xFFFFu) + 0.5f) * 1.52587890625e-05f;
     } else {
-        const u32x4 w = philox4x32_10(p0 >> 2, field, clip, stream, k0, k1);
-        u[0] = (float)(w.x >> 8) * 5.9604644775390625e-08f;
-        u[1] = (float)(w.y >> 8) * 5.9604644775390625e-08f;
-        u[2] = (float)(w.z >> 8) * 5.9604644775390625e-08f;
-        u[3] = (float)(w.w >> 8) * 5.9604644775390625e-08f;
+        const uint32_t x[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ua[j] = ((float)(x[j] >> 16) + 0.5f) * 1.52587890625e-05f;
+            ub[j] = ((float)(x[j] & 0xFFFFu) + 0.5f) * 1.52587890625e-05f;
+        }
     }
 }
 
@@ -138,9 +145,8 @@ template <int VEC>
 __device__ __forceinline__ void v2e_native_thres(const V2eParams &P, uint64_t seed, uint32_t clip, uint32_t fa, uint32_t p0,
                                                  double (&pt)[VEC], double (&nt)[VEC])
 {
-    float ga[VEC], gb[VEC];
-    field_gauss32<VEC>(seed, clip, fa, kStreamV2e, p0, ga);
-    field_gauss32<VEC>(seed, clip, fa + 1u, kStreamV2e, p0, gb);
+    float ga[VEC], gb[VEC];                 // the two normals of one Box-Muller pair per pixel (block fa)
+    field_gauss_pairs<VEC>(seed, clip, fa, kStreamV2e, p0, ga, gb);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         double a, b;
@@ -424,8 +430,8 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
     }
     if constexpr (RNG == kRngPhilox) {
         v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFThresA, p0, pt, nt);
-        float g[VEC];
-        field_gauss32<VEC>(a.seed, clip_id, kV2eFNoiseRate, kStreamV2e, p0, g);
+        float g[VEC], g_unused[VEC];
+        field_gauss_pairs<VEC>(a.seed, clip_id, kV2eFNoiseRate, kStreamV2e, p0, g, g_unused);
         const float c = (float)(2.302585092994046 * P.noise_rate_cov_decades);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) nrate[j] = expf_det(c * g[j]);
@@ -466,6 +472,9 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
     uint32_t n_on = 0, n_off = 0;
     const bool want_counts = a.counts != nullptr;
 
+    float gleak_pend[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) gleak_pend[j] = 0.0f;
     Raw<IN, VEC> nxt = load_raw<IN, VEC>(a.frames, in_base + a.frame_stride);
     for (int k = 0; k < a.K; ++k) {
         const int i = k + 1;
@@ -498,11 +507,14 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
         float gleak[VEC];
         float u_sp[VEC], u_sn[VEC];
         if constexpr (RNG == kRngPhilox) {
-            if (leak) field_gauss32<VEC>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i + 2u, kStreamV2e, p0, gleak);
-            if (shot) {
-                field_uniform24<VEC>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i + 3u, kStreamV2e, p0, u_sp);
-                field_uniform24<VEC>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i + 4u, kStreamV2e, p0, u_sn);
+            if (leak) {                     // one Box-Muller pair per pixel and couple of frame pairs (2m, 2m+1): block of pair 2m
+                if ((k & 1) == 0) field_gauss_pairs<VEC>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)(k >> 1) + 2u, kStreamV2e, p0, gleak, gleak_pend);
+                else {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) gleak[j] = gleak_pend[j];
+                }
             }
+            if (shot) field_uniform16x2<VEC>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i + 3u, kStreamV2e, p0, u_sp, u_sn);
         }
         const acc_t wl = BIN == kBinBilinear ? s_wlo[k] : (acc_t)1, wh = BIN == kBinBilinear ? s_whi[k] : (acc_t)0;
 
