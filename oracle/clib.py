@@ -78,11 +78,40 @@ def philox_uniform_field(seed, clip_id, field, n_pix, stream=0):
     return out
 
 
-def philox_gauss_field(seed, clip_id, field, n_pix, stream=0, comp=0):
+def noise_rounds():
+    """Philox rounds of the per-time-step noise fields (7); every other native field uses 10."""
+    return int(lib().oracle_noise_rounds())
+
+
+def philox_gauss_field(seed, clip_id, field, n_pix, stream=0, comp=0, rounds=10):
     """Normal `comp` (0: first, 1: second) of every pixel's Box-Muller pair in Philox block `field`."""
     out = np.empty(n_pix, dtype=np.float32)
     lib().oracle_philox_gauss_field(C.c_uint64(seed), C.c_uint32(clip_id & 0xFFFFFFFF), C.c_uint32(field),
-                                    C.c_uint32(stream), C.c_int64(n_pix), C.c_int(comp), _p(out))
+                                    C.c_uint32(stream), C.c_int64(n_pix), C.c_int(comp), C.c_int(rounds), _p(out))
+    return out
+
+
+def philox_uniform16_field(seed, clip_id, field, n_pix, stream=1, low=0):
+    """Native shot-noise uniforms (midpoint grid, 16 bits): high (ON) or low (OFF) half of every pixel's word in block `field`."""
+    out = np.empty(n_pix, dtype=np.float32)
+    lib().oracle_philox_uniform16_field(C.c_uint64(seed), C.c_uint32(clip_id & 0xFFFFFFFF), C.c_uint32(field), C.c_uint32(stream),
+                                        C.c_int64(n_pix), C.c_int(low), _p(out))
+    return out
+
+
+def expf_det(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    lib().oracle_expf_det_vec(_p(x), C.c_int64(x.size), _p(out))
+    return out
+
+
+def poisson_inv_f32(lam, u):
+    """The native Poisson sampler (float32 inversion), elementwise: counts as int64."""
+    lam = np.ascontiguousarray(lam, dtype=np.float32)
+    u = np.ascontiguousarray(np.broadcast_to(u, lam.shape), dtype=np.float32)
+    out = np.empty(lam.shape, dtype=np.int64)
+    lib().oracle_poisson_inv_f32_vec(_p(lam), _p(u), C.c_int64(lam.size), _p(out))
     return out
 
 

@@ -50,9 +50,10 @@ void oracle_floor_divide_vec(const double *a, const double *b, double *q, int64_
 }
 
 /* ------------------------------------------------------------------ Philox4x32-10 */
-static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+#define ORACLE_NOISE_ROUNDS 7   /* per-time-step noise fields (base noise, leak jitter, shot uniforms); all other fields: 10 */
+static void philox4x32_r(uint32_t c[4], uint32_t k0, uint32_t k1, int rounds)
 {
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
@@ -63,6 +64,8 @@ static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
 }
+
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) { philox4x32_r(c, k0, k1, 10); }
 
 void oracle_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
 {
@@ -149,13 +152,17 @@ static double px_uniform53(uint64_t seed, uint32_t clip, uint32_t field, uint32_
 }
 
 /* normal `comp` (0/1) of pixel p's Box-Muller pair in block `field`: word p&3 of Philox block (p>>2, field, clip, stream) */
-static float px_gauss(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream, uint32_t p, int comp)
+static float px_gauss_r(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream, uint32_t p, int comp, int rounds)
 {
     uint32_t c[4] = {p >> 2, field, clip, stream};
-    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    philox4x32_r(c, (uint32_t)seed, (uint32_t)(seed >> 32), rounds);
     float g0, g1;
     gauss16_pair(c[p & 3u], &g0, &g1);
     return comp ? g1 : g0;
+}
+static float px_gauss(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream, uint32_t p, int comp)
+{
+    return px_gauss_r(seed, clip, field, stream, p, comp, 10);
 }
 
 void oracle_philox_uniform_field(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream,
@@ -165,10 +172,11 @@ void oracle_philox_uniform_field(uint64_t seed, uint32_t clip, uint32_t field, u
 }
 
 void oracle_philox_gauss_field(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream,
-                               int64_t n_pix, int comp, float *out)
+                               int64_t n_pix, int comp, int rounds, float *out)
 {
-    for (int64_t p = 0; p < n_pix; ++p) out[p] = px_gauss(seed, clip, field, stream, (uint32_t)p, comp);
+    for (int64_t p = 0; p < n_pix; ++p) out[p] = px_gauss_r(seed, clip, field, stream, (uint32_t)p, comp, rounds);
 }
+int oracle_noise_rounds(void) { return ORACLE_NOISE_ROUNDS; }
 
 /* ------------------------------------------------------------------ ESIM + binning, one clip */
 enum { ORACLE_IN_U8 = 0, ORACLE_IN_F32 = 1 };
@@ -237,7 +245,7 @@ int oracle_esim_voxel_clip(const void *frames, int in_dtype, int64_t N, int64_t 
                 pot += (double)d;
             }
             double g = 0.0;
-            if (rng_mode == ORACLE_RNG_PHILOX) { if (base_std != 0.0) g = (double)px_gauss(seed, clip_id, 3u + (uint32_t)(k >> 1), 0, (uint32_t)p, (int)(k & 1)); }   /* 0*g adds nothing; block 3+m serves pairs 2m, 2m+1 */
+            if (rng_mode == ORACLE_RNG_PHILOX) { if (base_std != 0.0) g = (double)px_gauss_r(seed, clip_id, 3u + (uint32_t)(k >> 1), 0, (uint32_t)p, (int)(k & 1), ORACLE_NOISE_ROUNDS); }   /* 0*g adds nothing; block 3+m serves pairs 2m, 2m+1 */
             else if (rng_mode == ORACLE_RNG_REPLAY) g = rp->g_base[k * HW + p];
             double base = base_std * g;                            /* :44 */
             if (!noise_external) { pot += base; pot += hot; }      /* :48-49 */
@@ -359,19 +367,55 @@ float oracle_expf_det(float x) { return expf_det(x); }
 static float px_uniform16(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream, uint32_t p, int low)
 {
     uint32_t c[4] = {p >> 2, field, clip, stream};
-    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    philox4x32_r(c, (uint32_t)seed, (uint32_t)(seed >> 32), ORACLE_NOISE_ROUNDS);
     const uint32_t w = c[p & 3u];
     return ((float)(low ? (w & 0xFFFFu) : (w >> 16)) + 0.5f) * 1.52587890625e-05f;
 }
 
+/* exp(-lam) for the shot-noise sampler: degree-6 minimax polynomial on [0,1] (1.5e-8; exactly 1 at 0), expf_det above */
+static float exp_neg_f32(float lam)
+{
+    if (lam > 1.0f) return expf_det(-lam);
+    float e = 0x1.be1ddep-11f;
+    e = fmaf(e, lam, -0x1.f60198p-8f);
+    e = fmaf(e, lam, 0x1.51c0fcp-5f);
+    e = fmaf(e, lam, -0x1.5507a6p-3f);
+    e = fmaf(e, lam, 0x1.fff9acp-2f);
+    e = fmaf(e, lam, -0x1.ffffcep-1f);
+    e = fmaf(e, lam, 1.0f);
+    return e;
+}
+
+/* Native Poisson sampler: float32 inversion from one uniform.  Counts 0..3 from the thresholds p0, p0(1+l), p0(1+l+l^2/2)
+ * (p0 = exp(-l)); beyond that the running-sum loop.  Same sequence as v2v_amd/csrc/v2v_v2e.hpp, restated. */
 static float poisson_inv_f32(float lam, float u)
 {
-    if (!(lam > 0.0f)) return 0.0f;
-    float p = expf_det(-lam), s = p, x = 0.0f;
-    while (u > s && x < 64.0f) { x += 1.0f; p = p * (lam / x); s = s + p; }
+    if (!(lam > 0.0f)) return 0.0f;               /* also NaN; on the device p0 = 1 or NaN gives the same 0 */
+    const float p0 = exp_neg_f32(lam);
+    const float hl = lam * 0.5f;
+    const float q1 = lam + 1.0f;
+    const float q2 = fmaf(hl, lam, q1);
+    const float s1 = p0 * q1, s2 = p0 * q2;
+    float x = (float)((u > p0) + (u > s1) + (u > s2));
+    if (u > s2) {
+        float p = p0 * (hl * lam), s = s2;
+        x = 2.0f;
+        do { x += 1.0f; p = p * (lam / x); s = s + p; } while (u > s && x < 64.0f);
+    }
     return x;
 }
 float oracle_poisson_inv_f32(float lam, float u) { return poisson_inv_f32(lam, u); }
+
+/* vector forms for the golden generator (tests/golden/make_goldens.py G14) and the statistical tests */
+void oracle_expf_det_vec(const float *x, int64_t n, float *out) { for (int64_t i = 0; i < n; ++i) out[i] = expf_det(x[i]); }
+void oracle_poisson_inv_f32_vec(const float *lam, const float *u, int64_t n, int64_t *out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = (int64_t)poisson_inv_f32(lam[i], u[i]);
+}
+void oracle_philox_uniform16_field(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream, int64_t n_pix, int low, float *out)
+{
+    for (int64_t p = 0; p < n_pix; ++p) out[p] = px_uniform16(seed, clip, field, stream, (uint32_t)p, low);
+}
 
 enum { V2E_PN_RELATED = 0, V2E_SPATIAL_INDEPENDENT = 1, V2E_SPATIAL_TEMPORAL_INDEPENDENT = 2 };
 enum { V2E_F_THRES_A = 0, V2E_F_NOISE_RATE = 2, V2E_F_FRAME0 = 16, V2E_F_STRIDE = 8 };
@@ -509,7 +553,7 @@ int oracle_v2e_voxel_clip(const void *frames, int in_dtype, int64_t N, int64_t H
             }
             if (P->leak_rate_hz > 0) {                                            /* subtract_leak_current */
                 double g;
-                if (rng_mode == ORACLE_RNG_PHILOX) g = (double)px_gauss(seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * (k >> 1) + 2), V2E_STREAM, (uint32_t)p, (int)(k & 1));
+                if (rng_mode == ORACLE_RNG_PHILOX) g = (double)px_gauss_r(seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * (k >> 1) + 2), V2E_STREAM, (uint32_t)p, (int)(k & 1), ORACLE_NOISE_ROUNDS);
                 else g = rp->leak_randn[k * HW + p];
                 const float a32 = (float)P->leak_rate_hz * nrate;
                 const double curr = (double)a32 * (1 - P->leak_jitter_fraction * g);
@@ -529,15 +573,20 @@ int oracle_v2e_voxel_clip(const void *frames, int in_dtype, int64_t N, int64_t H
                 if (rng_mode == ORACLE_RNG_PHILOX) {
                     double fac;
                     if (in_f32) fac = (double)(1.0f - 0.75f * i01_32); else fac = 1 - 0.75 * i01_64;
-                    /* lambda = (intensity factor * threshold factor) * (rate/2 * dt / frame mean); float32 inversion */
+                    /* lambda = (intensity factor * threshold factor) * (rate/2 * dt / frame mean), all float32 (the frame
+                     * mean itself comes from the 2^32 fixed-point float64 sums above); float32 inversion */
                     const double mean_p = ((double)sum_pos[k] / 4294967296.0) / (double)HW;
                     const double mean_n = ((double)sum_neg[k] / 4294967296.0) / (double)HW;
                     const double f = (P->shot_noise_rate_hz / 2) * dt;
-                    const double scale_p = f / mean_p, scale_n = f / mean_n;
-                    const double lam_p = (fac * (pos_nominal / pt)) * scale_p;
-                    const double lam_n = (fac * (neg_nominal / nt)) * scale_n;
-                    sp = (double)poisson_inv_f32((float)lam_p, px_uniform16(seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * i + 3), V2E_STREAM, (uint32_t)p, 0));
-                    sn = (double)poisson_inv_f32((float)lam_n, px_uniform16(seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * i + 3), V2E_STREAM, (uint32_t)p, 1));
+                    /* per pixel: intensity factor x float32 reciprocal threshold (biased low by 2^-22: the same value
+                     * that estimates the floor-divide quotient on the device); per frame: nominal threshold x rate scale */
+                    const float scale_p = (float)(f / mean_p) * (float)pos_nominal, scale_n = (float)(f / mean_n) * (float)neg_nominal;
+                    const float fac32 = (float)fac;
+                    const float inv_p = (float)((1.0 / pt) * 0x1.fffff8p-1), inv_n = (float)((1.0 / nt) * 0x1.fffff8p-1);
+                    const float lam_p = (fac32 * inv_p) * scale_p;
+                    const float lam_n = (fac32 * inv_n) * scale_n;
+                    sp = (double)poisson_inv_f32(lam_p, px_uniform16(seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * i + 3), V2E_STREAM, (uint32_t)p, 0));
+                    sn = (double)poisson_inv_f32(lam_n, px_uniform16(seed, clip_id, (uint32_t)(V2E_F_FRAME0 + V2E_F_STRIDE * i + 3), V2E_STREAM, (uint32_t)p, 1));
                 } else {
                     sp = (double)rp->shot_pos[k * HW + p]; sn = (double)rp->shot_neg[k * HW + p];
                 }

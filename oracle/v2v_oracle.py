@@ -168,12 +168,12 @@ def philox_uniform53(seed: int, clip_id: int, field: int, n_pix: int, stream: in
     return (a * 67108864.0 + b) / 9007199254740992.0
 
 
-def philox_gauss32(seed: int, clip_id: int, field: int, n_pix: int, stream: int = STREAM_ESIM, comp: int = 0):
+def philox_gauss32(seed: int, clip_id: int, field: int, n_pix: int, stream: int = STREAM_ESIM, comp: int = 0, rounds: int = 10):
     """float32 standard normals from Philox words through the 16+16-bit fp32 Box-Muller of oracle/v2v_oracle.c
     (bit-identical op sequence to the device's; needs the built C oracle because NumPy has no fma).
     Pixel p: word p&3 of block (p>>2, field, clip_id, stream) -> one Box-Muller pair; comp picks its member."""
     from oracle import clib  # local import: the C twin is optional for everything else
-    return clib.philox_gauss_field(seed, clip_id, field, n_pix, stream, comp)
+    return clib.philox_gauss_field(seed, clip_id, field, n_pix, stream, comp, rounds)
 
 
 class PhiloxFieldRNG:
@@ -193,13 +193,14 @@ class PhiloxFieldRNG:
     def randn(self, h, w):
         # draw 0: hot-pixel normals (first member of block 2); draw 1+k: base noise of frame pair k = member k&1 of
         # block 3 + (k>>1) -- one Philox block and one Box-Muller pair per pixel serve two consecutive pairs
+        from oracle import clib
         if self._n_randn == 0:
-            field, comp = FIELD_HOT_GAUSS, 0
+            field, comp, rounds = FIELD_HOT_GAUSS, 0, 10
         else:
             k = self._n_randn - 1
-            field, comp = FIELD_BASE0 + (k >> 1), k & 1
+            field, comp, rounds = FIELD_BASE0 + (k >> 1), k & 1, clib.noise_rounds()     # per-step field: Philox4x32-7
         self._n_randn += 1
-        return philox_gauss32(self.seed, self.clip_id, field, h * w, comp=comp).astype(np.float64).reshape(h, w)
+        return philox_gauss32(self.seed, self.clip_id, field, h * w, comp=comp, rounds=rounds).astype(np.float64).reshape(h, w)
 
 
 # ----------------------------------------------------------------------------------------

@@ -223,8 +223,8 @@ def g11_philox_fed():
             finally:
                 np.random.rand, np.random.randn = real_rand, real_randn
             out[f"ext{int(ext)}_{dt_tag}"] = v
-    out["gauss_field3"] = clib.philox_gauss_field(seed, clip_id, 3, 1024)
-    out["gauss_field3b"] = clib.philox_gauss_field(seed, clip_id, 3, 1024, comp=1)
+    out["gauss_field3"] = clib.philox_gauss_field(seed, clip_id, 3, 1024, rounds=clib.noise_rounds())
+    out["gauss_field3b"] = clib.philox_gauss_field(seed, clip_id, 3, 1024, comp=1, rounds=clib.noise_rounds())
     out["uniform_field0"] = clib.philox_uniform_field(seed, clip_id, 0, 1024)
     save("g11_philox_fed.npz", **out)
 
@@ -294,10 +294,81 @@ def g9_v2e():
     save("g9_v2e.npz", **out)
 
 
+def g14_v2e_native():
+    """The reference's v2e video_to_voxel (data/v2v_core_v2e.py:556-581) run on the DEVICE-NATIVE random fields: np.random.normal /
+    randn / poisson are replaced by the Philox fields of v2v_amd/csrc/v2v_v2e.hpp in the reference's own draw order (:334-349
+    _init, :417-421 per-frame thresholds, :201 leak jitter, :102-103 shot noise), np.random.poisson by the native float32
+    inversion sampler fed with the device's 16-bit uniforms, and np.exp on the float32 leak-rate array (:349) by the native
+    expf (NumPy's float32 exp is a SIMD kernel no other implementation reproduces bit for bit).  Pins native mode -- the
+    fixed-point frame mean, the float32 shot-noise means and the sampler -- to the reference itself."""
+    from oracle import clib
+    clib.build()
+    F_THRES, F_NRATE, F0, FS, STREAM = 0, 2, 16, 8, 1
+    video = O.synth_clip_s1(10, 32, 32, seed=1414, dtype=np.uint8)
+    n, h, w = video.shape
+    seed, clip_id = 0x0DDC0FFEE123, 5
+    r7 = clib.noise_rounds()
+    cases = {
+        "pn_noisy_u8": (np.uint8, "pn_related", 30, 0.1, 5.0),
+        "pn_noisy_f32": (np.float32, "pn_related", 30, 0.1, 5.0),
+        "pn_shot_only_f32": (np.float32, "pn_related", 0, 0, 20.0),
+        "si_leak_u8": (np.uint8, "spatial_independent", 0, 0.1, 0),
+        "sti_noisy_u8": (np.uint8, "spatial_temporal_independent", 30, 0.1, 5.0),
+        "sti_shot_f32": (np.float32, "spatial_temporal_independent", 0, 0, 5.0),
+    }
+    out = {"video": video, "case_names": np.array(list(cases)), "seed": np.array(seed, dtype=np.uint64), "clip_id": np.array(clip_id)}
+    real = (np.random.normal, np.random.randn, np.random.poisson, np.exp)
+    for name, (dt, model, cutoff, leak, shot) in cases.items():
+        temporal = model == "spatial_temporal_independent"
+        st = {"normal": 0, "randn": 0, "poisson": 0}
+
+        def gauss(field, comp, rounds=10):
+            return clib.philox_gauss_field(seed, clip_id, field, h * w, STREAM, comp, rounds).astype(np.float64).reshape(h, w)
+
+        def normal(loc=0.0, scale=1.0, size=None):
+            c = st["normal"]; st["normal"] += 1
+            if temporal:       # draws 0,1: frame-0 pre-draw (:417-421, overwritten by _init); 2,3: _init; then 2 per frame i >= 1
+                frame = 0 if c < 4 else (c - 4) // 2 + 1
+                field = F_THRES if c in (2, 3) else F0 + FS * frame
+            else:
+                field = F_THRES
+            return loc + scale * gauss(field, c & 1)
+
+        def randn(*shape):
+            c = st["randn"]; st["randn"] += 1
+            if c == 0:
+                return gauss(F_NRATE, 0)
+            k = c - 1                                             # leak jitter of frame pair k: member k&1 of couple k>>1
+            return gauss(F0 + FS * (k >> 1) + 2, k & 1, r7)
+
+        def poisson(lam):
+            c = st["poisson"]; st["poisson"] += 1
+            i = c // 2 + 1                                        # frame index; even draw = ON, odd = OFF
+            u = clib.philox_uniform16_field(seed, clip_id, F0 + FS * i + 3, h * w, STREAM, low=c & 1).reshape(h, w)
+            return clib.poisson_inv_f32(np.asarray(lam, dtype=np.float64).astype(np.float32), u)
+
+        def exp(x, *a, **k):
+            x = np.asarray(x)
+            return clib.expf_det(x).reshape(x.shape) if x.dtype == np.float32 else real[3](x, *a, **k)
+        np.random.normal, np.random.randn, np.random.poisson, np.exp = normal, randn, poisson, exp
+        try:
+            vox = v2v_core_v2e.video_to_voxel(video.astype(dt), 24, model, 0.5, 0.1, 0.0, 0.1, cutoff, leak, 0, shot, 0.1, 0.1, seed=11)
+        finally:
+            np.random.normal, np.random.randn, np.random.poisson, np.exp = real
+        assert st["normal"] == (4 + 2 * (n - 1) if temporal else 2) and st["randn"] == 1 + (n - 1 if leak > 0 else 0)
+        assert st["poisson"] == (2 * (n - 1) if shot > 0 else 0)
+        out[f"{name}__args"] = np.array([24, list(O.V2E_MODELS).index(model), 0.5, 0.1, 0.0, 0.1, cutoff, leak, 0, shot, 0.1, 0.1])
+        out[f"{name}__dtype"] = np.array(np.dtype(dt).name)
+        assert np.array_equal(vox, vox.astype(np.int16))
+        out[f"{name}__voxels"] = vox.astype(np.int16)
+        print(f"  g14 {name}: |events| = {int(np.abs(vox).sum())}")
+    save("g14_v2e_native.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14"]
     fns = {"g1": g1_luts, "g2": g2_g3_esim_clean, "g4": g4_esim_noisy, "g5": g5_floor_divide,
-           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g12": g12_events_to_voxel_torch,
+           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g12": g12_events_to_voxel_torch,
            "g13": g13_normalize_batch_voxel}
     for w in which:
         fns[w]()

@@ -267,7 +267,7 @@ int v2v_v2e_voxel_hip(const void *frames, int in_dtype, int64_t B, int64_t N, in
     const int64_t nblocks = B * a.blocks_per_clip;
     if (nblocks > 0x7FFFFFFF) return fail(V2V_ERR_SHAPE, "grid too large");
     const bool out64 = out_dtype == V2V_F64;
-    const size_t lds = 256 * sizeof(float) + (size_t)K * 5 * sizeof(double) /* per-frame constants */ + (bin_mode == V2V_BIN_BILINEAR ? (size_t)K * (2 * (out64 ? sizeof(double) : sizeof(float)) + sizeof(int)) : 0);
+    const size_t lds = 256 * 16 /* per-intensity records */ + (size_t)K * 32 /* per-frame constants */ + (bin_mode == V2V_BIN_BILINEAR ? (size_t)K * (2 * (out64 ? sizeof(double) : sizeof(float)) + sizeof(int)) : 0);
     if (lds > 64 * 1024) return fail(V2V_ERR_SHAPE, "too many frame pairs for the LDS tables (%zu bytes > 64 KiB): split the clip", lds);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (presum) {

@@ -15,6 +15,12 @@ namespace v2v {
 #ifndef V2V_DEPTH
 #define V2V_DEPTH 4
 #endif
+#ifndef V2V_V2E_DEPTH
+#define V2V_V2E_DEPTH 2     // frames in flight per work-item of the v2e kernel (even)
+#endif
+#ifndef V2V_V2E_MIN_WAVES
+#define V2V_V2E_MIN_WAVES 3  // __launch_bounds__ occupancy target of the v2e kernel (waves per SIMD): 2 -> 3 waves is worth 12 % (2.27 -> 2.06 ms, config 3) despite ~25 spilled dwords; 4 spills the loop (3.3 ms)
+#endif
 #ifndef V2V_MIN_WAVES
 #define V2V_MIN_WAVES 1
 #endif

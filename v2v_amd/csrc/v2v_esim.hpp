@@ -39,6 +39,17 @@ static __device__ float g_lut_esim32[256] = {V2V_LUT_ESIM32_VALUES};
 static const double kLutEsim64[256] = {V2V_LUT_ESIM64_VALUES};
 static const float kLutEsim32[256] = {V2V_LUT_ESIM32_VALUES};
 
+// float32 content that is not an integer in 0..255: the reference's float32 expression (v2v_core_esim.py:3-4,33-34).
+// Out of line: the pow/log bodies (~1.5k instructions per inlined copy, 8 copies per kernel) only bloat the time loop.
+#ifndef V2V_SLOWPATH_ATTR
+#define V2V_SLOWPATH_ATTR __attribute__((noinline))
+#endif
+__device__ V2V_SLOWPATH_ATTR float log_generic_f32(float v)
+{
+    const float lin = powf(v / 255.0f, 2.2f) * 255.0f;
+    return logf(0.001f + lin / 255.0f);
+}
+
 // Log intensity of the VEC pixels of one raw vector.
 //  u8 : one LDS lookup per pixel (float64 table).
 //  f32: values that are integers in 0..255 take the float32 table (bitwise NumPy's float32 result); anything
@@ -49,12 +60,19 @@ template <int IN, int VEC>
 __device__ __forceinline__ void pix_logs(const Raw<IN, VEC> &r, const typename LutT<IN>::type *lut,
                                          typename LutT<IN>::type (&out)[VEC])
 {
+    using lut_t = typename LutT<IN>::type;
+    // table entry by BYTE offset: shift + mask (two full-rate VALU ops) instead of a bit-field extract and a
+    // shift-add (two half-rate ones) per pixel
+    auto at = [&](uint32_t byte_off) { return *reinterpret_cast<const lut_t *>(reinterpret_cast<const unsigned char *>(lut) + byte_off); };
+    constexpr uint32_t kSh = sizeof(lut_t) == 8 ? 3u : 2u, kMask = 255u << kSh;
     if constexpr (IN == kInU8) {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            uint32_t idx;
-            if constexpr (VEC == 4) idx = (r.v >> (8 * j)) & 0xFFu; else idx = r.v;
-            out[j] = lut[idx];
+        if constexpr (VEC == 4) {
+            out[0] = at((r.v << kSh) & kMask);
+            out[1] = at((r.v >> (8u - kSh)) & kMask);
+            out[2] = at((r.v >> (16u - kSh)) & kMask);
+            out[3] = at((r.v >> (24u - kSh)) & kMask);
+        } else {
+            out[0] = lut[r.v];
         }
     } else {
         unsigned long long bad = 0;                            // wave-level mask (SGPR pair): any lane, any pixel
@@ -63,23 +81,19 @@ __device__ __forceinline__ void pix_logs(const Raw<IN, VEC> &r, const typename L
             const float v = raw_f32<VEC>(r, j);
             // v + 2^23 puts an integer v in 0..255 into the low mantissa byte (one cheap add instead of a
             // convert); the byte is always a valid index, and converting it back exposes every other input
-            const uint32_t a = __float_as_uint(v + 8388608.0f) & 255u;
-            out[j] = lut[a];
-            bad |= __ballot((float)a != v);                    // non-integer, negative, > 255, NaN
+            const uint32_t b = __float_as_uint(v + 8388608.0f);
+            out[j] = at((b << kSh) & kMask);
+            bad |= __ballot((float)(b & 255u) != v);           // non-integer, negative, > 255, NaN
         }
         if (__builtin_expect(bad != 0, 0)) {                   // scalar test; lanes with clean pixels skip the bodies below
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const float v = raw_f32<VEC>(r, j);
-                if ((float)(__float_as_uint(v + 8388608.0f) & 255u) != v) {
-                    const float lin = powf(v / 255.0f, 2.2f) * 255.0f;
-                    out[j] = logf(0.001f + lin / 255.0f);
-                }
+                if ((float)(__float_as_uint(v + 8388608.0f) & 255u) != v) out[j] = log_generic_f32(v);
             }
         }
     }
 }
-
 
 // NOISE  : false -> the caller guarantees base_noise_std == 0 and hot_pixel_fraction == 0 for every clip
 //          (V2V_FLAG_NO_NOISE); the noise adds, their registers and the Gaussian generator disappear.
@@ -96,8 +110,9 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
     static_assert(NOISE || !EXT, "external noise needs the noise path");
     using lut_t = typename LutT<IN>::type;
     using acc_t = typename std::conditional<OUT64, double, float>::type;
-    // float32 bilinear accumulators are kept as {lower bin, upper bin} pairs: one v_pk_fma_f32 per pixel and pair
-    constexpr bool PK = !OUT64 && BIN == kBinBilinear;
+    // float32 bilinear accumulation of 4 pixels: v_pk_fma_f32 on pixel pairs (4 instead of 8 fma per step); the planes
+    // stay in consecutive registers for the 16-byte stores
+    constexpr bool PK = !OUT64 && BIN == kBinBilinear && VEC == 4;
     extern __shared__ __align__(16) unsigned char s_raw[];
     lut_t *s_lut = reinterpret_cast<lut_t *>(s_raw);
     acc_t *s_wlo = reinterpret_cast<acc_t *>(s_raw + 256 * sizeof(lut_t));
@@ -197,23 +212,13 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
 
     // ---- binning state
     acc_t acc_lo[VEC], acc_hi[VEC];
-    f32x2 acc2[PK ? VEC : 1];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { acc_lo[j] = 0; acc_hi[j] = 0; }
-#pragma unroll
-    for (int j = 0; j < (PK ? VEC : 1); ++j) acc2[j] = f32x2{0.0f, 0.0f};
     // plane of the lower bin leaves the accumulators, the upper bin becomes the lower one
     auto flush_lower = [&](int seg) {
-        if constexpr (PK) {
-            float lo[VEC];
+        store_vec<VEC, acc_t>(a.out, (int64_t)clip * a.Tb * a.HW + p0 + (int64_t)seg * a.HW, acc_lo);
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) { lo[j] = acc2[j].x; acc2[j] = f32x2{acc2[j].y, 0.0f}; }
-            store_vec<VEC, float>(a.out, (int64_t)clip * a.Tb * a.HW + p0 + (int64_t)seg * a.HW, lo);
-        } else {
-            store_vec<VEC, acc_t>(a.out, (int64_t)clip * a.Tb * a.HW + p0 + (int64_t)seg * a.HW, acc_lo);
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) { acc_lo[j] = acc_hi[j]; acc_hi[j] = 0; }
-        }
+        for (int j = 0; j < VEC; ++j) { acc_lo[j] = acc_hi[j]; acc_hi[j] = 0; }
     };
     int cur_seg = 0;          // BILINEAR: bin index acc_lo belongs to (wave-uniform)
     int next_k = 0x7FFFFFFF;  // BILINEAR: first pair of segment cur_seg+1 (wave-uniform, kept scalar)
@@ -235,7 +240,7 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
 
     // SYM (compile-time tag): C+ == C- for this clip (wave-uniform), so no per-lane threshold selection.
     // PAR (compile-time tag): k & 1 -- the time loop is unrolled by an even factor from an even k.
-    auto step = [&](auto sym_tag, auto par_tag, int k, const Raw<IN, VEC> &raw) {
+    auto step = [&](auto sym_tag, auto par_tag, int k, const Raw<IN, VEC> &raw) __attribute__((always_inline)) {
         constexpr bool SYM = decltype(sym_tag)::value;
         constexpr int PAR = decltype(par_tag)::value;
         if constexpr (BIN == kBinBilinear) {
@@ -270,8 +275,7 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
         }
         acc_t wl = 1, wh = 0;
         if constexpr (BIN == kBinBilinear) { wl = s_wlo[k]; wh = s_whi[k]; }
-        f32x2 w2 = f32x2{0.0f, 0.0f};
-        if constexpr (PK) w2 = f32x2{(float)wl, (float)wh};
+
         lut_t ln[VEC];
         pix_logs<IN, VEC>(raw, s_lut, ln);
 
@@ -308,6 +312,7 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
         }
         // Phase B: reset the potential (v2v_core_esim.py:57-58), signed count, binning.
         float qabs[VEC];
+        float vfs[PK ? VEC : 1];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const double qt = q[j] * thr[j];
@@ -329,11 +334,23 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
                 qabs[j] = qf;
                 float vf = __uint_as_float(__float_as_uint(qf) ^ sgn[j]);
                 if constexpr (EXT) { double vox = (double)vf; vox = vox + base[j]; vox = vox + hot[j]; vf = (float)vox; }
-                if constexpr (BIN == kBinBilinear) {
-                    acc2[j] = pk_fma(f32x2{vf, vf}, w2, acc2[j]);
+                if constexpr (PK) {
+                    vfs[j] = vf;
+                } else if constexpr (BIN == kBinBilinear) {
+                    acc_lo[j] = __builtin_fmaf(vf, wl, acc_lo[j]);
+                    acc_hi[j] = __builtin_fmaf(vf, wh, acc_hi[j]);
                 } else {
                     acc_lo[j] = acc_lo[j] + vf;
                 }
+            }
+        }
+        if constexpr (PK) {
+#pragma unroll
+            for (int j = 0; j < VEC; j += 2) {
+                const f32x2 v2 = f32x2{vfs[j], vfs[j + 1]};
+                const f32x2 lo = pk_fma(v2, pk_splat((float)wl), f32x2{(float)acc_lo[j], (float)acc_lo[j + 1]});
+                const f32x2 hi = pk_fma(v2, pk_splat((float)wh), f32x2{(float)acc_hi[j], (float)acc_hi[j + 1]});
+                acc_lo[j] = lo.x; acc_lo[j + 1] = lo.y; acc_hi[j] = hi.x; acc_hi[j + 1] = hi.y;
             }
         }
         if (want_counts) {                                             // wave-uniform

@@ -66,45 +66,22 @@ __device__ __forceinline__ double poisson_inv(double lam, double u)
 
 __device__ __forceinline__ float expf_det(float x);
 
-// native shot noise: float32 inversion from one 24-bit uniform
-__device__ __forceinline__ float poisson_inv_f32(float lam, float u)
-{
-    if (!(lam > 0.0f)) return 0.0f;
-    float p = expf_det(-lam), s = p, x = 0.0f;
-    while (u > s && x < 64.0f) { x += 1.0f; p = p * (lam / x); s = s + p; }
-    return x;
-}
-
-// The same inversion split for the kernel: counts 0..2 without a branch or a division (lam/1 and lam/2 are exact as
-// lam and lam*0.5), and a tail loop that a wave enters only when some lane needs a count >= 3 (P ~ lam^3/6).
-struct PoissonHead { float x, p2, s2; bool more; };
-__device__ __forceinline__ PoissonHead poisson_head_f32(float lam, float u)
-{
-    const float p0 = expf_det(-lam);
-    const float p1 = p0 * lam, s1 = p0 + p1;
-    const float p2 = p1 * (lam * 0.5f), s2 = s1 + p2;
-    const bool c1 = (lam > 0.0f) && (u > p0), c2 = c1 && (u > s1);
-    PoissonHead h;
-    h.x = (c1 ? 1.0f : 0.0f) + (c2 ? 1.0f : 0.0f);
-    h.p2 = p2; h.s2 = s2;
-    h.more = c2 && (u > s2);
-    return h;
-}
+// tail of the inversion (count > 3): entered with count 2 reached (p = its probability, s = the cumulative sum) and u > s
 __device__ __forceinline__ float poisson_tail_f32(float lam, float u, float p, float s)
 {
-    float x = 2.0f;                                    // entered with count 2 reached and u > s
+    float x = 2.0f;
     do { x += 1.0f; p = p * (lam / x); s = s + p; } while (u > s && x < 64.0f);
     return x;
 }
 
 // shot-noise uniforms of VEC pixels: ONE Philox block per 4 pixels and frame; word j -> pixel j, its high half the ON and
 // its low half the OFF uniform, both on the midpoint grid (n + 1/2) / 2^16 in (0,1)
-template <int VEC>
+template <int VEC, int ROUNDS = 10>
 __device__ __forceinline__ void field_uniform16x2(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream, uint32_t p0,
                                                   float (&ua)[VEC], float (&ub)[VEC])
 {
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    const u32x4 w = philox4x32_10(p0 >> 2, field, clip, stream, k0, k1);
+    const u32x4 w = philox4x32<ROUNDS>(p0 >> 2, field, clip, stream, k0, k1);
     if constexpr (VEC == 1) {
         const uint32_t j = p0 & 3u;
         const uint32_t x = j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w;
@@ -348,9 +325,28 @@ __global__ void __launch_bounds__(kBlock) v2e_shot_sum_kernel(const V2eArgs a)
         atomicAdd(reinterpret_cast<unsigned long long *>(&a.shot_sums[(int64_t)clip * a.K * 2 + t]), s_sum[t]);
 }
 
-// Per-frame constants every work-item of a clip shares (time step, low-pass step, shot-noise scale, refractory cap):
+// ---- native shot-noise sampler (float32 inversion from one uniform; the CPU oracle restates it) ----------------------
+// exp(-lam) on [0,1]: degree-6 minimax polynomial (1.5e-8; p(0) = 1 exactly, so lam = 0 never fires); above 1 the
+// range-reduced expf_det.  Written on 2-vectors: the ON and OFF means of a pixel go through one packed chain.
+__device__ __forceinline__ f32x2 exp_neg_small_x2(f32x2 lam)
+{
+    f32x2 e = pk_splat(0x1.be1ddep-11f);
+    e = pk_fma(e, lam, pk_splat(-0x1.f60198p-8f));
+    e = pk_fma(e, lam, pk_splat(0x1.51c0fcp-5f));
+    e = pk_fma(e, lam, pk_splat(-0x1.5507a6p-3f));
+    e = pk_fma(e, lam, pk_splat(0x1.fff9acp-2f));
+    e = pk_fma(e, lam, pk_splat(-0x1.ffffcep-1f));
+    e = pk_fma(e, lam, pk_splat(1.0f));
+    return e;
+}
+
+// Per-frame constants every work-item of a clip shares (time step, low-pass step, refractory cap, shot-noise scales):
 // tabulated once per workgroup in LDS -- they cost float64 divisions, which the time loop must not repeat.
-constexpr int kV2eFrameConsts = 5;   // {dt, dt/tau, scale_pos, scale_neg, refractory cap}
+struct __align__(16) V2eFrameConst { double dt, dt_tau, cap; float scale_p, scale_n; };      // 32 bytes
+// Per-intensity terms (lin_log value, inten01, shot-noise intensity factor): ONE 16-byte LDS entry per 8-bit intensity,
+// one ds_read_b128 per pixel and frame instead of three table reads with three address computations.
+struct __align__(16) V2eIntenF32 { float logv, i01, fac, pad; };          // float32 input: inten01 is float32 (NumPy)
+struct __align__(16) V2eIntenU8 { double i01; float logv, fac; };          // uint8 input: inten01 is float64
 
 // FEAT < 0: model features are read from the parameters at run time (wave-uniform branches); FEAT >= 0: compile-time
 // bit mask {1 low-pass, 2 leak, 4 shot noise, 16 per-frame thresholds} for the specialised instances (the refractory
@@ -358,44 +354,53 @@ constexpr int kV2eFrameConsts = 5;   // {dt, dt/tau, scale_pos, scale_neg, refra
 enum { kV2eLowpass = 1, kV2eLeak = 2, kV2eShot = 4, kV2eTemporal = 16 };
 
 template <int IN, int VEC, int BIN, int RNG, bool OUT64, int FEAT = -1>
-__global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
+__global__ void __launch_bounds__(kBlock, V2V_V2E_MIN_WAVES) v2e_voxel_kernel(const V2eArgs a)
 {
     using acc_t = typename std::conditional<OUT64, double, float>::type;
+    using inten_t = typename std::conditional<IN == kInU8, V2eIntenU8, V2eIntenF32>::type;
+    static_assert(sizeof(V2eFrameConst) == 32 && sizeof(inten_t) == 16, "LDS record layout");
+    constexpr bool PK = !OUT64 && BIN == kBinBilinear && VEC == 4;        // packed bilinear accumulation (see the ESIM kernel)
     extern __shared__ __align__(16) unsigned char s_raw[];
-    float *s_lut = reinterpret_cast<float *>(s_raw);
-    double *s_fc = reinterpret_cast<double *>(s_raw + 256 * sizeof(float));
-    acc_t *s_wlo = reinterpret_cast<acc_t *>(s_fc + (size_t)kV2eFrameConsts * a.K);
+    inten_t *s_int = reinterpret_cast<inten_t *>(s_raw);                                        // [256]
+    V2eFrameConst *s_fc = reinterpret_cast<V2eFrameConst *>(s_raw + 256 * sizeof(inten_t));     // [K]
+    acc_t *s_wlo = reinterpret_cast<acc_t *>(s_fc + a.K);
     acc_t *s_whi = s_wlo + a.K;
     int *s_seg = reinterpret_cast<int *>(s_whi + a.K);
-    s_lut[threadIdx.x] = a.lut[threadIdx.x];
-    __shared__ __align__(16) unsigned char s_tab[kV2eTableBytes];
-    const V2eIntenTables tb = v2e_build_tables<IN>(s_tab, a.P.uint8_wrap);
     const int clip = blockIdx.x / a.blocks_per_clip;
     const int blk = blockIdx.x - clip * a.blocks_per_clip;
     const V2eParams &P = a.P;
     const bool lowpass = FEAT < 0 ? P.cutoff_hz > 0 : (FEAT & kV2eLowpass) != 0;
     const bool leak = FEAT < 0 ? P.leak_rate_hz > 0 : (FEAT & kV2eLeak) != 0;
     const bool shot = FEAT < 0 ? P.shot_noise_rate_hz > 0 : (FEAT & kV2eShot) != 0;
-    const bool refractory = P.refractory_period_s > 0;   // always a run-time (wave-uniform) switch: two v_min per pixel
+    const bool refractory = P.refractory_period_s > 0;   // always a run-time (wave-uniform) switch
     const bool temporal = FEAT < 0 ? P.threshold_model == kV2eSpatialTemporalIndependent : (FEAT & kV2eTemporal) != 0;
+    {   // ---- workgroup prologue: the two LDS tables
+        double i64, fac; float i32;
+        v2e_inten_direct<IN>((float)threadIdx.x, P.uint8_wrap, i64, i32, fac);
+        inten_t e;
+        e.logv = a.lut[threadIdx.x];
+        e.fac = (float)fac;
+        if constexpr (IN == kInU8) e.i01 = i64; else { e.i01 = i32; e.pad = 0.0f; }
+        s_int[threadIdx.x] = e;
+    }
     const double tau = lowpass ? 1 / (3.141592653589793 * 2 * P.cutoff_hz) : 0.0;
+    const double pos_nominal = P.thres_mean_mean + P.thres_diff_mean / 2, neg_nominal = P.thres_mean_mean - P.thres_diff_mean / 2;
     for (int k = threadIdx.x; k < a.K; k += kBlock) {
         const int i = k + 1;
         const double dt = (double)i / P.fps - (double)(i - 1) / P.fps;                  // t_frame - t_previous (:440)
-        double *fc = s_fc + (size_t)kV2eFrameConsts * k;
-        fc[0] = dt;
-        fc[1] = lowpass ? dt / tau : 0.0;
-        double scale_p = 0.0, scale_n = 0.0;
+        V2eFrameConst fc;
+        fc.dt = dt;
+        fc.dt_tau = lowpass ? dt / tau : 0.0;
+        fc.scale_p = 0.0f; fc.scale_n = 0.0f;
         if (RNG == kRngPhilox && shot) {                                                // generate_shot_noise (:86-100)
             const double mean_p = ((double)a.shot_sums[((int64_t)clip * a.K + k) * 2] / 4294967296.0) / (double)a.HW;
             const double mean_n = ((double)a.shot_sums[((int64_t)clip * a.K + k) * 2 + 1] / 4294967296.0) / (double)a.HW;
             const double f = (P.shot_noise_rate_hz / 2) * dt;
-            scale_p = f / mean_p;
-            scale_n = f / mean_n;
+            fc.scale_p = (float)(f / mean_p) * (float)pos_nominal;      // x nominal threshold: the per-pixel factor is 1/threshold
+            fc.scale_n = (float)(f / mean_n) * (float)neg_nominal;
         }
-        fc[2] = scale_p;
-        fc[3] = scale_n;
-        fc[4] = refractory ? (double)(int)(dt / P.refractory_period_s) : 0.0;
+        fc.cap = refractory ? (double)(int)(dt / P.refractory_period_s) : 0.0;
+        s_fc[k] = fc;
         if constexpr (BIN == kBinBilinear) {
             const double t_norm = ((double)k - 0.0) / ((double)(a.K - 1) - 0.0) * (double)(a.Tb - 1);
             int b0 = (int)floor(t_norm);
@@ -414,7 +419,6 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
     const uint32_t clip_id = (uint32_t)(a.clip_id0 + (uint64_t)clip);
     const bool lp32 = !lowpass || (IN == kInF32);
     const bool base32 = lp32 && !leak;
-    const double pos_nominal = P.thres_mean_mean + P.thres_diff_mean / 2, neg_nominal = P.thres_mean_mean - P.thres_diff_mean / 2;
     const int64_t in_base = (int64_t)clip * a.clip_stride + p0;
     const int64_t pix_base = (int64_t)clip * a.HW + p0;
 
@@ -426,7 +430,7 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
         float x[VEC];
         v2e_pixels<IN, VEC>(r0, x);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) { lp_f[j] = base_f[j] = v2e_linlog(x[j], s_lut); lp64[j] = base64[j] = (double)lp_f[j]; }
+        for (int j = 0; j < VEC; ++j) { lp_f[j] = base_f[j] = v2e_linlog(x[j], a.lut); lp64[j] = base64[j] = (double)lp_f[j]; }
     }
     if constexpr (RNG == kRngPhilox) {
         v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFThresA, p0, pt, nt);
@@ -445,23 +449,23 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
         }
     }
 
-    // per-pixel constants derived from the thresholds (recomputed per frame only for the temporal model):
-    // low-biased reciprocals for the exact floor-divide, and the shot-noise threshold factors nominal/threshold
-    double inv_p[VEC], inv_n[VEC], pre_p[VEC], pre_n[VEC];
+    // per-pixel constants derived from the thresholds (recomputed per frame only for the temporal model): float32
+    // reciprocals biased low by 2^-22 -- the quotient estimate of the exact floor-divide (never above the true quotient,
+    // short by one with probability ~3e-7 x quotient -> rare fix-up path; quotients below ~3e6) and, times the nominal
+    // threshold, the threshold factor of the shot-noise mean.  float32: two registers per pixel instead of six.
+    float inv_p[VEC], inv_n[VEC];
     auto derive_thres = [&]() {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            inv_p[j] = (1.0 / pt[j]) * 0x1.ffffffffffffcp-1;
-            inv_n[j] = (1.0 / nt[j]) * 0x1.ffffffffffffcp-1;
-            pre_p[j] = pos_nominal / pt[j];
-            pre_n[j] = neg_nominal / nt[j];
+            inv_p[j] = (float)((1.0 / pt[j]) * 0x1.fffff8p-1);
+            inv_n[j] = (float)((1.0 / nt[j]) * 0x1.fffff8p-1);
         }
     };
     derive_thres();
 
-    double leak_cur[VEC];                                  // float32 product leak_rate_hz * noise_rate_array (:204), widened
+    float leak_cur[VEC];                                   // float32 product leak_rate_hz * noise_rate_array (:204)
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) leak_cur[j] = (double)((float)P.leak_rate_hz * nrate[j]);
+    for (int j = 0; j < VEC; ++j) leak_cur[j] = (float)P.leak_rate_hz * nrate[j];
 
     acc_t acc_lo[VEC], acc_hi[VEC];
 #pragma unroll
@@ -471,15 +475,14 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
     const int64_t out_base = (int64_t)clip * planes_per_clip * a.HW + p0;
     uint32_t n_on = 0, n_off = 0;
     const bool want_counts = a.counts != nullptr;
-
     float gleak_pend[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) gleak_pend[j] = 0.0f;
-    Raw<IN, VEC> nxt = load_raw<IN, VEC>(a.frames, in_base + a.frame_stride);
-    for (int k = 0; k < a.K; ++k) {
+
+    // PAR (compile-time): k & 1 -- the leak-jitter normals come as Box-Muller pairs shared by two consecutive frame pairs
+    auto step = [&](auto par_tag, int k, const Raw<IN, VEC> &raw) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_tag)::value;
         const int i = k + 1;
-        const Raw<IN, VEC> raw = nxt;
-        nxt = load_raw<IN, VEC>(a.frames, in_base + (int64_t)(i + 1 <= a.K ? i + 1 : a.K) * a.frame_stride);
         if constexpr (BIN == kBinBilinear) {
             const int seg = __builtin_amdgcn_readfirstlane(s_seg[k]);
             while (cur_seg < seg) {
@@ -489,8 +492,8 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
                 ++cur_seg;
             }
         }
-        const double *fc = s_fc + (size_t)kV2eFrameConsts * k;                          // wave-uniform LDS reads
-        const double dt = fc[0], dt_tau = fc[1], scale_p = fc[2], scale_n = fc[3], cap = fc[4];
+        const V2eFrameConst fc = s_fc[k];                                               // wave-uniform LDS read
+        const double dt = fc.dt, dt_tau = fc.dt_tau, cap = fc.cap;
         const float dt_tau32 = (float)dt_tau;
         if (temporal) {                                                                 // thresholds redrawn per frame (:417-421)
             if constexpr (RNG == kRngPhilox) v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i, p0, pt, nt);
@@ -507,21 +510,21 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
         float gleak[VEC];
         float u_sp[VEC], u_sn[VEC];
         if constexpr (RNG == kRngPhilox) {
-            if (leak) {                     // one Box-Muller pair per pixel and couple of frame pairs (2m, 2m+1): block of pair 2m
-                if ((k & 1) == 0) field_gauss_pairs<VEC>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)(k >> 1) + 2u, kStreamV2e, p0, gleak, gleak_pend);
+            if (leak) {                     // one Box-Muller pair per pixel and couple of frame pairs (2m, 2m+1): block of couple m
+                if constexpr (PAR == 0) field_gauss_pairs<VEC, kNoiseRounds>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)(k >> 1) + 2u, kStreamV2e, p0, gleak, gleak_pend);
                 else {
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) gleak[j] = gleak_pend[j];
                 }
             }
-            if (shot) field_uniform16x2<VEC>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i + 3u, kStreamV2e, p0, u_sp, u_sn);
+            if (shot) field_uniform16x2<VEC, kNoiseRounds>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i + 3u, kStreamV2e, p0, u_sp, u_sn);
         }
         const acc_t wl = BIN == kBinBilinear ? s_wlo[k] : (acc_t)1, wh = BIN == kBinBilinear ? s_whi[k] : (acc_t)0;
 
-        // ---- lin_log (:445) + intensity terms: table reads by the 8-bit intensity; a wave leaves the table path only
-        // when some float32 pixel is not an integer in 0..255
-        float x[VEC], log_new[VEC], i01_32[VEC];
-        double i01_64[VEC], fac[VEC];
+        // ---- lin_log (:445) + intensity terms: one 16-byte table entry per pixel, indexed by the 8-bit intensity; a wave
+        // leaves the table path only when some float32 pixel is not an integer in 0..255
+        float x[VEC], log_new[VEC], i01_32[VEC], fac32[VEC];
+        double i01_64[VEC];
         v2e_pixels<IN, VEC>(raw, x);
         uint32_t mismatch = 0;                            // != 0 iff some float32 pixel is not an integer in 0..255 (or NaN)
 #pragma unroll
@@ -529,25 +532,34 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
             uint32_t idx;
             if constexpr (IN == kInU8) idx = VEC == 4 ? (raw.v >> (8 * j)) & 0xFFu : raw.v;
             else { idx = __float_as_uint(x[j] + 8388608.0f) & 255u; mismatch |= __float_as_uint((float)idx - x[j]); }
-            log_new[j] = s_lut[idx];
-            if (shot) fac[j] = tb.fac[idx]; else fac[j] = 0.0;
-            if constexpr (IN == kInU8) { i01_64[j] = lowpass ? tb.i01_64[idx] : 0.0; i01_32[j] = 0.0f; }
-            else { i01_32[j] = lowpass ? tb.i01_32[idx] : 0.0f; i01_64[j] = 0.0; }
+            const inten_t e = s_int[idx];
+            log_new[j] = e.logv;
+            fac32[j] = e.fac;
+            if constexpr (IN == kInU8) { i01_64[j] = e.i01; i01_32[j] = 0.0f; }
+            else { i01_32[j] = e.i01; i01_64[j] = 0.0; }
         }
         if constexpr (IN != kInU8) {
-            if (__builtin_expect(mismatch != 0, 0)) {
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(mismatch != 0) != 0, 0)) {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    log_new[j] = v2e_linlog(x[j], s_lut);
-                    v2e_inten<IN>(x[j], P.uint8_wrap, tb, i01_64[j], i01_32[j], fac[j]);
+                    if ((float)(__float_as_uint(x[j] + 8388608.0f) & 255u) != x[j]) {
+                        double fac;
+                        log_new[j] = v2e_linlog(x[j], a.lut);
+                        v2e_inten_direct<IN>(x[j], P.uint8_wrap, i01_64[j], i01_32[j], fac);
+                        fac32[j] = (float)fac;
+                    }
                 }
             }
         }
 
         // ---- low pass, leak, event map: floor_divide(clip(+-diff, 0), thres) as floor(x * low-biased reciprocal) with
         // the exact fma residual; the correction (quotient one short, or a non-finite operand) is a rare wave-level path
-        double dif[VEC], fpos[VEC], fneg[VEC];
+        double fpos[VEC], fneg[VEC];
         unsigned long long fix = 0;                       // wave-level masks (SGPR pairs): no per-lane bool materialised
+        auto cur_diff = [&](int j) -> double {            // lp - base in NumPy's dtypes (recomputed by the rare fix-up path)
+            if (lp32 && base32) { const float d = lp_f[j] - base_f[j]; return (double)d; }
+            return (lp32 ? (double)lp_f[j] : lp64[j]) - base64[j];
+        };
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             if (lowpass) {                                                              // low_pass_filter (:139-182)
@@ -570,18 +582,15 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
                 if constexpr (RNG == kRngPhilox) g = (double)gleak[j];
                 else g = a.r_leak_randn[((int64_t)clip * a.K + k) * a.HW + p0 + j];
                 const double jit = P.leak_jitter_fraction * g;
-                const double curr = leak_cur[j] * (1 - jit);
+                const double curr = (double)leak_cur[j] * (1 - jit);
                 const double dl = dt * curr * pt[j];
                 base64[j] = base64[j] - dl;
             }
-            double diff;
-            if (lp32 && base32) { const float d = lp_f[j] - base_f[j]; diff = (double)d; }
-            else diff = (lp32 ? (double)lp_f[j] : lp64[j]) - base64[j];
+            const double diff = cur_diff(j);
             // compute_event_map (:42-62).  The residuals are taken against +-diff itself: for the side that is clipped
             // to zero they are negative (check passes), for a NaN difference they are NaN (check fails -> exact path)
-            dif[j] = diff;
-            fpos[j] = floor(__builtin_fmax(diff, 0.0) * inv_p[j]);
-            fneg[j] = floor(__builtin_fmax(-diff, 0.0) * inv_n[j]);
+            fpos[j] = floor(__builtin_fmax(diff, 0.0) * (double)inv_p[j]);
+            fneg[j] = floor(__builtin_fmax(-diff, 0.0) * (double)inv_n[j]);
             const double rp = __builtin_fma(-fpos[j], pt[j], diff), rn = __builtin_fma(-fneg[j], nt[j], -diff);
             fix |= __ballot(!(rp < pt[j]));
             fix |= __ballot(!(rn < nt[j]));
@@ -589,11 +598,13 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
         if (__builtin_expect(fix != 0, 0)) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                const double diff = dif[j], nd = -diff;
+                double diff = cur_diff(j);
+                asm volatile("" : "+v"(diff));             // opaque: recomputed here, not kept alive from the common path
+                const double nd = -diff;
                 const double pos_frame = diff > 0 ? diff : (diff == diff ? 0.0 : diff);
                 const double neg_frame = nd > 0 ? nd : (nd == nd ? 0.0 : nd);
-                fpos[j] = floor(pos_frame * inv_p[j]);
-                fneg[j] = floor(neg_frame * inv_n[j]);
+                fpos[j] = floor(pos_frame * (double)inv_p[j]);
+                fneg[j] = floor(neg_frame * (double)inv_n[j]);
                 { const double r = __builtin_fma(-fpos[j], pt[j], pos_frame); if (r >= pt[j]) fpos[j] += 1.0; else if (!(r < pt[j])) fpos[j] = pos_frame / pt[j]; }
                 { const double r = __builtin_fma(-fneg[j], nt[j], neg_frame); if (r >= nt[j]) fneg[j] += 1.0; else if (!(r < nt[j])) fneg[j] = neg_frame / nt[j]; }
             }
@@ -601,26 +612,48 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
 
         if (shot) {                                                                     // generate_shot_noise (:65-105)
             if constexpr (RNG == kRngPhilox) {
-                float lam_p[VEC], lam_n[VEC];
-                PoissonHead hp[VEC], hn[VEC];
+                // mean = (intensity factor / threshold) x (nominal threshold x rate/2 dt / frame mean) in float32; inversion
+                // from the 16-bit uniforms: counts 0..3 from three thresholds p0, p0(1+l), p0(1+l+l^2/2) without a branch or
+                // a division.  Wave-level rare paths (a mean above 1; a count above 3) recompute what they need, so the
+                // common path keeps no per-pixel temporaries alive across them.
+                const f32x2 sc = f32x2{fc.scale_p, fc.scale_n};
+                auto mean_of = [&](int j) { return (pk_splat(fac32[j]) * f32x2{inv_p[j], inv_n[j]}) * sc; };
+                auto p0_of = [&](f32x2 lam) {
+                    f32x2 pz = exp_neg_small_x2(lam);
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(lam.x > 1.0f || lam.y > 1.0f) != 0, 0)) {
+                        if (lam.x > 1.0f) pz.x = expf_det(-lam.x);
+                        if (lam.y > 1.0f) pz.y = expf_det(-lam.y);
+                    }
+                    return pz;
+                };
+                int cnt_p[VEC], cnt_n[VEC];
                 unsigned long long more = 0;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    lam_p[j] = (float)((fac[j] * pre_p[j]) * scale_p);
-                    lam_n[j] = (float)((fac[j] * pre_n[j]) * scale_n);
-                    hp[j] = poisson_head_f32(lam_p[j], u_sp[j]);
-                    hn[j] = poisson_head_f32(lam_n[j], u_sn[j]);
-                    more |= __ballot(hp[j].more) | __ballot(hn[j].more);
+                    const f32x2 lam = mean_of(j);
+                    const f32x2 pz = p0_of(lam);
+                    const f32x2 q1 = lam + pk_splat(1.0f);
+                    const f32x2 q2 = pk_fma(lam * pk_splat(0.5f), lam, q1);
+                    const f32x2 s1 = pz * q1, s2 = pz * q2;
+                    const float up = u_sp[j], un = u_sn[j];
+                    cnt_p[j] = (int)(up > pz.x) + (int)(up > s1.x) + (int)(up > s2.x);
+                    cnt_n[j] = (int)(un > pz.y) + (int)(un > s1.y) + (int)(un > s2.y);
+                    more |= __ballot(up > s2.x) | __ballot(un > s2.y);
                 }
                 if (__builtin_expect(more != 0, 0)) {
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) {
-                        if (hp[j].more) hp[j].x = poisson_tail_f32(lam_p[j], u_sp[j], hp[j].p2, hp[j].s2);
-                        if (hn[j].more) hn[j].x = poisson_tail_f32(lam_n[j], u_sn[j], hn[j].p2, hn[j].s2);
+                        f32x2 lam = mean_of(j);
+                        asm volatile("" : "+v"(lam));      // opaque: a recomputation, not a value kept alive from the common path
+                        const f32x2 pz = p0_of(lam);
+                        const f32x2 hl = lam * pk_splat(0.5f);
+                        const f32x2 s2 = pz * pk_fma(hl, lam, lam + pk_splat(1.0f));
+                        if (u_sp[j] > s2.x) cnt_p[j] = (int)poisson_tail_f32(lam.x, u_sp[j], pz.x * (hl.x * lam.x), s2.x);
+                        if (u_sn[j] > s2.y) cnt_n[j] = (int)poisson_tail_f32(lam.y, u_sn[j], pz.y * (hl.y * lam.y), s2.y);
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) { fpos[j] = fpos[j] + (double)hp[j].x; fneg[j] = fneg[j] + (double)hn[j].x; }
+                for (int j = 0; j < VEC; ++j) { fpos[j] = fpos[j] + (double)cnt_p[j]; fneg[j] = fneg[j] + (double)cnt_n[j]; }
             } else {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
@@ -631,12 +664,17 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
             }
         }
 
+        if (refractory) {                                                               // intended semantics of :534-537
+            asm volatile("" ::: "memory");                                              // keep it a (scalar) branch, not eight selects
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            if (refractory) {                                                           // intended semantics of :534-537
+            for (int j = 0; j < VEC; ++j) {
                 fpos[j] = fpos[j] > cap ? cap : fpos[j];
                 fneg[j] = fneg[j] > cap ? cap : fneg[j];
             }
+        }
+        float vfs[PK ? VEC : 1];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
             if (base32) {                                                               // in-place += on a float32 array (:547-548)
                 const double up = fpos[j] * pt[j];
                 base_f[j] = (float)((double)base_f[j] + up);
@@ -659,12 +697,23 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
                 }
             } else {
                 const float vf = (float)vox;
-                if constexpr (BIN == kBinBilinear) {
+                if constexpr (PK) {
+                    vfs[j] = vf;
+                } else if constexpr (BIN == kBinBilinear) {
                     acc_lo[j] = __builtin_fmaf(vf, wl, acc_lo[j]);
                     acc_hi[j] = __builtin_fmaf(vf, wh, acc_hi[j]);
                 } else {
                     acc_lo[j] = acc_lo[j] + vf;
                 }
+            }
+        }
+        if constexpr (PK) {
+#pragma unroll
+            for (int j = 0; j < VEC; j += 2) {
+                const f32x2 v2 = f32x2{vfs[j], vfs[j + 1]};
+                const f32x2 lo = pk_fma(v2, pk_splat((float)wl), f32x2{(float)acc_lo[j], (float)acc_lo[j + 1]});
+                const f32x2 hi = pk_fma(v2, pk_splat((float)wh), f32x2{(float)acc_hi[j], (float)acc_hi[j + 1]});
+                acc_lo[j] = lo.x; acc_lo[j + 1] = lo.y; acc_hi[j] = hi.x; acc_hi[j + 1] = hi.y;
             }
         }
         if (want_counts) {
@@ -680,6 +729,33 @@ __global__ void __launch_bounds__(kBlock) v2e_voxel_kernel(const V2eArgs a)
                 ++plane;
             }
         }
+    };
+
+    // ---- time loop: register ring of kV2eDepth frames, reloaded right after use (clamped, unconditional loads), unrolled
+    //      by an even factor so that the parity of k is a compile-time constant
+    constexpr int kRing = V2V_V2E_DEPTH;
+    static_assert(kRing % 2 == 0, "the v2e time loop must be unrolled by an even factor (leak-jitter pairs)");
+    {
+        Raw<IN, VEC> ring[kRing];
+#pragma unroll
+        for (int u = 0; u < kRing; ++u) {
+            const int f = (1 + u <= a.K) ? 1 + u : a.K;
+            ring[u] = load_raw<IN, VEC>(a.frames, in_base + (int64_t)f * a.frame_stride);
+        }
+        int k0 = 0;
+        for (; k0 + kRing <= a.K; k0 += kRing) {
+            static_for(std::make_integer_sequence<int, kRing>{}, [&](auto u_tag) {
+                constexpr int u = decltype(u_tag)::value;
+                const int k = k0 + u;
+                step(std::integral_constant<int, (u & 1)>{}, k, ring[u]);
+                const int fn = k + 1 + kRing;
+                ring[u] = load_raw<IN, VEC>(a.frames, in_base + (int64_t)(fn <= a.K ? fn : a.K) * a.frame_stride);
+            });
+        }
+        static_for(std::make_integer_sequence<int, kRing - 1>{}, [&](auto u_tag) {
+            constexpr int u = decltype(u_tag)::value;
+            if (k0 + u < a.K) step(std::integral_constant<int, (u & 1)>{}, k0 + u, ring[u]);
+        });
     }
     if constexpr (BIN == kBinBilinear) {
         store_vec<VEC, acc_t>(a.out, out_base + (int64_t)cur_seg * a.HW, acc_lo);
