@@ -1,6 +1,7 @@
-"""V2V_RNG_PHILOX_FAST: the base-noise Gaussians come from Philox4x32-7 + hardware transcendentals, so the field is
-not the oracle's bit for bit.  Parity for this mode is DISTRIBUTIONAL: the injected noise must be standard normal,
-and the simulator's event statistics must match the exact mode within sampling error."""
+"""V2V_RNG_PHILOX_FAST: the base-noise Gaussians come from the same Philox words and 16+16-bit grids as the exact generator,
+but through the hardware transcendental units, so the field is the oracle's only to ~1e-5, not bit for bit.  Parity for this
+mode: the injected field equals the exact one within 5e-5, it is standard normal, and the simulator's event statistics
+match the exact mode within sampling error."""
 import numpy as np
 import pytest
 import torch
@@ -24,14 +25,14 @@ def test_fast_noise_is_standard_normal():
     assert abs(g.mean()) < 4 / np.sqrt(g.size) and abs(g.std() - 1) < 4 / np.sqrt(2 * g.size)
     assert abs(stats.skew(g)) < 0.02 and abs(stats.kurtosis(g)) < 0.04
     assert stats.kstest(g[:100000], "norm").pvalue > 1e-3
-    # tails: the 2^-24 uniform grid reaches ~5.7 sigma
-    assert 4.3 < np.abs(g).max() < 6.0
-    # no correlation between neighbouring pixels / consecutive pairs, and it differs from the exact field
+    # tails: the 2^-16 midpoint grid reaches 4.86 sigma
+    assert 4.2 < np.abs(g).max() < 4.9
+    # no correlation between neighbouring pixels / consecutive pairs; and it IS the exact field up to the hardware functions' ulps
     f = g.reshape(8, 128, 256)
     assert abs(np.corrcoef(f[:, :, :-1].ravel(), f[:, :, 1:].ravel())[0, 1]) < 0.01
     assert abs(np.corrcoef(f[:-1].ravel(), f[1:].ravel())[0, 1]) < 0.01
     exact = _noise_field(E, "philox").reshape(-1)
-    assert abs(np.corrcoef(g, exact)[0, 1]) < 0.01
+    assert np.abs(g - exact).max() < 5e-5 and np.corrcoef(g, exact)[0, 1] > 0.99999999
     assert abs(exact.mean()) < 4 / np.sqrt(g.size) and abs(stats.kurtosis(exact)) < 0.04
 
 

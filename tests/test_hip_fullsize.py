@@ -1,0 +1,132 @@
+"""-m gpu parity at the FULL sizes BASELINE.json names (configs 2, 3, 4), not at toy shapes: the whole batch goes through
+one launch exactly as bench.py times it, then the first, a middle and the last clip (32-bit index arithmetic breaks at
+the END of a 2.1 GB batch, not at clip 0) are compared with the C oracle, and per-clip ON/OFF totals of the WHOLE batch
+with the oracle's totals (OpenMP over the host cores).  Bars: integer counts / SUM voxels bit-exact; float32 bilinear voxels
+rtol = atol = 1e-5 (north_star)."""
+import numpy as np
+import pytest
+
+from oracle import v2v_oracle as O
+
+gpu = pytest.mark.gpu
+SEED = 20240001
+
+
+def _sample_ids(b):
+    return sorted({0, b // 2 - 1, b // 2, b - 1})
+
+
+@gpu
+@pytest.mark.parametrize("dt_name", ["float32", "uint8"])
+@pytest.mark.parametrize("params", [[0.2, 0.2, 0.0, 0.0, 0.0], [0.2, 0.3, 0.05, 5e-4, 1.0]], ids=["fixedC_clean", "asym_noisy"])
+def test_cfg2_full_batch_256x32x256x256(oracle_c, luts, dt_name, params):
+    """BASELINE config 2: 256 clips of 32x256x256, 5 temporal-bilinear bins, one launch."""
+    import torch
+    from v2v_amd import esim
+    b, n, h, w, tb = 256, 32, 256, 256, 5
+    dt = getattr(torch, dt_name)
+    frames = esim.synth_clips(b, n, h, w, dtype=dt, seed=SEED, clip_id0=0)
+    counts = torch.zeros((b, 2), dtype=torch.int64, device="cuda")
+    out = esim.esim_voxel_batch(frames, params, bin_mode="bilinear", num_bins=tb, seed=SEED, clip_id0=0, counts=counts)
+    torch.cuda.synchronize()
+    assert out.shape == (b, tb, h, w) and out.dtype == torch.float32 and bool(torch.isfinite(out).all())
+    # (1) sampled clips, every voxel
+    for c in _sample_ids(b):
+        host = frames[c:c + 1].cpu().numpy()
+        want, tot = oracle_c.esim_voxel(host, params, luts, seed=SEED, clip_id0=c, bin_mode=oracle_c.BIN_BILINEAR, num_bins=tb)
+        np.testing.assert_allclose(out[c].cpu().numpy().astype(np.float64), want[0], rtol=1e-5, atol=1e-5, err_msg=f"clip {c}")
+        assert np.array_equal(counts[c].cpu().numpy(), tot[0]), f"clip {c} ON/OFF totals"
+    # (2) ON/OFF totals of all 256 clips (bit-exact integers) -- the whole batch through the oracle, OpenMP over clips
+    host_all = frames.cpu().numpy()
+    _, totals = oracle_c.esim_voxel(host_all, params, luts, seed=SEED, clip_id0=0, bin_mode=oracle_c.BIN_BILINEAR, num_bins=tb)
+    assert np.array_equal(counts.cpu().numpy(), totals)
+    # (3) size-independent property: a sub-batch taken from the END of the batch reproduces its clips bit for bit
+    tail = esim.esim_voxel_batch(frames[-3:], params, bin_mode="bilinear", num_bins=tb, seed=SEED, clip_id0=b - 3)
+    assert torch.equal(tail, out[-3:])
+
+
+@gpu
+def test_cfg2_full_batch_sum_mode_exact(oracle_c, luts):
+    """Same batch, N = 31 frames -> (N-1) = 30 = 2 x 5 x 3: SUM binning (the voxel grid V2V trains on), bit-exact integers."""
+    import torch
+    from v2v_amd import esim
+    b, n, h, w = 256, 31, 256, 256
+    frames = esim.synth_clips(b, n, h, w, dtype=torch.uint8, seed=SEED, clip_id0=0)
+    p = [0.25, 0.2, 0.05, 5e-4, 1.0]
+    out = esim.esim_voxel_batch(frames, p, bin_mode="sum", num_bins=5, frames_per_bin=3, seed=SEED, clip_id0=0)
+    assert out.shape == (b, 2, 5, h, w)
+    for c in _sample_ids(b):
+        want, _ = oracle_c.esim_voxel(frames[c:c + 1].cpu().numpy(), p, luts, seed=SEED, clip_id0=c, bin_mode=oracle_c.BIN_SUM, num_bins=5,
+                                      frames_per_bin=3)
+        assert np.array_equal(out[c].cpu().numpy().astype(np.float64), want[0]), f"clip {c}"
+
+
+V2E_NOISY = [24, "pn_related", 0.5, 0.1, 0.0, 0.1, 30, 0.1, 0, 5.0, 0.1, 0.1]
+
+
+@gpu
+@pytest.mark.parametrize("dt_name", ["float32", "uint8"])
+def test_cfg3_v2e_full_batch_256x32x256x256(oracle_c, luts, dt_name):
+    """BASELINE config 3: the v2e model (per-pixel thresholds, low-pass, leak, shot noise) on the same 256-clip batch; three
+    sampled clips against the C oracle: float64 counts exact, float32 bilinear grid to 1e-5."""
+    import torch
+    from v2v_amd import esim, v2e
+    b, n, h, w, tb = 256, 32, 256, 256, 5
+    frames = esim.synth_clips(b, n, h, w, dtype=getattr(torch, dt_name), seed=SEED, clip_id0=0)
+    vp = v2e.make_params(*V2E_NOISY)
+    counts = torch.zeros((b, 2), dtype=torch.int64, device="cuda")
+    out = v2e.v2e_voxel_batch(frames, vp, bin_mode="bilinear", num_bins=tb, seed=SEED, clip_id0=0, counts=counts)
+    torch.cuda.synchronize()
+    assert out.shape == (b, tb, h, w) and bool(torch.isfinite(out).all())
+    for c in (0, b // 2, b - 1):
+        host = frames[c:c + 1].cpu().numpy()
+        want, tot = oracle_c.v2e_voxel(host, oracle_c.v2e_params(*V2E_NOISY), luts, seed=SEED, clip_id0=c, bin_mode=oracle_c.BIN_BILINEAR,
+                                       num_bins=tb)
+        assert np.array_equal(counts[c].cpu().numpy(), tot[0]), f"clip {c}: ON/OFF totals"
+        np.testing.assert_allclose(out[c].cpu().numpy().astype(np.float64), want[0], rtol=1e-5, atol=1e-5, err_msg=f"clip {c}")
+    # per-pair counts of the last clip, bit-exact (float64 SUM mode, 31 planes)
+    c = b - 1
+    sub = v2e.v2e_voxel_batch(frames[c:c + 1], vp, bin_mode="sum", num_bins=n - 1, seed=SEED, clip_id0=c, out_dtype=torch.float64)
+    want, _ = oracle_c.v2e_voxel(frames[c:c + 1].cpu().numpy(), oracle_c.v2e_params(*V2E_NOISY), luts, seed=SEED, clip_id0=c,
+                                 bin_mode=oracle_c.BIN_SUM, num_bins=n - 1)
+    assert np.array_equal(sub.cpu().numpy(), want)
+
+
+@gpu
+@pytest.mark.parametrize("n,bin_mode", [(41, "sum"), (40, "bilinear")])
+def test_cfg4_720p_to_256_pipeline(oracle_c, luts, n, bin_mode):
+    """BASELINE config 4 at its real geometry: decoded 1280x720x3 frames, keep_top_percentile 0.54, crop -> 256x256, flip,
+    N = 41 frames (SUM, the reference's assert holds) and N = 40 (temporal-bilinear): GPU front-end against the OpenCV-algorithm
+    restatement (oracle/frontend_oracle.py; parity with cv2 itself is unpinned -- OpenCV is not in the image), then the
+    simulator on the front-end's output against the C oracle, on sampled clips."""
+    import torch
+    from oracle import frontend_oracle as FO
+    from v2v_amd import esim, frontend
+    b, sh, sw, crop, tb = 6, 720, 1280, 256, 5
+    g = np.random.default_rng(404 + n)
+    # decoded BGR frames with real colour content (three different channels), resident in HBM
+    base = esim.synth_clips(b, n, sh, sw, dtype=torch.uint8, seed=SEED + 7, clip_id0=0)
+    raw = torch.stack([base, base.flip(-1), 255 - base], dim=-1).contiguous()                       # [B,T,720,1280,3]
+    keep_h = int(sh * 0.54)                                                                           # v2v_datasets.py:73
+    min_scale = max(0, crop / keep_h, crop / sw)
+    scale = g.uniform(min_scale, max(1.3, min_scale), size=b)                                        # :260-272
+    cb = (crop / scale).astype(np.int64)
+    table = np.stack([[g.integers(0, keep_h - c + 1), g.integers(0, sw - c + 1), c, int(g.random() > 0.5)] for c in cb]).astype(np.int32)
+    idx = np.stack([np.sort(g.integers(0, n, size=n)) if i % 2 else np.arange(n) for i in range(b)]).astype(np.int32)   # pauses repeat frames
+    _, gray = frontend.prepare_clips_batch(raw, table, idx, crop, "gray")
+    params = np.stack([[0.2 + 0.01 * i, 0.3, 0.05, 5e-4, 1.0] for i in range(b)])
+    kw = dict(bin_mode=bin_mode, num_bins=tb, seed=SEED, clip_id0=100)
+    counts = torch.zeros((b, 2), dtype=torch.int64, device="cuda")
+    out = esim.esim_voxel_batch(gray, params, counts=counts, **kw)
+    torch.cuda.synchronize()
+    for c in (0, b // 2, b - 1):
+        _, want_gray = FO.frontend(raw[c].cpu().numpy(), int(table[c, 2]), int(table[c, 0]), int(table[c, 1]), bool(table[c, 3]), crop, idx[c])
+        assert np.array_equal(gray[c].cpu().numpy(), want_gray), f"front-end clip {c}"
+        bm = oracle_c.BIN_SUM if bin_mode == "sum" else oracle_c.BIN_BILINEAR
+        want, tot = oracle_c.esim_voxel(want_gray[None], params[c], luts, seed=SEED, clip_id0=100 + c, bin_mode=bm, num_bins=tb)
+        got = out[c].cpu().numpy().astype(np.float64)
+        if bin_mode == "sum":
+            assert np.array_equal(got, want[0]), f"clip {c}"
+        else:
+            np.testing.assert_allclose(got, want[0], rtol=1e-5, atol=1e-5, err_msg=f"clip {c}")
+        assert np.array_equal(counts[c].cpu().numpy(), tot[0])

@@ -190,3 +190,75 @@ def test_hip_native_shot_noise_statistics():
     # per-clip totals are independent draws: their spread is Poisson too
     per_clip = counts.cpu().numpy().astype(np.float64)
     assert abs(per_clip.var(axis=0).mean() / (h * w * lam) - 1) < 0.5
+
+
+@gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_replay_equals_reference_golden(golden, name):
+    import torch
+    from v2v_amd import v2e
+    g = golden("g9_v2e.npz")
+    video, args, fields, want = _case(g, name)
+    params = v2e.make_params(*args)
+    k = video.shape[0] - 1
+    rep = {kk: torch.from_numpy(np.ascontiguousarray(a))[None] for kk, a in fields.items()}
+    out = v2e.v2e_voxel_batch(torch.from_numpy(video)[None].cuda(), params, bin_mode="sum", num_bins=k, rng_mode="replay",
+                              replay=rep, out_dtype=torch.float64)
+    assert np.array_equal(out[0, 0].cpu().numpy(), want)
+
+
+@gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_video_to_voxel_dropin_numpy_stream(golden, name):
+    """Full drop-in call: seed -> host draws in the reference's order -> GPU.  np.exp(float32) of the leak-rate
+    factor is host-SIMD dependent (<= 1 ulp), so allow a vanishing number of flipped counts."""
+    from v2v_amd import v2e
+    g = golden("g9_v2e.npz")
+    video, args, fields, want = _case(g, name)
+    got = v2e.video_to_voxel(video, *args, seed=11, rng="numpy")
+    assert got.dtype == np.float64 and got.shape == want.shape
+    assert np.count_nonzero(got != want) <= 2
+
+
+@gpu
+@pytest.mark.parametrize("dt", [np.uint8, np.float32])
+@pytest.mark.parametrize("model,cutoff,leak,refr,shot", [("pn_related", 30, 0.1, 0, 5.0), ("spatial_independent", 0, 0, 0, 0),
+                                                          ("spatial_temporal_independent", 30, 0.1, 1 / 240, 5.0),
+                                                          ("pn_related", 0, 0.1, 0, 0)])
+@pytest.mark.parametrize("bin_mode", ["sum", "bilinear"])
+def test_hip_philox_equals_c_oracle(oracle_c, luts, dt, model, cutoff, leak, refr, shot, bin_mode):
+    import torch
+    from v2v_amd import v2e
+    b, n, h, w = 3, 11, 24, 40
+    video = np.stack([O.synth_clip_s1(n, h, w, seed=300 + i, dtype=dt) for i in range(b)])
+    args = [24, model, 0.5, 0.1, 0.0, 0.1, cutoff, leak, refr, shot, 0.1, 0.1]
+    bm = oracle_c.BIN_SUM if bin_mode == "sum" else oracle_c.BIN_BILINEAR
+    want, totals = oracle_c.v2e_voxel(video, oracle_c.v2e_params(*args), luts, seed=0xABCDEF123, clip_id0=5, bin_mode=bm,
+                                      num_bins=5, frames_per_bin=2 if bin_mode == "sum" else 1)
+    counts = torch.zeros((b, 2), dtype=torch.int64, device="cuda")
+    got = v2e.v2e_voxel_batch(torch.from_numpy(video).cuda(), v2e.make_params(*args), bin_mode=bin_mode, num_bins=5,
+                              frames_per_bin=2 if bin_mode == "sum" else 1, seed=0xABCDEF123, clip_id0=5,
+                              out_dtype=torch.float64, counts=counts)
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(counts.cpu().numpy(), totals)
+    got32 = v2e.v2e_voxel_batch(torch.from_numpy(video).cuda(), v2e.make_params(*args), bin_mode=bin_mode, num_bins=5,
+                                frames_per_bin=2 if bin_mode == "sum" else 1, seed=0xABCDEF123, clip_id0=5)
+    np.testing.assert_allclose(got32.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    # batch / shard invariance
+    part = v2e.v2e_voxel_batch(torch.from_numpy(video[1:]).cuda(), v2e.make_params(*args), bin_mode=bin_mode, num_bins=5,
+                               frames_per_bin=2 if bin_mode == "sum" else 1, seed=0xABCDEF123, clip_id0=6, out_dtype=torch.float64)
+    assert torch.equal(part, got[1:])
+
+
+@gpu
+def test_hip_v2e_errors():
+    import torch
+    from v2v_amd import v2e
+    with pytest.raises(ValueError):
+        v2e.make_params(24, "spatial_independent_temporal_changing", 0.5, 0.1, 0, 0.1, 0, 0, 0, 0, 0.1, 0.1)
+    f = torch.zeros((1, 8, 8, 8), dtype=torch.uint8, device="cuda")
+    p = v2e.make_params(24, "pn_related", 0.5, 0.1, 0, 0.1, 0, 0, 0, 0, 0.1, 0.1)
+    with pytest.raises(AssertionError):
+        v2e.v2e_voxel_batch(f, p, num_bins=5)
+    with pytest.raises(ValueError):
+        v2e.v2e_voxel_batch(f, p, num_bins=7, rng_mode="replay")
