@@ -5,12 +5,14 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path (ONE launch of v2v_esim_voxel_hip) over one batch of synthetic clips
-that is already resident in HBM.  Workload at N=1: BASELINE configs[1] -- 256 clips of 32x256x256 float32
-(integer-valued), C+=C-=0.2, 5 temporal-bilinear voxel bins.  With N>1 GPUs every rank gets its own 256
-clips (global clip ids rank*256..), no data-path collective: weak scaling.  Rank 0 prints ONE JSON line.
-Other --workload values (the remaining BASELINE configs and variants) are parity-test cases and secondary
-measurements, not the headline.
+A "step" is one pass of the hot path (ONE launch of v2v_esim_voxel_hip) over one batch of synthetic clips that is
+already resident in HBM.  Workload at N=1: BASELINE configs[1] -- 256 clips of 32x256x256 float32 (integer-valued),
+C+ = C- = 0.2, 5 temporal-bilinear voxel bins, simulated with the REFERENCE'S OWN EventEmulator constructor defaults
+(data/v2v_core_esim.py:8-16: base_noise_std 0.1, hot_pixel_fraction 1e-3, hot_pixel_std 0.1), i.e. with the noise the
+reference always applies.  With N>1 GPUs every rank gets its own 256 clips (global clip ids rank*256..), no data-path
+collective: weak scaling.  Rank 0 prints ONE JSON line.  The default run also times every other BASELINE config and
+variant once each (`also_measured`: own kernel time, algorithmic bytes, fraction of the HBM peak), outside the timed
+region; they are parity-test cases and secondary measurements, never the headline.
 """
 import argparse
 import json
@@ -28,36 +30,35 @@ MEASURED_CEILINGS_GBPS = {"read_only_sweep": 6100.0, "float4_copy": 5200.0,
                           "cfg2_access_pattern_without_arithmetic": 6170.0}
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (measured copy ceiling ~6290)
 
+REF_DEFAULTS = [0.2, 0.2, 0.1, 0.001, 0.1]        # EventEmulator() defaults (v2v_core_esim.py:8-16): what "fixed C = 0.2" runs
+DATASET_STYLE = [0.2, 0.3, 0.05, 5e-4, 1.0]       # asymmetric thresholds + noise as imgs_to_voxels samples them (v2v_datasets.py:368-386)
+NOISE_FREE = [0.2, 0.2, 0.0, 0.0, 0.0]            # the noise-free symmetric fast path (V2V_FLAG_NO_NOISE kernels): NOT reachable from the dataset
 V2E_NOISY = [24, "pn_related", 0.5, 0.1, 0.0, 0.1, 30, 0.1, 0, 5.0, 0.1, 0.1]     # SURVEY §8d S3 (v2v_core_v2e.py:365-375,600)
+_CFG2 = dict(model="esim", b=256, n=32, h=256, w=256, dtype="float32", bin="bilinear", tb=5, fpb=1)
 WORKLOADS = {
-    "cfg2_esim_f32_256x32x256x256_bilinear5": dict(model="esim", b=256, n=32, h=256, w=256, dtype="float32", bin="bilinear", tb=5, fpb=1,
-                                                   params=[0.2, 0.2, 0.0, 0.0, 0.0]),
-    "cfg2_noise_on": dict(model="esim", b=256, n=32, h=256, w=256, dtype="float32", bin="bilinear", tb=5, fpb=1,
-                          params=[0.2, 0.2, 0.05, 5e-4, 1.0]),
-    "cfg2_noise_on_fast": dict(model="esim", b=256, n=32, h=256, w=256, dtype="float32", bin="bilinear", tb=5, fpb=1,
-                               params=[0.2, 0.2, 0.05, 5e-4, 1.0], rng="philox_fast"),
-    "cfg2_u8": dict(model="esim", b=256, n=32, h=256, w=256, dtype="uint8", bin="bilinear", tb=5, fpb=1, params=[0.2, 0.2, 0.0, 0.0, 0.0]),
-    "cfg2_asym": dict(model="esim", b=256, n=32, h=256, w=256, dtype="float32", bin="bilinear", tb=5, fpb=1,
-                      params=[0.2, 0.3, 0.0, 0.0, 0.0]),
-    "cfg3_v2e_f32_256x32x256x256_bilinear5": dict(model="v2e", b=256, n=32, h=256, w=256, dtype="float32", bin="bilinear", tb=5, fpb=1,
-                                                  params=V2E_NOISY),
-    "cfg3_v2e_u8": dict(model="v2e", b=256, n=32, h=256, w=256, dtype="uint8", bin="bilinear", tb=5, fpb=1, params=V2E_NOISY),
-    "cfg4_u8_256x41x256x256_sum5": dict(model="esim", b=256, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1,
-                                        params=[0.2, 0.3, 0.05, 5e-4, 1.0]),
+    "cfg2_esim_f32_256x32x256x256_bilinear5": dict(_CFG2, params=REF_DEFAULTS),
+    "cfg2_noise_free": dict(_CFG2, params=NOISE_FREE),
+    "cfg2_dataset_style": dict(_CFG2, params=DATASET_STYLE),
+    "cfg2_fast_rng": dict(_CFG2, params=REF_DEFAULTS, rng="philox_fast"),
+    "cfg2_u8": dict(_CFG2, dtype="uint8", params=REF_DEFAULTS),
+    "cfg2_u8_noise_free": dict(_CFG2, dtype="uint8", params=NOISE_FREE),
+    "cfg3_v2e_f32_256x32x256x256_bilinear5": dict(_CFG2, model="v2e", params=V2E_NOISY),
+    "cfg3_v2e_u8": dict(_CFG2, model="v2e", dtype="uint8", params=V2E_NOISY),
+    "cfg4_u8_256x41x256x256_sum5": dict(model="esim", b=256, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1, params=DATASET_STYLE),
     # BASELINE config 4 (per GPU): decoded 720p BGR frames resident in HBM -> GPU front-end (cvtColor, crop, resize to
     # 256x256, flip) -> fused sim + sum binning.  41 frames so that (N-1) % 5 == 0 as the reference asserts.
     "cfg4_pipeline_720p_to_256_41f_sum5": dict(model="pipeline", b=24, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1,
-                                               params=[0.2, 0.3, 0.05, 5e-4, 1.0], src_hw=(720, 1280)),
+                                               params=DATASET_STYLE, src_hw=(720, 1280)),
     # BASELINE config 5 (per GPU): config 4's pipeline feeding a random-init E2VID-shaped recurrent UNet (bf16 autocast,
-    # stock PyTorch ops, tools/e2vid_consumer.py) -- end-to-end "dataloader -> model forward" throughput.
+    # tools/e2vid_consumer.py) -- end-to-end "dataloader -> model forward" throughput.
     "cfg5_pipeline_plus_e2vid_bf16": dict(model="pipeline", b=8, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1,
-                                          params=[0.2, 0.3, 0.05, 5e-4, 1.0], src_hw=(720, 1280), consumer=True),
-    "train_u8_12x201x128x128_sum5": dict(model="esim", b=12, n=201, h=128, w=128, dtype="uint8", bin="sum", tb=5, fpb=1,
-                                         params=[0.2, 0.2, 0.05, 5e-4, 1.0]),
-    "cfg1_plumbing_u8_1x8x128x128": dict(model="esim", b=1, n=8, h=128, w=128, dtype="uint8", bin="sum", tb=7, fpb=1,
-                                         params=[0.2, 0.2, 0.0, 0.0, 0.0]),
+                                          params=DATASET_STYLE, src_hw=(720, 1280), consumer=True),
+    "train_u8_12x201x128x128_sum5": dict(model="esim", b=12, n=201, h=128, w=128, dtype="uint8", bin="sum", tb=5, fpb=1, params=DATASET_STYLE),
+    "cfg1_plumbing_u8_1x8x128x128": dict(model="esim", b=1, n=8, h=128, w=128, dtype="uint8", bin="sum", tb=7, fpb=1, params=NOISE_FREE),
 }
 DEFAULT_WORKLOAD = "cfg2_esim_f32_256x32x256x256_bilinear5"
+ALSO_MEASURED = ["cfg2_noise_free", "cfg2_dataset_style", "cfg2_fast_rng", "cfg2_u8", "cfg3_v2e_f32_256x32x256x256_bilinear5", "cfg3_v2e_u8",
+                 "cfg4_u8_256x41x256x256_sum5", "cfg4_pipeline_720p_to_256_41f_sum5", "train_u8_12x201x128x128_sum5"]
 
 
 def cpu_baseline(frames_host, wl, budget_s=12.0):
@@ -68,9 +69,7 @@ def cpu_baseline(frames_host, wl, budget_s=12.0):
     n_done, t0 = 0, time.perf_counter()
     np.random.seed(0)
     for clip in frames_host:
-        if wl["model"] == "esim":
-            counts = O.esim_video_to_voxel(clip, *wl["params"], put_noise_external=False, rng=O.GlobalNumpyRNG, use_lut=False)
-        elif wl["model"] == "pipeline":
+        if wl["model"] in ("esim", "pipeline"):
             counts = O.esim_video_to_voxel(clip, *wl["params"], put_noise_external=False, rng=O.GlobalNumpyRNG, use_lut=False)
         else:
             counts = O.v2e_video_to_voxel(clip, *wl["params"], seed=None)
@@ -82,7 +81,7 @@ def cpu_baseline(frames_host, wl, budget_s=12.0):
     grids = n_done * (1 if wl["bin"] == "bilinear" else (frames_host.shape[1] - 1) // (wl["tb"] * wl["fpb"]))
     return {"value": grids / dt, "unit": "voxel grids/s", "cores": 1, "kind": "port",
             "sample": f"{n_done} of the batch's clips ({'x'.join(map(str, frames_host.shape[1:]))} {frames_host.dtype}), "
-                      f"oracle/v2v_oracle.py NumPy port of the reference's op sequence (float64 state), single thread, {dt:.1f} s"}
+                      f"oracle/v2v_oracle.py NumPy port of the reference's op sequence (float64 state, noise on), single thread, {dt:.1f} s"}
 
 
 def _pool_clip(job):
@@ -129,7 +128,7 @@ def cpu_baseline_c(frames_host, wl):
     t0 = time.perf_counter()
     if wl["model"] in ("esim", "pipeline"):
         clib.esim_voxel(frames_host, wl["params"], O.load_luts(), rng_mode=clib.RNG_PHILOX, seed=1, bin_mode=bm,
-                        num_bins=wl["tb"], frames_per_bin=wl["fpb"], threads=cores)
+                        num_bins=wl["tb"], frames_per_bin=wl["fpb"])
     else:
         clib.v2e_voxel(frames_host, clib.v2e_params(*wl["params"]), O.load_luts(), seed=1, bin_mode=bm, num_bins=wl["tb"],
                        frames_per_bin=wl["fpb"])
@@ -137,6 +136,151 @@ def cpu_baseline_c(frames_host, wl):
     grids = frames_host.shape[0] * (1 if wl["bin"] == "bilinear" else (frames_host.shape[1] - 1) // (wl["tb"] * wl["fpb"]))
     return {"value": grids / dt, "unit": "voxel grids/s", "cores": cores, "kind": "port",
             "sample": f"{frames_host.shape[0]} clips, oracle/v2v_oracle.c scalar C port (table-driven), OpenMP over clips, {dt:.1f} s"}
+
+
+class Workload:
+    """One benchmark workload resident on `dev`: inputs, the output buffer, the step closure and its byte accounting."""
+
+    def __init__(self, name, dev, rank, world, batch=0):
+        import torch
+        from v2v_amd import esim, sharding
+        wl = WORKLOADS[name]
+        self.name, self.wl, self.dev = name, wl, dev
+        b = self.b = batch or wl["b"]
+        n, h, w, bin_mode, tb, fpb, params = wl["n"], wl["h"], wl["w"], wl["bin"], wl["tb"], wl["fpb"], wl["params"]
+        tdtype = getattr(torch, wl["dtype"])
+        self.clip_id0 = clip_id0 = sharding.weak_shard(b, rank, world).lo          # batch shard: global clip ids, no exchange
+        self.raw = None
+        if wl["model"] == "pipeline":
+            import numpy as np
+            from v2v_amd import frontend
+            sh, sw = wl["src_hw"]
+            gray_video = esim.synth_clips(b, n, sh, sw, dtype=torch.uint8, seed=20240001, clip_id0=clip_id0, device=dev)
+            self.raw = raw = gray_video.unsqueeze(-1).expand(b, n, sh, sw, 3).contiguous()              # decoded BGR frames [B,T,720,1280,3]
+            del gray_video
+            g = np.random.default_rng(20240001 + rank)
+            keep_h = int(sh * 0.54)                                                          # keep_top_percentile (v2v_datasets.py:73)
+            min_scale = max(0, h / keep_h, h / sw)
+            scale = g.uniform(min_scale, max(1.3, min_scale), size=b)                        # :260-272
+            cb = (h / scale).astype(np.int64)
+            table = np.stack([[g.integers(0, keep_h - c + 1), g.integers(0, sw - c + 1), c, int(g.random() > 0.5)] for c in cb]).astype(np.int32)
+            idx = np.tile(np.arange(n, dtype=np.int32), (b, 1))
+            table_d, idx_d = torch.as_tensor(table, device=dev), torch.as_tensor(idx, device=dev)
+            cb_max = int(cb.max())
+            self.frames = frontend.prepare_clips_batch(raw, table_d, idx_d, h, "gray", validate=False, max_crop_before=cb_max)[1]
+            src_bytes = int((cb.astype(np.int64) ** 2).sum()) * 3 * n
+        else:
+            self.frames = esim.synth_clips(b, n, h, w, dtype=tdtype, seed=20240001, clip_id0=clip_id0, device=dev)
+        shape = (b, (n - 1) // (tb * fpb), tb, h, w) if bin_mode == "sum" else (b, tb, h, w)
+        self.out = out = torch.empty(shape, dtype=torch.float32, device=dev)
+        self.alg_bytes = esim.algorithmic_bytes(tdtype, b, n, h, w, bin_mode, tb, fpb)
+        self.grids_per_step = b * (shape[1] if bin_mode == "sum" else 1)
+        frames = self.frames
+
+        if wl["model"] == "pipeline":
+            ptensor = torch.tensor(params, dtype=torch.float64, device=dev)
+            self.kernel_name = "frontend_tile_kernel + esim_voxel_kernel"
+            self.alg_bytes += src_bytes + b * n * h * w              # source crop regions read once + uint8 clips written once
+            consumer = None
+            if wl.get("consumer"):
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from e2vid_consumer import E2VIDShapedConsumer, forward_sequence
+                torch.manual_seed(0)
+                consumer = E2VIDShapedConsumer(num_bins=tb).to(dev).eval()
+                self.kernel_name += " + E2VID-shaped UNet forward (bf16 autocast)"
+
+            def step():
+                gray = frontend.prepare_clips_batch(raw, table_d, idx_d, h, "gray", validate=False, max_crop_before=cb_max)[1]
+                esim.esim_voxel_batch(gray, ptensor, bin_mode=bin_mode, num_bins=tb, frames_per_bin=fpb, rng_mode="philox",
+                                      seed=20240001, clip_id0=clip_id0, out=out, validate=False, no_noise=False)
+                if consumer is not None:
+                    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                        forward_sequence(consumer, out)
+        elif wl["model"] == "esim":
+            ptensor = torch.tensor(params, dtype=torch.float64, device=dev)
+            self.kernel_name = "esim_voxel_kernel"
+            no_noise = params[2] == 0 and params[3] <= 0
+
+            def step():
+                esim.esim_voxel_batch(frames, ptensor, bin_mode=bin_mode, num_bins=tb, frames_per_bin=fpb, rng_mode=wl.get("rng", "philox"),
+                                      seed=20240001, clip_id0=clip_id0, out=out, validate=False, no_noise=no_noise)
+        else:
+            from v2v_amd import v2e
+            vparams = v2e.make_params(*params)
+            self.kernel_name = "v2e_voxel_kernel (+ v2e_shot_sum_kernel pre-pass)"
+
+            def step():
+                v2e.v2e_voxel_batch(frames, vparams, bin_mode=bin_mode, num_bins=tb, frames_per_bin=fpb, rng_mode="philox",
+                                    seed=20240001, clip_id0=clip_id0, out=out)
+        self.step = step
+
+    def parity(self):
+        """Light guard outside the timed region: clip 0 AND the last clip of this rank against the C oracle."""
+        import numpy as np
+        from oracle import clib, v2v_oracle as O
+        wl = self.wl
+        bm = clib.BIN_BILINEAR if wl["bin"] == "bilinear" else clib.BIN_SUM
+        verdicts = []
+        for c in sorted({0, self.b - 1}):
+            host = self.frames[c:c + 1].cpu().numpy()
+            if wl["model"] in ("esim", "pipeline"):
+                want, _ = clib.esim_voxel(host, wl["params"], O.load_luts(), rng_mode=clib.RNG_PHILOX, seed=20240001,
+                                          clip_id0=self.clip_id0 + c, bin_mode=bm, num_bins=wl["tb"], frames_per_bin=wl["fpb"])
+            else:
+                want, _ = clib.v2e_voxel(host, clib.v2e_params(*wl["params"]), O.load_luts(), seed=20240001, clip_id0=self.clip_id0 + c,
+                                         bin_mode=bm, num_bins=wl["tb"], frames_per_bin=wl["fpb"])
+            got = self.out[c:c + 1].cpu().numpy().astype(np.float64)
+            if wl.get("rng") == "philox_fast":   # hardware-transcendental noise field: equal to 5e-5, not bit for bit
+                verdicts.append("statistical: |sum| ratio %.4f" % (np.abs(got).sum() / max(np.abs(want).sum(), 1e-9)))
+            else:
+                verdicts.append("ok" if np.allclose(got, want, rtol=1e-5, atol=1e-5) else "MISMATCH")
+        return verdicts[0] if len(set(verdicts)) == 1 else "; ".join(verdicts)
+
+    def free(self):
+        self.frames = self.out = self.raw = self.step = None
+
+
+def time_launches(step, steps, torch):
+    """Per-launch HIP events on the stream the kernels are launched on (torch's current stream)."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for s, e in ev:
+        s.record()
+        step()
+        e.record()
+    torch.cuda.synchronize()
+    return sorted(s.elapsed_time(e) for s, e in ev)
+
+
+def maybe_graph(step, torch, dev, want):
+    """Multi-launch steps (front-end + simulator [+ consumer]) are replayed from one captured hipGraph: the C-ABI entry
+    points only enqueue kernels on the caller's stream (no allocation, no synchronisation), so they capture as they are."""
+    if not want:
+        return step, False
+    try:
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        for _ in range(2):
+            graph.replay()
+        torch.cuda.synchronize()
+        return graph.replay, True
+    except Exception as exc:  # noqa: BLE001 - capture is an optimisation; fall back to eager launches
+        print(f"[bench] hipGraph capture unavailable ({type(exc).__name__}: {exc}); eager launches", file=sys.stderr, flush=True)
+        return step, False
+
+
+def load_traffic(name):
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # rocprofv3 --pmc passes, see profiles/README.md
+    try:
+        return json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def main():
@@ -147,6 +291,7 @@ def main():
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads of the default run")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses cuda:0 (tests the N>1 code path on a 1-GPU box)")
@@ -155,7 +300,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from v2v_amd import esim, sharding
+    from v2v_amd import sharding
     rank, local_rank, world = sharding.env_rank_world()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -166,201 +311,106 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = sharding.init_process_group(args.backend, dev)  # RCCL; used for the barrier + max-over-ranks only
+    backend = dist.get_backend() if dist is not None else None
 
-    wl = WORKLOADS[args.workload]
-    b = args.batch or wl["b"]
-    n, h, w, bin_mode, tb, fpb, params = wl["n"], wl["h"], wl["w"], wl["bin"], wl["tb"], wl["fpb"], wl["params"]
-    tdtype = getattr(torch, wl["dtype"])
-    shard = sharding.weak_shard(b, rank, world)            # batch shard: global clip ids, no exchange
-    clip_id0 = shard.lo
-    if wl["model"] == "pipeline":
-        import numpy as np
-        from v2v_amd import frontend
-        sh, sw = wl["src_hw"]
-        gray_video = esim.synth_clips(b, n, sh, sw, dtype=torch.uint8, seed=20240001, clip_id0=clip_id0, device=dev)
-        raw = gray_video.unsqueeze(-1).expand(b, n, sh, sw, 3).contiguous()              # decoded BGR frames [B,T,720,1280,3]
-        del gray_video
-        g = np.random.default_rng(20240001 + rank)
-        keep_h = int(sh * 0.54)                                                          # keep_top_percentile (v2v_datasets.py:73)
-        min_scale = max(0, h / keep_h, h / sw)
-        scale = g.uniform(min_scale, max(1.3, min_scale), size=b)                        # :260-272
-        cb = (h / scale).astype(np.int64)
-        table = np.stack([[g.integers(0, keep_h - c + 1), g.integers(0, sw - c + 1), c, int(g.random() > 0.5)] for c in cb]).astype(np.int32)
-        idx = np.tile(np.arange(n, dtype=np.int32), (b, 1))
-        table_d, idx_d = torch.as_tensor(table, device=dev), torch.as_tensor(idx, device=dev)
-        frames = frontend.prepare_clips_batch(raw, table_d, idx_d, h, "gray", validate=False, max_crop_before=int(cb.max()))[1]
-        src_bytes = int((cb.astype(np.int64) ** 2).sum()) * 3 * n
-    else:
-        frames = esim.synth_clips(b, n, h, w, dtype=tdtype, seed=20240001, clip_id0=clip_id0, device=dev)
-    shape = (b, (n - 1) // (tb * fpb), tb, h, w) if bin_mode == "sum" else (b, tb, h, w)
-    out = torch.empty(shape, dtype=torch.float32, device=dev)
-    alg_bytes = esim.algorithmic_bytes(tdtype, b, n, h, w, bin_mode, tb, fpb)
-    grids_per_step = b * (shape[1] if bin_mode == "sum" else 1)
-
-    if wl["model"] == "pipeline":
-        ptensor = torch.tensor(params, dtype=torch.float64, device=dev)
-        kernel_name = "frontend_kernel + esim_voxel_kernel"
-        alg_bytes += src_bytes + b * n * h * w                 # source crop regions read once + uint8 clips written once
-        consumer = None
-        if wl.get("consumer"):
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            from e2vid_consumer import E2VIDShapedConsumer, forward_sequence
-            torch.manual_seed(0)
-            consumer = E2VIDShapedConsumer(num_bins=tb).to(dev).eval()
-            kernel_name += " + E2VID-shaped UNet forward (bf16 autocast, stock PyTorch)"
-
-        def step():
-            gray = frontend.prepare_clips_batch(raw, table_d, idx_d, h, "gray", validate=False, max_crop_before=int(cb.max()))[1]
-            esim.esim_voxel_batch(gray, ptensor, bin_mode=bin_mode, num_bins=tb, frames_per_bin=fpb, rng_mode="philox",
-                                  seed=20240001, clip_id0=clip_id0, out=out, validate=False, no_noise=False)
-            if consumer is not None:
-                with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
-                    forward_sequence(consumer, out)
-    elif wl["model"] == "esim":
-        ptensor = torch.tensor(params, dtype=torch.float64, device=dev)
-        kernel_name = "esim_voxel_kernel"
-
-        def step():
-            esim.esim_voxel_batch(frames, ptensor, bin_mode=bin_mode, num_bins=tb, frames_per_bin=fpb, rng_mode=wl.get("rng", "philox"),
-                                  seed=20240001, clip_id0=clip_id0, out=out, validate=False,
-                                  no_noise=(params[2] == 0 and params[3] <= 0))
-    else:
-        from v2v_amd import v2e
-        vparams = v2e.make_params(*params)
-        kernel_name = "v2e_voxel_kernel (+ v2e_shot_sum_kernel pre-pass)"
-
-        def step():
-            v2e.v2e_voxel_batch(frames, vparams, bin_mode=bin_mode, num_bins=tb, frames_per_bin=fpb, rng_mode="philox",
-                                seed=20240001, clip_id0=clip_id0, out=out)
-
+    W = Workload(args.workload, dev, rank, world, args.batch)
+    wl = W.wl
+    step = W.step
     for _ in range(args.warmup):
         step()
-    # Multi-launch steps (front-end + simulator [+ consumer]) are replayed from one captured hipGraph: the C-ABI entry
-    # points only enqueue kernels on the caller's stream (no allocation, no synchronisation), so they capture as they are.
-    use_graph = args.hip_graph == "on" or (args.hip_graph == "auto" and wl["model"] == "pipeline")
-    if use_graph:
-        try:
-            torch.cuda.synchronize()
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                step()
-            step = graph.replay
-            for _ in range(2):
-                step()
-            torch.cuda.synchronize()
-        except Exception as exc:  # noqa: BLE001 - capture is an optimisation; fall back to eager launches
-            print(f"[bench] hipGraph capture unavailable ({type(exc).__name__}: {exc}); eager launches", file=sys.stderr, flush=True)
-            use_graph = False
+    step, use_graph = maybe_graph(step, torch, dev, args.hip_graph == "on" or (args.hip_graph == "auto" and wl["model"] == "pipeline"))
     sharding.barrier(dist, local_rank)
-    # per-launch HIP events on the stream the kernel is launched on (torch's current stream)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for s, e in ev:
-        s.record()
-        step()
-        e.record()
-    torch.cuda.synchronize()
+    kern_ms = time_launches(step, args.steps, torch)
     sharding.barrier(dist, local_rank)
     elapsed = sharding.max_over_ranks(dist, time.perf_counter() - t0, dev)
-    kern_ms = sorted(s.elapsed_time(e) for s, e in ev)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
 
-    # light parity guard outside the timed region (clip 0 of rank 0 against the C oracle) + the CPU baseline
+    # parity guard outside the timed region (first + last clip of rank 0 against the C oracle) + the CPU baseline
     parity = cpu = cpu_c = cpu_pool = None
     if rank == 0:
         try:
-            import numpy as np
-            from oracle import clib, v2v_oracle as O
+            from oracle import clib
             clib.build()
-            host = frames[:1].cpu().numpy()
-            bm = clib.BIN_BILINEAR if bin_mode == "bilinear" else clib.BIN_SUM
-            if wl["model"] in ("esim", "pipeline"):
-                want, _ = clib.esim_voxel(host, params, O.load_luts(), rng_mode=clib.RNG_PHILOX, seed=20240001,
-                                          clip_id0=clip_id0, bin_mode=bm, num_bins=tb, frames_per_bin=fpb)
-            else:
-                want, _ = clib.v2e_voxel(host, clib.v2e_params(*params), O.load_luts(), seed=20240001, clip_id0=clip_id0,
-                                         bin_mode=bm, num_bins=tb, frames_per_bin=fpb)
-            got = out[:1].cpu().numpy().astype(np.float64)
-            if wl.get("rng") == "philox_fast":   # different (hardware-transcendental) noise field: distributional parity only
-                parity = "statistical: |sum| ratio %.4f" % (np.abs(got).sum() / max(np.abs(want).sum(), 1e-9))
-            else:
-                parity = "ok" if np.allclose(got, want, rtol=1e-5, atol=1e-5) else "MISMATCH"
+            parity = W.parity()
             if world == 1 and not args.no_cpu_baseline:
-                sample = frames[: min(b, 256)].cpu().numpy()
+                sample = W.frames[: min(W.b, 256)].cpu().numpy()
                 cpu = cpu_baseline(sample, wl, budget_s=args.cpu_budget)
                 cpu_c = cpu_baseline_c(sample, wl)
                 try:
                     cpu_pool = cpu_baseline_pool(sample, wl)
                 except Exception as exc:  # noqa: BLE001 - secondary figure
                     cpu_pool = {"error": f"{type(exc).__name__}: {exc}"}
+                del sample
         except Exception as exc:  # the oracle is a checker; never let it take the measurement down
             parity = f"unchecked ({type(exc).__name__}: {exc})"
 
     # Secondary measurements on rank 0 at N=1, outside the timed region; never the headline value.
     also, host_input = None, None
-    if rank == 0 and world == 1 and args.workload == DEFAULT_WORKLOAD and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and args.workload == DEFAULT_WORKLOAD and not args.no_cpu_baseline and not args.no_also and not args.batch:
         try:
-            def timed(fn, reps=10):
-                fn()
-                torch.cuda.synchronize()
-                a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a_.record()
-                for _ in range(reps):
-                    fn()
-                b_.record()
-                torch.cuda.synchronize()
-                return a_.elapsed_time(b_) / reps
-            noisy = torch.tensor([0.2, 0.2, 0.05, 5e-4, 1.0], dtype=torch.float64, device=dev)
-            also = {}
-            for tag, mode in (("noise_on_exact_rng", "philox"), ("noise_on_fast_rng", "philox_fast")):
-                ms = timed(lambda: esim.esim_voxel_batch(frames, noisy, bin_mode=bin_mode, num_bins=tb, frames_per_bin=fpb,
-                                                         rng_mode=mode, seed=20240001, clip_id0=clip_id0, out=out, validate=False))
-                also[tag] = {"ms_per_launch": ms, "grids_per_s": grids_per_step / (ms * 1e-3), "sim_params": [0.2, 0.2, 0.05, 5e-4, 1.0]}
             # host-resident input: the boundary takes device pointers, so a host pipeline pays the PCIe copy first
-            n_host = min(b, 32)
-            host_batch = frames[:n_host].cpu()
+            n_host = min(W.b, 32)
+            host_batch = W.frames[:n_host].cpu()
             t_h = time.perf_counter()
             dev_copy = host_batch.to(dev)
             torch.cuda.synchronize()
             h2d_s = time.perf_counter() - t_h
             h2d_gbps = host_batch.numel() * host_batch.element_size() / h2d_s / 1e9
-            per_batch_s = b * n * h * w * frames.element_size() / (h2d_gbps * 1e9) + kern_avg_ms * 1e-3
-            host_input = {"h2d_GBps_pageable": h2d_gbps, "pcie_inclusive_grids_per_s": grids_per_step / per_batch_s,
+            per_batch_s = W.frames.numel() * W.frames.element_size() / (h2d_gbps * 1e9) + kern_avg_ms * 1e-3
+            pinned = host_batch.pin_memory()
+            t_h = time.perf_counter()
+            dev_copy = pinned.to(dev, non_blocking=True)
+            torch.cuda.synchronize()
+            pin_gbps = host_batch.numel() * host_batch.element_size() / (time.perf_counter() - t_h) / 1e9
+            host_input = {"h2d_GBps_pageable": h2d_gbps, "h2d_GBps_pinned": pin_gbps,
+                          "pcie_inclusive_grids_per_s": W.grids_per_step / per_batch_s,
                           "note": "pageable host memory, copy then launch, no overlap; reported for context, never `value`"}
-            del dev_copy, host_batch
-        except Exception as exc:
-            also = {"error": f"{type(exc).__name__}: {exc}"}
+            del dev_copy, host_batch, pinned
+        except Exception as exc:  # noqa: BLE001
+            host_input = {"error": f"{type(exc).__name__}: {exc}"}
+        also = {}
+        for name in ALSO_MEASURED:
+            try:
+                S = Workload(name, dev, 0, 1)
+                for _ in range(3):
+                    S.step()
+                s_step, s_graph = maybe_graph(S.step, torch, dev, S.wl["model"] == "pipeline")
+                ms = time_launches(s_step, 12, torch)
+                avg = sum(ms) / len(ms)
+                ach = S.alg_bytes / (avg * 1e-3) / 1e9
+                also[name] = {"kernel": S.kernel_name, "kernel_ms_avg": avg, "kernel_ms_p50": ms[len(ms) // 2], "grids_per_s": S.grids_per_step / (avg * 1e-3),
+                              "algorithmic_bytes_per_launch": S.alg_bytes, "achieved_GBps": ach, "frac_of_hbm_peak": ach / HBM_PEAK_GBPS,
+                              "traffic_bytes_per_launch": load_traffic(name), "sim_params": S.wl["params"], "input_dtype": S.wl["dtype"],
+                              "bin_mode": S.wl["bin"], "launch": "hipGraph replay" if s_graph else "eager", "parity_check": S.parity()}
+                S.free()
+                del S, s_step
+                torch.cuda.empty_cache()
+            except Exception as exc:  # noqa: BLE001 - a secondary figure must not take the headline down
+                also[name] = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # rocprofv3 --pmc pass, see profiles/README.md
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
+        achieved = W.alg_bytes / (kern_avg_ms * 1e-3) / 1e9
         line = {
-            "metric": "voxel grids/sec", "value": grids_per_step * world * args.steps / elapsed, "unit": "voxel grids/s",
+            "metric": "voxel grids/sec", "value": W.grids_per_step * world * args.steps / elapsed, "unit": "voxel grids/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": args.workload, "model": wl["model"], "clips_per_gpu": b, "frames": n, "height": h, "width": w,
-                       "input_dtype": wl["dtype"], "bin_mode": bin_mode, "num_bins": tb, "frames_per_bin": fpb,
-                       "sim_params": params, "rng": "philox4x32-10 on device",
-                       "sharding": f"batch over {world} GPU(s), no collective", "grid": [tb, h, w],
+            "data": "synthetic", "dist_backend": backend,
+            "config": {"workload": args.workload, "model": wl["model"], "clips_per_gpu": W.b, "frames": wl["n"], "height": wl["h"], "width": wl["w"],
+                       "input_dtype": wl["dtype"], "output_dtype": "float32", "state_dtype": "float64 (potential, floor-divide)",
+                       "bin_mode": wl["bin"], "num_bins": wl["tb"], "frames_per_bin": wl["fpb"],
+                       "sim_params": wl["params"], "sim_params_note": "pos_thres, neg_thres, base_noise_std, hot_pixel_fraction, hot_pixel_std"
+                       + (" = EventEmulator() constructor defaults of the reference (noise on)" if wl["params"] == REF_DEFAULTS else ""),
+                       "rng": "philox4x32 on device (10 rounds per-clip fields, 7 rounds per-step noise fields)",
+                       "sharding": f"batch over {world} GPU(s), no collective", "grid": [wl["tb"], wl["h"], wl["w"]],
                        "launch": "hipGraph replay" if use_graph else "eager"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": kernel_name, "algorithmic_bytes_per_launch": alg_bytes,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(args.workload),
+                         "kernel": W.kernel_name, "algorithmic_bytes_per_launch": W.alg_bytes,
                          "measured_ceilings_GBps": MEASURED_CEILINGS_GBPS,
                          "kernel_ms_avg": kern_avg_ms, "kernel_ms_p10": kern_ms[len(kern_ms) // 10],
-                         "kernel_ms_p50": kern_ms[len(kern_ms) // 2], "kernel_ms_p90": kern_ms[(len(kern_ms) * 9) // 10]},
+                         "kernel_ms_p50": kern_ms[len(kern_ms) // 2], "kernel_ms_p90": kern_ms[(len(kern_ms) * 9) // 10],
+                         "note": "noise-on launches are VALU-issue-bound, not HBM-bound (DESIGN.md §4.1); `frac` is still quoted against the HBM peak"},
             "cpu_baseline": cpu,
             "cpu_baseline_numpy_pool": cpu_pool,
             "cpu_baseline_c_omp": cpu_c,

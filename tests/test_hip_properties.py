@@ -70,6 +70,34 @@ def test_bench_contract_json():
     assert abs(d["value"] - 8 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
 
 
+def test_bench_two_ranks_under_torch_distributed_run():
+    """The N > 1 path exactly as the driver launches it -- `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`
+    -- on this 1-GPU box: both ranks share cuda:0 (--share-gpu) and rendezvous over gloo (RCCL refuses two ranks on one
+    device).  Checks the JSON contract for N = 2: one line from rank 0, n_gpus 2, the backend that really ran, global clip ids
+    per rank, an aggregate of BOTH ranks' grids."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "16",
+           "--share-gpu", "--backend", "gloo"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dist_backend"] == "gloo" and d["scaling"] == "weak" and d["steps"] == 4
+    assert d["config"]["clips_per_gpu"] == 16 and "2 GPU(s)" in d["config"]["sharding"]
+    assert d["parity_check"] == "ok" and d["cpu_baseline"] is None and d["also_measured"] is None      # rank-0-at-N=1 extras stay off
+    assert abs(d["value"] - 2 * 16 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-6                 # whole-job aggregate over both ranks
+    single = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--batch", "16",
+                             "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    s1 = json.loads([l for l in single.stdout.splitlines() if l.startswith("{")][0])
+    assert s1["dist_backend"] is None and 0.3 < d["value"] / s1["value"] < 2.5                          # two ranks on ONE device: ~1x, never 0
+
+
 def test_shapes_at_the_edges_vs_oracle(oracle_c, luts):
     """The reference's training shape (201 frames, 128x128, 40x5 bins), an odd-sized frame (scalar path, 101x203),
     and many tiny clips in one launch -- all bit-exact against the scalar C oracle."""

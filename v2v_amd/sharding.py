@@ -49,9 +49,10 @@ def env_rank_world():
 def init_process_group(backend: str | None = None, device: torch.device | None = None):
     """One process per GPU, launched by torch.distributed.run; returns the module or None for world size 1.
 
-    The data path never communicates, so the process group only serves the barrier and the max-over-ranks of the
-    timing: if RCCL cannot be brought up (driver/IPC problems) the group silently falls back to gloo rather than
-    losing the measurement."""
+    The data path never communicates: the process group only serves the barrier and the max-over-ranks of the timing.
+    The backend is the one asked for ("nccl" == RCCL on a GPU box, "gloo" for CPU dry runs) on EVERY rank or the call
+    raises: a rank that quietly fell back to another backend would leave its peers waiting inside an RCCL collective
+    until the timeout.  Callers record `dist.get_backend()` next to their results."""
     _, _, world = env_rank_world()
     if world <= 1:
         return None
@@ -63,19 +64,14 @@ def init_process_group(backend: str | None = None, device: torch.device | None =
         return dist
     if backend == "nccl":
         try:
-            try:
-                dist.init_process_group(backend="nccl", device_id=device)
-            except TypeError:                      # older torch: no device_id argument
-                dist.init_process_group(backend="nccl")
-            probe = torch.zeros(1, device=device if device is not None else "cuda")
-            dist.all_reduce(probe)                 # forces communicator creation now, not inside the timed region
-            torch.cuda.synchronize()
-            return dist
-        except Exception as exc:                   # noqa: BLE001 - any RCCL bring-up failure
-            print(f"[v2v_amd.sharding] RCCL unavailable ({type(exc).__name__}: {exc}); using gloo for the barrier", flush=True)
-            if dist.is_initialized():
-                dist.destroy_process_group()
-    dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="nccl", device_id=device)
+        except TypeError:                          # older torch: no device_id argument
+            dist.init_process_group(backend="nccl")
+        probe = torch.zeros(1, device=device if device is not None else "cuda")
+        dist.all_reduce(probe)                     # forces communicator creation now, not inside a timed region; raises on failure
+        torch.cuda.synchronize()
+        return dist
+    dist.init_process_group(backend=backend)
     return dist
 
 
