@@ -48,9 +48,9 @@ typedef enum v2v_rng_mode {
                         /* do not depend on batch size or on how the batch is sharded over GPUs        */
     V2V_RNG_REPLAY = 2, /* caller supplies the fields (e.g. drawn from np.random in the reference's    */
                         /* order): bit-exact replay of a reference run                                 */
-    V2V_RNG_PHILOX_FAST = 3 /* ESIM only: like PHILOX, but the per-pair base-noise Gaussians come from   */
-                        /* Philox4x32-7 + hardware log/sqrt/sin/cos (not reproducible on a CPU): same     */
-                        /* distribution, ~4x cheaper noise; parity for this mode is statistical          */
+    V2V_RNG_PHILOX_FAST = 3 /* accepted as an alias of V2V_RNG_PHILOX: the exact generator (one Philox word per */
+                        /* Box-Muller pair, packed float32 polynomials) runs as fast as the round-1 variant on */
+                        /* the hardware transcendental units did, so that non-reproducible variant is gone      */
 } v2v_rng_mode;
 
 typedef enum v2v_bin_mode {

@@ -115,6 +115,14 @@ def poisson_inv_f32(lam, u):
     return out
 
 
+def bgr_to_gray(img):
+    """data/v2v_datasets.py:19-22 on a [...,3] uint8 stack, in NumPy's own evaluation order (golden G15)."""
+    img = np.ascontiguousarray(img[..., :3], dtype=np.uint8)
+    out = np.empty(img.shape[:-1], dtype=np.uint8)
+    lib().oracle_bgr_to_gray(_p(img), C.c_int64(out.size), _p(out))
+    return out
+
+
 def esim_voxel(frames, params, luts, *, noise_external=False, rng_mode=RNG_PHILOX, seed=0, clip_id0=0,
                bin_mode=BIN_SUM, num_bins=5, frames_per_bin=1, replay=None, threads=None):
     """frames [B,N,H,W] uint8 or float32 (integer-valued); params [5] or [B,5].

@@ -9,8 +9,7 @@ golden vectors exist.  What is restated below is OpenCV's published 8-bit algori
 float source coordinate (dx+0.5)*scale-0.5, 11-bit fixed-point weights, two-pass int32 accumulation with the
 (>>4, >>16, +2, >>2) vertical rounding; exact 2x2 box average when both scales are exactly 2; color.cpp: BGR2GRAY
 with 14-bit coefficients 1868/9617/4899).  bgr_to_gray (np.dot + truncation, v2v_datasets.py:19-22) is the reference's
-own NumPy code; its BLAS summation order is not a fixed scalar formula, so it is restated as
-multiply-add left to right and agrees with np.dot on all but ~1e-5 of colours.
+own NumPy code and IS pinned: golden G15 holds its output on all 2^24 colours (see bgr_to_gray_scalar).
 """
 from __future__ import annotations
 
@@ -68,9 +67,11 @@ def cv_bgr2gray_u8(img: np.ndarray) -> np.ndarray:
 
 
 def bgr_to_gray_scalar(img: np.ndarray) -> np.ndarray:
-    """v2v_datasets.py:19-22 as a scalar formula: float64 multiply-add left to right, truncating cast."""
-    b, g, r = (img[..., k].astype(np.float64) for k in range(3))
-    return ((b * 0.5870 + g * 0.1140) + r * 0.2989).astype(np.uint8)
+    """v2v_datasets.py:19-22 as a scalar formula.  np.dot on the reference's 4-D stack evaluates
+    fma(r, w2, fma(g, w1, b * w0)) in float64 (OpenBLAS ddot: sequential FMA accumulation); pinned over all 2^24 colours by
+    golden G15.  NumPy has no fma, so the formula lives in the C oracle."""
+    from oracle import clib
+    return clib.bgr_to_gray(img)
 
 
 def frontend(raw, crop_before, min_i, min_j, flip, crop_size, img_idxes, all_di=None, all_dj=None, color_mode="gray"):

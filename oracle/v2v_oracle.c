@@ -638,6 +638,21 @@ int oracle_v2e_voxel_batch(const void *frames, int in_dtype, int64_t B, int64_t 
     return rc;
 }
 
+/* ------------------------------------------------------------------ bgr_to_gray (data/v2v_datasets.py:19-22) */
+/* gray = np.dot(img[..., :3], [0.5870, 0.1140, 0.2989]).astype(uint8).  For the 3-D / 4-D stacks the reference passes, NumPy
+ * 2.2.6 (OpenBLAS 0.3.29 ddot: sequential FMA accumulation over the 3 channels) evaluates
+ *     fma(r, w2, fma(g, w1, b * w0))            -- b, g, r = channels 0, 1, 2
+ * which golden G15 (the reference's own function on all 2^24 colours) pins bit for bit.  (A 2-D [M,3] array goes through
+ * dgemv and a different order, fma(r, w2, fma(b, w0, g * w1)); the reference never passes one.) */
+void oracle_bgr_to_gray(const uint8_t *bgr, int64_t n_pix, uint8_t *gray)
+{
+    for (int64_t i = 0; i < n_pix; ++i) {
+        const double b = bgr[3 * i], g = bgr[3 * i + 1], r = bgr[3 * i + 2];
+        const double v = fma(r, 0.2989, fma(g, 0.1140, b * 0.5870));
+        gray[i] = (uint8_t)v;                     /* truncating cast of a value in [0, 255) */
+    }
+}
+
 /* ------------------------------------------------------------------ make_voxel (testh5.py:60-90) */
 /* ts_us: int64 microseconds already shifted to ts[0]=0 (the Python side does the float math that
  * the reference does in numpy: ((ts-ts[0])*1e6).astype(int64)); ps01 in {0,1}. out [Tb,H,W] float64. */

@@ -365,10 +365,23 @@ def g14_v2e_native():
     save("g14_v2e_native.npz", **out)
 
 
+def g15_bgr_to_gray():
+    """The reference's bgr_to_gray (data/v2v_datasets.py:19-22) on ALL 2^24 colours, passed as the 4-D [N,H,W,3] stack the
+    reference passes (np.dot's evaluation order depends on the array's dimensionality): sha256 of the full [256,256,256]
+    table (index b, g, r) + four b-planes for debugging."""
+    import hashlib
+    b, g, r = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")
+    stack = np.stack([b, g, r], axis=-1)                      # [256,256,256,3]
+    gray = ref_ds.bgr_to_gray(stack)
+    assert gray.dtype == np.uint8 and gray.shape == (256, 256, 256)
+    save("g15_bgr_to_gray.npz", sha256=np.array(hashlib.sha256(gray.tobytes()).hexdigest()), planes_b=np.array([0, 37, 128, 255]),
+         planes=gray[[0, 37, 128, 255]])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14", "g15"]
     fns = {"g1": g1_luts, "g2": g2_g3_esim_clean, "g4": g4_esim_noisy, "g5": g5_floor_divide,
-           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g12": g12_events_to_voxel_torch,
+           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g15": g15_bgr_to_gray, "g12": g12_events_to_voxel_torch,
            "g13": g13_normalize_batch_voxel}
     for w in which:
         fns[w]()

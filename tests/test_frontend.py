@@ -19,11 +19,36 @@ def test_oracle_resize_properties():
     assert np.array_equal(box, ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8))
 
 
-def test_oracle_gray_matches_reference_numpy_on_samples():
-    g = np.random.default_rng(1)
-    im = g.integers(0, 256, size=(8, 64, 64, 3), dtype=np.uint8)
+def _all_colours():
+    b, g, r = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")
+    return np.stack([b, g, r], axis=-1)                                          # [256,256,256,3], index (b, g, r)
+
+
+def test_oracle_bgr_to_gray_equals_reference_on_all_colours(golden):
+    """bgr_to_gray (v2v_datasets.py:19-22) is byte work: exact.  The restated order fma(r,w2, fma(g,w1, b*w0)) against golden G15
+    = the reference's function on all 2^24 colours; and against this host's own np.dot on the same 4-D stack."""
+    import hashlib
+    g15 = golden("g15_bgr_to_gray.npz")
+    got = F.bgr_to_gray_scalar(_all_colours())
+    assert hashlib.sha256(got.tobytes()).hexdigest() == str(g15["sha256"])
+    assert np.array_equal(got[g15["planes_b"]], g15["planes"])
+    im = np.random.default_rng(1).integers(0, 256, size=(8, 64, 64, 3), dtype=np.uint8)
     ref = np.dot(im[..., :3], [0.5870, 0.1140, 0.2989]).astype(np.uint8)      # the reference's own line (v2v_datasets.py:21)
-    assert np.count_nonzero(ref != F.bgr_to_gray_scalar(im)) <= max(1, int(2e-5 * ref.size))
+    assert np.array_equal(ref, F.bgr_to_gray_scalar(im))
+
+
+@pytest.mark.gpu
+def test_hip_bgr_to_gray_equals_reference_on_all_colours(golden):
+    """The GPU front-end's gray_in_bgr_out conversion on an image holding every one of the 2^24 colours (identity resize)."""
+    import hashlib
+    import torch
+    from v2v_amd import frontend
+    g15 = golden("g15_bgr_to_gray.npz")
+    img = _all_colours().reshape(1, 4096, 4096, 3)
+    _, gray = frontend.prepare_clip(torch.from_numpy(img).cuda(), 4096, 0, 0, False, 4096, [0], color_mode="gray_in_bgr_out")
+    got = gray.cpu().numpy().reshape(256, 256, 256)
+    assert np.array_equal(got[g15["planes_b"]], g15["planes"])
+    assert hashlib.sha256(got.tobytes()).hexdigest() == str(g15["sha256"])
 
 
 @pytest.mark.gpu

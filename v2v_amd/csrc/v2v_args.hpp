@@ -7,7 +7,7 @@
 namespace v2v {
 
 enum { kInU8 = 0, kInF32 = 1 };
-enum { kRngNone = 0, kRngPhilox = 1, kRngReplay = 2, kRngPhiloxFast = 3 };
+enum { kRngNone = 0, kRngPhilox = 1, kRngReplay = 2 };
 enum { kBinSum = 0, kBinBilinear = 1 };
 constexpr int kBlock = 256;
 

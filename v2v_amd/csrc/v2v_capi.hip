@@ -115,6 +115,7 @@ int v2v_esim_voxel_keyed_hip(const void *frames, int in_dtype, int64_t B, int64_
     if (params_stride != 0 && params_stride < 5) return fail(V2V_ERR_PARAM, "params_stride must be 0 or >= 5");
     if (num_bins < 1 || frames_per_bin < 1) return fail(V2V_ERR_PARAM, "num_bins and frames_per_bin must be >= 1");
     if (rng_mode < V2V_RNG_NONE || rng_mode > V2V_RNG_PHILOX_FAST) return fail(V2V_ERR_MODE, "unknown rng_mode %d", rng_mode);
+    if (rng_mode == V2V_RNG_PHILOX_FAST) rng_mode = V2V_RNG_PHILOX;             // alias (see the header)
     if (rng_mode == V2V_RNG_REPLAY && (!replay || !replay->u_init || !replay->u_hot || !replay->g_hot || !replay->g_base))
         return fail(V2V_ERR_MODE, "rng_mode REPLAY needs all four replay fields");
     if (bin_mode == V2V_BIN_SUM) {
@@ -162,7 +163,6 @@ int v2v_esim_voxel_keyed_hip(const void *frames, int in_dtype, int64_t B, int64_
     const dim3 grid((unsigned)nblocks);
     const bool out64 = out_dtype == V2V_F64;
     const bool noise = !(flags & V2V_FLAG_NO_NOISE);
-    if (!noise && rng_mode == V2V_RNG_PHILOX_FAST) rng_mode = V2V_RNG_PHILOX;   // no Gaussians drawn: the modes coincide
     if (!noise && (flags & V2V_FLAG_NOISE_EXTERNAL)) return fail(V2V_ERR_PARAM, "V2V_FLAG_NO_NOISE and V2V_FLAG_NOISE_EXTERNAL are exclusive");
     if (!noise && rng_mode == V2V_RNG_REPLAY) return fail(V2V_ERR_PARAM, "V2V_FLAG_NO_NOISE is not available in replay mode");
     const size_t lds = 256 * (in_dtype == V2V_U8 ? sizeof(double) : sizeof(float)) +

@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
     double hot[NOISE ? VEC : 1];
     {
         double u0[VEC];
-        if constexpr (RNG == kRngPhilox || RNG == kRngPhiloxFast) {
+        if constexpr (RNG == kRngPhilox) {
             field_uniform53<VEC>(seed_, clip_id, kFieldPotInit, kStreamEsim, p0, u0);
         } else if constexpr (RNG == kRngReplay) {
 #pragma unroll
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
         if constexpr (NOISE) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) hot[j] = 0.0;
-            if constexpr (RNG == kRngPhilox || RNG == kRngPhiloxFast) {
+            if constexpr (RNG == kRngPhilox) {
                 if (hot_frac > 0.0) {                                  // uniform: skipping is exact (u >= 0)
                     double u1[VEC];
                     float gh[VEC], gh_unused[VEC];
@@ -254,12 +254,11 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
         if constexpr (NOISE) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) base[j] = 0.0;
-            if constexpr (RNG == kRngPhilox || RNG == kRngPhiloxFast) {
+            if constexpr (RNG == kRngPhilox) {
                 if (has_base) {                                        // uniform (scalar); 0*g adds nothing
                     float g[VEC];
                     if constexpr (PAR == 0) {
-                        if constexpr (RNG == kRngPhiloxFast) field_gauss_pairs_fast<VEC>(seed_, clip_id, kFieldBase0 + (uint32_t)(k >> 1), kStreamEsim, p0, g, g_pend);
-                        else field_gauss_pairs<VEC, kNoiseRounds>(seed_, clip_id, kFieldBase0 + (uint32_t)(k >> 1), kStreamEsim, p0, g, g_pend);
+                        field_gauss_pairs<VEC, kNoiseRounds>(seed_, clip_id, kFieldBase0 + (uint32_t)(k >> 1), kStreamEsim, p0, g, g_pend);
                     } else {
 #pragma unroll
                         for (int j = 0; j < VEC; ++j) g[j] = g_pend[j];

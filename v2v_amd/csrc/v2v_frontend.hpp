@@ -141,9 +141,12 @@ __global__ void __launch_bounds__(256) frontend_kernel(const FrontendArgs a_in)
         }
         if (a.out_imgs) for (int c = 0; c < a.Cout; ++c) a.out_imgs[(obase + j) * a.Cout + c] = (uint8_t)vals[c];
         int gray = vals[0];
-        if (a.Cout == 3) {                                   // bgr_to_gray (v2v_datasets.py:19-22): float64, truncating cast
-            const double s01 = (double)vals[0] * 0.5870 + (double)vals[1] * 0.1140;
-            gray = (int)(uint8_t)(s01 + (double)vals[2] * 0.2989);
+        if (a.Cout == 3) {
+            // bgr_to_gray (v2v_datasets.py:19-22): np.dot on the reference's [N,H,W,3] stack accumulates the three channels
+            // with sequential float64 FMAs -- fma(r, w2, fma(g, w1, b*w0)) -- then truncates; bit-exact on all 2^24 colours
+            // (golden G15, tests/test_frontend.py)
+            const double s = __builtin_fma((double)vals[1], 0.1140, (double)vals[0] * 0.5870);
+            gray = (int)(uint8_t)__builtin_fma((double)vals[2], 0.2989, s);
         }
         packed |= (uint32_t)(gray & 0xFF) << (8 * j);
     }

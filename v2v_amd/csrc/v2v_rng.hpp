@@ -170,39 +170,4 @@ __device__ __forceinline__ void field_gauss_pairs(uint64_t seed, uint32_t clip, 
     }
 }
 
-// ---- fast (non bit-reproducible on a CPU) Gaussian pairs: V2V_RNG_PHILOX_FAST -----------------------------------
-// The SAME Philox words, radius and angle grids as the exact generator, but Box-Muller on the hardware transcendental
-// units (v_log_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32, ~1 ulp, not IEEE-exact): the field equals the exact one to
-// ~1e-5 absolute, but not bit for bit, so a CPU cannot reproduce the event counts exactly; parity for this mode is
-// "same field to 5e-5" + distributional (tests/test_hip_fast_noise.py).
-__device__ __forceinline__ void gauss16_fast(uint32_t w, float &g0, float &g1)
-{
-    const float u1 = ((float)(w >> 16) + 0.5f) * 1.52587890625e-05f;                  // (0,1)
-    const float rev = ((float)(w & 0xFFFFu) + 0.5f) * 1.52587890625e-05f - 0.5f;     // (-1/2,1/2) revolutions = 2x / 2pi
-    const float r = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1), log2 based
-    g0 = r * __builtin_amdgcn_cosf(rev);
-    g1 = r * __builtin_amdgcn_sinf(rev);
-}
-
-template <int VEC>
-__device__ __forceinline__ void field_gauss_pairs_fast(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream,
-                                                       uint32_t p0, float (&ga)[VEC], float (&gb)[VEC])
-{
-    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    if constexpr (VEC == 1) {
-        const u32x4 w = philox4x32<kNoiseRounds>(p0 >> 2, field, clip, stream, k0, k1);
-        const uint32_t j = p0 & 3u;
-        gauss16_fast(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, ga[0], gb[0]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < VEC; j += 4) {
-            const u32x4 w = philox4x32<kNoiseRounds>((p0 + j) >> 2, field, clip, stream, k0, k1);
-            gauss16_fast(w.x, ga[j], gb[j]);
-            gauss16_fast(w.y, ga[j + 1], gb[j + 1]);
-            gauss16_fast(w.z, ga[j + 2], gb[j + 2]);
-            gauss16_fast(w.w, ga[j + 3], gb[j + 3]);
-        }
-    }
-}
-
 }  // namespace v2v

@@ -61,18 +61,44 @@ def sample_sim_params(threshold_range, max_thres_pos_neg_gap, base_noise_std_ran
             "hot_pixel_fraction": hot_pixel_fraction, "hot_pixel_std": hot_pixel_std}
 
 
+def draw_sim_seed() -> int:
+    """Seed half of the device RNG key of one sample: 62 bits from the global np.random stream (a power-of-two range: exactly
+    one 64-bit draw, no rejection loop).  With the sample index as the other half of the key, two samples share their noise
+    fields only if both halves collide (a 31-bit seed alone collided about twice per 1e5 samples)."""
+    return int(np.random.randint(0, 2**62, dtype=np.int64))
+
+
+def synthetic_frame_source(dataset, sample_idx, start_frame, end_frame, crop_size_before_resize, min_i, min_j, flip, need_h, need_w):
+    """A `frame_source` without OpenCV or video files: a smooth random-walk video that is a pure function of the clip's first
+    frame index (its own generator; the global np.random stream is untouched).  Module-level, hence picklable: usable with
+    spawned DataLoader workers and by the tests / synthetic end-to-end runs."""
+    g = np.random.default_rng(1000 + start_frame)
+    c = 3 if dataset.color_mode == "gray_in_bgr_out" else 1
+    base = g.uniform(0, 255, size=(need_h, need_w, c))
+    out = []
+    for _ in range(end_frame - start_frame):
+        base = np.clip(base + g.normal(0, 6, size=base.shape), 0, 255)
+        f = base.astype(np.uint8)
+        out.append((f[:, ::-1] if flip else f).copy())
+    return out
+
+
 class WebvidDatasetV2(torch.utils.data.Dataset):
     """Same constructor, config keys, defaults, `__len__`, `__getitem__` contract as the reference class.
 
     Extra (optional) config keys understood by this implementation only:
-        sim_rng        'philox' (default; device RNG keyed by a seed drawn from np.random per sample), 'philox_fast'
-                       (same, noise Gaussians from the hardware transcendental units: ~30 % faster noisy launches,
-                       distributional parity only) or 'numpy' (fields drawn on the host from the global stream in
-                       the reference's order: bit-exact replay)
+        sim_rng        'philox' (default; device RNG keyed by {a 62-bit seed drawn from np.random per sample, sample_idx} --
+                       ONE extra global draw per sample compared with the reference, so the crop/scale/pause draws of
+                       later samples differ from a reference run with the same np.random seed; only 'numpy' reproduces the
+                       reference's stream), 'philox_fast' (alias of 'philox' since round 2) or 'numpy' (fields drawn on
+                       the host from the global stream in the reference's order: bit-exact replay)
         sim_device     device of the simulator launch, default 'cuda'
         output_device  'cpu' (default: what default_collate / pin_memory expect) or 'cuda' (skip the round trip)
-        frame_source   callable(dataset, sample_idx, start_frame, end_frame, crop_size_before_resize, min_i, min_j,
-                       flip) -> list of [H,W,C] uint8 frames; replaces OpenCV decoding (tests, synthetic benches)
+        frame_source   callable(dataset, sample_idx, start_frame, end_frame, crop_size_before_resize, min_i, min_j, flip,
+                       need_h, need_w) -> list of end_frame - start_frame uint8 frames ALREADY cropped, resized to
+                       [need_h, need_w, C] and flipped (need_* = crop_size + the shake margin; C = 1 for color_mode
+                       'gray', 3 for 'gray_in_bgr_out'); replaces OpenCV decoding (tests, synthetic benches).  Must be
+                       picklable (a module-level function) when DataLoader workers are spawned; see synthetic_frame_source
         video_size     (width, height) reported for every video when frame_source is used
     """
 
@@ -269,8 +295,9 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
                                      all_dj if shake else None, self.color_mode, want_imgs=self.color_mode != "gray")
 
     # ------------------------------------------------------------------ the hot path
-    def imgs_to_voxels(self, imgs, num_bins, frames_per_bin, FPS, pos_thres=None, neg_thres=None):
+    def imgs_to_voxels(self, imgs, num_bins, frames_per_bin, FPS, pos_thres=None, neg_thres=None, *, clip_id: int = 0):
         """[N,H,W] uint8 -> (v2e_params dict, [L,num_bins,H,W] voxels).  v2v_datasets.py:363-410.
+        clip_id (this implementation only): second half of the device RNG key; __getitem__ passes the sample index.
 
         Returns a float64 ndarray like the reference when `imgs` is a NumPy array, a float32 CUDA tensor when it is
         a CUDA tensor.  Same AssertionError when (N-1) % (num_bins*frames_per_bin) != 0."""
@@ -291,8 +318,8 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
             vox = esim.esim_voxel_batch(frames[None], plist, rng_mode="replay",
                                         replay=[torch.from_numpy(f)[None] for f in fields], **kw)[0]
         else:
-            seed = int(np.random.randint(0, 2**31 - 1))          # worker seeding / fixed_seed still govern the noise
-            vox = esim.esim_voxel_batch(frames[None], plist, rng_mode=self.sim_rng, seed=seed, **kw)[0]
+            seed = draw_sim_seed()                               # worker seeding / fixed_seed still govern the noise
+            vox = esim.esim_voxel_batch(frames[None], plist, rng_mode=self.sim_rng, seed=seed, clip_id0=int(clip_id), **kw)[0]
         return params, (vox.cpu().numpy() if is_np else vox)
 
     # ------------------------------------------------------------------ sample assembly
@@ -352,12 +379,12 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
             v2e_params = sample_sim_params(self.threshold_range, self.max_thres_pos_neg_gap, self.base_noise_std_range,
                                            self.hot_pixel_fraction_range, self.hot_pixel_std_range, self.use_fixed_thresholds,
                                            pos, neg, self.scale_noise_strength, self.put_noise_external)
-            sim_seed = int(np.random.randint(0, 2**31 - 1))       # same draw order as imgs_to_voxels(sim_rng='philox')
+            sim_seed = draw_sim_seed()                            # same draw order as imgs_to_voxels(sim_rng='philox')
             voxels = None
         else:
             dev = torch.device(self.sim_device)
             gray_d = gray if isinstance(gray, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(gray)).to(dev)
-            v2e_params, voxels = self.imgs_to_voxels(gray_d, self.num_bins, self.frames_per_bin, 24, pos, neg)   # [L(+1),Tb,H,W] f32
+            v2e_params, voxels = self.imgs_to_voxels(gray_d, self.num_bins, self.frames_per_bin, 24, pos, neg, clip_id=sample_idx)   # [L(+1),Tb,H,W] f32
         if self.output_additional_evs:
             all_imgs = all_imgs[self.frames_per_img:]
         if not self.output_additional_frame:
@@ -379,7 +406,7 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
                 "frame": frames.contiguous(),
                 "sim_frames": torch.from_numpy(np.ascontiguousarray(gray)),                            # uint8 [N,H,W]
                 "sim_params": torch.tensor([v2e_params[k] for k in keys], dtype=torch.float64),
-                "sim_key": torch.tensor([sim_seed, 0], dtype=torch.int64),
+                "sim_key": torch.tensor([sim_seed, int(sample_idx)], dtype=torch.int64),
                 "data_source_idx": torch.tensor(self.data_source_idx),
                 "v2e_params": v2e_params,
             }
