@@ -218,6 +218,15 @@ int v2v_normalize_pad_hip(const float *voxel, int64_t B, int64_t planes, int64_t
 int v2v_events_to_voxel_f32_hip(const float *ts, const int64_t *xs, const int64_t *ys, const float *ps, int64_t n, int discrete,
                                 int num_bins, int64_t H, int64_t W, float *out_voxel, uint64_t *dropped, void *stream);
 
+/* Segmented form of the float32 twin: every "between frames" voxel grid of a Monash-format sequence in ONE launch.
+ * Replaces the per-index loop of scripts/esim_to_voxel.py:29-36 over DynamicH5Dataset.__getitem__ (data/dataset.py:176-199,
+ * 419-427): events [seg[f], seg[f+1]) form grid f; ts float64 as stored in the file -- (ts - ts[seg[f]]).astype(float32) is
+ * applied per interval on the device (:194); ps float32 already in {-1,+1} (:385); intervals with fewer than `min_events`
+ * events stay zero (:189-190 uses 3).  out_voxel float32 [n_segments, num_bins, H, W]. */
+int v2v_events_to_voxel_f32_segmented_hip(const double *ts, const int64_t *xs, const int64_t *ys, const float *ps, int64_t n,
+                                          const int64_t *seg_offsets, int64_t n_segments, int min_events, int discrete, int num_bins,
+                                          int64_t H, int64_t W, float *out_voxel, uint64_t *dropped, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

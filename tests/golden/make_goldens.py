@@ -27,8 +27,9 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 sys.path.insert(0, ROOT)
 
-for m in ("cv2", "h5py", "ffmpeg", "event_voxel_builder"):      # absent here; only IO code touches them
+for m in ("cv2", "h5py", "ffmpeg", "event_voxel_builder", "torchvision", "torchvision.transforms"):   # absent here; only IO / augmentation code touches them
     sys.modules.setdefault(m, types.ModuleType(m))
+sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
 sys.modules["event_voxel_builder"].EventVoxelBuilder = object
 sys.path.insert(0, REF)
 
@@ -378,10 +379,117 @@ def g15_bgr_to_gray():
          planes=gray[[0, 37, 128, 255]])
 
 
+class _FakeH5:
+    """Just enough of h5py.File for the reference's real-data loaders (data/testh5.py:33-50,101-143; data/dataset.py:375-427),
+    backed by an in-memory Monash-layout sequence.  Test infrastructure of the golden generator only."""
+
+    class _Dset:
+        def __init__(self, arr, attrs=None):
+            self._a, self.attrs, self.shape = arr, dict(attrs or {}), arr.shape
+
+        def __getitem__(self, k):
+            return self._a[k]
+
+        def __len__(self):
+            return len(self._a)
+
+    class _Group:
+        def __init__(self, items):
+            self._items = items
+
+        def keys(self):
+            return self._items.keys()
+
+        def __iter__(self):
+            return iter(self._items)
+
+        def __len__(self):
+            return len(self._items)
+
+        def __getitem__(self, k):
+            return self._items[k]
+
+    store = None          # set by the golden function: {"events": {...}, "images": {name: (array, attrs)}, "attrs": {...}}
+
+    def __init__(self, path, mode="r"):
+        s = _FakeH5.store
+        self.attrs = dict(s["attrs"])
+        self._groups = {"events": _FakeH5._Group({k: _FakeH5._Dset(v) for k, v in s["events"].items()}),
+                        "images": _FakeH5._Group({k: _FakeH5._Dset(a, at) for k, (a, at) in sorted(s["images"].items())})}
+
+    def keys(self):
+        return self._groups.keys()
+
+    def __getitem__(self, path):
+        node = self
+        for part in path.split("/"):
+            node = node._groups[part] if node is self else node[part]
+        return node
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def g16_monash_sequence():
+    """A small event sequence in the Monash HDF5 layout + what the REFERENCE's own loaders make of it:
+    TestH5Dataset.__getitem__ (data/testh5.py:96-173, two configurations) and DynamicH5Dataset.__getitem__ as
+    scripts/esim_to_voxel.py:29-50 stacks and casts it (temporal_bilinear False / True).  h5py is not installed, so the
+    reference's `h5py.File` is served by _FakeH5 above from the arrays that are also stored in the fixture."""
+    import torch
+    g = np.random.default_rng(1616)
+    H, W, n_img = 36, 48, 9
+    counts = [700, 650, 0, 1, 2, 900, 800, 3, 640]                                 # events before image i (an empty, a 1-, a 2- and a 3-event interval)
+    n_ev = int(sum(counts))
+    img_ts = np.cumsum(g.uniform(0.02, 0.05, size=n_img)) + 10.0
+    ts = np.concatenate([np.sort(g.uniform(img_ts[i - 1] if i else 10.0, img_ts[i], size=c)) for i, c in enumerate(counts)])
+    ts[counts[0] + counts[1] + 1: counts[0] + counts[1] + 3] = ts[counts[0] + counts[1] + 1]        # the 2-event interval: equal timestamps (dt == 0)
+    xs = g.integers(0, W, size=n_ev).astype(np.uint16)
+    ys = g.integers(0, H, size=n_ev).astype(np.uint16)
+    ps = (g.random(n_ev) < 0.5).astype(np.uint8)
+    event_idx = np.cumsum(counts).astype(np.int64)
+    images = g.integers(0, 256, size=(n_img, H, W)).astype(np.uint8)
+    keys = ["image{:09d}".format(i) for i in range(n_img)]
+    _FakeH5.store = {"events": {"ts": ts, "xs": xs, "ys": ys, "ps": ps},
+                     "images": {k: (images[i], {"event_idx": event_idx[i], "timestamp": img_ts[i]}) for i, k in enumerate(keys)},
+                     "attrs": {"sensor_resolution": np.array([H, W]), "num_events": n_ev, "num_imgs": n_img, "source": "hqf"}}
+    sys.modules["h5py"].File = _FakeH5
+    out = {"events/ts": ts, "events/xs": xs, "events/ys": ys, "events/ps": ps, "images/stack": images, "images/keys": np.array(keys),
+           "images/event_idx": event_idx, "images/timestamp": img_ts, "attrs/sensor_resolution": np.array([H, W]),
+           "attrs/num_events": np.array(n_ev), "attrs/num_imgs": np.array(n_img), "attrs/source": np.array("hqf")}
+    cfgs = {"a": {"sequence_length": 4, "num_bins": 5, "dataset_name": "hqf"},
+            "b": {"sequence_length": 5, "warm_up_length": 1, "num_bins": 3, "interpolate_bins": True, "output_additional_frame": True,
+                  "output_additional_evs": True, "image_range": 1, "dataset_name": "hqf"}}
+    for tag, cfg in cfgs.items():
+        ds = ref_th5.TestH5Dataset("/fake/hqf_h5/bike_bay_hdr.h5", cfg)
+        out[f"th5_{tag}__len"] = np.array(len(ds))
+        out[f"th5_{tag}__samples"] = np.array(ds.samples)
+        for i in range(len(ds)):
+            s = ds[i]
+            assert s["sequence_name"] == ["bike_bay_hdr"] * len(s["frame_idx"])
+            out[f"th5_{tag}__{i}__frame"] = s["frame"].numpy()
+            out[f"th5_{tag}__{i}__events"] = s["events"].numpy()
+            out[f"th5_{tag}__{i}__meta"] = np.stack([s["real_begin_idx"].numpy(), s["frame_idx"].numpy()])
+            out[f"th5_{tag}__{i}__source"] = np.array(int(s["data_source_idx"]))
+    from data.dataset import DynamicH5Dataset
+    for tb in (False, True):
+        ds = DynamicH5Dataset(data_path="/fake/esim_h5/seq.h5", temporal_bilinear=tb)
+        items = [ds[i] for i in range(len(ds))]
+        tag = "bil" if tb else "nobi"
+        out[f"cache_{tag}__frames"] = np.stack([it["frame"].numpy() for it in items]).astype(np.float32)          # esim_to_voxel.py:38-50
+        out[f"cache_{tag}__flow_is_zero"] = np.array(all(float(it["flow"].abs().sum()) == 0 for it in items))
+        out[f"cache_{tag}__events"] = np.stack([it["events"].numpy() for it in items]).astype(np.float32)
+        out[f"cache_{tag}__timestamps"] = np.stack([it["timestamp"] for it in items]).astype(np.float32)
+        out[f"cache_{tag}__dt"] = np.stack([it["dt"] for it in items]).astype(np.float32)
+    save("g16_monash_sequence.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14", "g15", "g16"]
     fns = {"g1": g1_luts, "g2": g2_g3_esim_clean, "g4": g4_esim_noisy, "g5": g5_floor_divide,
-           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g15": g15_bgr_to_gray, "g12": g12_events_to_voxel_torch,
+           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g15": g15_bgr_to_gray, "g16": g16_monash_sequence, "g12": g12_events_to_voxel_torch,
            "g13": g13_normalize_batch_voxel}
     for w in which:
         fns[w]()

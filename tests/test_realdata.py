@@ -1,0 +1,113 @@
+"""Real-data side of `make_voxel`: the Monash-layout reader, the TestH5Dataset drop-in (data/testh5.py:14-173)
+and the cached-voxel writer (scripts/esim_to_voxel.py:17-56 over DynamicH5Dataset, data/dataset.py:176-231,375-427) against
+golden G16 = the REFERENCE's own loaders run on the committed fixture sequence (tests/golden/make_goldens.py::g16)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g16_monash_sequence.npz")
+CFGS = {"a": {"sequence_length": 4, "num_bins": 5, "dataset_name": "hqf"},
+        "b": {"sequence_length": 5, "warm_up_length": 1, "num_bins": 3, "interpolate_bins": True, "output_additional_frame": True,
+              "output_additional_evs": True, "image_range": 1, "dataset_name": "hqf"}}
+
+
+def test_monash_store_reads_the_layout(golden):
+    from v2v_amd import monash
+    g = golden("g16_monash_sequence.npz")
+    with monash.open_sequence(FIX) as f:
+        assert f.image_keys == ["image%09d" % i for i in range(9)] and f.image(f.image_keys[3]).shape == (36, 48)
+        assert int(f.image_attr("image000000004", "event_idx")) == int(g["images/event_idx"][4])
+        assert np.array_equal(f.events("ts", 10, 20), g["events/ts"][10:20]) and f.attr("source") == "hqf" and not f.has_flow()
+        assert list(f.attr("sensor_resolution")) == [36, 48] and int(f.attr("num_imgs")) == 9
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_testh5_sample_table_equals_reference(golden, tag):
+    """Host logic only (no GPU): the (begin, real_begin, end) table of data/testh5.py:43-52 incl. warm-up overlap."""
+    from v2v_amd.testh5 import TestH5Dataset
+    g = golden("g16_monash_sequence.npz")
+    ds = TestH5Dataset(FIX, CFGS[tag])
+    assert len(ds) == int(g[f"th5_{tag}__len"]) and np.array_equal(np.array(ds.samples), g[f"th5_{tag}__samples"])
+    assert (ds.H, ds.W) == (36, 48) and ds.sequence_name == "g16_monash_sequence"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_testh5_getitem_equals_reference(golden, tag):
+    """Every sample of the fixture sequence: same dict as the reference's __getitem__.  Discrete bins: exact; interpolated bins:
+    the same float64 terms summed by atomics in another order, then cast to float32 like the reference does (1e-6)."""
+    from v2v_amd.testh5 import TestH5Dataset
+    g = golden("g16_monash_sequence.npz")
+    ds = TestH5Dataset(FIX, CFGS[tag])
+    for i in range(len(ds)):
+        s = ds[i]
+        assert set(s) == {"frame", "events", "data_source_idx", "sequence_name", "real_begin_idx", "frame_idx"}
+        assert s["frame"].dtype == torch.float32 and np.array_equal(s["frame"].numpy(), g[f"th5_{tag}__{i}__frame"])
+        want = g[f"th5_{tag}__{i}__events"]
+        assert s["events"].dtype == torch.float32 and s["events"].shape == want.shape
+        if CFGS[tag].get("interpolate_bins"):
+            np.testing.assert_allclose(s["events"].numpy(), want, rtol=1e-6, atol=1e-6)
+        else:
+            assert np.array_equal(s["events"].numpy(), want)
+        assert np.array_equal(np.stack([s["real_begin_idx"].numpy(), s["frame_idx"].numpy()]), g[f"th5_{tag}__{i}__meta"])
+        assert int(s["data_source_idx"]) == int(g[f"th5_{tag}__{i}__source"]) and s["data_source_idx"].dtype == torch.int64
+        assert s["sequence_name"] == ["g16_monash_sequence"] * s["frame_idx"].numel()
+    # make_voxel(self, evs) itself, on one interval (data/testh5.py:60-90)
+    lo, hi = int(g["images/event_idx"][0]), int(g["images/event_idx"][1])
+    one = ds.make_voxel([g["events/ts"][lo:hi], g["events/xs"][lo:hi], g["events/ys"][lo:hi], g["events/ps"][lo:hi]])
+    assert one.shape == (ds.num_bins, 36, 48) and one.dtype == np.float64
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bilinear", [False, True])
+def test_voxel_cache_equals_reference_loader(golden, tmp_path, bilinear):
+    """scripts/esim_to_voxel.py:17-56: all `between_frames` grids of the sequence in one segmented launch == the stacked,
+    float32-cast items of the reference's DynamicH5Dataset (incl. the < 3 events -> empty grid rule and dt / timestamps)."""
+    from v2v_amd import voxel_cache
+    g = golden("g16_monash_sequence.npz")
+    tag = "bil" if bilinear else "nobi"
+    out = tmp_path / f"cache_{tag}.npz"
+    data = voxel_cache.convert(FIX, str(out), temporal_bilinear=bilinear)
+    z = np.load(out)
+    for k in ("frames", "flow", "events", "timestamps", "dt"):
+        assert z[k].dtype == np.float32 and np.array_equal(z[k], data[k])
+    assert np.array_equal(z["frames"], g[f"cache_{tag}__frames"]) and bool(g[f"cache_{tag}__flow_is_zero"]) and not z["flow"].any()
+    assert np.array_equal(z["timestamps"], g[f"cache_{tag}__timestamps"]) and np.array_equal(z["dt"], g[f"cache_{tag}__dt"])
+    want = g[f"cache_{tag}__events"]
+    assert z["events"].shape == want.shape == (8, 5, 36, 48)
+    if bilinear:
+        np.testing.assert_allclose(z["events"], want, rtol=1e-5, atol=1e-5)      # float32 atomics: torch's index_put_ order differs
+    else:
+        assert np.array_equal(z["events"], want)
+    assert not z["events"][2].any() and not z["events"][3].any() and not z["events"][4].any()    # 0, 1 and 2 events: empty grids
+
+
+@pytest.mark.gpu
+def test_event_kernels_edge_semantics():
+    """Index and time-span corner cases of the scatter kernels follow the reference's primitives: np.add.at / index_put_ wrap a
+    negative index once, np.ravel_multi_index raises; an event of the segmented form outside every interval is ignored even if
+    it points outside the sensor; a zero time span gives NaN bilinear weights in every bin of the touched pixel."""
+    from v2v_amd import voxel
+    h, w, nb = 6, 8, 4
+    ts = np.array([0.0, 0.1, 0.2, 0.3]); xs = np.array([1, -1, 3, 2]); ys = np.array([0, 2, -2, 5]); ps = np.array([1, 0, 1, 1])
+    want = np.zeros((nb, h, w))
+    pol = ps.astype(np.int8) * 2 - 1
+    tus = ((ts - ts[0]) * 1e6).astype(np.int64)
+    np.add.at(want, (np.floor(tus / ((tus[-1] + 0.001) / nb)).astype(np.uint8), ys, xs), pol)       # data/testh5.py:70-75, negative indices wrap
+    assert np.array_equal(voxel.make_voxel([ts, xs, ys, ps], h, w, nb, interpolate_bins=False), want)
+    with pytest.raises(IndexError):
+        voxel.make_voxel([ts, xs - 20, ys, ps], h, w, nb, interpolate_bins=False)
+    with pytest.raises((IndexError, ValueError)):
+        voxel.events_to_voxel(xs, ys, ts, pol.astype(float), nb, (h, w))                            # ravel_multi_index: negative -> error
+    # segmented: events 0 and 3 lie outside [1, 3) and point anywhere
+    seg = voxel.make_voxels_segmented([ts, np.array([99, 1, 3, -77]), np.array([99, 2, 1, 0]), ps], [1, 3], h, w, nb)
+    assert seg.shape == (1, nb, h, w) and seg.sum() == 0 and np.abs(seg).sum() == 2
+    # zero time span: NaN in every bin of the pixel, zero elsewhere (event_utils.py:713-719 with dt == 0)
+    v = voxel.events_to_voxel(np.array([2, 2]), np.array([1, 1]), np.array([0.5, 0.5]), np.array([1.0, 1.0]), nb, (h, w))
+    assert np.isnan(v[:, 1, 2]).all() and np.nansum(np.abs(v)) == 0 and np.isnan(v).sum() == nb
+    t32 = voxel.events_to_voxel_torch(torch.tensor([2]), torch.tensor([1]), torch.tensor([0.5]), torch.tensor([1.0]), nb, sensor_size=(h, w))
+    assert bool(torch.isnan(t32[:, 1, 2]).all()) and int(torch.isnan(t32).sum()) == nb
+    t32 = voxel.events_to_voxel_torch(torch.tensor([-1, 2]), torch.tensor([-1, 0]), torch.tensor([0.0, 1.0]), torch.tensor([1.0, 1.0]), nb, sensor_size=(h, w))
+    assert float(t32[0, h - 1, w - 1]) == 1.0 and float(t32[nb - 1, 0, 2]) == 1.0                    # index_put_ wraps

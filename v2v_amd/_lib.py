@@ -20,7 +20,7 @@ ABI_VERSION = 1
 
 EXPORTS = ("v2v_version", "v2v_last_error", "v2v_device_count", "v2v_lut_get", "v2v_lut_set",
            "v2v_esim_voxel_hip", "v2v_esim_voxel_keyed_hip", "v2v_esim_voxel_bytes", "v2v_synth_clips_hip", "v2v_events_to_voxel_hip", "v2v_events_to_voxel_segmented_hip",
-           "v2v_v2e_voxel_hip", "v2v_v2e_workspace_bytes", "v2v_events_to_voxel_f32_hip", "v2v_frontend_hip", "v2v_frontend_batch_hip",
+           "v2v_v2e_voxel_hip", "v2v_v2e_workspace_bytes", "v2v_events_to_voxel_f32_hip", "v2v_events_to_voxel_f32_segmented_hip", "v2v_frontend_hip", "v2v_frontend_batch_hip",
            "v2v_normalize_pad_hip", "v2v_postops_workspace_bytes")
 EV_MAKE_VOXEL_DISCRETE, EV_MAKE_VOXEL_INTERP, EV_BILINEAR = 0, 1, 2
 
@@ -90,6 +90,9 @@ def lib():
     L.v2v_events_to_voxel_segmented_hip.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                                     C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                                     C.c_void_p]
+    L.v2v_events_to_voxel_f32_segmented_hip.restype = C.c_int
+    L.v2v_events_to_voxel_f32_segmented_hip.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                                        C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.v2v_events_to_voxel_f32_hip.restype = C.c_int
     L.v2v_events_to_voxel_f32_hip.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                               C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]

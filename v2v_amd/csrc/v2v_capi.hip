@@ -450,22 +450,25 @@ int v2v_normalize_pad_hip(const float *voxel, int64_t B, int64_t planes, int64_t
     return e == hipSuccess ? V2V_OK : hip_fail(e, "normalize_pad launch");
 }
 
-int v2v_events_to_voxel_f32_hip(const float *ts, const int64_t *xs, const int64_t *ys, const float *ps, int64_t n, int discrete,
-                                int num_bins, int64_t H, int64_t W, float *out_voxel, uint64_t *dropped, void *stream)
+static int events_f32_launch(const float *ts, const double *ts64, const int64_t *xs, const int64_t *ys, const float *ps, int64_t n,
+                             const int64_t *seg, int64_t n_seg, int min_events, int discrete, int num_bins, int64_t H, int64_t W,
+                             float *out_voxel, uint64_t *dropped, void *stream, const char *who)
 {
-    if (!out_voxel || !dropped) return fail(V2V_ERR_NULL, "v2v_events_to_voxel_f32_hip: out_voxel/dropped is NULL");
-    if (n < 0 || H < 1 || W < 1 || num_bins < 1) return fail(V2V_ERR_SHAPE, "need n>=0, H,W>=1, num_bins>=1");
-    if (n > 0 && (!ts || !xs || !ys || !ps)) return fail(V2V_ERR_NULL, "v2v_events_to_voxel_f32_hip: event arrays are NULL");
-    if (!aligned(out_voxel, 4) || !aligned(dropped, 8) || !aligned(ts, 4) || !aligned(xs, 8) || !aligned(ys, 8) || !aligned(ps, 4))
+    if (!out_voxel || !dropped) return fail(V2V_ERR_NULL, "%s: out_voxel/dropped is NULL", who);
+    if (n < 0 || H < 1 || W < 1 || num_bins < 1 || n_seg < 1) return fail(V2V_ERR_SHAPE, "need n>=0, H,W>=1, num_bins>=1, n_segments>=1");
+    if (n > 0 && ((!ts && !ts64) || !xs || !ys || !ps)) return fail(V2V_ERR_NULL, "%s: event arrays are NULL", who);
+    if (!aligned(out_voxel, 4) || !aligned(dropped, 8) || !aligned(ts, 4) || !aligned(ts64, 8) || !aligned(xs, 8) || !aligned(ys, 8) || !aligned(ps, 4) ||
+        !aligned(seg, 8))
         return fail(V2V_ERR_ALIGN, "buffers not aligned to their element size");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(out_voxel, 0, sizeof(float) * (size_t)num_bins * H * W, s);
+    hipError_t e = hipMemsetAsync(out_voxel, 0, sizeof(float) * (size_t)n_seg * num_bins * H * W, s);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(out_voxel)");
     e = hipMemsetAsync(dropped, 0, sizeof(uint64_t), s);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dropped)");
     if (n == 0) return V2V_OK;
     v2v::EventArgsF32 a{};
-    a.ts = ts; a.xs = xs; a.ys = ys; a.ps = ps; a.n = n; a.discrete = discrete ? 1 : 0; a.Tb = num_bins; a.H = H; a.W = W;
+    a.ts = ts; a.ts64 = ts64; a.seg = seg; a.n_seg = n_seg; a.min_events = min_events;
+    a.xs = xs; a.ys = ys; a.ps = ps; a.n = n; a.discrete = discrete ? 1 : 0; a.Tb = num_bins; a.H = H; a.W = W;
     a.out = out_voxel;
     a.dropped = reinterpret_cast<unsigned long long *>(dropped);
     const int64_t nblocks = (n + 255) / 256;
@@ -473,6 +476,22 @@ int v2v_events_to_voxel_f32_hip(const float *ts, const int64_t *xs, const int64_
     hipLaunchKernelGGL(v2v::events_to_voxel_f32_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, a);
     e = hipGetLastError();
     return e == hipSuccess ? V2V_OK : hip_fail(e, "events_to_voxel_f32_kernel launch");
+}
+
+int v2v_events_to_voxel_f32_hip(const float *ts, const int64_t *xs, const int64_t *ys, const float *ps, int64_t n, int discrete,
+                                int num_bins, int64_t H, int64_t W, float *out_voxel, uint64_t *dropped, void *stream)
+{
+    return events_f32_launch(ts, nullptr, xs, ys, ps, n, nullptr, 1, 0, discrete, num_bins, H, W, out_voxel, dropped, stream,
+                             "v2v_events_to_voxel_f32_hip");
+}
+
+int v2v_events_to_voxel_f32_segmented_hip(const double *ts, const int64_t *xs, const int64_t *ys, const float *ps, int64_t n,
+                                          const int64_t *seg_offsets, int64_t n_segments, int min_events, int discrete, int num_bins,
+                                          int64_t H, int64_t W, float *out_voxel, uint64_t *dropped, void *stream)
+{
+    if (!seg_offsets) return fail(V2V_ERR_NULL, "v2v_events_to_voxel_f32_segmented_hip: seg_offsets is NULL");
+    return events_f32_launch(nullptr, ts, xs, ys, ps, n, seg_offsets, n_segments, min_events, discrete, num_bins, H, W, out_voxel, dropped,
+                             stream, "v2v_events_to_voxel_f32_segmented_hip");
 }
 
 }  // extern "C"

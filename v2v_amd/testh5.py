@@ -1,0 +1,91 @@
+"""`TestH5Dataset` -- drop-in for data/testh5.py:14-173 (the real-data validation loader around `make_voxel`).
+
+Same constructor `(h5_path, configs)`, config keys and defaults (:17-58), sample table (:43-52), `make_voxel(evs)` (:60-90)
+and `__getitem__` dict (:96-173: frame [L(+1),1,H,W] float32, events [L(+1),Tb,H,W] float32, data_source_idx, sequence_name,
+real_begin_idx, frame_idx).  The reference voxelises one image interval at a time with np.add.at on the host; here ALL
+intervals of a sample go through ONE segmented launch of the HIP scatter kernel (v2v_events_to_voxel_segmented_hip):
+the events of [event_idx[begin], event_idx[end]) are uploaded once and the per-image `event_idx` attrs are the segment
+offsets.  File access: v2v_amd/monash.py (.h5 through h5py, or the .npz form of the same layout).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from . import monash, voxel
+from .datasets import data_sources
+
+
+class TestH5Dataset(torch.utils.data.Dataset, voxel.MakeVoxelMixin):
+    __test__ = False                                          # not a pytest class
+
+    def __init__(self, h5_path, configs):
+        self.h5_path = h5_path
+        self.sequence_name = os.path.basename(h5_path).split(".")[0]                     # :20
+        self.configs = configs
+        self.dataset_name = configs.get("dataset_name", "hqf")
+        self.sequence_length = configs.get("sequence_length", 40)
+        self.warm_up_length = configs.get("warm_up_length", 0)
+        self.max_samples = configs.get("max_samples", None)
+        self.num_bins = configs.get("num_bins", 5)
+        self.interpolate_bins = configs.get("interpolate_bins", False)
+        self.image_range = configs.get("image_range", 255)
+        assert self.image_range in [255, 1], "image_range should be 255 or 1."
+        self.device = configs.get("sim_device", "cuda")                                  # this implementation only
+        with monash.open_sequence(h5_path) as f:
+            self.img_keys = sorted(f.image_keys)
+            self.total_frame_cnt = len(self.img_keys)
+            img_shape = f.image(self.img_keys[0]).shape
+            self.H, self.W = img_shape[0], img_shape[1]
+            self.samples = []                                                            # (begin, real_begin, end), :43-52
+            for i in range(0, self.total_frame_cnt - 1, self.sequence_length - self.warm_up_length):
+                begin = max(0, i - self.warm_up_length)
+                end_idx = min(self.total_frame_cnt - 1, begin + self.sequence_length)
+                self.samples.append((begin, i - begin, end_idx))
+        if self.max_samples is not None:
+            self.samples = self.samples[:self.max_samples]
+        self.output_additional_frame = configs.get("output_additional_frame", False)
+        self.output_additional_evs = configs.get("output_additional_evs", False)
+
+    def __len__(self):
+        return len(self.samples)
+
+    def get_img(self, f, idx):
+        return f.image(self.img_keys[idx])
+
+    def __getitem__(self, idx):
+        begin, real_begin, end = self.samples[idx]
+        with monash.open_sequence(self.h5_path) as f:
+            frames = [torch.tensor(self.get_img(f, i + 1), dtype=torch.float32).unsqueeze(0) for i in range(begin, end)]   # :105-106
+            ev_idx = [int(f.image_attr(self.img_keys[i], "event_idx")) for i in range(begin, end + 1)]                    # :108-109
+            first = begin
+            if self.output_additional_evs:                                               # :133-143: the interval before `begin`
+                pre_idx = max(0, begin - 1)
+                ev_idx = [int(f.image_attr(self.img_keys[pre_idx], "event_idx"))] + ev_idx
+            lo, hi = ev_idx[0], ev_idx[-1]
+            evs = [f.events(k, lo, hi) for k in ("ts", "xs", "ys", "ps")]
+            first_frame = self.get_img(f, begin) if self.output_additional_frame else None
+        seg = np.asarray(ev_idx, dtype=np.int64) - lo
+        if np.any(np.diff(seg) < 0):                          # pre_idx == begin (begin == 0): an empty leading interval
+            seg = np.maximum.accumulate(seg)
+        # ps of hqf h5 files are in {0,1} (:69); one segmented launch = one make_voxel per image interval (:111-119)
+        grids = voxel.make_voxels_segmented([np.asarray(evs[0], dtype=np.float64), evs[1], evs[2], evs[3]], seg, self.H, self.W, self.num_bins,
+                                            self.interpolate_bins, device=self.device)
+        all_events = torch.as_tensor(grids).to(torch.float32).cpu()                      # torch.tensor(voxel, dtype=float32), :120
+        all_frames = torch.stack(frames, dim=0)
+        if self.output_additional_frame:                                                 # :129-131,149-150
+            ff = torch.tensor(first_frame, dtype=torch.float32).unsqueeze(0).unsqueeze(0)
+            all_frames = torch.cat([ff, all_frames], dim=0)
+        if self.image_range == 1:
+            all_frames = all_frames / 255.0
+        n = end - begin
+        return {
+            "frame": all_frames,
+            "events": all_events,
+            "data_source_idx": torch.tensor(data_sources.index(self.dataset_name.lower()), dtype=torch.int64),
+            "sequence_name": [self.sequence_name] * n,
+            "real_begin_idx": torch.tensor([real_begin] * n, dtype=torch.int64),
+            "frame_idx": torch.tensor(list(range(begin, end)), dtype=torch.int64),
+        }
