@@ -112,6 +112,16 @@ int v2v_esim_voxel_keyed_hip(const void *frames, int in_dtype, int64_t B, int64_
                              const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
                              void *out_voxel, int out_dtype, int64_t *out_counts, void *stream);
 
+/* Same, writing the voxel planes into a PADDED layout: rows of out_row_pitch >= W elements, planes of out_plane_size >=
+ * out_row_pitch*(H-1)+W elements -- e.g. the H,W -> multiples-of-16 padding of forward_sequence (model/train_utils.py:322-326)
+ * written by the simulator itself instead of a later copy.  Only the H x W interior of every plane is written: the caller
+ * zeroes the padding once (it is never touched again). */
+int v2v_esim_voxel_padded_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W,
+                              int64_t clip_stride, int64_t frame_stride, const double *params, int64_t params_stride,
+                              uint32_t flags, int rng_mode, uint64_t seed, uint64_t clip_id0, const uint64_t *clip_keys,
+                              const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
+                              void *out_voxel, int out_dtype, int64_t out_row_pitch, int64_t out_plane_size, int64_t *out_counts, void *stream);
+
 /* Algorithmic HBM bytes of one v2v_esim_voxel_hip call (input read once + output written once);
  * the figure bench.py's roofline is computed from.  Returns a negative v2v_status on bad arguments. */
 int64_t v2v_esim_voxel_bytes(int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W, int bin_mode,
@@ -212,6 +222,16 @@ int v2v_frontend_batch_hip(const uint8_t *src, int64_t B, int64_t T, int64_t Hs,
 int64_t v2v_postops_workspace_bytes(int64_t B);
 int v2v_normalize_pad_hip(const float *voxel, int64_t B, int64_t planes, int64_t H, int64_t W, int normalize, int pad_to,
                           float *out, void *workspace, void *stream);
+
+/* Same with (a) an input that is already padded -- planes of H_in x W_in >= H x W, pads zero, as v2v_esim_voxel_padded_hip
+ * writes them; out may then alias voxel (in-place normalise) -- and (b) a choice of the k-th value method:
+ *   V2V_NORM_NONE   pad only
+ *   V2V_NORM_RADIX  exact 3-pass radix select, any float32 content (unpadded input only): 3 + 1 reads, 1 write
+ *   V2V_NORM_COUNT  exact counting select for INTEGER-valued voxels with |v| <= 255 (the SUM-mode grids V2V trains on, without
+ *                   external noise): 1 + 1 reads, 1 write; a sample holding any other value comes out as NaN (loud, no fallback) */
+typedef enum v2v_norm_method { V2V_NORM_NONE = 0, V2V_NORM_RADIX = 1, V2V_NORM_COUNT = 2 } v2v_norm_method;
+int v2v_normalize_pad_ex_hip(const float *voxel, int64_t B, int64_t planes, int64_t H, int64_t W, int64_t H_in, int64_t W_in, int method,
+                             int pad_to, float *out, void *workspace, void *stream);
 
 /* float32 twin: replaces events_to_voxel_torch (utils/event_utils.py:466-507; only caller data/dataset.py:328).
  * ts/ps float32, out float32 [num_bins,H,W]; discrete != 0 selects the `temporal_bilinear=False` branch (:502-505). */

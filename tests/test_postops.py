@@ -49,3 +49,49 @@ def test_hip_pad_and_fused(golden):
     assert np.array_equal(postops.normalize_batch_voxel(big).cpu().numpy(), want)
     with pytest.raises(ValueError):
         postops.normalize_batch_voxel(torch.zeros((1, 1, 1, 3, 3), device="cuda"))      # < 100 elements: kthvalue(0) raises in torch
+
+
+@pytest.mark.gpu
+def test_hip_counting_select_equals_reference_golden(golden):
+    """Integer-valued voxels through the counting path (1 + 1 reads instead of 3 + 1): same bits as the reference's function."""
+    import torch
+    from v2v_amd import postops
+    g = golden("g13_normalize_batch_voxel.npz")
+    got = postops.normalize_batch_voxel(torch.from_numpy(g["counts"]).cuda(), method="count").cpu().numpy()
+    assert np.array_equal(got[[0, 2]], g["counts_norm"][[0, 2]])
+    assert np.isnan(got[1]).all()                                                # G13's sample 1 is scaled by 0.2: not integer-valued
+    # non-integer content is refused loudly: NaN for that sample, never a silently wrong scale
+    bad = postops.normalize_batch_voxel(torch.from_numpy(g["soft"]).cuda(), method="count")
+    assert bool(torch.isnan(bad).any(dim=(1, 2, 3, 4)).all())
+    big = torch.round(torch.randn((4, 8, 5, 128, 128), device="cuda") * 3)
+    big[1] *= 40                                                                 # values beyond +-255 in one sample only
+    out = postops.normalize_batch_voxel(big, method="count").cpu().numpy()
+    want = _oracle_normalize(big.cpu().numpy())
+    assert np.isnan(out[1]).all() and np.array_equal(out[[0, 2, 3]], want[[0, 2, 3]])
+
+
+@pytest.mark.gpu
+def test_simulator_writes_the_padded_layout_and_normalises_in_place(oracle_c, luts):
+    """f-2 end to end: the simulator writes its SUM-mode grids straight into the x16-padded buffer (odd frame size 36 x 52 ->
+    48 x 64), the counting normaliser runs in place on it (pad zeros excluded from the k-th values), and the result equals
+    simulate -> normalize_batch_voxel (NumPy restatement pinned by G13) -> zero-pad."""
+    import torch
+    from oracle import v2v_oracle as O
+    from v2v_amd import esim, postops
+    b, n, h, w = 3, 21, 36, 52
+    video = np.stack([O.synth_clip_s1(n, h, w, seed=40 + i, dtype=np.uint8) for i in range(b)])
+    p = [0.12, 0.15, 0.05, 1e-3, 0.5]
+    frames = torch.from_numpy(video).cuda()
+    plain = esim.esim_voxel_batch(frames, p, bin_mode="sum", num_bins=5, frames_per_bin=2, seed=5)                  # [3,2,5,36,52]
+    want_counts, _ = oracle_c.esim_voxel(video, p, luts, seed=5, bin_mode=oracle_c.BIN_SUM, num_bins=5, frames_per_bin=2)
+    assert np.array_equal(plain.cpu().numpy(), want_counts.astype(np.float32))
+    padded = esim.esim_voxel_batch(frames, p, bin_mode="sum", num_bins=5, frames_per_bin=2, seed=5, pad_to=16)      # [3,2,5,48,64]
+    assert padded.shape == (b, 2, 5, 48, 64) and torch.equal(padded[..., :h, :w], plain)
+    assert not padded[..., h:, :].any() and not padded[..., :, w:].any()
+    bil = esim.esim_voxel_batch(frames.float(), p, bin_mode="bilinear", num_bins=5, seed=5, pad_to=16)
+    assert torch.equal(bil[..., :h, :w], esim.esim_voxel_batch(frames.float(), p, bin_mode="bilinear", num_bins=5, seed=5)) and not bil[..., h:, :].any()
+    out = postops.normalize_and_pad(padded.clone(), True, 16, method="count", valid_hw=(h, w), inplace=True)
+    want = np.zeros((b, 2, 5, 48, 64), dtype=np.float32)
+    want[..., :h, :w] = _oracle_normalize(want_counts.astype(np.float32))
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert np.array_equal(postops.normalize_and_pad(plain, True, 16, method="radix").cpu().numpy(), want)           # the general path agrees

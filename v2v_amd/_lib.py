@@ -20,9 +20,10 @@ ABI_VERSION = 1
 
 EXPORTS = ("v2v_version", "v2v_last_error", "v2v_device_count", "v2v_lut_get", "v2v_lut_set",
            "v2v_esim_voxel_hip", "v2v_esim_voxel_keyed_hip", "v2v_esim_voxel_bytes", "v2v_synth_clips_hip", "v2v_events_to_voxel_hip", "v2v_events_to_voxel_segmented_hip",
-           "v2v_v2e_voxel_hip", "v2v_v2e_workspace_bytes", "v2v_events_to_voxel_f32_hip", "v2v_events_to_voxel_f32_segmented_hip", "v2v_frontend_hip", "v2v_frontend_batch_hip",
+           "v2v_v2e_voxel_hip", "v2v_v2e_workspace_bytes", "v2v_events_to_voxel_f32_hip", "v2v_events_to_voxel_f32_segmented_hip", "v2v_esim_voxel_padded_hip", "v2v_normalize_pad_ex_hip", "v2v_frontend_hip", "v2v_frontend_batch_hip",
            "v2v_normalize_pad_hip", "v2v_postops_workspace_bytes")
 EV_MAKE_VOXEL_DISCRETE, EV_MAKE_VOXEL_INTERP, EV_BILINEAR = 0, 1, 2
+NORM_NONE, NORM_RADIX, NORM_COUNT = 0, 1, 2
 
 
 class EsimReplay(C.Structure):
@@ -78,6 +79,11 @@ def lib():
         C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
         C.c_void_p, C.c_int64, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p,
         C.POINTER(EsimReplay), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.v2v_esim_voxel_padded_hip.restype = C.c_int
+    L.v2v_esim_voxel_padded_hip.argtypes = [
+        C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+        C.c_void_p, C.c_int64, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p,
+        C.POINTER(EsimReplay), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     L.v2v_esim_voxel_bytes.restype = C.c_int64
     L.v2v_esim_voxel_bytes.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
     L.v2v_synth_clips_hip.restype = C.c_int
@@ -104,6 +110,9 @@ def lib():
                                                                            C.c_void_p, C.c_void_p, C.c_void_p]
     L.v2v_postops_workspace_bytes.restype = C.c_int64
     L.v2v_postops_workspace_bytes.argtypes = [C.c_int64]
+    L.v2v_normalize_pad_ex_hip.restype = C.c_int
+    L.v2v_normalize_pad_ex_hip.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]
     L.v2v_normalize_pad_hip.restype = C.c_int
     L.v2v_normalize_pad_hip.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_void_p]

@@ -105,6 +105,18 @@ int v2v_esim_voxel_keyed_hip(const void *frames, int in_dtype, int64_t B, int64_
                              const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
                              void *out_voxel, int out_dtype, int64_t *out_counts, void *stream)
 {
+    return v2v_esim_voxel_padded_hip(frames, in_dtype, B, N, H, W, clip_stride, frame_stride, params, params_stride, flags, rng_mode, seed,
+                                     clip_id0, clip_keys, replay, bin_mode, num_bins, frames_per_bin, out_voxel, out_dtype, W, H * W,
+                                     out_counts, stream);
+}
+
+int v2v_esim_voxel_padded_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W,
+                              int64_t clip_stride, int64_t frame_stride, const double *params, int64_t params_stride,
+                              uint32_t flags, int rng_mode, uint64_t seed, uint64_t clip_id0, const uint64_t *clip_keys,
+                              const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
+                              void *out_voxel, int out_dtype, int64_t out_row_pitch, int64_t out_plane_size, int64_t *out_counts, void *stream)
+{
+    if (out_row_pitch < W || out_plane_size < out_row_pitch * (H - 1) + W) return fail(V2V_ERR_SHAPE, "out_row_pitch / out_plane_size smaller than the frame");
     if (!frames || !params || !out_voxel) return fail(V2V_ERR_NULL, "v2v_esim_voxel_hip: frames/params/out_voxel is NULL");
     if (B < 0 || N < 2 || H < 1 || W < 1) return fail(V2V_ERR_SHAPE, "need B>=0, N>=2, H,W>=1 (got B=%lld N=%lld H=%lld W=%lld)", (long long)B, (long long)N, (long long)H, (long long)W);
     const int64_t HW = H * W, K = N - 1;
@@ -133,11 +145,12 @@ int v2v_esim_voxel_keyed_hip(const void *frames, int in_dtype, int64_t B, int64_
 
     // 4 pixels per work-item when every row segment a lane touches is 16-byte (fp32) / 4-byte (u8) aligned
     bool vec4 = (HW % 4 == 0) && (frame_stride % 4 == 0) && (B == 1 || clip_stride % 4 == 0) &&
-                aligned(frames, 4 * in_sz) && aligned(out_voxel, 16);
+                aligned(frames, 4 * in_sz) && aligned(out_voxel, 16) &&
+                (out_row_pitch == W ? out_plane_size % 4 == 0 : (W % 4 == 0 && out_row_pitch % 4 == 0 && out_plane_size % 4 == 0));
     // Small batches (the reference's training shape, 12 clips of 128x128 = 768 waves) are issue-bound on one wave per
     // SIMD; measured: 1 pixel per work-item (4x the waves) is SLOWER (0.19 vs 0.16 ms) because the per-4-pixel RNG
     // block is then recomputed per pixel.  Batch more clips instead.  V2V_FORCE_VEC=1|4 overrides (tuning only).
-    if (const char *fv = getenv("V2V_FORCE_VEC")) { if (fv[0] == '1') vec4 = false; else if (fv[0] == '4' && (HW % 4 == 0)) vec4 = true; }
+    if (const char *fv = getenv("V2V_FORCE_VEC")) { if (fv[0] == '1') vec4 = false; }
     const int vec = vec4 ? 4 : 1;
 
     v2v::EsimArgs a{};
@@ -158,6 +171,9 @@ int v2v_esim_voxel_keyed_hip(const void *frames, int in_dtype, int64_t B, int64_
     a.fpb = frames_per_bin;
     a.blocks_per_clip = (int32_t)((HW + (int64_t)v2v::kBlock * vec - 1) / ((int64_t)v2v::kBlock * vec));
     a.noise_external = (flags & V2V_FLAG_NOISE_EXTERNAL) ? 1u : 0u;
+    a.W = (int32_t)W;
+    a.out_pitch = out_row_pitch;
+    a.out_plane = out_plane_size;
     const int64_t nblocks = B * a.blocks_per_clip;
     if (nblocks > 0x7FFFFFFF) return fail(V2V_ERR_SHAPE, "grid too large");
     const dim3 grid((unsigned)nblocks);
@@ -411,15 +427,24 @@ int v2v_frontend_batch_hip(const uint8_t *src, int64_t B, int64_t T, int64_t Hs,
 int64_t v2v_postops_workspace_bytes(int64_t B)
 {
     if (B < 0) return V2V_ERR_SHAPE;
-    return B * 2 * ((int64_t)sizeof(v2v::SelectState) + (int64_t)v2v::kSelBins * (int64_t)sizeof(unsigned int));
+    return B * 2 * ((int64_t)sizeof(v2v::SelectState) + (int64_t)v2v::kSelBins * (int64_t)sizeof(unsigned int)) + B * 16;
 }
 
 int v2v_normalize_pad_hip(const float *voxel, int64_t B, int64_t planes, int64_t H, int64_t W, int normalize, int pad_to,
                           float *out, void *workspace, void *stream)
 {
+    return v2v_normalize_pad_ex_hip(voxel, B, planes, H, W, H, W, normalize ? V2V_NORM_RADIX : V2V_NORM_NONE, pad_to, out, workspace, stream);
+}
+
+int v2v_normalize_pad_ex_hip(const float *voxel, int64_t B, int64_t planes, int64_t H, int64_t W, int64_t H_in, int64_t W_in, int method,
+                             int pad_to, float *out, void *workspace, void *stream)
+{
     if (!voxel || !out) return fail(V2V_ERR_NULL, "v2v_normalize_pad_hip: voxel/out is NULL");
-    if (B < 0 || planes < 1 || H < 1 || W < 1 || pad_to < 1) return fail(V2V_ERR_SHAPE, "need B>=0, planes,H,W,pad_to>=1");
+    if (B < 0 || planes < 1 || H < 1 || W < 1 || pad_to < 1 || H_in < H || W_in < W) return fail(V2V_ERR_SHAPE, "need B>=0, planes,H,W,pad_to>=1, H_in>=H, W_in>=W");
+    if (method < V2V_NORM_NONE || method > V2V_NORM_COUNT) return fail(V2V_ERR_MODE, "unknown normalisation method %d", method);
+    const bool normalize = method != V2V_NORM_NONE;
     if (normalize && !workspace) return fail(V2V_ERR_NULL, "normalisation needs a workspace of v2v_postops_workspace_bytes(B)");
+    if (method == V2V_NORM_RADIX && (H_in != H || W_in != W)) return fail(V2V_ERR_MODE, "the radix select reads unpadded input; use V2V_NORM_COUNT for padded input");
     if (!aligned(voxel, 4) || !aligned(out, 4) || (workspace && !aligned(workspace, 16))) return fail(V2V_ERR_ALIGN, "buffers misaligned");
     if (B == 0) return V2V_OK;
     const int64_t per_sample = planes * H * W;
@@ -428,8 +453,9 @@ int v2v_normalize_pad_hip(const float *voxel, int64_t B, int64_t planes, int64_t
     if (normalize && (min_k < 1 || max_k < 1)) return fail(V2V_ERR_SHAPE, "k-th value undefined: fewer than 100 elements per sample (torch.kthvalue would raise)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int Hp = (int)((H + pad_to - 1) / pad_to * pad_to), Wp = (int)((W + pad_to - 1) / pad_to * pad_to);
+    if (out == voxel && (Hp != H_in || Wp != W_in)) return fail(V2V_ERR_SHAPE, "in-place normalisation needs identical input and output layouts");
     v2v::SelectState *st = static_cast<v2v::SelectState *>(workspace);
-    if (normalize) {
+    if (method == V2V_NORM_RADIX) {
         unsigned int *hist = reinterpret_cast<unsigned int *>(st + B * 2);
         hipError_t e = hipMemsetAsync(hist, 0, sizeof(unsigned int) * (size_t)B * 2 * v2v::kSelBins, s);
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(hist)");
@@ -441,11 +467,22 @@ int v2v_normalize_pad_hip(const float *voxel, int64_t B, int64_t planes, int64_t
             hipLaunchKernelGGL(v2v::select_hist_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, voxel, per_sample, st, hist, shifts[p], bits[p]);
             hipLaunchKernelGGL(v2v::select_pick_kernel, dim3((unsigned)(B * 2)), dim3(256), 0, s, st, hist, shifts[p], bits[p]);
         }
+    } else if (method == V2V_NORM_COUNT) {
+        static_assert(v2v::kCntBins <= 2 * v2v::kSelBins, "the counting histogram reuses the radix workspace");
+        unsigned int *hist = reinterpret_cast<unsigned int *>(st + B * 2);
+        unsigned int *bad = hist + (size_t)B * 2 * v2v::kSelBins;
+        hipError_t e = hipMemsetAsync(hist, 0, sizeof(unsigned int) * ((size_t)B * 2 * v2v::kSelBins + (size_t)B), s);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(hist)");
+        const int64_t per_in = planes * H_in * W_in;
+        const unsigned gx = (unsigned)std::min<int64_t>((per_in + 256 * 8 - 1) / (256 * 8), 512);
+        hipLaunchKernelGGL(v2v::count_hist_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, voxel, per_in, hist, bad);
+        hipLaunchKernelGGL(v2v::count_pick_kernel, dim3((unsigned)((B * 2 + 255) / 256)), dim3(256), 0, s, st, hist, bad, B * 2,
+                           (uint64_t)(per_in - per_sample), (uint64_t)(min_k - 1), (uint64_t)(max_k - 1));
     }
     const int64_t per_out = planes * Hp * Wp;
     const unsigned gx2 = (unsigned)std::min<int64_t>((per_out + 256 * 4 - 1) / (256 * 4), 2048);
     hipLaunchKernelGGL(v2v::normalize_pad_kernel, dim3(gx2, (unsigned)B), dim3(256), 0, s, voxel, out, st, normalize ? 1 : 0, planes,
-                       (int)H, (int)W, Hp, Wp);
+                       (int)H, (int)W, Hp, Wp, (int)H_in, (int)W_in);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? V2V_OK : hip_fail(e, "normalize_pad launch");
 }

@@ -150,6 +150,9 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
     const int blk = blockIdx.x - clip * a.blocks_per_clip;
     const uint32_t p0 = (uint32_t)(blk * kBlock + threadIdx.x) * VEC;
     if (p0 >= (uint32_t)a.HW) return;
+    // output planes may be padded (row pitch >= W, plane size >= pitch * H: the consumer's x16 padding written in place); the
+    // VEC pixels of a work-item share a row (VEC == 4 needs W % 4 == 0), and a plane is stored a handful of times per clip
+    const int64_t pix_off = (a.out_pitch == a.W) ? (int64_t)p0 : (int64_t)(p0 / (uint32_t)a.W) * a.out_pitch + (p0 % (uint32_t)a.W);
 
     const double *pp = a.params + (int64_t)clip * a.params_stride;
     // thresholds and their (slightly low) reciprocals live in VGPRs: they are selected per lane by polarity
@@ -216,7 +219,7 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
     for (int j = 0; j < VEC; ++j) { acc_lo[j] = 0; acc_hi[j] = 0; }
     // plane of the lower bin leaves the accumulators, the upper bin becomes the lower one
     auto flush_lower = [&](int seg) {
-        store_vec<VEC, acc_t>(a.out, (int64_t)clip * a.Tb * a.HW + p0 + (int64_t)seg * a.HW, acc_lo);
+        store_vec<VEC, acc_t>(a.out, ((int64_t)clip * a.Tb + seg) * a.out_plane + pix_off, acc_lo);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { acc_lo[j] = acc_hi[j]; acc_hi[j] = 0; }
     };
@@ -227,7 +230,7 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
     }
     int sub = 0, plane = 0;   // SUM: pairs accumulated into the current plane, plane index
     const int64_t planes_per_clip = (BIN == kBinSum) ? (a.K / a.fpb) : a.Tb;
-    const int64_t out_base = (int64_t)clip * planes_per_clip * a.HW + p0;
+    const int64_t out_base = (int64_t)clip * planes_per_clip * a.out_plane + pix_off;
     uint32_t n_all = 0, n_off = 0;
     const bool want_counts = a.counts != nullptr;
 
@@ -362,7 +365,7 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
         }
         if constexpr (BIN == kBinSum) {
             if (++sub == a.fpb) {                                      // wave-uniform
-                store_vec<VEC, acc_t>(a.out, out_base + (int64_t)plane * a.HW, acc_lo);
+                store_vec<VEC, acc_t>(a.out, out_base + (int64_t)plane * a.out_plane, acc_lo);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) acc_lo[j] = 0;
                 sub = 0;

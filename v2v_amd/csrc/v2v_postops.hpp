@@ -9,6 +9,15 @@
 // (LDS histogram per workgroup, one global atomic per non-empty bin), a tiny kernel walks the 2048 bins to pick the
 // bucket holding rank k, and the final pass leaves the exact float.  Two ranks per sample (1 % and 99 %) share every
 // pass.  Traffic: 3 reads for the select + 1 read + 1 (padded) write for the normalise; streaming, HBM-bound.
+//
+// Integer-valued voxels (the SUM-mode grids V2V trains on, data/v2v_datasets.py:399-400, without external noise) take the
+// COUNTING path instead: one pass histograms the values (|v| <= 255) per sample, a tiny kernel reads the two k-th values off
+// the cumulative counts, and the normalise pass follows -- 1 read + 1 read + 1 write instead of 3 + 1 + 1, still exact.
+// The histogram is NOT accumulated inside the simulator's epilogue: with frames_per_bin = 1 (every training config) the
+// simulator stores a plane every time step and is VALU-issue-bound, so counting there (convert, clamp, LDS atomic per voxel,
+// +~20 VALU instructions per 4-pixel step on ~190) costs more than this memory-bound pass over the finished tensor
+// (157 MB at the training shape = 0.03 ms).  Both input and output may carry a padded row pitch / plane size, so the simulator
+// can write straight into the x16-padded buffer (v2v_esim_voxel_padded_hip) and the normalise runs in place.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -91,13 +100,14 @@ __global__ void select_init_kernel(SelectState *st, int64_t n_sw, uint64_t rank_
 
 // out[b, p, 0:H, 0:W] = normalised voxel, zero elsewhere (padded to Hp x Wp)
 __global__ void __launch_bounds__(256) normalize_pad_kernel(const float *x, float *out, const SelectState *st, int normalize,
-                                                           int64_t planes, int H, int W, int Hp, int Wp)
+                                                           int64_t planes, int H, int W, int Hp, int Wp, int Hin, int Win)
 {
     const int sample = blockIdx.y;
     float pos_max = 1.0f, neg_max = 1.0f;
     if (normalize) {
-        pos_max = fmaxf(key_float(st[sample * 2 + 1].prefix), 1.0f);          // torch.clamp(kth(0.99), min=1)
-        neg_max = fmaxf(-key_float(st[sample * 2].prefix), 1.0f);             // torch.clamp(-kth(0.01), min=1)
+        const float hi = key_float(st[sample * 2 + 1].prefix), lo = -key_float(st[sample * 2].prefix);
+        pos_max = hi < 1.0f ? 1.0f : hi;                                      // torch.clamp(kth(0.99), min=1): a NaN stays a NaN
+        neg_max = lo < 1.0f ? 1.0f : lo;                                      // torch.clamp(-kth(0.01), min=1)
     }
     const int64_t per_out = planes * Hp * Wp;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_out; i += (int64_t)gridDim.x * 256) {
@@ -107,11 +117,68 @@ __global__ void __launch_bounds__(256) normalize_pad_kernel(const float *x, floa
         const int64_t p = r / Hp;
         float v = 0.0f;
         if (xw < W && yh < H) {
-            v = x[((int64_t)sample * planes + p) * H * W + (int64_t)yh * W + xw];
+            v = x[((int64_t)sample * planes + p) * Hin * Win + (int64_t)yh * Win + xw];     // input planes may be padded too (Hin x Win >= H x W)
             if (normalize) v = v > 0.0f ? v / pos_max : v / neg_max;            // torch.where(voxel > 0, ...)
         }
         out[(int64_t)sample * per_out + i] = v;
     }
+}
+
+// ---- counting path (integer-valued voxels, |v| <= kCntMax) ------------------------------------------------------------
+constexpr int kCntMax = 255, kCntBins = 2 * kCntMax + 1;
+
+// hist[sample][v + kCntMax] += 1 over the sample's (possibly padded) planes; bad[sample] != 0 if a value is not an integer
+// in range.  Zeros (the bulk of a voxel grid) are counted per wave with one ballot instead of 64 same-address LDS atomics.
+__global__ void __launch_bounds__(256) count_hist_kernel(const float *x, int64_t per_sample, unsigned int *hist, unsigned int *bad)
+{
+    __shared__ unsigned int lh[kCntBins + 1];
+    const int sample = blockIdx.y;
+    for (int i = threadIdx.x; i <= kCntBins; i += 256) lh[i] = 0;
+    __syncthreads();
+    const float *xs = x + (int64_t)sample * per_sample;
+    unsigned int zeros = 0;
+    bool any_bad = false;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < per_sample; i0 += (int64_t)gridDim.x * 256) {
+        const int64_t i = i0 + threadIdx.x;
+        const bool in = i < per_sample;
+        const float v = in ? xs[i] : 0.0f;
+        const int iv = (int)v;
+        const bool ok = (float)iv == v && iv >= -kCntMax && iv <= kCntMax;
+        any_bad |= in && !ok;
+        const unsigned long long zmask = __ballot(in && v == 0.0f);
+        if ((threadIdx.x & 63) == 0) zeros += (unsigned int)__popcll(zmask);
+        if (in && ok && iv != 0) atomicAdd(&lh[iv + kCntMax], 1u);
+    }
+    if ((threadIdx.x & 63) == 0 && zeros) atomicAdd(&lh[kCntMax], zeros);
+    if (any_bad) lh[kCntBins] = 1u;                             // benign race: every writer stores 1
+    __syncthreads();
+    unsigned int *gh = hist + (int64_t)sample * kCntBins;
+    for (int i = threadIdx.x; i < kCntBins; i += 256)
+        if (lh[i]) atomicAdd(&gh[i], lh[i]);
+    if (threadIdx.x == 0 && lh[kCntBins]) atomicExch(&bad[sample], 1u);
+}
+
+// one thread per (sample, which): walk the cumulative counts to the bin holding 0-based rank k; pad zeros (n_pad per sample,
+// counted with the data) are removed from bin 0 first.  A sample with a bad value gets NaN k-th values (its output is NaN).
+__global__ void count_pick_kernel(SelectState *st, const unsigned int *hist, const unsigned int *bad, int64_t n_sw, uint64_t n_pad,
+                                  uint64_t rank_lo, uint64_t rank_hi)
+{
+    const int64_t sw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sw >= n_sw) return;
+    const int64_t sample = sw >> 1;
+    const unsigned int *h = hist + sample * kCntBins;
+    uint64_t r = (sw & 1) ? rank_hi : rank_lo;
+    int b = 0;
+    for (; b < kCntBins - 1; ++b) {
+        const uint64_t c = (b == kCntMax) ? (uint64_t)h[b] - n_pad : (uint64_t)h[b];
+        if (r < c) break;
+        r -= c;
+    }
+    SelectState s;
+    s.prefix = bad[sample] ? float_key(__uint_as_float(0x7FC00000u)) : float_key((float)(b - kCntMax));
+    s.prefix_mask = 0xFFFFFFFFu;
+    s.rank = 0;
+    st[sw] = s;
 }
 
 }  // namespace v2v

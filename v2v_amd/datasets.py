@@ -433,13 +433,17 @@ class SimulatingCollator:
     voxels the per-sample path (`defer_sim: false`, sim_rng 'philox') produces for the same draws."""
 
     def __init__(self, num_bins=5, frames_per_bin=1, put_noise_external=False, output_additional_evs=False,
-                 device="cuda", output_device=None, rng_mode="philox"):
+                 device="cuda", output_device=None, rng_mode="philox", pad_to=1, normalize=False):
         self.num_bins, self.frames_per_bin = num_bins, frames_per_bin
         self.put_noise_external = put_noise_external
         self.output_additional_evs = output_additional_evs
         self.device = torch.device(device)
         self.output_device = torch.device(output_device) if output_device is not None else self.device
         self.rng_mode = rng_mode
+        # consumer-side post-ops done where the voxels are produced (model/train_utils.py:147-166, 322-326): the simulator writes
+        # into the x`pad_to`-padded layout, and `normalize` applies normalize_batch_voxel in place (exact counting select on the
+        # integer SUM-mode grids; radix select when the noise is external).  Then run the model with normalize_voxels: false.
+        self.pad_to, self.normalize = int(pad_to), bool(normalize)
 
     @classmethod
     def from_configs(cls, configs, **kw):
@@ -469,7 +473,14 @@ class SimulatingCollator:
         no_noise = bool((pa[:, 2] == 0).all() and (pa[:, 3] <= 0).all())
         vox = esim.esim_voxel_batch(clips, params.to(self.device), bin_mode="sum", num_bins=self.num_bins,
                                     frames_per_bin=self.frames_per_bin, rng_mode=self.rng_mode, clip_keys=keys,
-                                    put_noise_external=self.put_noise_external, no_noise=no_noise)   # [B,L(+1),Tb,H,W]
+                                    put_noise_external=self.put_noise_external, no_noise=no_noise, pad_to=self.pad_to)   # [B,L(+1),Tb,Hp,Wp]
+        if self.normalize:
+            from . import postops
+            h, w = clips.shape[-2:]
+            if self.put_noise_external:                       # non-integer voxels: exact radix select on the unpadded interior
+                vox = postops.normalize_and_pad(vox[..., :h, :w], True, self.pad_to, method="radix")
+            else:
+                vox = postops.normalize_and_pad(vox, True, self.pad_to, method="count", valid_hw=(h, w), inplace=True)
         batch["events"] = vox.to(self.output_device)
         batch["frame"] = batch["frame"].to(self.output_device)
         return batch

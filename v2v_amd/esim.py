@@ -41,7 +41,7 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
                      put_noise_external: bool = False, out_dtype: torch.dtype = torch.float32,
                      out: Optional[torch.Tensor] = None, counts: Optional[torch.Tensor] = None,
                      replay: Optional[Sequence[torch.Tensor]] = None, validate: bool = True,
-                     no_noise: Optional[bool] = None, clip_keys: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     no_noise: Optional[bool] = None, clip_keys: Optional[torch.Tensor] = None, pad_to: int = 1) -> torch.Tensor:
     """Simulate a batch of clips and bin the events, in one kernel launch on the current stream.
 
     frames  [B,N,H,W] uint8 or float32 CUDA tensor (grayscale; dims 2,3 contiguous).
@@ -51,6 +51,8 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
     counts  optional int64 [B,2] tensor; ON/OFF event totals per clip are ADDED into it.
     clip_keys  optional int64 [B,2] tensor of per-clip {seed, clip id} (overrides seed / clip_id0 + b): clip b then
             gets exactly the result of simulating it alone with that seed and clip id.
+    pad_to    > 1: the voxel planes are written straight into a buffer whose H, W are padded with zeros to multiples of
+            pad_to (forward_sequence's PAD = 16, model/train_utils.py:322-326); the returned tensor has the padded shape.
     no_noise  True asserts base_noise_std == 0 and hot_pixel_fraction == 0 for every clip, which selects the
             kernel variant without the noise adds (identical results).  Default: detected from `params` when
             they are host values, False when `params` is already a device tensor.
@@ -78,13 +80,18 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
     k = n - 1
     if bin_mode not in BIN_MODES:
         raise ValueError(f"bin_mode must be one of {list(BIN_MODES)}")
+    hp, wp = (h + pad_to - 1) // pad_to * pad_to, (w + pad_to - 1) // pad_to * pad_to
     if bin_mode == "sum":
         assert k % (num_bins * frames_per_bin) == 0, "(N-1) % (num_bins*frames_per_bin) != 0"   # v2v_datasets.py:365
-        shape = (b, k // (num_bins * frames_per_bin), num_bins, h, w)
+        shape = (b, k // (num_bins * frames_per_bin), num_bins, hp, wp)
     else:
-        shape = (b, num_bins, h, w)
+        shape = (b, num_bins, hp, wp)
     if out is None:
         out = torch.empty(shape, dtype=out_dtype, device=frames.device)
+        if hp != h:
+            out[..., h:, :] = 0                                 # only the padding is zeroed; the kernel writes every interior element
+        if wp != w:
+            out[..., :h, w:] = 0
         if b == 0:
             return out
     elif tuple(out.shape) != shape or not out.is_contiguous() or out.dtype not in _OUT or out.device != frames.device:
@@ -112,7 +119,7 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
         if tuple(clip_keys.shape) != (b, 2):
             raise ValueError("clip_keys must be [B,2] (seed, clip id)")
     with torch.cuda.device(frames.device):
-        rc = _lib.lib().v2v_esim_voxel_keyed_hip(
+        rc = _lib.lib().v2v_esim_voxel_padded_hip(
             C.c_void_p(frames.data_ptr()), _TORCH_IN[frames.dtype], b, n, h, w,
             frames.stride(0) if b > 1 else n * frames.stride(1), frames.stride(1),
             C.c_void_p(p.data_ptr()), pstride,
@@ -120,7 +127,7 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
             RNG_MODES[rng_mode], C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_uint64(clip_id0),
             C.c_void_p(clip_keys.data_ptr()) if clip_keys is not None else None,
             C.byref(rp) if rp is not None else None, BIN_MODES[bin_mode], num_bins, frames_per_bin,
-            C.c_void_p(out.data_ptr()), _OUT[out.dtype],
+            C.c_void_p(out.data_ptr()), _OUT[out.dtype], wp, hp * wp,
             C.c_void_p(counts.data_ptr()) if counts is not None else None, _lib.stream_ptr())
     _lib.check(rc)
     # The launch is asynchronous: PyTorch's caching allocator keeps freed blocks stream-ordered, so dropping
