@@ -317,3 +317,28 @@ def test_neg_pos_voxel_wrappers_compose_like_the_reference():
                                          sensor_size=(h, w))
     torch.testing.assert_close(tpos - tneg, signed, rtol=1e-5, atol=1e-5)
     assert float(tpos.min()) >= 0 and float(tneg.min()) >= 0
+
+
+@pytest.mark.gpu
+def test_host_stager_double_buffers_keep_batches_apart():
+    """v2v_amd/staging.py: batch k+1 is copied (page-locked buffer, copy stream) while batch k is consumed; with two slots per
+    shape and the loop order of SimulatingLoader every batch must arrive intact -- also from pageable and from pinned sources."""
+    from v2v_amd import esim as E
+    from v2v_amd.staging import HostStager
+    st = HostStager("cuda")
+    g = torch.Generator().manual_seed(0)
+    batches = [torch.randint(0, 256, (3, 11, 32, 48), dtype=torch.uint8, generator=g) for _ in range(7)]
+    batches[2], batches[5] = batches[2].pin_memory(), batches[5].pin_memory()
+    p = [0.2, 0.3, 0.05, 1e-3, 0.5]
+    want = [E.esim_voxel_batch(b.cuda(), p, bin_mode="sum", num_bins=5, frames_per_bin=2, seed=3) for b in batches]
+    got = []
+    nxt = st.stage(batches[0])
+    for k in range(len(batches)):
+        cur = nxt
+        if k + 1 < len(batches):
+            nxt = st.stage(batches[k + 1])               # look-ahead copy, as SimulatingLoader does
+        got.append(E.esim_voxel_batch(st.ready(cur), p, bin_mode="sum", num_bins=5, frames_per_bin=2, seed=3))
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert len(st._slots) == 1 and len(next(iter(st._slots.values()))) == 2

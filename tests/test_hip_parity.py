@@ -242,3 +242,33 @@ def test_error_behaviour(E):
     assert rc == _lib.ERR_NULL and b"NULL" in _lib.lib().v2v_last_error()
     out = E.esim_voxel_batch(f[:0], [0.2, 0.2, 0, 0, 0])
     assert out.shape == (0, 4, 5, 8, 8)
+
+
+def test_float64_non_integer_video_is_a_stated_deviation(luts):
+    """The reference runs non-integer float64 video through float64 pow/log; the fused kernel's generic path is float32.
+    The wrapper says so (RuntimeWarning) and the deviation stays inside the stated bound: <= 1e-4 of the pixel-steps differ
+    from the float64 NumPy restatement on the same np.random stream, each by one count."""
+    import warnings
+    from v2v_amd import esim as E
+    g = np.random.default_rng(8)
+    base = g.uniform(5, 250, size=(48, 64))
+    video = np.stack([np.clip(base + 9.0 * np.sin(0.35 * k + base / 40.0), 0, 255) for k in range(12)])       # float64, non-integer
+    p = [0.21, 0.27, 0.03, 1e-3, 0.4]
+    np.random.seed(4242)
+    want = O.esim_video_to_voxel(video, *p, put_noise_external=False, rng=O.GlobalNumpyRNG, use_lut=False)
+    np.random.seed(4242)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        got = E.EventEmulator(*p, rng="numpy").video_to_voxel(video)
+    assert any(issubclass(r.category, RuntimeWarning) and "float32 log path" in str(r.message) for r in rec)
+    diff = got != want
+    assert diff.mean() <= 1e-4 and (np.abs(got - want)[diff] <= 1).all()
+    # integer-valued float64 content takes the exact table path: no warning, no difference
+    vi = np.round(video)
+    np.random.seed(7)
+    want_i = O.esim_video_to_voxel(vi, *p, put_noise_external=False, rng=O.GlobalNumpyRNG, use_lut=False)
+    np.random.seed(7)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got_i = E.EventEmulator(*p, rng="numpy").video_to_voxel(vi)
+    assert np.array_equal(got_i, want_i)

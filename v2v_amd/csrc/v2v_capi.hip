@@ -64,8 +64,17 @@ int v2v_lut_set(int which, const void *src)
 {
     if (!src) return fail(V2V_ERR_NULL, "v2v_lut_set: src is NULL");
     if (which < 0 || which > 2) return fail(V2V_ERR_PARAM, "v2v_lut_set: which=%d", which);
+    // the tables are per-device symbols: a host that drives several GPUs from one process gets the same table on all of them
     void *p = const_cast<void *>(src);
-    const hipError_t e = which == 2 ? v2v::lut_v2e_copy(p, true) : which == 1 ? v2v::lut_esim32_copy(p, true) : v2v::lut_esim64_copy(p, true);
+    int ndev = 0, cur = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return hip_fail(hipGetLastError(), "v2v_lut_set: no device");
+    (void)hipGetDevice(&cur);
+    hipError_t e = hipSuccess;
+    for (int d = 0; d < ndev && e == hipSuccess; ++d) {
+        e = hipSetDevice(d);
+        if (e == hipSuccess) e = which == 2 ? v2v::lut_v2e_copy(p, true) : which == 1 ? v2v::lut_esim32_copy(p, true) : v2v::lut_esim64_copy(p, true);
+    }
+    (void)hipSetDevice(cur);
     return e == hipSuccess ? V2V_OK : hip_fail(e, "v2v_lut_set");
 }
 
@@ -149,8 +158,10 @@ int v2v_esim_voxel_padded_hip(const void *frames, int in_dtype, int64_t B, int64
                 (out_row_pitch == W ? out_plane_size % 4 == 0 : (W % 4 == 0 && out_row_pitch % 4 == 0 && out_plane_size % 4 == 0));
     // Small batches (the reference's training shape, 12 clips of 128x128 = 768 waves) are issue-bound on one wave per
     // SIMD; measured: 1 pixel per work-item (4x the waves) is SLOWER (0.19 vs 0.16 ms) because the per-4-pixel RNG
-    // block is then recomputed per pixel.  Batch more clips instead.  V2V_FORCE_VEC=1|4 overrides (tuning only).
-    if (const char *fv = getenv("V2V_FORCE_VEC")) { if (fv[0] == '1') vec4 = false; }
+    // block is then recomputed per pixel.  Batch more clips instead.
+#ifdef V2V_FORCE_SCALAR_PATH       // kernel-tuning builds only: no environment lookups on the product's launch path
+    vec4 = false;
+#endif
     const int vec = vec4 ? 4 : 1;
 
     v2v::EsimArgs a{};
@@ -336,7 +347,11 @@ int v2v_events_to_voxel_segmented_hip(const double *ts, const int64_t *xs, const
 // keeps the rectangles on the device); tiles that do not fit fall back to global reads inside the kernel.
 static hipError_t launch_frontend(const v2v::FrontendArgs &a, int64_t B, int64_t max_crop_before, hipStream_t s)
 {
-    static const bool force_gather = getenv("V2V_FRONTEND_GATHER") != nullptr;      // tuning/debug: always the gather kernel
+#ifdef V2V_FRONTEND_FORCE_GATHER   // kernel-tuning builds only: always the gather kernel
+    const bool force_gather = true;
+#else
+    const bool force_gather = false;
+#endif
     const bool tiled = !force_gather && a.gray_first && a.Cs == 3 && !a.out_imgs && !a.di && a.need_h == a.crop && a.need_w == a.crop &&
                        a.Hs <= 32767 && a.Ws <= 32767;                        // 16-bit source coordinates in the LDS coefficient tables
     if (tiled) {

@@ -444,6 +444,14 @@ class SimulatingCollator:
         # into the x`pad_to`-padded layout, and `normalize` applies normalize_batch_voxel in place (exact counting select on the
         # integer SUM-mode grids; radix select when the noise is external).  Then run the model with normalize_voxels: false.
         self.pad_to, self.normalize = int(pad_to), bool(normalize)
+        self._stager = None
+
+    @property
+    def stager(self):
+        if self._stager is None:
+            from .staging import HostStager
+            self._stager = HostStager(self.device)
+        return self._stager
 
     @classmethod
     def from_configs(cls, configs, **kw):
@@ -464,11 +472,11 @@ class SimulatingCollator:
         """batch = default-collated deferred samples (sim_frames [B,N,H,W] uint8, sim_params [B,5], sim_key [B,2])."""
         batch = dict(batch)
         clips, params, keys = batch.pop("sim_frames"), batch.pop("sim_params"), batch.pop("sim_key")
-        if self.device.type == "cuda" and not clips.is_cuda:
-            try:                                   # page-locked staging when the host allows it (RLIMIT_MEMLOCK)
-                clips = clips.pin_memory().to(self.device, non_blocking=True)
-            except RuntimeError:
-                clips = clips.to(self.device)
+        staged = batch.pop("_staged_clips", None)     # SimulatingLoader started this batch's H2D copy one batch ahead
+        if staged is not None:
+            clips = self.stager.ready(staged)
+        elif self.device.type == "cuda" and not clips.is_cuda:
+            clips = self.stager.ready(self.stager.stage(clips))   # page-locked double buffers + copy stream (v2v_amd/staging.py)
         pa = params.cpu().numpy()
         no_noise = bool((pa[:, 2] == 0).all() and (pa[:, 3] <= 0).all())
         vox = esim.esim_voxel_batch(clips, params.to(self.device), bin_mode="sum", num_bins=self.num_bins,
@@ -501,5 +509,16 @@ class SimulatingLoader:
         return len(self.loader)
 
     def __iter__(self):
-        for raw in self.loader:
-            yield self.collator.simulate(raw)
+        # one batch of look-ahead: batch k+1's clips cross PCIe (page-locked double buffers, copy stream) while batch k is
+        # simulated; the simulator's stream only waits on the copy's event
+        it = iter(self.loader)
+        stage = (lambda raw: dict(raw, _staged_clips=self.collator.stager.stage(raw["sim_frames"]))) \
+            if self.collator.device.type == "cuda" else (lambda raw: raw)
+        try:
+            nxt = stage(next(it))
+        except StopIteration:
+            return
+        for raw in it:
+            cur, nxt = nxt, stage(raw)
+            yield self.collator.simulate(cur)
+        yield self.collator.simulate(nxt)

@@ -212,6 +212,13 @@ class EventEmulator(object):
                 if np.array_equal(iv, v) and iv.min(initial=0) >= 0 and iv.max(initial=0) <= 255:
                     v = iv.astype(np.uint8)          # integer-valued: the float64 table path is exact
                 else:
+                    # The reference would run its pow/log in float64 here (v2v_core_esim.py:33-34).  The fused kernel's generic
+                    # (non-table) path is float32: same algorithm, log intensities accurate to ~1e-7 instead of ~1e-16, so a
+                    # potential that ends within that distance of a threshold multiple can yield a count that differs by one.
+                    import warnings
+                    warnings.warn("EventEmulator.video_to_voxel: non-integer %s video is simulated through the float32 log path; "
+                                  "counts can differ from the reference's float64 path on ~1e-5 of the pixel-steps" % v.dtype,
+                                  RuntimeWarning, stacklevel=2)
                     v = v.astype(np.float32)
             frames = torch.from_numpy(np.ascontiguousarray(v)).to(self.device)
         else:
