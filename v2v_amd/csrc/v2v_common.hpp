@@ -44,21 +44,21 @@ template <> struct Raw<kInF32, 1> { float v; };
 template <> struct Raw<kInU8, 4> { uint32_t v; };
 template <> struct Raw<kInU8, 1> { uint8_t v; };
 
-template <int IN, int VEC>
+template <int IN, int VEC, bool NT = (V2V_NT_LOADS != 0)>
 __device__ __forceinline__ Raw<IN, VEC> load_raw(const void *base, int64_t elem_off)
 {
     Raw<IN, VEC> r;
     if constexpr (IN == kInF32 && VEC == 4) {
         typedef float f32x4 __attribute__((ext_vector_type(4)));
-#if V2V_NT_LOADS
-        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(static_cast<const float *>(base) + elem_off));
-#else
-        const f32x4 t = *reinterpret_cast<const f32x4 *>(static_cast<const float *>(base) + elem_off);
-#endif
+        const f32x4 *ptr = reinterpret_cast<const f32x4 *>(static_cast<const float *>(base) + elem_off);
+        f32x4 t;
+        if constexpr (NT) t = __builtin_nontemporal_load(ptr); else t = *ptr;
         r.v = make_float4(t.x, t.y, t.z, t.w);
     } else if constexpr (IN == kInF32) r.v = static_cast<const float *>(base)[elem_off];
-    else if constexpr (VEC == 4) r.v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(base) + elem_off));
-    else r.v = static_cast<const uint8_t *>(base)[elem_off];
+    else if constexpr (VEC == 4) {
+        const uint32_t *ptr = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(base) + elem_off);
+        if constexpr (NT) r.v = __builtin_nontemporal_load(ptr); else r.v = *ptr;
+    } else r.v = static_cast<const uint8_t *>(base)[elem_off];
     return r;
 }
 

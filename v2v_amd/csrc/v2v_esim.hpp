@@ -56,15 +56,20 @@ __device__ V2V_SLOWPATH_ATTR float log_generic_f32(float v)
 //       else -- detected with a convert/round-trip compare, one wave-level test per vector -- is recomputed with
 //       the reference's float32 expression (v2v_core_esim.py:3-4,33-34).  Device powf/logf are within 1-2 ulp
 //       of NumPy's float32 kernels, hence the 1e-5 count-flip tolerance stated for non-integer content.
+// LDS table entries: uint8 input -> the float64 log value; float32 input -> {float32 log value, (float)index}: the index
+// comes back with the value in one ds_read_b64, so the validity test needs no convert (4 of ~100 VALU slots per step)
+template <int IN> struct LutEntry { using type = double; };
+template <> struct LutEntry<kInF32> { using type = float2; };
+
 template <int IN, int VEC>
-__device__ __forceinline__ void pix_logs(const Raw<IN, VEC> &r, const typename LutT<IN>::type *lut,
+__device__ __forceinline__ void pix_logs(const Raw<IN, VEC> &r, const typename LutEntry<IN>::type *lut,
                                          typename LutT<IN>::type (&out)[VEC])
 {
-    using lut_t = typename LutT<IN>::type;
+    using ent_t = typename LutEntry<IN>::type;
     // table entry by BYTE offset: shift + mask (two full-rate VALU ops) instead of a bit-field extract and a
     // shift-add (two half-rate ones) per pixel
-    auto at = [&](uint32_t byte_off) { return *reinterpret_cast<const lut_t *>(reinterpret_cast<const unsigned char *>(lut) + byte_off); };
-    constexpr uint32_t kSh = sizeof(lut_t) == 8 ? 3u : 2u, kMask = 255u << kSh;
+    auto at = [&](uint32_t byte_off) { return *reinterpret_cast<const ent_t *>(reinterpret_cast<const unsigned char *>(lut) + byte_off); };
+    constexpr uint32_t kSh = 3u, kMask = 255u << kSh;
     if constexpr (IN == kInU8) {
         if constexpr (VEC == 4) {
             out[0] = at((r.v << kSh) & kMask);
@@ -82,8 +87,9 @@ __device__ __forceinline__ void pix_logs(const Raw<IN, VEC> &r, const typename L
             // v + 2^23 puts an integer v in 0..255 into the low mantissa byte (one cheap add instead of a
             // convert); the byte is always a valid index, and converting it back exposes every other input
             const uint32_t b = __float_as_uint(v + 8388608.0f);
-            out[j] = at((b << kSh) & kMask);
-            bad |= __ballot((float)(b & 255u) != v);           // non-integer, negative, > 255, NaN
+            const float2 e = at((b << kSh) & kMask);
+            out[j] = e.x;
+            bad |= __ballot(e.y != v);                         // e.y = (float)(b & 255): non-integer, negative, > 255, NaN
         }
         if (__builtin_expect(bad != 0, 0)) {                   // scalar test; lanes with clean pixels skip the bodies below
 #pragma unroll
@@ -114,14 +120,15 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
     // stay in consecutive registers for the 16-byte stores
     constexpr bool PK = !OUT64 && BIN == kBinBilinear && VEC == 4;
     extern __shared__ __align__(16) unsigned char s_raw[];
-    lut_t *s_lut = reinterpret_cast<lut_t *>(s_raw);
-    acc_t *s_wlo = reinterpret_cast<acc_t *>(s_raw + 256 * sizeof(lut_t));
+    using ent_t = typename LutEntry<IN>::type;
+    ent_t *s_lut = reinterpret_cast<ent_t *>(s_raw);
+    acc_t *s_wlo = reinterpret_cast<acc_t *>(s_raw + 256 * sizeof(ent_t));
     acc_t *s_whi = s_wlo + a.K;
     int *s_kb = reinterpret_cast<int *>(s_whi + a.K);      // [Tb] first pair index of each bin segment
 
     // ---- workgroup prologue: tables into LDS
     if constexpr (IN == kInU8) s_lut[threadIdx.x] = g_lut_esim64[threadIdx.x];
-    else s_lut[threadIdx.x] = g_lut_esim32[threadIdx.x];
+    else s_lut[threadIdx.x] = make_float2(g_lut_esim32[threadIdx.x], (float)threadIdx.x);
     if constexpr (BIN == kBinBilinear) {
         // Pair k contributes to bins seg(k) and seg(k)+1 with the float64 weights of event_utils.py:715-719:
         // t_norm = (k - 0)/((K-1) - 0)*(Tb-1), w_b = max(0, 1 - |t_norm - b|); every other bin's weight is exactly 0.

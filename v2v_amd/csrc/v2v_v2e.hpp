@@ -242,16 +242,18 @@ __device__ __forceinline__ double wave_sum_f64(double v)
 // geometry or the CPU oracle's loop order.  While every term is below 2^44 a wave's 256 terms sum exactly in float64
 // (< 2^52): the lanes accumulate and reduce in float64 (one v_rndne + one v_add per term instead of a 64-bit integer
 // convert and add-with-carry) and only the wave total is converted; larger terms take the integer path.
-template <int IN, int VEC>
-__global__ void __launch_bounds__(kBlock) v2e_shot_sum_kernel(const V2eArgs a)
+// DEPTH: frames in flight per work-item (register ring).
+// (A fused variant -- the blocks_per_clip workgroups of a clip as a team in one persistent cooperative launch: sums, team
+// barrier on a device-scope counter, simulation with the re-read served by the Infinity Cache -- was built and measured in round
+// 2: 2.58 ms against 2.04 ms for these two kernels on config 3.  At the simulator's 3 waves per SIMD the summing phase reads at
+// half the rate of this 8-waves-per-SIMD kernel, and the team barrier turns the per-workgroup load balance of a plain launch into
+// a max over 64 members.  It was removed; DESIGN.md section 4.3c keeps the numbers.)
+template <int IN, int VEC, bool NT, int DEPTH>
+__device__ __forceinline__ void v2e_presum_body(const V2eArgs &a, const int clip, const int blk, unsigned char *s_tab, unsigned long long *s_sum)
 {
-    __shared__ __align__(16) unsigned char s_tab[kV2eTableBytes];
-    extern __shared__ __align__(16) unsigned long long s_sum[];          // [K,2] workgroup partial sums
     const V2eIntenTables tb = v2e_build_tables<IN>(s_tab, a.P.uint8_wrap);
     for (int t = threadIdx.x; t < 2 * a.K; t += kBlock) s_sum[t] = 0ull;
     __syncthreads();
-    const int clip = blockIdx.x / a.blocks_per_clip;
-    const int blk = blockIdx.x - clip * a.blocks_per_clip;
     const uint32_t p0 = (uint32_t)(blk * kBlock + threadIdx.x) * VEC;
     const bool active = p0 < (uint32_t)a.HW;
     const V2eParams &P = a.P;
@@ -267,11 +269,8 @@ __global__ void __launch_bounds__(kBlock) v2e_shot_sum_kernel(const V2eArgs a)
     for (int j = 0; j < VEC; ++j) { pre_p[j] = 0.0; pre_n[j] = 0.0; }
     if (active) { v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFThresA, p0, pt, nt); derive(); }
     const int64_t in_base = (int64_t)clip * a.clip_stride + (active ? p0 : 0u);
-    Raw<IN, VEC> nxt = load_raw<IN, VEC>(a.frames, in_base + a.frame_stride);
-    for (int k = 0; k < a.K; ++k) {
+    auto frame_sum = [&](int k, const Raw<IN, VEC> &raw) __attribute__((always_inline)) {
         const int i = k + 1;
-        const Raw<IN, VEC> raw = nxt;
-        nxt = load_raw<IN, VEC>(a.frames, in_base + (int64_t)(i + 1 <= a.K ? i + 1 : a.K) * a.frame_stride);
         if (temporal && active) { v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i, p0, pt, nt); derive(); }
         float x[VEC];
         double fac[VEC];
@@ -317,12 +316,40 @@ __global__ void __launch_bounds__(kBlock) v2e_shot_sum_kernel(const V2eArgs a)
             atomicAdd(&s_sum[2 * k], (unsigned long long)sp);
             atomicAdd(&s_sum[2 * k + 1], (unsigned long long)sn);
         }
+    };
+    {   // register ring of DEPTH frames, reloaded right after use (clamped, unconditional loads)
+        Raw<IN, VEC> ring[DEPTH];
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) ring[u] = load_raw<IN, VEC, NT>(a.frames, in_base + (int64_t)(1 + u <= a.K ? 1 + u : a.K) * a.frame_stride);
+        int k0 = 0;
+        for (; k0 + DEPTH <= a.K; k0 += DEPTH) {
+            static_for(std::make_integer_sequence<int, DEPTH>{}, [&](auto u_tag) {
+                constexpr int u = decltype(u_tag)::value;
+                const Raw<IN, VEC> raw = ring[u];
+                const int fn = k0 + u + 1 + DEPTH;
+                ring[u] = load_raw<IN, VEC, NT>(a.frames, in_base + (int64_t)(fn <= a.K ? fn : a.K) * a.frame_stride);
+                frame_sum(k0 + u, raw);
+            });
+        }
+        static_for(std::make_integer_sequence<int, DEPTH - 1>{}, [&](auto u_tag) {
+            constexpr int u = decltype(u_tag)::value;
+            if (k0 + u < a.K) frame_sum(k0 + u, ring[u]);
+        });
     }
     // one global atomic per (workgroup, frame, sign): ~256 waves of a clip adding into the same address every frame
     // serialised at the memory side and cost more than the whole read of the clip
     __syncthreads();
     for (int t = threadIdx.x; t < 2 * a.K; t += kBlock)
         atomicAdd(reinterpret_cast<unsigned long long *>(&a.shot_sums[(int64_t)clip * a.K * 2 + t]), s_sum[t]);
+}
+
+template <int IN, int VEC>
+__global__ void __launch_bounds__(kBlock) v2e_shot_sum_kernel(const V2eArgs a)
+{
+    __shared__ __align__(16) unsigned char s_tab[kV2eTableBytes];
+    extern __shared__ __align__(16) unsigned long long s_sum[];          // [K,2] workgroup partial sums
+    const int clip = blockIdx.x / a.blocks_per_clip;
+    v2e_presum_body<IN, VEC, true, 4>(a, clip, blockIdx.x - clip * a.blocks_per_clip, s_tab, s_sum);
 }
 
 // ---- native shot-noise sampler (float32 inversion from one uniform; the CPU oracle restates it) ----------------------
@@ -353,21 +380,18 @@ struct __align__(16) V2eIntenU8 { double i01; float logv, fac; };          // ui
 // cap stays a run-time switch in every instance)
 enum { kV2eLowpass = 1, kV2eLeak = 2, kV2eShot = 4, kV2eTemporal = 16 };
 
-template <int IN, int VEC, int BIN, int RNG, bool OUT64, int FEAT = -1>
-__global__ void __launch_bounds__(kBlock, V2V_V2E_MIN_WAVES) v2e_voxel_kernel(const V2eArgs a)
+template <int IN, int VEC, int BIN, int RNG, bool OUT64, int FEAT>
+__device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, const int blk, unsigned char *s_raw)
 {
     using acc_t = typename std::conditional<OUT64, double, float>::type;
     using inten_t = typename std::conditional<IN == kInU8, V2eIntenU8, V2eIntenF32>::type;
     static_assert(sizeof(V2eFrameConst) == 32 && sizeof(inten_t) == 16, "LDS record layout");
     constexpr bool PK = !OUT64 && BIN == kBinBilinear && VEC == 4;        // packed bilinear accumulation (see the ESIM kernel)
-    extern __shared__ __align__(16) unsigned char s_raw[];
     inten_t *s_int = reinterpret_cast<inten_t *>(s_raw);                                        // [256]
     V2eFrameConst *s_fc = reinterpret_cast<V2eFrameConst *>(s_raw + 256 * sizeof(inten_t));     // [K]
     acc_t *s_wlo = reinterpret_cast<acc_t *>(s_fc + a.K);
     acc_t *s_whi = s_wlo + a.K;
     int *s_seg = reinterpret_cast<int *>(s_whi + a.K);
-    const int clip = blockIdx.x / a.blocks_per_clip;
-    const int blk = blockIdx.x - clip * a.blocks_per_clip;
     const V2eParams &P = a.P;
     const bool lowpass = FEAT < 0 ? P.cutoff_hz > 0 : (FEAT & kV2eLowpass) != 0;
     const bool leak = FEAT < 0 ? P.leak_rate_hz > 0 : (FEAT & kV2eLeak) != 0;
@@ -565,7 +589,7 @@ __global__ void __launch_bounds__(kBlock, V2V_V2E_MIN_WAVES) v2e_voxel_kernel(co
             if (lowpass) {                                                              // low_pass_filter (:139-182)
                 if constexpr (IN == kInF32) {
                     float eps = i01_32[j] * dt_tau32;
-                    eps = eps > 1.0f ? 1.0f : eps;
+                    eps = __builtin_fminf(eps, 1.0f);                               // np.minimum (:173); eps is never NaN here: one v_min_f32
                     const float ta = (1.0f - eps) * lp_f[j], tb2 = eps * log_new[j];
                     lp_f[j] = ta + tb2;
                 } else {
@@ -635,10 +659,14 @@ __global__ void __launch_bounds__(kBlock, V2V_V2E_MIN_WAVES) v2e_voxel_kernel(co
                     const f32x2 q1 = lam + pk_splat(1.0f);
                     const f32x2 q2 = pk_fma(lam * pk_splat(0.5f), lam, q1);
                     const f32x2 s1 = pz * q1, s2 = pz * q2;
-                    const float up = u_sp[j], un = u_sn[j];
-                    cnt_p[j] = (int)(up > pz.x) + (int)(up > s1.x) + (int)(up > s2.x);
-                    cnt_n[j] = (int)(un > pz.y) + (int)(un > s1.y) + (int)(un > s2.y);
-                    more |= __ballot(up > s2.x) | __ballot(un > s2.y);
+                    // count = [u > p0] + [u > s1] + [u > s2]: the sign bit of (threshold - u) IS that comparison (an IEEE difference
+                    // is negative exactly when u is larger), so three packed subtractions, shifts and one add3 replace six
+                    // compare + select pairs
+                    const f32x2 uu = f32x2{u_sp[j], u_sn[j]};
+                    const f32x2 d0 = pz - uu, d1 = s1 - uu, d2 = s2 - uu;
+                    cnt_p[j] = (int)((__float_as_uint(d0.x) >> 31) + (__float_as_uint(d1.x) >> 31) + (__float_as_uint(d2.x) >> 31));
+                    cnt_n[j] = (int)((__float_as_uint(d0.y) >> 31) + (__float_as_uint(d1.y) >> 31) + (__float_as_uint(d2.y) >> 31));
+                    more |= __ballot((int)__float_as_uint(d2.x) < 0) | __ballot((int)__float_as_uint(d2.y) < 0);
                 }
                 if (__builtin_expect(more != 0, 0)) {
 #pragma unroll
@@ -775,6 +803,14 @@ __global__ void __launch_bounds__(kBlock, V2V_V2E_MIN_WAVES) v2e_voxel_kernel(co
         }
         if ((threadIdx.x & 63) == 0) { atomicAdd(&a.counts[2 * clip], on); atomicAdd(&a.counts[2 * clip + 1], off); }
     }
+}
+
+template <int IN, int VEC, int BIN, int RNG, bool OUT64, int FEAT = -1>
+__global__ void __launch_bounds__(kBlock, V2V_V2E_MIN_WAVES) v2e_voxel_kernel(const V2eArgs a)
+{
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    const int clip = blockIdx.x / a.blocks_per_clip;
+    v2e_main_body<IN, VEC, BIN, RNG, OUT64, FEAT>(a, clip, blockIdx.x - clip * a.blocks_per_clip, s_raw);
 }
 
 }  // namespace v2v

@@ -51,13 +51,13 @@ hipError_t launch_v2e(bool in_u8, bool vec4, int bin, int rng, bool out64, bool 
     const V2eParams &P = a.P;
     const bool spec = vec4 && !out64 && rng == V2V_RNG_PHILOX && P.threshold_model != kV2eSpatialTemporalIndependent;
     if (spec) {
+        const int feat = (P.cutoff_hz > 0 ? kV2eLowpass : 0) | (P.leak_rate_hz > 0 ? kV2eLeak : 0) | (P.shot_noise_rate_hz > 0 ? kV2eShot : 0);
         if (presum) {
             if (in_u8) hipLaunchKernelGGL((v2e_shot_sum_kernel<kInU8, 4>), grid, dim3(kBlock), (size_t)a.K * 16, s, a);
             else hipLaunchKernelGGL((v2e_shot_sum_kernel<kInF32, 4>), grid, dim3(kBlock), (size_t)a.K * 16, s, a);
             const hipError_t e1 = hipGetLastError();
             if (e1 != hipSuccess) return e1;
         }
-        const int feat = (P.cutoff_hz > 0 ? kV2eLowpass : 0) | (P.leak_rate_hz > 0 ? kV2eLeak : 0) | (P.shot_noise_rate_hz > 0 ? kV2eShot : 0);
         return in_u8 ? launch_v2e_spec_u8(bin, feat, a, grid, lds, s) : launch_v2e_spec_f32(bin, feat, a, grid, lds, s);
     }
     if (in_u8) return vec4 ? launch_v2e_t<kInU8, 4>(bin, rng, out64, presum, a, grid, lds, s) : launch_v2e_t<kInU8, 1>(bin, rng, out64, presum, a, grid, lds, s);
