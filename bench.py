@@ -52,12 +52,16 @@ WORKLOADS = {
     # tools/e2vid_consumer.py) -- end-to-end "dataloader -> model forward" throughput.
     "cfg5_pipeline_plus_e2vid_bf16": dict(model="pipeline", b=8, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1,
                                           params=DATASET_STYLE, src_hw=(720, 1280), consumer=True),
+    # the same with the consumer's three ConvLSTM blocks on the fused matrix-core kernel
+    "cfg5_fused_convlstm": dict(model="pipeline", b=8, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1,
+                                params=DATASET_STYLE, src_hw=(720, 1280), consumer="fused"),
     "train_u8_12x201x128x128_sum5": dict(model="esim", b=12, n=201, h=128, w=128, dtype="uint8", bin="sum", tb=5, fpb=1, params=DATASET_STYLE),
     "cfg1_plumbing_u8_1x8x128x128": dict(model="esim", b=1, n=8, h=128, w=128, dtype="uint8", bin="sum", tb=7, fpb=1, params=NOISE_FREE),
 }
 DEFAULT_WORKLOAD = "cfg2_esim_f32_256x32x256x256_bilinear5"
 ALSO_MEASURED = ["cfg2_noise_free", "cfg2_dataset_style", "cfg2_u8", "cfg3_v2e_f32_256x32x256x256_bilinear5", "cfg3_v2e_u8",
-                 "cfg4_u8_256x41x256x256_sum5", "cfg4_pipeline_720p_to_256_41f_sum5", "train_u8_12x201x128x128_sum5"]
+                 "cfg4_u8_256x41x256x256_sum5", "cfg4_pipeline_720p_to_256_41f_sum5", "train_u8_12x201x128x128_sum5",
+                 "cfg5_pipeline_plus_e2vid_bf16", "cfg5_fused_convlstm"]
 
 
 def cpu_baseline(frames_host, wl, budget_s=12.0):
@@ -185,8 +189,8 @@ class Workload:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 from e2vid_consumer import E2VIDShapedConsumer, forward_sequence
                 torch.manual_seed(0)
-                consumer = E2VIDShapedConsumer(num_bins=tb).to(dev).eval()
-                self.kernel_name += " + E2VID-shaped UNet forward (bf16 autocast)"
+                consumer = E2VIDShapedConsumer(num_bins=tb, fused_convlstm=wl["consumer"] == "fused").to(dev).eval()
+                self.kernel_name += " + E2VID-shaped UNet forward (bf16 autocast" + (", fused ConvLSTM steps)" if wl["consumer"] == "fused" else ")")
 
             def step():
                 gray = frontend.prepare_clips_batch(raw, table_d, idx_d, h, "gray", validate=False, max_crop_before=cb_max)[1]

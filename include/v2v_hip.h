@@ -39,7 +39,7 @@ typedef enum v2v_status {
     V2V_ERR_PARAM = -8   /* invalid scalar parameter                                                */
 } v2v_status;
 
-typedef enum v2v_dtype { V2V_U8 = 0, V2V_F32 = 1, V2V_F64 = 2 } v2v_dtype;
+typedef enum v2v_dtype { V2V_U8 = 0, V2V_F32 = 1, V2V_F64 = 2, V2V_BF16 = 3 /* consumer-side entry points only */ } v2v_dtype;
 
 /* Where the simulator's random fields come from (reference: global np.random, v2v_core_esim.py:29,37,38,44) */
 typedef enum v2v_rng_mode {
@@ -246,6 +246,26 @@ int v2v_events_to_voxel_f32_hip(const float *ts, const int64_t *xs, const int64_
 int v2v_events_to_voxel_f32_segmented_hip(const double *ts, const int64_t *xs, const int64_t *ys, const float *ps, int64_t n,
                                           const int64_t *seg_offsets, int64_t n_segments, int min_events, int discrete, int num_bins,
                                           int64_t H, int64_t W, float *out_voxel, uint64_t *dropped, void *stream);
+
+/* ---- consumer side, SURVEY §8f rank 4: the recurrent encoders' ConvLSTM step as one matrix-core kernel --------------------
+ * Replaces ConvLSTM.forward (model/submodules.py:179-235): Gates = Conv2d(2C -> 4C, 3x3, pad 1) over cat(x, h_prev), chunk
+ * into in/remember/out/cell gates (:218), sigmoid x3 + tanh (:221-226), cell = remember*c_prev + in*cell_gate (:229),
+ * hidden = out*tanh(cell) (:230).  bf16 operands, fp32 accumulation and fp32 cell state (a precision choice of THIS kernel:
+ * the tests state the tolerance against the fp32 module).  Activations are NHWC: x, h_prev, h_state [B,H,W,C] bf16;
+ * c_prev, c_state [B,H,W,C] fp32; h_nchw (optional) the same hidden state as [B,C,H,W] in h_nchw_dtype (V2V_F32 or V2V_BF16: the
+ * dtype the module's input had, :202-203) for the stock layers downstream.
+ * h_prev == NULL and c_prev == NULL mean the zero state (prev_state=None, :196-209).  c_state may alias c_prev; h_state must
+ * not alias h_prev.  tile_rows: pixels per workgroup tile, 64 or 128; 0 = pick by image size.
+ * Requirements (else V2V_ERR_SHAPE): C % 64 == 0, (B*H*W) % 64 == 0 (% 128 with tile_rows = 128), (H*W) % 4 == 0. */
+int v2v_convlstm_packed_bytes(int64_t C, uint64_t *bytes);   /* size of the packed weight buffer: 4C*2C*9 bf16 */
+/* gates_weight: the module's Gates.weight, fp32 [4C, 2C, 3, 3] on the device -> packed bf16 (once per weight update) */
+int v2v_convlstm_pack_weights_hip(const float *gates_weight, int64_t C, void *packed, void *stream);
+int v2v_convlstm_step_hip(const void *x, const void *h_prev, const float *c_prev, const void *packed, const float *gates_bias,
+                          int64_t B, int64_t H, int64_t W, int64_t C, void *h_state, float *c_state, void *h_nchw, int h_nchw_dtype, int tile_rows,
+                          void *stream);
+/* fp32 or bf16 [B,C,H,W] (src_dtype V2V_F32 / V2V_BF16) -> bf16 [B,H,W,C] (relu != 0: through max(x,0), the activation in front of the recurrent block,
+ * model/submodules.py:267-271 RecurrentConvLayer = ConvLayer(relu) -> ConvLSTM).  C % 64 == 0 and (H*W) % 64 == 0. */
+int v2v_nchw_to_nhwc_bf16_hip(const void *src, int src_dtype, int64_t B, int64_t C, int64_t H, int64_t W, int relu, void *dst, void *stream);
 
 #ifdef __cplusplus
 }

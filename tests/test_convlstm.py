@@ -1,0 +1,198 @@
+"""Fused ConvLSTM step against the reference's module semantics (model/submodules.py:179-235), restated with
+stock PyTorch ops: Conv2d(2C -> 4C, 3x3, pad 1) over cat(x, h), chunk(4) -> in / remember / out / cell gates, sigmoid x3 + tanh,
+cell = remember * c + in * cell_gate, hidden = out * tanh(cell).
+
+Tolerances (floating point; the kernel multiplies in bf16 and accumulates in fp32):
+  * against the fp64 evaluation of the SAME bf16-rounded operands: 2e-5 absolute (summation order + hardware exp/rcp)
+  * against the plain fp32 module on unrounded operands: 2e-2 absolute (bf16 has 8 bits of mantissa; gates are in [-1, 1])
+"""
+import numpy as np
+import pytest
+
+TOL_SAME_OPERANDS = 2e-5
+TOL_FP32_MODULE = 2e-2
+
+
+def _ref_step(x, h, c, weight, bias, dtype):
+    """The reference's forward (:211-230) in `dtype` on CPU; x, h, c [B,C,H,W]."""
+    import torch
+    import torch.nn.functional as F
+    gates = F.conv2d(torch.cat([x, h], 1).to(dtype), weight.to(dtype), bias.to(dtype), padding=1)
+    i, r, o, g = gates.chunk(4, 1)
+    cell = torch.sigmoid(r) * c.to(dtype) + torch.sigmoid(i) * torch.tanh(g)
+    return torch.sigmoid(o) * torch.tanh(cell), cell
+
+
+def _bf16_round(t):
+    import torch
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _case(b, c, h, w, seed, scale=1.0):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((b, c, h, w), generator=g) * scale
+    hp = torch.tanh(torch.randn((b, c, h, w), generator=g))
+    cp = torch.randn((b, c, h, w), generator=g)
+    k = 1.0 / np.sqrt(2 * c * 9)
+    weight = (torch.rand((4 * c, 2 * c, 3, 3), generator=g) * 2 - 1) * k * 3
+    bias = (torch.rand((4 * c,), generator=g) * 2 - 1) * 0.5
+    return x, hp, cp, weight, bias
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,tile_rows", [((2, 64, 16, 16), 0), ((2, 64, 16, 16), 128), ((2, 64, 16, 16), 64), ((1, 128, 8, 24), 0),
+                                               ((3, 64, 12, 16), 64), ((1, 256, 8, 8), 0), ((2, 64, 64, 64), 0)])
+def test_step_matches_reference_semantics(shape, tile_rows):
+    import torch
+    from v2v_amd import convlstm as CL
+    b, c, h, w = shape
+    x, hp, cp, weight, bias = _case(b, c, h, w, seed=sum(shape) + tile_rows)
+    dev = "cuda"
+    packed = CL.pack_gate_weights(weight.to(dev))
+    xn, hn = CL.nchw_to_nhwc_bf16(x.to(dev)), CL.nchw_to_nhwc_bf16(hp.to(dev))
+    cn = cp.to(dev).permute(0, 2, 3, 1).contiguous()
+    h_state, c_state, h_nchw = CL.convlstm_step(xn, hn, cn, packed, bias.to(dev), tile_rows=tile_rows)
+    torch.cuda.synchronize()
+    want_h, want_c = _ref_step(_bf16_round(x), _bf16_round(hp), cp, _bf16_round(weight), bias, torch.float64)
+    got_h, got_c = h_nchw.cpu().double(), c_state.permute(0, 3, 1, 2).cpu().double()
+    assert float((got_c - want_c).abs().max()) < TOL_SAME_OPERANDS
+    assert float((got_h - want_h).abs().max()) < TOL_SAME_OPERANDS
+    # the bf16 state the next step reads is the round-to-nearest-even of the fp32 hidden output, in NHWC
+    assert torch.equal(h_state, h_nchw.permute(0, 2, 3, 1).to(torch.bfloat16))
+    f32_h, f32_c = _ref_step(x, hp, cp, weight, bias, torch.float32)
+    assert float((got_h.float() - f32_h).abs().max()) < TOL_FP32_MODULE and float((got_c.float() - f32_c).abs().max()) < TOL_FP32_MODULE
+
+
+@pytest.mark.gpu
+def test_zero_state_and_in_place_cell():
+    import torch
+    from v2v_amd import convlstm as CL
+    x, _, _, weight, bias = _case(2, 64, 8, 16, seed=5)
+    dev = "cuda"
+    packed, xn = CL.pack_gate_weights(weight.to(dev)), CL.nchw_to_nhwc_bf16(x.to(dev))
+    zh, zc = torch.zeros_like(xn), torch.zeros(xn.shape, dtype=torch.float32, device=dev)
+    a = CL.convlstm_step(xn, None, None, packed, bias.to(dev))                      # prev_state=None (:196-209): K over x only
+    bb = CL.convlstm_step(xn, zh, zc, packed, bias.to(dev))
+    assert torch.equal(a[0], bb[0]) and torch.equal(a[1], bb[1]) and torch.equal(a[2], bb[2])
+    c_buf = torch.randn(xn.shape, dtype=torch.float32, device=dev)
+    keep = c_buf.clone()
+    out_of_place = CL.convlstm_step(xn, a[0], keep, packed, bias.to(dev))
+    in_place = CL.convlstm_step(xn, a[0], c_buf, packed, bias.to(dev), c_out=c_buf)
+    assert in_place[1].data_ptr() == c_buf.data_ptr() and torch.equal(in_place[1], out_of_place[1]) and torch.equal(in_place[0], out_of_place[0])
+
+
+@pytest.mark.gpu
+def test_layout_and_packing_kernels_are_exact():
+    import torch
+    from v2v_amd import convlstm as CL
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((2, 128, 8, 16), generator=g).cuda()
+    x[0, 0, 0, 0], x[0, 1, 0, 0] = float("nan"), float("inf")
+    got = CL.nchw_to_nhwc_bf16(x)
+    want = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    nan = torch.isnan(want)
+    assert int(nan.sum()) == 1 and torch.equal(torch.isnan(got), nan)
+    assert torch.equal(got.view(torch.int16)[~nan], want.contiguous().view(torch.int16)[~nan])       # inf, signs, ties-to-even
+    assert torch.equal(CL.nchw_to_nhwc_bf16(x[1:], relu=True), torch.relu(x[1:]).permute(0, 2, 3, 1).to(torch.bfloat16).contiguous())
+    xb = x[1:].to(torch.bfloat16)
+    assert torch.equal(CL.nchw_to_nhwc_bf16(xb), xb.permute(0, 2, 3, 1).contiguous())                  # bf16 source: a pure transpose
+    c = 128
+    w = torch.randn((4 * c, 2 * c, 3, 3), generator=g).cuda()
+    packed = CL.pack_gate_weights(w)
+    # layout of v2v_convlstm.hpp: [col tile][tap][chunk][wn][gate][c32][k] <- weight[gate*C + t*64 + wn*32 + c32, cc*64 + k, ky, kx]
+    v = w.view(4, c // 64, 2, 32, 2 * c // 64, 64, 3, 3).permute(1, 6, 7, 4, 2, 0, 3, 5).contiguous().to(torch.bfloat16).reshape(-1)
+    assert torch.equal(packed, v)
+
+
+@pytest.mark.gpu
+def test_module_is_a_drop_in_over_a_sequence():
+    """Same constructor / parameter names / forward contract as the reference's ConvLSTM; 6 recurrent steps against the stock
+    fp32 module with the SAME weights (error does not blow up through the recurrence); the cached bf16 state and a cloned
+    float32 prev_state give identical bits."""
+    import torch
+    import torch.nn as nn
+    from v2v_amd import convlstm as CL
+
+    class StockConvLSTM(nn.Module):                                              # restatement of model/submodules.py:179-235
+        def __init__(self, input_size, hidden_size, kernel_size):
+            super().__init__()
+            self.Gates = nn.Conv2d(input_size + hidden_size, 4 * hidden_size, kernel_size, padding=kernel_size // 2)
+
+        def forward(self, input_, prev_state=None):
+            if prev_state is None:
+                prev_state = (torch.zeros_like(input_), torch.zeros_like(input_))
+            i, r, o, g = self.Gates(torch.cat((input_, prev_state[0]), 1)).chunk(4, 1)
+            cell = torch.sigmoid(r) * prev_state[1] + torch.sigmoid(i) * torch.tanh(g)
+            return torch.sigmoid(o) * torch.tanh(cell), cell
+
+    torch.manual_seed(11)
+    stock = StockConvLSTM(64, 64, 3).cuda().eval()
+    fused = CL.ConvLSTM(64, 64, 3).cuda().eval()
+    fused.load_state_dict(stock.state_dict())                                   # same parameter names
+    xs = torch.relu(torch.randn((6, 2, 64, 16, 32), device="cuda"))
+    with torch.no_grad():
+        s_ref = s_fused = s_clone = None
+        for t in range(6):
+            h_ref, c_ref = stock(xs[t], s_ref)
+            s_ref = (h_ref, c_ref)
+            h, cell = fused(xs[t], s_fused)
+            s_fused = (h, cell)
+            assert h.shape == h_ref.shape and cell.shape == c_ref.shape and h.dtype == torch.float32 and h.is_contiguous()
+            assert float((h - h_ref).abs().max()) < TOL_FP32_MODULE and float((cell - c_ref).abs().max()) < 2 * TOL_FP32_MODULE
+            h2, cell2 = fused(xs[t], s_clone)                                      # prev_state rebuilt from float32 clones
+            assert torch.equal(h2, h) and torch.equal(cell2, cell)
+            s_clone = (h.clone(), cell.clone())
+        # under autocast the stock layers hand over bfloat16: hidden comes back in bfloat16 (the RNE of the float32 result),
+        # the cell state stays float32
+        hb, cb = fused(xs[1].to(torch.bfloat16), (s_fused[0].to(torch.bfloat16), s_fused[1]))
+        hf, cf = fused(xs[1].to(torch.bfloat16).float(), (s_fused[0].to(torch.bfloat16).float(), s_fused[1]))
+        assert hb.dtype == torch.bfloat16 and cb.dtype == torch.float32 and torch.equal(hb, hf.to(torch.bfloat16)) and torch.equal(cb, cf)
+    with pytest.raises(RuntimeError):
+        fused(xs[0])                                                             # grad mode: loud, no silent graph break
+    with pytest.raises(ValueError), torch.no_grad():
+        CL.ConvLSTM(32, 32, 3).cuda().eval()(xs[0][:, :32].contiguous())          # hidden_size % 64 != 0: refused, no fallback
+    with pytest.raises(ValueError):
+        CL.ConvLSTM(64, 64, 5)
+
+
+@pytest.mark.gpu
+def test_consumer_with_fused_blocks_tracks_the_stock_consumer():
+    """tools/e2vid_consumer.py with its three recurrent blocks on the fused kernel against the all-stock fp32 network with the
+    same weights, 4 recurrent time steps: the prediction differs by bf16 operand rounding only (2 % of its spread)."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from e2vid_consumer import E2VIDShapedConsumer, forward_sequence
+    torch.manual_seed(2)
+    stock = E2VIDShapedConsumer().cuda().eval()
+    fused = E2VIDShapedConsumer(fused_convlstm=True).cuda().eval()
+    fused.load_stock_state_dict(stock.state_dict())
+    events = torch.round(torch.randn((2, 4, 5, 64, 64), device="cuda") * 2)
+    with torch.no_grad():
+        want, got = forward_sequence(stock, events), forward_sequence(fused, events)
+    for a, b in zip(want, got):
+        assert a.shape == b.shape and float((a - b).abs().max()) < 0.02 * float(a.std()) + 1e-3
+
+
+def test_shape_errors_are_reported_without_a_gpu():
+    """Argument checks of the C ABI run before any HIP call."""
+    import ctypes as C
+    from v2v_amd import _lib
+    L = _lib.lib()
+    n = C.c_uint64(0)
+    assert L.v2v_convlstm_packed_bytes(64, C.byref(n)) == 0 and n.value == 4 * 64 * 2 * 64 * 9 * 2
+    assert L.v2v_convlstm_packed_bytes(48, C.byref(n)) == _lib.ERR_SHAPE
+    buf = (C.c_char * 4096)()
+    p = C.cast(buf, C.c_void_p)
+    assert L.v2v_convlstm_step_hip(p, None, None, p, p, 1, 8, 8, 32, p, p, None, 1, 0, None) == _lib.ERR_SHAPE          # C % 64
+    assert L.v2v_convlstm_step_hip(p, None, None, p, p, 1, 5, 5, 64, p, p, None, 1, 0, None) == _lib.ERR_SHAPE          # B*H*W % 64
+    assert L.v2v_convlstm_step_hip(p, None, None, p, p, 1, 8, 8, 64, p, p, None, 1, 128, None) == _lib.ERR_SHAPE        # 64 px, tile 128
+    assert L.v2v_convlstm_step_hip(p, None, None, p, p, 1, 8, 8, 64, p, p, None, 1, 32, None) == _lib.ERR_PARAM
+    assert L.v2v_convlstm_step_hip(p, p, None, p, p, 1, 8, 8, 64, p, p, None, 1, 0, None) == _lib.ERR_PARAM             # h_state aliases
+    assert L.v2v_convlstm_step_hip(None, None, None, p, p, 1, 8, 8, 64, p, p, None, 1, 0, None) == _lib.ERR_NULL
+    assert b"x/packed" in L.v2v_last_error()
+    assert L.v2v_convlstm_step_hip(p, None, None, p, p, 1, 8, 8, 64, p, p, p, _lib.U8, 0, None) == _lib.ERR_DTYPE
+    assert L.v2v_nchw_to_nhwc_bf16_hip(p, _lib.F64, 1, 64, 8, 8, 0, p, None) == _lib.ERR_DTYPE
+    assert L.v2v_nchw_to_nhwc_bf16_hip(p, _lib.F32, 1, 32, 8, 8, 0, p, None) == _lib.ERR_SHAPE

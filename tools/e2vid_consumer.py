@@ -1,8 +1,9 @@
 """Load generator for BASELINE config 5: a random-init recurrent UNet with the SHAPE of the reference's E2VIDRecurrent
 (model/model.py:216-223 -> model/unet.py:252-310 with the kwargs of config/train_v2v_e2vid_10k.yaml:21-30: 5 bins,
 3 encoders, base 32 channels, ConvLSTM, 2 residual blocks, sum skips, bilinear-upsample decoders, 1x1 prediction).
-Stock PyTorch-ROCm ops only -- it is NOT part of the accelerated path or of the product package (SURVEY: model families
-are out of scope); bench.py uses it to measure how fast the fused simulator can feed a consumer.
+Stock PyTorch-ROCm ops by default -- it is NOT part of the product package (SURVEY: model families are out of scope);
+bench.py uses it to measure how fast the fused simulator can feed a consumer.  fused_convlstm=True swaps the three recurrent
+blocks for v2v_amd.convlstm.ConvLSTM (the matrix-core ConvLSTM step), everything else stays stock.
 Parameter count matches the reference model: 10,710,401.
 """
 import torch
@@ -25,6 +26,20 @@ class _ConvLSTM(nn.Module):
         return h, (h, c)
 
 
+class _FusedConvLSTM(nn.Module):
+    """The recurrent block on the fused HIP kernel; takes the conv output BEFORE its ReLU.  Parameters live in cell.Gates
+    (the reference's name); E2VIDShapedConsumer.load_stock_state_dict maps a stock consumer's `gates` onto them."""
+
+    def __init__(self, ch):
+        super().__init__()
+        from v2v_amd.convlstm import ConvLSTM
+        self.cell = ConvLSTM(ch, ch, 3)
+
+    def forward(self, x_pre_relu, state):
+        h, c = self.cell(x_pre_relu, state, input_relu=True)
+        return h, (h, c)
+
+
 class _Res(nn.Module):
     def __init__(self, ch):
         super().__init__()
@@ -35,16 +50,23 @@ class _Res(nn.Module):
 
 
 class E2VIDShapedConsumer(nn.Module):
-    def __init__(self, num_bins=5, base=32, num_encoders=3, num_res=2):
+    def __init__(self, num_bins=5, base=32, num_encoders=3, num_res=2, fused_convlstm=False):
         super().__init__()
+        self.fused = fused_convlstm
         self.head = nn.Conv2d(num_bins, base, 5, padding=2)
         chans = [base * 2 ** i for i in range(num_encoders + 1)]
         self.enc = nn.ModuleList(nn.Conv2d(a, b, 5, stride=2, padding=2) for a, b in zip(chans[:-1], chans[1:]))
-        self.rec = nn.ModuleList(_ConvLSTM(b) for b in chans[1:])
+        self.rec = nn.ModuleList((_FusedConvLSTM if fused_convlstm else _ConvLSTM)(b) for b in chans[1:])
         self.res = nn.ModuleList(_Res(chans[-1]) for _ in range(num_res))
         self.dec = nn.ModuleList(nn.Conv2d(b, a, 5, padding=2) for a, b in reversed(list(zip(chans[:-1], chans[1:]))))
         self.pred = nn.Conv2d(base, 1, 1)
         self.states = [None] * num_encoders
+
+    def load_stock_state_dict(self, sd):
+        """Load the state_dict of a stock (fused_convlstm=False) consumer into this one, whichever kind it is."""
+        if self.fused:
+            sd = {k.replace(".gates.", ".cell.Gates.") if k.startswith("rec.") else k: v for k, v in sd.items()}
+        return self.load_state_dict(sd)
 
     def reset_states(self):
         self.states = [None] * len(self.enc)
@@ -53,7 +75,7 @@ class E2VIDShapedConsumer(nn.Module):
         x = F.relu(self.head(x))
         head, blocks = x, []
         for i, (conv, rec) in enumerate(zip(self.enc, self.rec)):
-            x, self.states[i] = rec(F.relu(conv(x)), self.states[i])
+            x, self.states[i] = rec(conv(x) if self.fused else F.relu(conv(x)), self.states[i])
             blocks.append(x)
         for r in self.res:
             x = r(x)

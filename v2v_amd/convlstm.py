@@ -1,0 +1,131 @@
+"""Fused ConvLSTM step of the consumer side: host side of v2v_convlstm_step_hip.
+
+    ConvLSTM(input_size, hidden_size, kernel_size)        model/submodules.py:179-235 -- same constructor, same `Gates`
+                                                          parameter names (state_dicts load unchanged), same
+                                                          forward(input_, prev_state=None) -> (hidden, cell)
+    convlstm_step(...)                                    the raw NHWC step
+    nchw_to_nhwc_bf16(x, relu=False)                      layout change in front of it
+
+The 3x3 gate convolution runs as an implicit GEMM on the bf16 matrix cores with fp32 accumulation and the gate / cell / hidden
+update fused on the accumulators (v2v_amd/csrc/v2v_convlstm.hpp).  Inference only (no autograd through the kernel: a call
+that would need a gradient raises).  No fallback: shapes the kernel does not take (hidden_size % 64, B*H*W % 64, kernel_size
+!= 3, input_size != hidden_size) raise ValueError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+_DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def nchw_to_nhwc_bf16(x: torch.Tensor, relu: bool = False) -> torch.Tensor:
+    """float32 or bfloat16 [B,C,H,W] -> bfloat16 [B,H,W,C] (optionally through ReLU) in one HIP kernel."""
+    _lib.require_gpu()
+    if not x.is_cuda or x.dtype not in _DTYPES or x.dim() != 4:
+        raise ValueError("x must be a float32 or bfloat16 CUDA tensor [B,C,H,W]")
+    x = x.contiguous()
+    b, c, h, w = x.shape
+    out = torch.empty((b, h, w, c), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().v2v_nchw_to_nhwc_bf16_hip(_ptr(x), _DTYPES[x.dtype], b, c, h, w, int(bool(relu)), _ptr(out), _lib.stream_ptr()))
+    return out
+
+
+def pack_gate_weights(weight: torch.Tensor) -> torch.Tensor:
+    """Gates.weight float32 [4C, 2C, 3, 3] -> the packed bfloat16 stream the kernel reads (flat tensor)."""
+    _lib.require_gpu()
+    if not weight.is_cuda or weight.dtype != torch.float32 or weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) \
+            or weight.shape[0] != 2 * weight.shape[1]:
+        raise ValueError("weight must be a float32 CUDA tensor [4C, 2C, 3, 3]")
+    c = weight.shape[0] // 4
+    n = C.c_uint64(0)
+    _lib.check(_lib.lib().v2v_convlstm_packed_bytes(c, C.byref(n)))
+    packed = torch.empty((n.value // 2,), dtype=torch.bfloat16, device=weight.device)
+    with torch.cuda.device(weight.device):
+        _lib.check(_lib.lib().v2v_convlstm_pack_weights_hip(_ptr(weight.detach().contiguous()), c, _ptr(packed), _lib.stream_ptr()))
+    return packed
+
+
+def convlstm_step(x, h_prev, c_prev, packed, bias, nchw_dtype=torch.float32, tile_rows: int = 0, c_out=None):
+    """One step on NHWC state.  x, h_prev: bfloat16 [B,H,W,C]; c_prev: float32 [B,H,W,C]; h_prev / c_prev None = zero state.
+    Returns (h_state bf16 NHWC, c_state fp32 NHWC, h as [B,C,H,W] in nchw_dtype -- float32 / bfloat16 -- or None when
+    nchw_dtype is None).  c_out may be c_prev (updated in place)."""
+    _lib.require_gpu()
+    if not x.is_cuda or x.dtype != torch.bfloat16 or x.dim() != 4 or not x.is_contiguous():
+        raise ValueError("x must be a contiguous bfloat16 CUDA tensor [B,H,W,C]")
+    b, h, w, c = x.shape
+    for name, t, dt in (("h_prev", h_prev, torch.bfloat16), ("c_prev", c_prev, torch.float32)):
+        if t is not None and (t.dtype != dt or tuple(t.shape) != (b, h, w, c) or not t.is_contiguous() or t.device != x.device):
+            raise ValueError(f"{name} must be a contiguous {dt} tensor [B,H,W,C] on x's device")
+    if bias.dtype != torch.float32 or bias.numel() != 4 * c or packed.dtype != torch.bfloat16 or packed.numel() != 4 * c * 2 * c * 9:
+        raise ValueError("bias must be float32 [4C] and packed the output of pack_gate_weights for the same C")
+    h_state = torch.empty_like(x)
+    c_state = c_out if c_out is not None else torch.empty((b, h, w, c), dtype=torch.float32, device=x.device)
+    if nchw_dtype is not None and nchw_dtype not in _DTYPES:
+        raise ValueError("nchw_dtype must be torch.float32, torch.bfloat16 or None")
+    h_nchw = torch.empty((b, c, h, w), dtype=nchw_dtype, device=x.device) if nchw_dtype is not None else None
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().v2v_convlstm_step_hip(_ptr(x), _ptr(h_prev), _ptr(c_prev), _ptr(packed), _ptr(bias.detach().contiguous()),
+                                                    b, h, w, c, _ptr(h_state), _ptr(c_state), _ptr(h_nchw), _DTYPES.get(nchw_dtype, _lib.F32), tile_rows,
+                                                    _lib.stream_ptr()))
+    return h_state, c_state, h_nchw
+
+
+class ConvLSTM(nn.Module):
+    """Drop-in for model/submodules.py:ConvLSTM (:179-235) on the fused kernel.
+
+    forward(input_, prev_state=None) -> (hidden, cell), both logically [B,C,H,W] as in the reference: `hidden` is a
+    contiguous NCHW tensor in the input's dtype (float32, or bfloat16 under autocast -- the reference's state takes the
+    input's dtype too, :202-203); `cell` is the kernel's float32 NHWC cell buffer seen through permute(0,3,1,2) (a
+    channels-last tensor; float32 even under autocast: the cell state is never rounded to bf16).  The bf16 NHWC copy of `hidden` that the next step's matrix-core GEMM reads is
+    kept beside it and reused when the (hidden, cell) pair comes back untouched (UNetRecurrent.forward, model/unet.py:293-296);
+    any other prev_state (cloned, loaded, edited) is converted from its float32 values, which gives the same bits."""
+
+    def __init__(self, input_size, hidden_size, kernel_size):
+        super().__init__()
+        if kernel_size != 3 or input_size != hidden_size:
+            raise ValueError("the fused ConvLSTM covers the configuration the reference instantiates "
+                             "(model/submodules.py:112: input_size == hidden_size, kernel_size=3)")
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.Gates = nn.Conv2d(input_size + hidden_size, 4 * hidden_size, kernel_size, padding=kernel_size // 2)
+        self._packed, self._packed_key = None, None
+        self._h_cache = None                                           # (hidden tensor, its version, bf16 NHWC twin)
+
+    def _weights(self):
+        w = self.Gates.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if self._packed_key != key:
+            self._packed, self._packed_key = pack_gate_weights(w.detach()), key
+        return self._packed
+
+    def forward(self, input_, prev_state=None, input_relu: bool = False):
+        """input_relu=True takes the PRE-activation output of the convolution in front (RecurrentConvLayer.conv,
+        model/submodules.py:110-116) and applies its ReLU inside the layout-change kernel."""
+        if torch.is_grad_enabled() and (input_.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise RuntimeError("v2v_amd.convlstm.ConvLSTM is inference-only (no autograd through the fused kernel): "
+                               "call it under torch.no_grad() / in eval mode")
+        x = nchw_to_nhwc_bf16(input_, relu=input_relu)
+        h_prev = c_prev = None
+        if prev_state is not None:
+            hidden, cell = prev_state
+            cache = self._h_cache
+            if cache is not None and cache[0] is hidden and cache[1] == hidden._version:
+                h_prev = cache[2]
+            else:
+                h_prev = nchw_to_nhwc_bf16(hidden)
+            c_prev = cell.permute(0, 2, 3, 1)
+            if c_prev.dtype != torch.float32 or not c_prev.is_contiguous():
+                c_prev = c_prev.float().contiguous()
+        h_state, c_state, h_nchw = convlstm_step(x, h_prev, c_prev, self._weights(), self.Gates.bias.detach().float(), nchw_dtype=input_.dtype)
+        self._h_cache = (h_nchw, h_nchw._version, h_state)
+        return h_nchw, c_state.permute(0, 3, 1, 2)

@@ -67,4 +67,20 @@ hipError_t lut_esim64_copy(void *host, bool to_device);
 hipError_t lut_esim32_copy(void *host, bool to_device);
 hipError_t lut_v2e_copy(void *host, bool to_device);
 
+// fused ConvLSTM step (v2v_convlstm_tu.hip; kernel + argument struct in v2v_convlstm.hpp)
+struct ConvLstmArgs {
+    const uint16_t *x, *h_prev;            // bf16 NHWC; h_prev may be null (zero state: its half of K is skipped)
+    const float *c_prev;                   // fp32 NHWC or null (zero)
+    const uint16_t *wp;                    // packed weights
+    const float *bias;                     // [4C] in the module's order (gate-major)
+    uint16_t *h_state;                     // bf16 NHWC
+    float *c_state;                        // fp32 NHWC
+    void *h_nchw;                          // optional NCHW copy of h for the layers downstream
+    int32_t h_nchw_bf16;                   // its dtype: 0 fp32, 1 bf16
+    int32_t B, H, W, C;
+};
+hipError_t launch_convlstm_step(const ConvLstmArgs &a, int tile_rows, hipStream_t s);   // tile_rows: 0 auto, 64 or 128
+hipError_t launch_convlstm_pack(const float *w, uint16_t *wp, int C, hipStream_t s);
+hipError_t launch_nchw_to_nhwc_bf16(const void *src, bool src_bf16, uint16_t *dst, int B, int C, int HW, int relu, hipStream_t s);
+
 }  // namespace v2v

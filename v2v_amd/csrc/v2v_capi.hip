@@ -546,4 +546,56 @@ int v2v_events_to_voxel_f32_segmented_hip(const double *ts, const int64_t *xs, c
                              stream, "v2v_events_to_voxel_f32_segmented_hip");
 }
 
+int v2v_convlstm_packed_bytes(int64_t C, uint64_t *bytes)
+{
+    if (!bytes) return fail(V2V_ERR_NULL, "v2v_convlstm_packed_bytes: bytes is NULL");
+    if (C < 64 || C % 64 != 0) return fail(V2V_ERR_SHAPE, "ConvLSTM kernel needs C %% 64 == 0 (got %lld)", (long long)C);
+    *bytes = (uint64_t)4 * C * 2 * C * 9 * 2;
+    return V2V_OK;
+}
+
+int v2v_convlstm_pack_weights_hip(const float *gates_weight, int64_t C, void *packed, void *stream)
+{
+    if (!gates_weight || !packed) return fail(V2V_ERR_NULL, "v2v_convlstm_pack_weights_hip: gates_weight/packed is NULL");
+    if (C < 64 || C % 64 != 0 || C > 4096) return fail(V2V_ERR_SHAPE, "ConvLSTM kernel needs C %% 64 == 0, C <= 4096 (got %lld)", (long long)C);
+    if (!aligned(gates_weight, 4) || !aligned(packed, 16)) return fail(V2V_ERR_ALIGN, "gates_weight needs 4-byte, packed 16-byte alignment");
+    const hipError_t e = v2v::launch_convlstm_pack(gates_weight, static_cast<uint16_t *>(packed), (int)C, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "convlstm_pack_kernel launch");
+}
+
+int v2v_convlstm_step_hip(const void *x, const void *h_prev, const float *c_prev, const void *packed, const float *gates_bias,
+                          int64_t B, int64_t H, int64_t W, int64_t C, void *h_state, float *c_state, void *h_nchw, int h_nchw_dtype, int tile_rows, void *stream)
+{
+    if (h_nchw && h_nchw_dtype != V2V_F32 && h_nchw_dtype != V2V_BF16) return fail(V2V_ERR_DTYPE, "h_nchw_dtype must be V2V_F32 or V2V_BF16");
+    if (!x || !packed || !gates_bias || !h_state || !c_state) return fail(V2V_ERR_NULL, "v2v_convlstm_step_hip: x/packed/gates_bias/h_state/c_state is NULL");
+    if (B < 1 || H < 1 || W < 1 || C < 64 || C % 64 != 0 || C > 4096) return fail(V2V_ERR_SHAPE, "need B,H,W >= 1 and C %% 64 == 0, C <= 4096");
+    if (tile_rows != 0 && tile_rows != 64 && tile_rows != 128) return fail(V2V_ERR_PARAM, "tile_rows must be 0 (auto), 64 or 128");
+    if ((B * H * W) % (tile_rows == 128 ? 128 : 64) != 0 || (H * W) % 4 != 0 || B * H * W * C > 0x7FFFFFFFLL)
+        return fail(V2V_ERR_SHAPE, "ConvLSTM kernel needs (B*H*W) %% 64 == 0 (128 with tile_rows = 128), (H*W) %% 4 == 0 and B*H*W*C < 2^31 (got %lldx%lldx%lldx%lld)",
+                    (long long)B, (long long)H, (long long)W, (long long)C);
+    if (h_state == h_prev || h_state == x) return fail(V2V_ERR_PARAM, "h_state must not alias h_prev or x (neighbouring tiles read them)");
+    if (!aligned(x, 16) || !aligned(h_prev, 16) || !aligned(packed, 16) || !aligned(h_state, 2) || !aligned(c_prev, 4) || !aligned(c_state, 4) ||
+        !aligned(gates_bias, 4) || !aligned(h_nchw, 16))
+        return fail(V2V_ERR_ALIGN, "x/h_prev/packed/h_nchw need 16-byte alignment");
+    v2v::ConvLstmArgs a{};
+    a.x = static_cast<const uint16_t *>(x); a.h_prev = static_cast<const uint16_t *>(h_prev); a.c_prev = c_prev;
+    a.wp = static_cast<const uint16_t *>(packed); a.bias = gates_bias;
+    a.h_state = static_cast<uint16_t *>(h_state); a.c_state = c_state; a.h_nchw = h_nchw; a.h_nchw_bf16 = h_nchw_dtype == V2V_BF16;
+    a.B = (int)B; a.H = (int)H; a.W = (int)W; a.C = (int)C;
+    const hipError_t e = v2v::launch_convlstm_step(a, tile_rows, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "convlstm_step_kernel launch");
+}
+
+int v2v_nchw_to_nhwc_bf16_hip(const void *src, int src_dtype, int64_t B, int64_t C, int64_t H, int64_t W, int relu, void *dst, void *stream)
+{
+    if (!src || !dst) return fail(V2V_ERR_NULL, "v2v_nchw_to_nhwc_bf16_hip: src/dst is NULL");
+    if (src_dtype != V2V_F32 && src_dtype != V2V_BF16) return fail(V2V_ERR_DTYPE, "src_dtype must be V2V_F32 or V2V_BF16");
+    if (B < 1 || H < 1 || W < 1 || C < 64 || C % 64 != 0 || (H * W) % 64 != 0 || B * (C / 64) * (H * W / 64) > 0x7FFFFFFFLL)
+        return fail(V2V_ERR_SHAPE, "need B,H,W >= 1, C %% 64 == 0, (H*W) %% 64 == 0");
+    if (!aligned(src, src_dtype == V2V_F32 ? 4 : 2) || !aligned(dst, 2)) return fail(V2V_ERR_ALIGN, "buffers misaligned");
+    const hipError_t e = v2v::launch_nchw_to_nhwc_bf16(src, src_dtype == V2V_BF16, static_cast<uint16_t *>(dst), (int)B, (int)C, (int)(H * W),
+                                                       relu ? 1 : 0, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "nchw_to_nhwc_bf16_kernel launch");
+}
+
 }  // extern "C"

@@ -1,0 +1,240 @@
+// v2v_convlstm.hpp -- fused ConvLSTM step of the consumer side (gfx950 MFMA).
+//
+// Replaces one ConvLSTM.forward of the reference's recurrent encoders (model/submodules.py:179-235):
+//     gates = Conv2d(2C -> 4C, 3x3, pad 1)(cat(x, h_prev));  i, r, o, g = gates.chunk(4, 1)
+//     c = sigmoid(r) * c_prev + sigmoid(i) * tanh(g);  h = sigmoid(o) * tanh(c)
+// as ONE kernel: the 3x3 convolution is an implicit GEMM on the bf16 matrix cores
+//     M = B*H*W pixels,  N = 4C gate columns,  K = 9 taps * 2C channels          (fp32 accumulation)
+// and the four gate activations + the cell/hidden update run on the accumulators in registers -- the [B,4C,H,W] gate tensor,
+// the cat() copy and the five elementwise passes of the stock graph never touch HBM.
+//
+// Layouts.  Activations are NHWC (channel-minor) bf16 so that one pixel's 64 channels of one tap are one 128-byte line:
+//   x, h_prev, h_state : [B,H,W,C] bf16        c_prev, c_state : [B,H,W,C] fp32        h_nchw (optional) : [B,C,H,W] fp32
+// Weights are packed once per module (v2v_convlstm_pack_weights_hip) into the order the kernel streams them:
+//   wp[col tile t = C/64][chunk ck = tap*(2C/64) + cc][column n = 0..255][k = 0..63] bf16,
+//   column n = wn*128 + gate*32 + c32  <->  output channel gate*C + t*64 + wn*32 + c32,   k <-> input channel cc*64 + k
+// i.e. every (tile, chunk) is one contiguous 32 KB block and a wave's four B fragments are the four gates of ITS 32 channels.
+//
+// Tiling.  A workgroup (4 waves) owns 128 consecutive pixels x 64 hidden channels (x 4 gates = 256 columns); wave (wm, wn)
+// owns 64 pixels x 32 channels x 4 gates = 2 x 4 accumulators of v_mfma_f32_32x32x16_bf16 (128 VGPRs).  K is walked in chunks
+// of 64 (one tap, 64 channels): the A tile (128 px x 64 k, 16 KB) and the B tile (256 cols x 64 k, 32 KB) of chunk k+1 are
+// brought into the other LDS buffer by global_load_lds_dwordx4 (no VGPR staging) while the MFMAs run on chunk k; out-of-image
+// taps read a 128-byte zero line instead.  LDS rows are 128 B; the 16-byte slot index is XORed with (row >> 1) & 7 -- applied
+// on the SOURCE address of the LDS-DMA (its LDS destination is lane-linear) and on the ds_read_b128 address -- which makes
+// every 16-lane group of a fragment read hit 16 distinct (row parity, slot) pairs = all 64 banks once.
+// Per chunk and wave: 24 ds_read_b128, 32 MFMAs (1024 matrix-core cycles), 12 LDS-DMA instructions, one barrier.
+// The default is the 64-pixel tile (MF = 1, 80 KB of LDS): two workgroups per CU cover each other's barrier waits.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "v2v_args.hpp"
+
+namespace v2v {
+
+constexpr int kClBK = 64, kClCh = 64, kClBN = 4 * kClCh;
+constexpr int kClBBytes = kClBN * kClBK * 2;
+// MF = 32-pixel accumulator rows per wave: 2 -> 128-pixel tiles (96 KB of LDS), 1 -> 64-pixel tiles (80 KB) for small images
+constexpr int cl_lds_bytes(int mf) { return 2 * (64 * mf * kClBK * 2 + kClBBytes); }
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 cl_bf16x8;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float cl_f32x16;
+
+
+__device__ __attribute__((aligned(128))) unsigned char g_cl_zero_line[128];      // zero-initialised: the padding source
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);   // NaN stays NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float cl_sigmoid(float v) { return __frcp_rn(1.0f + __expf(-v)); }
+__device__ __forceinline__ float cl_tanh(float v) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * v)) - 1.0f; }
+
+__device__ __forceinline__ void cl_glds16(const void *src, unsigned char *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+template <int MF>
+__global__ void __launch_bounds__(256, MF == 1 ? 2 : 1) convlstm_step_kernel(const ConvLstmArgs a)
+{
+    constexpr int kClBM = 64 * MF, kClABytes = kClBM * kClBK * 2, kClStage = kClABytes + kClBBytes;
+    extern __shared__ __attribute__((aligned(128))) unsigned char cl_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int C = a.C, HW = a.H * a.W;
+    const int n_ct = C / kClCh;                                  // column tiles
+    const int ct = blockIdx.x % n_ct;
+    const int64_t m0 = (int64_t)(blockIdx.x / n_ct) * kClBM;      // first pixel of the tile (flattened b,y,x)
+    const int cc_all = 2 * C / kClBK, cc_x = C / kClBK;
+    const int cc_eff = a.h_prev ? cc_all : cc_x;                  // zero state: skip h's chunks
+    const int n_chunks = 9 * cc_eff;
+
+    // ---- staging plan: wave w issues A pieces 4w..4w+3 (8 rows each) and B pieces 8w..8w+7 per chunk ----------------------
+    const int srow = lane >> 3, sslot = lane & 7;                 // this lane's (row in piece, LDS slot)
+    constexpr int NA = 2 * MF;                                    // A pieces per wave
+    int ay[NA], ax[NA];
+    int64_t apix[NA];
+    uint32_t aswz[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int row = (wave * NA + j) * 8 + srow;
+        const int64_t m = m0 + row;
+        const int p = (int)(m % HW);
+        ay[j] = p / a.W;
+        ax[j] = p % a.W;
+        apix[j] = m * C;                                          // element offset of the pixel's channel vector
+        aswz[j] = (uint32_t)((sslot ^ ((row >> 1) & 7)) * 8);     // source channel offset inside the 64-channel chunk
+    }
+    uint32_t boff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = (wave * 8 + j) * 8 + srow;
+        boff[j] = (uint32_t)(row * kClBK + (sslot ^ ((row >> 1) & 7)) * 8);
+    }
+    const uint16_t *wtile = a.wp + (int64_t)ct * 9 * cc_all * (kClBN * kClBK);
+
+    auto stage = [&](int ck, int buf) __attribute__((always_inline)) {
+        const int tap = ck / cc_eff, cc = ck - tap * cc_eff;
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const uint16_t *src = cc < cc_x ? a.x : a.h_prev;
+        const int c0 = (cc < cc_x ? cc : cc - cc_x) * kClBK;
+        unsigned char *abase = cl_lds + buf * kClStage, *bbase = abase + kClABytes;
+        const int64_t shift = ((int64_t)dy * a.W + dx) * C + c0;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const bool in = (unsigned)(ay[j] + dy) < (unsigned)a.H && (unsigned)(ax[j] + dx) < (unsigned)a.W;
+            const void *g = in ? (const void *)(src + apix[j] + shift + aswz[j]) : (const void *)g_cl_zero_line;
+            cl_glds16(g, abase + (wave * NA + j) * 1024);
+        }
+        const uint16_t *wchunk = wtile + (int64_t)(tap * cc_all + cc) * (kClBN * kClBK);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cl_glds16(wchunk + boff[j], bbase + (wave * 8 + j) * 1024);
+    };
+
+    // ---- fragment read plan ------------------------------------------------------------------------------------------------
+    const int fr = lane & 31, fh = lane >> 5;
+    const uint32_t fsw = (uint32_t)((fr >> 1) & 7);
+    uint32_t koff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) koff[s] = ((uint32_t)(2 * s + fh) ^ fsw) << 4;
+    const uint32_t a_row = (uint32_t)((wm * 32 * MF + fr) * 128), b_row = (uint32_t)(kClABytes + (wn * 128 + fr) * 128);
+
+    cl_f32x16 acc[MF][4];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][g][r] = 0.0f;
+
+    stage(0, 0);
+    for (int ck = 0; ck < n_chunks; ++ck) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                         // chunk ck has landed; everyone is done with the other buffer
+        if (ck + 1 < n_chunks) stage(ck + 1, (ck + 1) & 1);
+        const unsigned char *base = cl_lds + (ck & 1) * kClStage;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            cl_bf16x8 af[MF], bf[4];
+#pragma unroll
+            for (int i = 0; i < MF; ++i) af[i] = *reinterpret_cast<const cl_bf16x8 *>(base + a_row + i * (32 * 128) + koff[s]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bf[g] = *reinterpret_cast<const cl_bf16x8 *>(base + b_row + g * (32 * 128) + koff[s]);
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[g], acc[i][g], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: gates -> cell / hidden, straight from the accumulators ---------------------------------------------------
+    // accumulator element r of lane l: column (channel) l & 31, row (pixel) (r & 3) + 8 (r >> 2) + 4 (l >> 5)
+    const int ch = ct * kClCh + wn * 32 + fr;
+    const float b_i = a.bias[ch], b_r = a.bias[C + ch], b_o = a.bias[2 * C + ch], b_g = a.bias[3 * C + ch];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float hv[4];
+            const int64_t mq = m0 + wm * 32 * MF + i * 32 + q * 8 + fh * 4;       // first of 4 consecutive pixels
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = q * 4 + e;
+                const int64_t idx = (mq + e) * C + ch;
+                const float gi = cl_sigmoid(acc[i][0][r] + b_i), gr = cl_sigmoid(acc[i][1][r] + b_r);
+                const float go = cl_sigmoid(acc[i][2][r] + b_o), gg = cl_tanh(acc[i][3][r] + b_g);
+                const float cp = a.c_prev ? a.c_prev[idx] : 0.0f;
+                const float cn = gr * cp + gi * gg;
+                const float hn = go * cl_tanh(cn);
+                a.c_state[idx] = cn;
+                a.h_state[idx] = f32_to_bf16_rne(hn);
+                hv[e] = hn;
+            }
+            if (a.h_nchw) {
+                const int64_t b = mq / HW, p = mq - b * HW;                  // HW % 4 == 0: the 4 pixels share an image
+                const int64_t o = (b * C + ch) * HW + p;
+                if (a.h_nchw_bf16) {
+                    const uint32_t lo = (uint32_t)f32_to_bf16_rne(hv[0]) | ((uint32_t)f32_to_bf16_rne(hv[1]) << 16);
+                    const uint32_t hi = (uint32_t)f32_to_bf16_rne(hv[2]) | ((uint32_t)f32_to_bf16_rne(hv[3]) << 16);
+                    *reinterpret_cast<uint2 *>(static_cast<uint16_t *>(a.h_nchw) + o) = make_uint2(lo, hi);
+                } else {
+                    *reinterpret_cast<float4 *>(static_cast<float *>(a.h_nchw) + o) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+                }
+            }
+        }
+    }
+}
+
+// fp32 or bf16 NCHW -> bf16 NHWC (optionally through a ReLU): the layout change between the stock convolution upstream and the
+// fused step.  One workgroup moves 64 pixels x 64 channels through LDS so that both sides are full-line accesses.
+__device__ __forceinline__ float cl_load_f32(const float *p, int64_t i) { return p[i]; }
+__device__ __forceinline__ float cl_load_f32(const uint16_t *p, int64_t i) { return __uint_as_float((uint32_t)p[i] << 16); }
+
+template <typename SRC>
+__global__ void __launch_bounds__(256) nchw_to_nhwc_bf16_kernel(const SRC *src, uint16_t *dst, int C, int HW, int relu)
+{
+    __shared__ float t[64][65];
+    const int n_ct = C / 64, n_pt = HW / 64;
+    const int ctile = blockIdx.x % n_ct;
+    const int ptile = (blockIdx.x / n_ct) % n_pt;
+    const int b = blockIdx.x / (n_ct * n_pt);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int c = ty * 16 + k;
+        float v = cl_load_f32(src, ((int64_t)b * C + ctile * 64 + c) * HW + ptile * 64 + tx);
+        if (relu) v = v > 0.0f ? v : (v != v ? v : 0.0f);                       // torch.relu keeps NaN
+        t[c][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int p = ty * 16 + k;
+        dst[((int64_t)b * HW + ptile * 64 + p) * C + ctile * 64 + tx] = f32_to_bf16_rne(t[tx][p]);
+    }
+}
+
+// [4C, 2C, 3, 3] fp32 (nn.Conv2d weight of ConvLSTM.Gates) -> packed bf16 (layout at the top of this file); one thread per element
+__global__ void __launch_bounds__(256) convlstm_pack_kernel(const float *w, uint16_t *wp, int C)
+{
+    const int64_t n = (int64_t)4 * C * 2 * C * 9;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int cc_all = 2 * C / kClBK;
+    int64_t r = i;
+    const int k = (int)(r % kClBK); r /= kClBK;
+    const int col = (int)(r % kClBN); r /= kClBN;
+    const int ck = (int)(r % (9 * cc_all)); r /= 9 * cc_all;
+    const int ct = (int)r;
+    const int tap = ck / cc_all, cc = ck % cc_all;
+    const int wn = col >> 7, gate = (col >> 5) & 3, c32 = col & 31;
+    const int oc = gate * C + ct * kClCh + wn * 32 + c32, ic = cc * kClBK + k;
+    wp[i] = f32_to_bf16_rne(w[((int64_t)oc * 2 * C + ic) * 9 + tap]);
+}
+
+}  // namespace v2v

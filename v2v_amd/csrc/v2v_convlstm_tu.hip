@@ -1,0 +1,53 @@
+// v2v_convlstm_tu.hip -- translation unit of the fused ConvLSTM step: launchers.
+#include "v2v_convlstm.hpp"
+#include "v2v_args.hpp"
+
+namespace v2v {
+
+namespace {
+template <int MF>
+hipError_t launch_step_mf(const ConvLstmArgs &a, hipStream_t s)
+{
+    // 80-96 KB of dynamic LDS is above the 64 KB a kernel gets by default: raise the limit once per device (kept out of the
+    // launch path so that a step captures into a hipGraph as a bare kernel node)
+    constexpr int lds = cl_lds_bytes(MF);
+    static bool raised[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev < 0 || dev >= 64 || !raised[dev]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convlstm_step_kernel<MF>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) raised[dev] = true;
+    }
+    const int64_t tiles = (int64_t)a.B * a.H * a.W / (64 * MF) * (a.C / kClCh);
+    hipLaunchKernelGGL((convlstm_step_kernel<MF>), dim3((unsigned)tiles), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+}  // namespace
+
+// tile_rows 0 = auto: 64-pixel tiles.  Two such workgroups (2 x 80 KB of LDS) share a CU, which hides each other's barrier
+// and LDS-DMA waits; measured 5-30 % faster than one 128-pixel workgroup per CU at every E2VID encoder shape
+// (profiles/r02b/convlstm_time.json), so the 128-pixel variant is only taken on request.
+hipError_t launch_convlstm_step(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
+{
+    return tile_rows == 128 ? launch_step_mf<2>(a, s) : launch_step_mf<1>(a, s);
+}
+
+hipError_t launch_convlstm_pack(const float *w, uint16_t *wp, int C, hipStream_t s)
+{
+    const int64_t n = (int64_t)4 * C * 2 * C * 9;
+    hipLaunchKernelGGL(convlstm_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, wp, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_nchw_to_nhwc_bf16(const void *src, bool src_bf16, uint16_t *dst, int B, int C, int HW, int relu, hipStream_t s)
+{
+    const int64_t blocks = (int64_t)B * (C / 64) * (HW / 64);
+    if (src_bf16)
+        hipLaunchKernelGGL(nchw_to_nhwc_bf16_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint16_t *>(src), dst, C, HW, relu);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_bf16_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float *>(src), dst, C, HW, relu);
+    return hipGetLastError();
+}
+
+}  // namespace v2v
