@@ -255,8 +255,8 @@ int v2v_events_to_voxel_f32_segmented_hip(const double *ts, const int64_t *xs, c
  * c_prev, c_state [B,H,W,C] fp32; h_nchw (optional) the same hidden state as [B,C,H,W] in h_nchw_dtype (V2V_F32 or V2V_BF16: the
  * dtype the module's input had, :202-203) for the stock layers downstream.
  * h_prev == NULL and c_prev == NULL mean the zero state (prev_state=None, :196-209).  c_state may alias c_prev; h_state must
- * not alias h_prev.  tile_rows: pixels per workgroup tile, 64 or 128; 0 = pick by image size.
- * Requirements (else V2V_ERR_SHAPE): C % 64 == 0, (B*H*W) % 64 == 0 (% 128 with tile_rows = 128), (H*W) % 4 == 0. */
+ * not alias h_prev.  tile_rows: pixels per workgroup tile, 64, 128 or 256; 0 = pick by image size.
+ * Requirements (else V2V_ERR_SHAPE): C % 64 == 0, (B*H*W) % 64 == 0 (% tile_rows when given), (H*W) % 4 == 0. */
 int v2v_convlstm_packed_bytes(int64_t C, uint64_t *bytes);   /* size of the packed weight buffer: 4C*2C*9 bf16 */
 /* gates_weight: the module's Gates.weight, fp32 [4C, 2C, 3, 3] on the device -> packed bf16 (once per weight update) */
 int v2v_convlstm_pack_weights_hip(const float *gates_weight, int64_t C, void *packed, void *stream);

@@ -61,10 +61,10 @@ def main():
             row["fused_module_bf16io_ms"] = timeit(lambda: fused(xb, stateb))
             xn = CL.nchw_to_nhwc_bf16(x)
             hs, cs, _ = CL.convlstm_step(xn, None, None, fused._weights(), fused.Gates.bias)
-            for tr in (64, 128):
+            for tr in (64, 128, 256):
                 row[f"fused_step_only_t{tr}_ms"] = timeit(lambda: CL.convlstm_step(xn, hs, cs, fused._weights(), fused.Gates.bias, nchw_dtype=torch.bfloat16,
                                                                                tile_rows=tr))
-            best = min(row["fused_step_only_t64_ms"], row["fused_step_only_t128_ms"])
+            best = min(row["fused_step_only_t64_ms"], row["fused_step_only_t128_ms"], row["fused_step_only_t256_ms"])
             row["fused_step_tflops"] = flops / best / 1e9
             row["conv_to_nhwc_ms"] = timeit(lambda: CL.nchw_to_nhwc_bf16(x))
         rows.append(row)

@@ -79,7 +79,7 @@ struct ConvLstmArgs {
     int32_t h_nchw_bf16;                   // its dtype: 0 fp32, 1 bf16
     int32_t B, H, W, C;
 };
-hipError_t launch_convlstm_step(const ConvLstmArgs &a, int tile_rows, hipStream_t s);   // tile_rows: 0 auto, 64 or 128
+hipError_t launch_convlstm_step(const ConvLstmArgs &a, int tile_rows, hipStream_t s);   // tile_rows: 0 auto, 64, 128 or 256
 hipError_t launch_convlstm_pack(const float *w, uint16_t *wp, int C, hipStream_t s);
 hipError_t launch_nchw_to_nhwc_bf16(const void *src, bool src_bf16, uint16_t *dst, int B, int C, int HW, int relu, hipStream_t s);
 

@@ -34,8 +34,9 @@ namespace v2v {
 
 constexpr int kClBK = 64, kClCh = 64, kClBN = 4 * kClCh;
 constexpr int kClBBytes = kClBN * kClBK * 2;
-// MF = 32-pixel accumulator rows per wave: 2 -> 128-pixel tiles (96 KB of LDS), 1 -> 64-pixel tiles (80 KB) for small images
-constexpr int cl_lds_bytes(int mf) { return 2 * (64 * mf * kClBK * 2 + kClBBytes); }
+// MF = 32-pixel accumulator blocks per wave (1 or 2), WM = wave rows (2 or 4; x 2 wave columns): the workgroup tile is
+// 32*MF*WM pixels -- 64 (4 waves, 80 KB of LDS), 128 (4 waves, 96 KB) or 256 (8 waves, 128 KB)
+constexpr int cl_lds_bytes(int mf, int wm) { return 2 * (32 * mf * wm * kClBK * 2 + kClBBytes); }
 
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 cl_bf16x8;
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float cl_f32x16;
@@ -59,13 +60,13 @@ __device__ __forceinline__ void cl_glds16(const void *src, unsigned char *lds_wa
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <int MF>
-__global__ void __launch_bounds__(256, MF == 1 ? 2 : 1) convlstm_step_kernel(const ConvLstmArgs a)
+template <int MF, int WM>
+__global__ void __launch_bounds__(128 * WM, (MF == 1 || WM == 4) ? 2 : 1) convlstm_step_kernel(const ConvLstmArgs a)
 {
-    constexpr int kClBM = 64 * MF, kClABytes = kClBM * kClBK * 2, kClStage = kClABytes + kClBBytes;
+    constexpr int kClBM = 32 * MF * WM, kClABytes = kClBM * kClBK * 2, kClStage = kClABytes + kClBBytes;
     extern __shared__ __attribute__((aligned(128))) unsigned char cl_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave % WM, wn = wave / WM;
     const int C = a.C, HW = a.H * a.W;
     const int n_ct = C / kClCh;                                  // column tiles
     const int ct = blockIdx.x % n_ct;
@@ -74,7 +75,7 @@ __global__ void __launch_bounds__(256, MF == 1 ? 2 : 1) convlstm_step_kernel(con
     const int cc_eff = a.h_prev ? cc_all : cc_x;                  // zero state: skip h's chunks
     const int n_chunks = 9 * cc_eff;
 
-    // ---- staging plan: wave w issues A pieces 4w..4w+3 (8 rows each) and B pieces 8w..8w+7 per chunk ----------------------
+    // ---- staging plan: wave w issues A pieces NA*w.. (8 rows each) and B pieces NB*w.. per chunk ----------------------
     const int srow = lane >> 3, sslot = lane & 7;                 // this lane's (row in piece, LDS slot)
     constexpr int NA = 2 * MF;                                    // A pieces per wave
     int ay[NA], ax[NA];
@@ -90,10 +91,11 @@ __global__ void __launch_bounds__(256, MF == 1 ? 2 : 1) convlstm_step_kernel(con
         apix[j] = m * C;                                          // element offset of the pixel's channel vector
         aswz[j] = (uint32_t)((sslot ^ ((row >> 1) & 7)) * 8);     // source channel offset inside the 64-channel chunk
     }
-    uint32_t boff[8];
+    constexpr int NB = 16 / WM;                                   // B pieces per wave
+    uint32_t boff[NB];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int row = (wave * 8 + j) * 8 + srow;
+    for (int j = 0; j < NB; ++j) {
+        const int row = (wave * NB + j) * 8 + srow;
         boff[j] = (uint32_t)(row * kClBK + (sslot ^ ((row >> 1) & 7)) * 8);
     }
     const uint16_t *wtile = a.wp + (int64_t)ct * 9 * cc_all * (kClBN * kClBK);
@@ -113,7 +115,7 @@ __global__ void __launch_bounds__(256, MF == 1 ? 2 : 1) convlstm_step_kernel(con
         }
         const uint16_t *wchunk = wtile + (int64_t)(tap * cc_all + cc) * (kClBN * kClBK);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) cl_glds16(wchunk + boff[j], bbase + (wave * 8 + j) * 1024);
+        for (int j = 0; j < NB; ++j) cl_glds16(wchunk + boff[j], bbase + (wave * NB + j) * 1024);
     };
 
     // ---- fragment read plan ------------------------------------------------------------------------------------------------

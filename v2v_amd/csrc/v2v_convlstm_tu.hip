@@ -5,32 +5,37 @@
 namespace v2v {
 
 namespace {
-template <int MF>
-hipError_t launch_step_mf(const ConvLstmArgs &a, hipStream_t s)
+template <int MF, int WM>
+hipError_t launch_step_t(const ConvLstmArgs &a, hipStream_t s)
 {
-    // 80-96 KB of dynamic LDS is above the 64 KB a kernel gets by default: raise the limit once per device (kept out of the
+    // 80-128 KB of dynamic LDS is above the 64 KB a kernel gets by default: raise the limit once per device (kept out of the
     // launch path so that a step captures into a hipGraph as a bare kernel node)
-    constexpr int lds = cl_lds_bytes(MF);
+    constexpr int lds = cl_lds_bytes(MF, WM);
     static bool raised[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (dev < 0 || dev >= 64 || !raised[dev]) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convlstm_step_kernel<MF>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convlstm_step_kernel<MF, WM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) raised[dev] = true;
     }
-    const int64_t tiles = (int64_t)a.B * a.H * a.W / (64 * MF) * (a.C / kClCh);
-    hipLaunchKernelGGL((convlstm_step_kernel<MF>), dim3((unsigned)tiles), dim3(256), lds, s, a);
+    const int64_t tiles = (int64_t)a.B * a.H * a.W / (32 * MF * WM) * (a.C / kClCh);
+    hipLaunchKernelGGL((convlstm_step_kernel<MF, WM>), dim3((unsigned)tiles), dim3(128 * WM), lds, s, a);
     return hipGetLastError();
 }
 }  // namespace
 
-// tile_rows 0 = auto: 64-pixel tiles.  Two such workgroups (2 x 80 KB of LDS) share a CU, which hides each other's barrier
-// and LDS-DMA waits; measured 5-30 % faster than one 128-pixel workgroup per CU at every E2VID encoder shape
-// (profiles/r02b/convlstm_time.json), so the 128-pixel variant is only taken on request.
+// tile_rows: pixels per workgroup tile (64, 128 or 256); 0 = auto.
 hipError_t launch_convlstm_step(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
 {
-    return tile_rows == 128 ? launch_step_mf<2>(a, s) : launch_step_mf<1>(a, s);
+    if (tile_rows == 0) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int64_t m = (int64_t)a.B * a.H * a.W;
+        tile_rows = (m % 256 == 0 && m / 256 * (a.C / kClCh) >= cus) ? 256 : 64;
+    }
+    if (tile_rows == 256) return launch_step_t<2, 4>(a, s);
+    return tile_rows == 128 ? launch_step_t<2, 2>(a, s) : launch_step_t<1, 2>(a, s);
 }
 
 hipError_t launch_convlstm_pack(const float *w, uint16_t *wp, int C, hipStream_t s)
