@@ -463,6 +463,22 @@ static double v2e_inten01_u8(uint8_t x, int wrap)
     return wrap ? (double)(uint8_t)(x + 20) / 275. : ((double)x + 20.0) / 275.;
 }
 
+/* Q(v) = rint(v * 2^20) clamped to +-(2^31 - 128), NaN -> 0: the fixed-point factors of the native shot-noise frame sum */
+static int32_t shot_quant(double v)
+{
+    double s = v * 1048576.0;
+    s = s > 2147483520.0 ? 2147483520.0 : s;
+    s = s < -2147483520.0 ? -2147483520.0 : s;
+    return s == s ? (int32_t)llrint(s) : 0;
+}
+/* the device keeps {low 32 bits, arithmetic high part} of the sum in two 64-bit accumulators and recombines them in float64 */
+static double shot_sum_value(__int128 s)
+{
+    const int64_t hi = (int64_t)(s >> 32);
+    const uint64_t lo = (uint64_t)(s & (__int128)0xFFFFFFFFu);
+    return (double)hi * 4294967296.0 + (double)lo;
+}
+
 /*
  * One clip.  frames [N,HW] u8 or f32 (integer-valued).  lut = golden G1 v2e32.  rng: PHILOX or REPLAY.
  * out: SUM -> [K/fpb, HW] ; BILINEAR -> [Tb, HW] (float64).  Follows generate_events (v2v_core_v2e.py:401-553)
@@ -490,11 +506,13 @@ int oracle_v2e_voxel_clip(const void *frames, int in_dtype, int64_t N, int64_t H
     const int shot = P->shot_noise_rate_hz > 0;
     int64_t on_total = 0, off_total = 0;
 
-    /* native shot noise: per-frame sums of the intensity/threshold factors in 2^32 fixed point (order-free) */
-    int64_t *sum_pos = NULL, *sum_neg = NULL;
+    /* native shot noise: per-frame INTEGER sums of Q(intensity factor) * Q(nominal / threshold), Q(v) = rint(v * 2^20) clamped
+     * (v2v_amd/csrc/v2v_v2e.hpp: shot_quant) -- exact, hence free of any summation order; 128-bit accumulators here, split at
+     * bit 32 and recombined in float64 exactly as the device does (one rounding) */
+    __int128 *sum_pos = NULL, *sum_neg = NULL;
     if (shot && rng_mode == ORACLE_RNG_PHILOX) {
-        sum_pos = (int64_t *)calloc((size_t)K, sizeof(int64_t));
-        sum_neg = (int64_t *)calloc((size_t)K, sizeof(int64_t));
+        sum_pos = (__int128 *)calloc((size_t)K, sizeof(__int128));
+        sum_neg = (__int128 *)calloc((size_t)K, sizeof(__int128));
         for (int64_t p = 0; p < HW; ++p) {
             double pt, nt;
             v2e_native_thres(P, seed, clip_id, V2E_F_THRES_A, (uint32_t)p, &pt, &nt);
@@ -504,8 +522,9 @@ int oracle_v2e_voxel_clip(const void *frames, int in_dtype, int64_t N, int64_t H
                 double fac;
                 if (in_f32) { const float i01 = (f32[i * HW + p] + 20.0f) / 275.0f; fac = (double)(1.0f - 0.75f * i01); }
                 else fac = 1 - 0.75 * v2e_inten01_u8(f8[i * HW + p], P->uint8_wrap);
-                sum_pos[k] += llrint(fac * (pos_nominal / pt) * 4294967296.0);
-                sum_neg[k] += llrint(fac * (neg_nominal / nt) * 4294967296.0);
+                const int64_t q = shot_quant(fac);
+                sum_pos[k] += (__int128)(q * (int64_t)shot_quant(pos_nominal / pt));
+                sum_neg[k] += (__int128)(q * (int64_t)shot_quant(neg_nominal / nt));
             }
         }
     }
@@ -574,9 +593,9 @@ int oracle_v2e_voxel_clip(const void *frames, int in_dtype, int64_t N, int64_t H
                     double fac;
                     if (in_f32) fac = (double)(1.0f - 0.75f * i01_32); else fac = 1 - 0.75 * i01_64;
                     /* lambda = (intensity factor * threshold factor) * (rate/2 * dt / frame mean), all float32 (the frame
-                     * mean itself comes from the 2^32 fixed-point float64 sums above); float32 inversion */
-                    const double mean_p = ((double)sum_pos[k] / 4294967296.0) / (double)HW;
-                    const double mean_n = ((double)sum_neg[k] / 4294967296.0) / (double)HW;
+                     * mean itself comes from the exact integer sums above); float32 inversion */
+                    const double mean_p = (shot_sum_value(sum_pos[k]) / 1099511627776.0) / (double)HW;
+                    const double mean_n = (shot_sum_value(sum_neg[k]) / 1099511627776.0) / (double)HW;
                     const double f = (P->shot_noise_rate_hz / 2) * dt;
                     /* per pixel: intensity factor x float32 reciprocal threshold (biased low by 2^-22: the same value
                      * that estimates the floor-divide quotient on the device); per frame: nominal threshold x rate scale */

@@ -10,6 +10,7 @@ enum { kInU8 = 0, kInF32 = 1 };
 enum { kRngNone = 0, kRngPhilox = 1, kRngReplay = 2 };
 enum { kBinSum = 0, kBinBilinear = 1 };
 constexpr int kBlock = 256;
+constexpr int kPreGroups = 4;              // VEC-pixel groups per work-item of the v2e frame-sum pre-pass
 
 struct EsimArgs {
     const void *frames;
@@ -40,7 +41,7 @@ struct V2eArgs {
     int64_t clip_stride, frame_stride;
     void *out;
     unsigned long long *counts;
-    long long *shot_sums;                    // [B,K,2] fixed-point sums (native shot noise) or nullptr
+    long long *shot_sums;                    // [B,K,4] integer sums {ON lo, ON hi, OFF lo, OFF hi} (native shot noise) or nullptr
     const float *lut;                        // 256-entry lin_log table in device memory (set by launch_v2e)
     const double *r_pos_thres, *r_neg_thres; // replay
     int64_t r_thres_frame_stride;
@@ -49,6 +50,7 @@ struct V2eArgs {
     const long long *r_shot_pos, *r_shot_neg;
     uint64_t seed, clip_id0;
     int32_t HW, K, Tb, fpb, blocks_per_clip;
+    int32_t pre_blocks_per_clip;             // workgroups per clip of the frame-sum pre-pass (16 pixels per work-item)
     V2eParams P;
 };
 

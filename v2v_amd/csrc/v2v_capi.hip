@@ -230,7 +230,7 @@ int v2v_synth_clips_hip(void *frames, int dtype, int64_t B, int64_t N, int64_t H
 int64_t v2v_v2e_workspace_bytes(int64_t B, int64_t N)
 {
     if (B < 0 || N < 2) return V2V_ERR_SHAPE;
-    return B * (N - 1) * 2 * (int64_t)sizeof(int64_t);
+    return B * (N - 1) * 4 * (int64_t)sizeof(int64_t);
 }
 
 int v2v_v2e_voxel_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W, int64_t clip_stride,
@@ -289,6 +289,7 @@ int v2v_v2e_voxel_hip(const void *frames, int in_dtype, int64_t B, int64_t N, in
     a.seed = seed; a.clip_id0 = clip_id0;
     a.HW = (int32_t)HW; a.K = (int32_t)K; a.Tb = num_bins; a.fpb = frames_per_bin;
     a.blocks_per_clip = (int32_t)((HW + (int64_t)v2v::kBlock * vec - 1) / ((int64_t)v2v::kBlock * vec));
+    a.pre_blocks_per_clip = (int32_t)((HW + (int64_t)v2v::kBlock * v2v::kPreGroups * vec - 1) / ((int64_t)v2v::kBlock * v2v::kPreGroups * vec));
     static_assert(sizeof(v2v::V2eParams) == sizeof(v2v_v2e_params), "v2e params layout");
     memcpy(&a.P, params, sizeof(a.P));
     const int64_t nblocks = B * a.blocks_per_clip;

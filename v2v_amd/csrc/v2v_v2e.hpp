@@ -11,8 +11,8 @@
 //   lp32   = (cutoff_hz <= 0) || float32 input     low-passed frame is float32, else float64
 //   base32 = lp32 && leak_rate_hz == 0              memorised frame is float32 (in-place += rounds to float32)
 // Shot noise needs the per-frame mean of (intensity factor x threshold factor) over the whole clip frame:
-// a pre-pass kernel accumulates it in 2^32 fixed point (order-independent, so the CPU oracle and any launch
-// geometry agree bit for bit); native Poisson sampling is inversion from one Philox uniform with an exp(-lambda)
+// a pre-pass kernel accumulates it as an exact integer sum of products of two 2^20 fixed-point factors (order-independent,
+// so the CPU oracle and any launch geometry agree bit for bit); native Poisson sampling is inversion from one Philox uniform with an exp(-lambda)
 // built from IEEE-exact operations.  Replay mode takes NumPy-drawn fields instead (bit-exact reference replay).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -211,123 +211,156 @@ __device__ __forceinline__ float v2e_linlog(float x, const float *lut)
     return (float)log((double)x / 255 + 0.01);          // non-integer content: within 1 ulp of NumPy's float64 log
 }
 
-// Wave-wide float64 sum on the VALU (DPP row shifts + four v_readlane): the LDS-routed __shfl_down version of this
-// reduction made the pre-pass LDS-issue-bound (24 ds_bpermute per frame and wave).  Every lane returns the total.
+// Wave-wide 64-bit integer sum on the VALU (DPP row shifts + four v_readlane per half): the LDS-routed __shfl_down version of
+// this reduction made the pre-pass LDS-issue-bound (24 ds_bpermute per frame and wave).  Every lane returns the total.
 template <int CTRL>
-__device__ __forceinline__ double dpp_mov_f64(double v)
+__device__ __forceinline__ long long dpp_mov_i64(long long v)
 {
-    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint64_t b = (uint64_t)v;
     const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xF, 0xF, true);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, true);
-    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+    return (long long)(((uint64_t)hi << 32) | lo);
 }
-__device__ __forceinline__ double readlane_f64(double v, int lane)
+__device__ __forceinline__ long long readlane_i64(long long v, int lane)
 {
-    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint64_t b = (uint64_t)v;
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, lane);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), lane);
-    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+    return (long long)(((uint64_t)hi << 32) | lo);
 }
-__device__ __forceinline__ double wave_sum_f64(double v)
+__device__ __forceinline__ long long wave_sum_i64(long long v)
 {
-    v += dpp_mov_f64<0x111>(v);          // row_shr:1 (lanes shifted in from outside the 16-lane row read 0)
-    v += dpp_mov_f64<0x112>(v);          // row_shr:2
-    v += dpp_mov_f64<0x114>(v);          // row_shr:4
-    v += dpp_mov_f64<0x118>(v);          // row_shr:8 -> lane 15 of every row holds the row total
-    return (readlane_f64(v, 15) + readlane_f64(v, 31)) + (readlane_f64(v, 47) + readlane_f64(v, 63));
+    v += dpp_mov_i64<0x111>(v);          // row_shr:1 (lanes shifted in from outside the 16-lane row read 0)
+    v += dpp_mov_i64<0x112>(v);          // row_shr:2
+    v += dpp_mov_i64<0x114>(v);          // row_shr:4
+    v += dpp_mov_i64<0x118>(v);          // row_shr:8 -> lane 15 of every row holds the row total
+    return (readlane_i64(v, 15) + readlane_i64(v, 31)) + (readlane_i64(v, 47) + readlane_i64(v, 63));
 }
 
-// ---- pre-pass: per (clip, frame) fixed-point sums of the shot-noise factors (native mode only)
-// Each pixel contributes rint(factor * 2^32) -- an integer, so the total does not depend on summation order, launch
-// geometry or the CPU oracle's loop order.  While every term is below 2^44 a wave's 256 terms sum exactly in float64
-// (< 2^52): the lanes accumulate and reduce in float64 (one v_rndne + one v_add per term instead of a 64-bit integer
-// convert and add-with-carry) and only the wave total is converted; larger terms take the integer path.
-// DEPTH: frames in flight per work-item (register ring).
+// ---- pre-pass: per (clip, frame) sums of the shot-noise factors (native mode only) -----------------------------------------
+// generate_shot_noise (:86-100) normalises the Poisson rate by the frame mean of (intensity factor x threshold factor).  The
+// native definition of that sum is an INTEGER one, so that it does not depend on summation order, launch geometry or the CPU
+// oracle's loop order:   S = sum over pixels of  Q(intensity factor) * Q(nominal threshold / pixel threshold),
+// Q(v) = rint(v * 2^20) clamped to +-(2^31 - 128) (NaN -> 0); mean = S / 2^40 / (H*W).  The intensity factor depends only on
+// the 8-bit intensity (256-entry LDS table of Q values), the threshold factor only on the pixel: one v_mad_i64_i32 per pixel,
+// frame and polarity.  A work-item owns kPreGroups x VEC pixels, so the two wave reductions per frame are shared by 16 pixels
+// per lane.  Sums leave the wave split at bit 32 ({low 32 bits, arithmetic high part}, each its own 64-bit accumulator), which
+// keeps every accumulator far from overflow for any frame size; the reader recombines them in float64 (one rounding).
 // (A fused variant -- the blocks_per_clip workgroups of a clip as a team in one persistent cooperative launch: sums, team
 // barrier on a device-scope counter, simulation with the re-read served by the Infinity Cache -- was built and measured in round
 // 2: 2.58 ms against 2.04 ms for these two kernels on config 3.  At the simulator's 3 waves per SIMD the summing phase reads at
-// half the rate of this 8-waves-per-SIMD kernel, and the team barrier turns the per-workgroup load balance of a plain launch into
-// a max over 64 members.  It was removed; DESIGN.md section 4.3c keeps the numbers.)
-template <int IN, int VEC, bool NT, int DEPTH>
-__device__ __forceinline__ void v2e_presum_body(const V2eArgs &a, const int clip, const int blk, unsigned char *s_tab, unsigned long long *s_sum)
+// half the rate of this kernel, and the team barrier turns the per-workgroup load balance of a plain launch into a max over
+// 64 members.  It was removed; DESIGN.md section 4.3c keeps the numbers.)
+constexpr double kShotQScale = 1048576.0;          // 2^20
+
+__device__ __forceinline__ int32_t shot_quant(double v)
 {
-    const V2eIntenTables tb = v2e_build_tables<IN>(s_tab, a.P.uint8_wrap);
-    for (int t = threadIdx.x; t < 2 * a.K; t += kBlock) s_sum[t] = 0ull;
+    double s = v * kShotQScale;
+    s = s > 2147483520.0 ? 2147483520.0 : s;
+    s = s < -2147483520.0 ? -2147483520.0 : s;
+    return s == s ? (int32_t)__builtin_rint(s) : 0;
+}
+__device__ __forceinline__ long long mad_i64_i32(int32_t a, int32_t b, long long c) { return (long long)a * (long long)b + c; }
+
+// shot_sums layout: [B, K, 4] = {ON low, ON high, OFF low, OFF high}
+__device__ __forceinline__ double shot_sum_value(const long long *s4, int which)
+{
+    return (double)s4[2 * which + 1] * 4294967296.0 + (double)s4[2 * which];
+}
+
+template <int IN, int VEC, bool NT, int DEPTH>
+__device__ __forceinline__ void v2e_presum_body(const V2eArgs &a, const int clip, const int blk, int32_t *s_q, unsigned long long *s_sum)
+{
+    {   // Q(intensity factor) per 8-bit intensity, in the dtype NumPy gives the factor (v2e_inten_direct)
+        double i64, fac; float i32;
+        v2e_inten_direct<IN>((float)threadIdx.x, a.P.uint8_wrap, i64, i32, fac);
+        s_q[threadIdx.x] = shot_quant(fac);
+    }
+    for (int t = threadIdx.x; t < 4 * a.K; t += kBlock) s_sum[t] = 0ull;
     __syncthreads();
-    const uint32_t p0 = (uint32_t)(blk * kBlock + threadIdx.x) * VEC;
-    const bool active = p0 < (uint32_t)a.HW;
     const V2eParams &P = a.P;
     const uint32_t clip_id = (uint32_t)(a.clip_id0 + (uint64_t)clip);
     const double pos_nominal = P.thres_mean_mean + P.thres_diff_mean / 2, neg_nominal = P.thres_mean_mean - P.thres_diff_mean / 2;
     const bool temporal = P.threshold_model == kV2eSpatialTemporalIndependent;
-    double pt[VEC], nt[VEC], pre_p[VEC], pre_n[VEC];
-    auto derive = [&]() {                       // nominal/threshold, pre-scaled by 2^32 (exact: a power of two)
+    uint32_t p0[kPreGroups];
+    bool active[kPreGroups];
+    int64_t in_base[kPreGroups];
+    int32_t cp[kPreGroups][VEC], cn[kPreGroups][VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) { pre_p[j] = (pos_nominal / pt[j]) * 4294967296.0; pre_n[j] = (neg_nominal / nt[j]) * 4294967296.0; }
+    for (int g = 0; g < kPreGroups; ++g) {
+        p0[g] = (uint32_t)((blk * kPreGroups + g) * kBlock + threadIdx.x) * VEC;
+        active[g] = p0[g] < (uint32_t)a.HW;
+        in_base[g] = (int64_t)clip * a.clip_stride + (active[g] ? p0[g] : 0u);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { cp[g][j] = 0; cn[g][j] = 0; }
+    }
+    auto derive = [&](int g, uint32_t field) {      // Q(nominal / threshold) of group g's pixels; stays 0 for pixels outside the frame
+        double pt[VEC], nt[VEC];
+        v2e_native_thres<VEC>(P, a.seed, clip_id, field, p0[g], pt, nt);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { cp[g][j] = shot_quant(pos_nominal / pt[j]); cn[g][j] = shot_quant(neg_nominal / nt[j]); }
     };
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { pre_p[j] = 0.0; pre_n[j] = 0.0; }
-    if (active) { v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFThresA, p0, pt, nt); derive(); }
-    const int64_t in_base = (int64_t)clip * a.clip_stride + (active ? p0 : 0u);
-    auto frame_sum = [&](int k, const Raw<IN, VEC> &raw) __attribute__((always_inline)) {
-        const int i = k + 1;
-        if (temporal && active) { v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i, p0, pt, nt); derive(); }
-        float x[VEC];
-        double fac[VEC];
-        v2e_pixels<IN, VEC>(raw, x);
-        uint32_t mismatch = 0;
+    for (int g = 0; g < kPreGroups; ++g)
+        if (active[g]) derive(g, kV2eFThresA);
+    auto frame_sum = [&](int k, const Raw<IN, VEC> (&raw)[kPreGroups]) __attribute__((always_inline)) {
+        long long sp = 0, sn = 0;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            uint32_t idx;
-            if constexpr (IN == kInU8) idx = VEC == 4 ? (raw.v >> (8 * j)) & 0xFFu : raw.v;
-            else { idx = __float_as_uint(x[j] + 8388608.0f) & 255u; mismatch |= __float_as_uint((float)idx - x[j]); }
-            fac[j] = tb.fac[idx];
-        }
-        if constexpr (IN != kInU8) {
-            if (__builtin_expect(mismatch != 0, 0)) {
+        for (int g = 0; g < kPreGroups; ++g) {
+            if (temporal && active[g]) derive(g, kV2eFFrame0 + kV2eFStride * (uint32_t)(k + 1));
+            float x[VEC];
+            int32_t q[VEC];
+            v2e_pixels<IN, VEC>(raw[g], x);
+            uint32_t mismatch = 0;
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) { double i64; float i32; v2e_inten<IN>(x[j], P.uint8_wrap, tb, i64, i32, fac[j]); }
+            for (int j = 0; j < VEC; ++j) {
+                uint32_t idx;
+                if constexpr (IN == kInU8) idx = VEC == 4 ? (raw[g].v >> (8 * j)) & 0xFFu : raw[g].v;
+                else { idx = __float_as_uint(x[j] + 8388608.0f) & 255u; mismatch |= __float_as_uint((float)idx - x[j]); }
+                q[j] = s_q[idx];
             }
-        }
-        double fp[VEC], fn[VEC], dsp = 0.0, dsn = 0.0;
-        bool big = false;
+            if constexpr (IN != kInU8) {
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(mismatch != 0) != 0, 0)) {     // some pixel is not an integer in 0..255
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            fp[j] = fac[j] * pre_p[j];
-            fn[j] = fac[j] * pre_n[j];
-            big |= !(__builtin_fabs(fp[j]) < 0x1p44) | !(__builtin_fabs(fn[j]) < 0x1p44);
-            dsp += __builtin_rint(fp[j]);
-            dsn += __builtin_rint(fn[j]);
-        }
-        long long sp, sn;
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(big && active) == 0, 1)) {
-            sp = (long long)wave_sum_f64(dsp);                           // exact: an integer below 2^52
-            sn = (long long)wave_sum_f64(dsn);
-        } else {
-            sp = 0; sn = 0;
-            if (active) {
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) { sp += __double2ll_rn(fp[j]); sn += __double2ll_rn(fn[j]); }
+                    for (int j = 0; j < VEC; ++j) {
+                        if ((float)(__float_as_uint(x[j] + 8388608.0f) & 255u) != x[j]) {
+                            double i64, fac; float i32;
+                            v2e_inten_direct<IN>(x[j], P.uint8_wrap, i64, i32, fac);
+                            q[j] = shot_quant(fac);
+                        }
+                    }
+                }
             }
 #pragma unroll
-            for (int s = 32; s > 0; s >>= 1) { sp += __shfl_down(sp, s, 64); sn += __shfl_down(sn, s, 64); }
+            for (int j = 0; j < VEC; ++j) { sp = mad_i64_i32(q[j], cp[g][j], sp); sn = mad_i64_i32(q[j], cn[g][j], sn); }
         }
+        sp = wave_sum_i64(sp);
+        sn = wave_sum_i64(sn);
         if ((threadIdx.x & 63) == 0) {                                   // LDS atomics: 4 waves per workgroup
-            atomicAdd(&s_sum[2 * k], (unsigned long long)sp);
-            atomicAdd(&s_sum[2 * k + 1], (unsigned long long)sn);
+            atomicAdd(&s_sum[4 * k], (unsigned long long)sp & 0xFFFFFFFFull);
+            atomicAdd(&s_sum[4 * k + 1], (unsigned long long)(sp >> 32));
+            atomicAdd(&s_sum[4 * k + 2], (unsigned long long)sn & 0xFFFFFFFFull);
+            atomicAdd(&s_sum[4 * k + 3], (unsigned long long)(sn >> 32));
         }
     };
-    {   // register ring of DEPTH frames, reloaded right after use (clamped, unconditional loads)
-        Raw<IN, VEC> ring[DEPTH];
+    {   // register ring of DEPTH frames x kPreGroups groups, reloaded right after use (clamped, unconditional loads)
+        Raw<IN, VEC> ring[DEPTH][kPreGroups];
 #pragma unroll
-        for (int u = 0; u < DEPTH; ++u) ring[u] = load_raw<IN, VEC, NT>(a.frames, in_base + (int64_t)(1 + u <= a.K ? 1 + u : a.K) * a.frame_stride);
+        for (int u = 0; u < DEPTH; ++u)
+#pragma unroll
+            for (int g = 0; g < kPreGroups; ++g)
+                ring[u][g] = load_raw<IN, VEC, NT>(a.frames, in_base[g] + (int64_t)(1 + u <= a.K ? 1 + u : a.K) * a.frame_stride);
         int k0 = 0;
         for (; k0 + DEPTH <= a.K; k0 += DEPTH) {
             static_for(std::make_integer_sequence<int, DEPTH>{}, [&](auto u_tag) {
                 constexpr int u = decltype(u_tag)::value;
-                const Raw<IN, VEC> raw = ring[u];
+                Raw<IN, VEC> raw[kPreGroups];
                 const int fn = k0 + u + 1 + DEPTH;
-                ring[u] = load_raw<IN, VEC, NT>(a.frames, in_base + (int64_t)(fn <= a.K ? fn : a.K) * a.frame_stride);
+#pragma unroll
+                for (int g = 0; g < kPreGroups; ++g) {
+                    raw[g] = ring[u][g];
+                    ring[u][g] = load_raw<IN, VEC, NT>(a.frames, in_base[g] + (int64_t)(fn <= a.K ? fn : a.K) * a.frame_stride);
+                }
                 frame_sum(k0 + u, raw);
             });
         }
@@ -336,20 +369,20 @@ __device__ __forceinline__ void v2e_presum_body(const V2eArgs &a, const int clip
             if (k0 + u < a.K) frame_sum(k0 + u, ring[u]);
         });
     }
-    // one global atomic per (workgroup, frame, sign): ~256 waves of a clip adding into the same address every frame
+    // one global atomic per (workgroup, frame, accumulator): ~256 waves of a clip adding into the same address every frame
     // serialised at the memory side and cost more than the whole read of the clip
     __syncthreads();
-    for (int t = threadIdx.x; t < 2 * a.K; t += kBlock)
-        atomicAdd(reinterpret_cast<unsigned long long *>(&a.shot_sums[(int64_t)clip * a.K * 2 + t]), s_sum[t]);
+    for (int t = threadIdx.x; t < 4 * a.K; t += kBlock)
+        atomicAdd(reinterpret_cast<unsigned long long *>(&a.shot_sums[(int64_t)clip * a.K * 4 + t]), s_sum[t]);
 }
 
 template <int IN, int VEC>
 __global__ void __launch_bounds__(kBlock) v2e_shot_sum_kernel(const V2eArgs a)
 {
-    __shared__ __align__(16) unsigned char s_tab[kV2eTableBytes];
-    extern __shared__ __align__(16) unsigned long long s_sum[];          // [K,2] workgroup partial sums
-    const int clip = blockIdx.x / a.blocks_per_clip;
-    v2e_presum_body<IN, VEC, true, 4>(a, clip, blockIdx.x - clip * a.blocks_per_clip, s_tab, s_sum);
+    __shared__ int32_t s_q[256];
+    extern __shared__ __align__(16) unsigned long long s_sum[];          // [K,4] workgroup partial sums
+    const int clip = blockIdx.x / a.pre_blocks_per_clip;
+    v2e_presum_body<IN, VEC, true, 2>(a, clip, blockIdx.x - clip * a.pre_blocks_per_clip, s_q, s_sum);
 }
 
 // ---- native shot-noise sampler (float32 inversion from one uniform; the CPU oracle restates it) ----------------------
@@ -417,8 +450,9 @@ __device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, 
         fc.dt_tau = lowpass ? dt / tau : 0.0;
         fc.scale_p = 0.0f; fc.scale_n = 0.0f;
         if (RNG == kRngPhilox && shot) {                                                // generate_shot_noise (:86-100)
-            const double mean_p = ((double)a.shot_sums[((int64_t)clip * a.K + k) * 2] / 4294967296.0) / (double)a.HW;
-            const double mean_n = ((double)a.shot_sums[((int64_t)clip * a.K + k) * 2 + 1] / 4294967296.0) / (double)a.HW;
+            const long long *s4 = a.shot_sums + ((int64_t)clip * a.K + k) * 4;
+            const double mean_p = (shot_sum_value(s4, 0) / 1099511627776.0) / (double)a.HW;      // / 2^40: two factors at 2^20
+            const double mean_n = (shot_sum_value(s4, 1) / 1099511627776.0) / (double)a.HW;
             const double f = (P.shot_noise_rate_hz / 2) * dt;
             fc.scale_p = (float)(f / mean_p) * (float)pos_nominal;      // x nominal threshold: the per-pixel factor is 1/threshold
             fc.scale_n = (float)(f / mean_n) * (float)neg_nominal;

@@ -12,6 +12,9 @@ static const float kLutV2e32[256] = {V2V_LUT_V2E32_VALUES};
 
 namespace {
 
+// the pre-pass covers kPreGroups x VEC pixels per work-item: its own grid (clips = main grid / blocks_per_clip)
+dim3 pre_grid(const V2eArgs &a, dim3 grid) { return dim3((grid.x / (unsigned)a.blocks_per_clip) * (unsigned)a.pre_blocks_per_clip); }
+
 template <int IN, int VEC, int BIN, int RNG>
 hipError_t launch_v2e_out(bool out64, const V2eArgs &a, dim3 grid, size_t lds, hipStream_t s)
 {
@@ -27,7 +30,7 @@ hipError_t launch_v2e_t(int bin, int rng, bool out64, bool presum, const V2eArgs
     return hipErrorInvalidValue;
 #endif
     if (presum) {
-        hipLaunchKernelGGL((v2e_shot_sum_kernel<IN, VEC>), grid, dim3(kBlock), (size_t)a.K * 16, s, a);
+        hipLaunchKernelGGL((v2e_shot_sum_kernel<IN, VEC>), pre_grid(a, grid), dim3(kBlock), (size_t)a.K * 32, s, a);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -53,8 +56,8 @@ hipError_t launch_v2e(bool in_u8, bool vec4, int bin, int rng, bool out64, bool 
     if (spec) {
         const int feat = (P.cutoff_hz > 0 ? kV2eLowpass : 0) | (P.leak_rate_hz > 0 ? kV2eLeak : 0) | (P.shot_noise_rate_hz > 0 ? kV2eShot : 0);
         if (presum) {
-            if (in_u8) hipLaunchKernelGGL((v2e_shot_sum_kernel<kInU8, 4>), grid, dim3(kBlock), (size_t)a.K * 16, s, a);
-            else hipLaunchKernelGGL((v2e_shot_sum_kernel<kInF32, 4>), grid, dim3(kBlock), (size_t)a.K * 16, s, a);
+            if (in_u8) hipLaunchKernelGGL((v2e_shot_sum_kernel<kInU8, 4>), pre_grid(a, grid), dim3(kBlock), (size_t)a.K * 32, s, a);
+            else hipLaunchKernelGGL((v2e_shot_sum_kernel<kInF32, 4>), pre_grid(a, grid), dim3(kBlock), (size_t)a.K * 32, s, a);
             const hipError_t e1 = hipGetLastError();
             if (e1 != hipSuccess) return e1;
         }
