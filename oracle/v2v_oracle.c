@@ -84,61 +84,35 @@ static float u32_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static uint32_t float_as_u32(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
 /*
- * Device-native normals: float32 Box-Muller on ONE 32-bit Philox word per pair (16-bit radius x 16-bit angle, both on
- * midpoint grids), written with IEEE-exact primitives only (+ - * fmaf and integer ops: no division, no sqrt, no libm)
- * so that gcc on the host and hipcc on gfx950 produce the same bits.  Not taken from the reference (which uses numpy's
- * MT19937 polar method, impossible to replay at bandwidth on a GPU); this is the definition of the device-native
- * noise fields, restated here independently of v2v_amd/csrc/v2v_rng.hpp (scalar fmaf chain vs packed v_pk_fma_f32).
- *   n = w >> 16:  u = (n + 1/2)/2^16,  t = -2 ln u = (16 - e) 2ln2 + L(f) for n + 1/2 = 2^e (1 + f), L a degree-7 minimax
- *                 polynomial; r = sqrt(t) by the integer seed + two tuned Newton steps on 1/sqrt (5.7e-7 relative)
- *   a = w & 0xFFFF: x = pi (a + 1/2)/2^16 - pi/2;  S = sqrt2 sin x, C = sqrt2 cos x (minimax in x^2)
- *   g0 = r cos 2x = r - (r S) S,   g1 = r sin 2x = (r S) C
- * Coefficients from tools/fit_gauss16.py.
+ * Device-native normals: TWO float32 deviates per 32-bit Philox word, one per 16-bit half, by table inversion.
+ * Not taken from the reference (which uses numpy's MT19937 polar method, impossible to replay at bandwidth on a GPU); this is
+ * the definition of the device-native noise fields, restated here independently of v2v_amd/csrc/v2v_rng.hpp.
+ *   half-word n: sign = n >> 15, magnitude index m = n & 0x7FFF  <->  probability 1/2 + (m + 1/2) / 2^16 (midpoint grid)
+ *   deviate = fmaf(float(m & 7), slope[m >> 3], intercept[m >> 3]), sign applied
+ * with the 4096 x {intercept, slope} table of tools/gen_gauss_icdf.py (least-squares lines through Phi^-1 on each bin of 8
+ * magnitudes; float32).  gauss_icdf.inc is DATA generated once (scipy.special.ndtri) and committed; the device holds the same
+ * text.  g0 comes from the high, g1 from the low half-word.
  */
+static const float gauss_icdf_tab[4096][2] = {
+#include "gauss_icdf.inc"
+};
+
+static float icdf16(uint32_t n)
+{
+    const uint32_t m = n & 0x7FFFu;
+    const float g = fmaf((float)(m & 7u), gauss_icdf_tab[m >> 3][1], gauss_icdf_tab[m >> 3][0]);
+    return u32_as_float(float_as_u32(g) ^ ((n & 0x8000u) << 16));
+}
+
 static void gauss16_pair(uint32_t w, float *g0, float *g1)
 {
-    const float xh = (float)(w >> 16) + 0.5f;
-    const uint32_t xb = float_as_u32(xh);
-    const float ef = (float)((int)(xb >> 23) - 143);
-    const float f = u32_as_float((xb & 0x007FFFFFu) | 0x3F800000u) - 1.0f;
-    float L = -0x1.57869cp-6f;
-    L = fmaf(L, f, 0x1.bb3e08p-4f);
-    L = fmaf(L, f, -0x1.10adbap-2f);
-    L = fmaf(L, f, 0x1.cc4bd8p-2f);
-    L = fmaf(L, f, -0x1.4fa778p-1f);
-    L = fmaf(L, f, 0x1.ff5d72p-1f);
-    L = fmaf(L, f, -0x1.fffc7ap+0f);
-    L = fmaf(L, f, -0x1.9cde6p-22f);
-    const float t = fmaf(ef, -0x1.62e43p+0f, L);
-    const float th = t * 0x1.007aa6p-1f;
-    float y = u32_as_float(0x5f374000u - (float_as_u32(t) >> 1));
-    float p = y * y;
-    float q = fmaf(-th, p, 0x1.804d8ep+0f);
-    y = y * q;
-    p = y * y;
-    q = fmaf(-th, p, 0x1.803d52p+0f);
-    const float r = (y * q) * t;
-
-    const float x = fmaf((float)(w & 0xFFFFu), 0x1.921fb6p-15f, -0x1.921e24p+0f);
-    const float z = x * x;
-    float S = -0x1.12b318p-12f;
-    S = fmaf(S, z, 0x1.813e8ap-7f);
-    S = fmaf(S, z, -0x1.e2b092p-3f);
-    S = fmaf(S, z, 0x1.6a09d4p+0f);
-    const float sn = x * S;
-    float c = 0x1.12ae8p-15f;
-    c = fmaf(c, z, -0x1.00cc2ap-9f);
-    c = fmaf(c, z, 0x1.e2aebap-5f);
-    c = fmaf(c, z, -0x1.6a09bap-1f);
-    c = fmaf(c, z, 0x1.6a09e6p+0f);
-    const float t1 = r * sn;
-    *g0 = fmaf(-t1, sn, r);
-    *g1 = t1 * c;
+    *g0 = icdf16(w >> 16);
+    *g1 = icdf16(w & 0xFFFFu);
 }
 
 void oracle_gauss16(uint32_t w, float out[2]) { gauss16_pair(w, &out[0], &out[1]); }
 
-/* all 2^16 radii (angle word 0x4000 -> ... ) / all components: exhaustive accuracy checks in the tests */
+/* many words at once: exhaustive accuracy checks in the tests */
 void oracle_gauss16_many(const uint32_t *w, int64_t n, float *g0, float *g1)
 {
     for (int64_t i = 0; i < n; ++i) gauss16_pair(w[i], &g0[i], &g1[i]);
@@ -443,7 +417,7 @@ static double v2e_floor_divide(double a, double b) { return oracle_floor_divide(
 static void v2e_native_thres(const oracle_v2e_params *P, uint64_t seed, uint32_t clip, uint32_t fa, uint32_t p,
                              double *pt, double *nt)
 {
-    const double ga = (double)px_gauss(seed, clip, fa, V2E_STREAM, p, 0);   /* the two normals of one Box-Muller pair */
+    const double ga = (double)px_gauss(seed, clip, fa, V2E_STREAM, p, 0);   /* the two deviates of the pixel's word */
     const double gb = (double)px_gauss(seed, clip, fa, V2E_STREAM, p, 1);
     double a, b;
     if (P->threshold_model == V2E_PN_RELATED) {

@@ -121,12 +121,17 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
     constexpr bool PK = !OUT64 && BIN == kBinBilinear && VEC == 4;
     extern __shared__ __align__(16) unsigned char s_raw[];
     using ent_t = typename LutEntry<IN>::type;
-    ent_t *s_lut = reinterpret_cast<ent_t *>(s_raw);
-    acc_t *s_wlo = reinterpret_cast<acc_t *>(s_raw + 256 * sizeof(ent_t));
+    // the inverse-CDF table of the Gaussian generator leads the dynamic LDS of the instances that draw device-native noise
+    constexpr bool ICDF = NOISE && RNG == kRngPhilox;
+    constexpr int kTabOff = ICDF ? kIcdfBytes : 0;
+    float2 *s_icdf = reinterpret_cast<float2 *>(s_raw);
+    ent_t *s_lut = reinterpret_cast<ent_t *>(s_raw + kTabOff);
+    acc_t *s_wlo = reinterpret_cast<acc_t *>(s_raw + kTabOff + 256 * sizeof(ent_t));
     acc_t *s_whi = s_wlo + a.K;
     int *s_kb = reinterpret_cast<int *>(s_whi + a.K);      // [Tb] first pair index of each bin segment
 
     // ---- workgroup prologue: tables into LDS
+    if constexpr (ICDF) icdf_to_lds(s_icdf);
     if constexpr (IN == kInU8) s_lut[threadIdx.x] = g_lut_esim64[threadIdx.x];
     else s_lut[threadIdx.x] = make_float2(g_lut_esim32[threadIdx.x], (float)threadIdx.x);
     if constexpr (BIN == kBinBilinear) {
@@ -200,7 +205,7 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
                     double u1[VEC];
                     float gh[VEC], gh_unused[VEC];
                     field_uniform53<VEC>(seed_, clip_id, kFieldHotMask, kStreamEsim, p0, u1);
-                    field_gauss_pairs<VEC>(seed_, clip_id, kFieldHotGauss, kStreamEsim, p0, gh, gh_unused);
+                    field_gauss_pairs<VEC>(seed_, clip_id, kFieldHotGauss, kStreamEsim, p0, s_icdf, gh, gh_unused);
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) hot[j] = (u1[j] < hot_frac) ? hot_std * (double)gh[j] : 0.0;   // :37-39
                 }
@@ -268,7 +273,7 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
                 if (has_base) {                                        // uniform (scalar); 0*g adds nothing
                     float g[VEC];
                     if constexpr (PAR == 0) {
-                        field_gauss_pairs<VEC, kNoiseRounds>(seed_, clip_id, kFieldBase0 + (uint32_t)(k >> 1), kStreamEsim, p0, g, g_pend);
+                        field_gauss_pairs<VEC, kNoiseRounds>(seed_, clip_id, kFieldBase0 + (uint32_t)(k >> 1), kStreamEsim, p0, s_icdf, g, g_pend);
                     } else {
 #pragma unroll
                         for (int j = 0; j < VEC; ++j) g[j] = g_pend[j];

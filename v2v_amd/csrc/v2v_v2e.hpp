@@ -120,10 +120,10 @@ __device__ __forceinline__ float expf_det(float x)
 // ON/OFF thresholds of VEC pixels from two Gaussian fields (normal(loc,scale) = loc + scale*g), clipped at 0.01
 template <int VEC>
 __device__ __forceinline__ void v2e_native_thres(const V2eParams &P, uint64_t seed, uint32_t clip, uint32_t fa, uint32_t p0,
-                                                 double (&pt)[VEC], double (&nt)[VEC])
+                                                 const float2 *tab, double (&pt)[VEC], double (&nt)[VEC])
 {
-    float ga[VEC], gb[VEC];                 // the two normals of one Box-Muller pair per pixel (block fa)
-    field_gauss_pairs<VEC>(seed, clip, fa, kStreamV2e, p0, ga, gb);
+    float ga[VEC], gb[VEC];                 // the two deviates of the pixel's word (block fa)
+    field_gauss_pairs<VEC>(seed, clip, fa, kStreamV2e, p0, tab, ga, gb);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         double a, b;
@@ -296,7 +296,7 @@ __device__ __forceinline__ void v2e_presum_body(const V2eArgs &a, const int clip
     }
     auto derive = [&](int g, uint32_t field) {      // Q(nominal / threshold) of group g's pixels; stays 0 for pixels outside the frame
         double pt[VEC], nt[VEC];
-        v2e_native_thres<VEC>(P, a.seed, clip_id, field, p0[g], pt, nt);
+        v2e_native_thres<VEC>(P, a.seed, clip_id, field, p0[g], g_gauss_icdf, pt, nt);     // one-off per pixel: table from global memory
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { cp[g][j] = shot_quant(pos_nominal / pt[j]); cn[g][j] = shot_quant(neg_nominal / nt[j]); }
     };
@@ -420,8 +420,12 @@ __device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, 
     using inten_t = typename std::conditional<IN == kInU8, V2eIntenU8, V2eIntenF32>::type;
     static_assert(sizeof(V2eFrameConst) == 32 && sizeof(inten_t) == 16, "LDS record layout");
     constexpr bool PK = !OUT64 && BIN == kBinBilinear && VEC == 4;        // packed bilinear accumulation (see the ESIM kernel)
-    inten_t *s_int = reinterpret_cast<inten_t *>(s_raw);                                        // [256]
-    V2eFrameConst *s_fc = reinterpret_cast<V2eFrameConst *>(s_raw + 256 * sizeof(inten_t));     // [K]
+    // the inverse-CDF table of the Gaussian generator leads the dynamic LDS of the device-native instances
+    constexpr int kTabOff = RNG == kRngPhilox ? kIcdfBytes : 0;
+    float2 *s_icdf = reinterpret_cast<float2 *>(s_raw);
+    if constexpr (RNG == kRngPhilox) icdf_to_lds(s_icdf);
+    inten_t *s_int = reinterpret_cast<inten_t *>(s_raw + kTabOff);                              // [256]
+    V2eFrameConst *s_fc = reinterpret_cast<V2eFrameConst *>(s_raw + kTabOff + 256 * sizeof(inten_t));     // [K]
     acc_t *s_wlo = reinterpret_cast<acc_t *>(s_fc + a.K);
     acc_t *s_whi = s_wlo + a.K;
     int *s_seg = reinterpret_cast<int *>(s_whi + a.K);
@@ -491,9 +495,9 @@ __device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, 
         for (int j = 0; j < VEC; ++j) { lp_f[j] = base_f[j] = v2e_linlog(x[j], a.lut); lp64[j] = base64[j] = (double)lp_f[j]; }
     }
     if constexpr (RNG == kRngPhilox) {
-        v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFThresA, p0, pt, nt);
+        v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFThresA, p0, s_icdf, pt, nt);
         float g[VEC], g_unused[VEC];
-        field_gauss_pairs<VEC>(a.seed, clip_id, kV2eFNoiseRate, kStreamV2e, p0, g, g_unused);
+        field_gauss_pairs<VEC>(a.seed, clip_id, kV2eFNoiseRate, kStreamV2e, p0, s_icdf, g, g_unused);
         const float c = (float)(2.302585092994046 * P.noise_rate_cov_decades);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) nrate[j] = expf_det(c * g[j]);
@@ -554,7 +558,7 @@ __device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, 
         const double dt = fc.dt, dt_tau = fc.dt_tau, cap = fc.cap;
         const float dt_tau32 = (float)dt_tau;
         if (temporal) {                                                                 // thresholds redrawn per frame (:417-421)
-            if constexpr (RNG == kRngPhilox) v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i, p0, pt, nt);
+            if constexpr (RNG == kRngPhilox) v2e_native_thres<VEC>(P, a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)i, p0, s_icdf, pt, nt);
             else {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
@@ -569,7 +573,7 @@ __device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, 
         float u_sp[VEC], u_sn[VEC];
         if constexpr (RNG == kRngPhilox) {
             if (leak) {                     // one Box-Muller pair per pixel and couple of frame pairs (2m, 2m+1): block of couple m
-                if constexpr (PAR == 0) field_gauss_pairs<VEC, kNoiseRounds>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)(k >> 1) + 2u, kStreamV2e, p0, gleak, gleak_pend);
+                if constexpr (PAR == 0) field_gauss_pairs<VEC, kNoiseRounds>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)(k >> 1) + 2u, kStreamV2e, p0, s_icdf, gleak, gleak_pend);
                 else {
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) gleak[j] = gleak_pend[j];
