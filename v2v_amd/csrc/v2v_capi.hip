@@ -193,7 +193,7 @@ int v2v_esim_voxel_padded_hip(const void *frames, int in_dtype, int64_t B, int64
     if (!noise && (flags & V2V_FLAG_NOISE_EXTERNAL)) return fail(V2V_ERR_PARAM, "V2V_FLAG_NO_NOISE and V2V_FLAG_NOISE_EXTERNAL are exclusive");
     if (!noise && rng_mode == V2V_RNG_REPLAY) return fail(V2V_ERR_PARAM, "V2V_FLAG_NO_NOISE is not available in replay mode");
     const size_t lds = (noise && rng_mode != V2V_RNG_REPLAY && rng_mode != V2V_RNG_NONE ? (size_t)v2v::kIcdfBytes : 0) /* Gaussian inverse-CDF table */ +
-                       256 * 8 /* log table: float64, or {float32 value, index} */ +
+                       256 * 8 /* log table: float64, or {float32 value, index} */ + 32 /* thresholds + reciprocals by polarity */ +
                        (bin_mode == V2V_BIN_BILINEAR ? (size_t)K * 2 * (out64 ? sizeof(double) : sizeof(float)) + (size_t)num_bins * sizeof(int) : 0);
     if (lds > 64 * 1024) return fail(V2V_ERR_SHAPE, "too many frame pairs for the LDS tables (%zu bytes > 64 KiB): split the clip", lds);
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -126,12 +126,20 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
     constexpr int kTabOff = ICDF ? kIcdfBytes : 0;
     float2 *s_icdf = reinterpret_cast<float2 *>(s_raw);
     ent_t *s_lut = reinterpret_cast<ent_t *>(s_raw + kTabOff);
-    acc_t *s_wlo = reinterpret_cast<acc_t *>(s_raw + kTabOff + 256 * sizeof(ent_t));
+    // {threshold, low-biased reciprocal} of the ON and the OFF side (16 bytes each): the asymmetric step selects by polarity with
+    // ONE 16-byte LDS read per pixel (address = sign bit >> 27) instead of four v_cndmask (4 cycles each on gfx950)
+    double *s_thr = reinterpret_cast<double *>(s_raw + kTabOff + 256 * sizeof(ent_t));
+    acc_t *s_wlo = reinterpret_cast<acc_t *>(s_raw + kTabOff + 256 * sizeof(ent_t) + 32);
     acc_t *s_whi = s_wlo + a.K;
     int *s_kb = reinterpret_cast<int *>(s_whi + a.K);      // [Tb] first pair index of each bin segment
 
     // ---- workgroup prologue: tables into LDS
     if constexpr (ICDF) icdf_to_lds(s_icdf);
+    if (threadIdx.x < 2) {
+        const double c = a.params[(int64_t)(blockIdx.x / a.blocks_per_clip) * a.params_stride + threadIdx.x];
+        s_thr[2 * threadIdx.x] = c;
+        s_thr[2 * threadIdx.x + 1] = (1.0 / c) * 0x1.ffffffffffffcp-1;       // same expression as inv_pos / inv_neg below
+    }
     if constexpr (IN == kInU8) s_lut[threadIdx.x] = g_lut_esim64[threadIdx.x];
     else s_lut[threadIdx.x] = make_float2(g_lut_esim32[threadIdx.x], (float)threadIdx.x);
     if constexpr (BIN == kBinBilinear) {
@@ -167,11 +175,11 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
     const int64_t pix_off = (a.out_pitch == a.W) ? (int64_t)p0 : (int64_t)(p0 / (uint32_t)a.W) * a.out_pitch + (p0 % (uint32_t)a.W);
 
     const double *pp = a.params + (int64_t)clip * a.params_stride;
-    // thresholds and their (slightly low) reciprocals live in VGPRs: they are selected per lane by polarity
-    double pos = pp[0], neg = pp[1];
+    // symmetric clips keep the threshold and its (slightly low) reciprocal in VGPRs; asymmetric ones read s_thr by polarity.
     // 1/C biased down by 2^-50 so that floor(|p| * inv) never exceeds the true quotient (one-sided correction)
-    double inv_pos = (1.0 / pos) * 0x1.ffffffffffffcp-1, inv_neg = (1.0 / neg) * 0x1.ffffffffffffcp-1;
-    asm volatile("" : "+v"(pos), "+v"(neg), "+v"(inv_pos), "+v"(inv_neg));
+    double pos = pp[0];
+    double inv_pos = (1.0 / pos) * 0x1.ffffffffffffcp-1;
+    asm volatile("" : "+v"(pos), "+v"(inv_pos));
     double base_std = 0.0, hot_frac = 0.0, hot_std = 0.0;
     if constexpr (NOISE) { base_std = pp[2]; hot_frac = pp[3]; hot_std = pp[4]; }
     const uint64_t seed_ = a.clip_keys ? a.clip_keys[2 * clip] : a.seed;
@@ -305,12 +313,19 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
             const lut_t d = ln[j] - lprev[j];                          // difference in the input's precision (:42)
             lprev[j] = ln[j];
             double p = pot[j] + (double)d;                             // :43
-            if constexpr (NOISE && !EXT) { p = p + base[j]; p = p + hot[j]; }   // :48-49
+            // :48-49.  (Skipping the hot-pixel add for waves without a hot pixel is exact -- x + (+0.0) is x unless x is -0.0,
+            // which a round-to-nearest sum with the never-negative-zero log difference cannot be -- but the scalar branch
+            // costs more than the four adds: +2.5 % on the same box, round 2.)
+            if constexpr (NOISE && !EXT) { p = p + base[j]; p = p + hot[j]; }
             sgn[j] = (uint32_t)__double2hiint(p) & 0x80000000u;
             mag[j] = fabs(p);
             double inv;
             if constexpr (SYM) { thr[j] = pos; inv = inv_pos; }
-            else { const bool neg_side = sgn[j] != 0u; thr[j] = neg_side ? neg : pos; inv = neg_side ? inv_neg : inv_pos; }
+            else {
+                const double2 ti = *reinterpret_cast<const double2 *>(reinterpret_cast<const unsigned char *>(s_thr) + (sgn[j] >> 27));
+                thr[j] = ti.x;
+                inv = ti.y;
+            }
             // inv is biased low, so the estimate never exceeds the true quotient; it is short by one only when
             // |p|/C sits within ~1e-15 above an integer -- and then (or for a NaN potential) r < C fails
             q[j] = floor(mag[j] * inv);
