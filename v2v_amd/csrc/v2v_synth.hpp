@@ -18,7 +18,7 @@ struct SynthArgs {
 };
 
 // Pixel noise of the synthetic clips: the round-1 float32 Box-Muller (two normals from two words), kept here so the
-// bench/test inputs stay the same clips as in round 1; the simulators use gauss16 (v2v_rng.hpp).  Cephes logf polynomial on [sqrt(.5), sqrt(2)],
+// bench/test inputs stay the same clips as in round 1; the simulators use the table-inversion generator of v2v_rng.hpp.  Cephes logf polynomial on [sqrt(.5), sqrt(2)],
 // Cephes sinf/cosf kernels on [-pi/4, pi/4], exact-sign rotation by (q + 1/2)*pi/2.
 __device__ __forceinline__ void synth_bm_pair(uint32_t a, uint32_t b, float &g0, float &g1)
 {
