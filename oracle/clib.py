@@ -58,7 +58,7 @@ def philox4x32(ctr, key):
 
 
 def gauss16(w):
-    """(g0, g1) of one 32-bit word through the native table-inversion generator (high half-word -> g0, low -> g1)."""
+    """(g0, g1) of one 32-bit word through the native table-inversion generator (top 14 bits of the high half-word -> g0, of the low -> g1)."""
     o = (C.c_float * 2)()
     lib().oracle_gauss16(C.c_uint32(w), o)
     return np.float32(o[0]), np.float32(o[1])

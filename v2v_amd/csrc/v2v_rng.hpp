@@ -7,9 +7,9 @@
 // Field ids (contract shared with the CPU oracle, which restates this file independently):
 //   0 potential-init uniform   1 hot-mask uniform   2 hot-pixel Gaussian   3+m base-noise Gaussians of pairs 2m, 2m+1
 // Uniforms are float64 on NumPy's 53-bit grid.  Gaussians are float32, TWO per 32-bit Philox word (one per 16-bit half, by
-// table inversion): word j of block (p>>2, field, clip, stream) belongs to pixel p = 4*(p>>2)+j, its first deviate serves the
+// direct table inversion of its top 14 bits): word j of block (p>>2, field, clip, stream) belongs to pixel p = 4*(p>>2)+j, its first deviate serves the
 // even and its second the odd member of a pair of consecutive time steps, so one Philox block feeds 4 pixels x 2 steps.
-// The transform is one table read and one fma: host (gcc) and device (hipcc) agree bit for bit.
+// The transform is one table read: host (gcc) and device (hipcc) agree bit for bit.
 // The whole library is compiled with -ffp-contract=off; every fused multiply-add below is explicit.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -59,14 +59,16 @@ __device__ __forceinline__ double uniform53(uint32_t a, uint32_t b)
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
 }
 
-// ---- float32 Gaussians by table inversion of 16-bit uniforms ---------------------------------------------------------------
-// half-word n: sign = n >> 15, magnitude index m = n & 0x7FFF, i.e. the probability 1/2 + (m + 1/2) / 2^16 on a midpoint grid;
-// deviate = Phi^-1 of it through a 4096-entry {intercept, slope} table (one entry per 8 consecutive m: the least-squares line
-// through the bin's 8 exact deviates, tools/gen_gauss_icdf.py):   g = fmaf(float(m & 7), slope, intercept), sign applied.
-// 2^16 distinct values, |g| <= 4.19, variance 0.99998, 4th moment 2.999; max error against Phi^-1 1.2e-4 below 3 sigma.
-// Per deviate: 3 integer ops, one convert, half a packed fma, one sign xor and ONE 8-byte LDS read -- the float32 Box-Muller
-// this replaces (one word -> radius and angle, degree-7 log, two Newton steps, degree-3/4 sine and cosine polynomials)
-// cost 18 packed instructions per pair and was the largest single item of the VALU-bound noise-on launch.
+// ---- float32 Gaussians by table inversion --------------------------------------------------------------------------------
+// half-word n of a Philox word: sign = n >> 15, magnitude index i = (n >> 2) & 0x1FFF (13 bits; the two low bits are unused),
+// i.e. the probability 1/2 + (i + 1/2) / 2^14 on a midpoint grid; deviate = Phi^-1 of it, read DIRECTLY from a table of 8192
+// float32 values (tools/gen_gauss_icdf.py, 32 KB).  2^14 distinct values, |g| <= 4.009, variance 0.99992, 4th moment 2.997.
+// Per deviate: one and (+ one shift for the high half) for the byte offset, ONE 4-byte LDS read, and + xor for the sign.
+// History: the float32 Box-Muller this replaces (one word -> radius and angle, degree-7 log, two Newton steps,
+// degree-3/4 sine and cosine polynomials) cost 18 packed instructions per pair and was the largest single item of the
+// VALU-bound noise-on launch; a 16-bit variant (4096 x {intercept, slope}, one convert + fma per deviate) measured 6-8 % slower
+// on the same box than this direct table for 1.5e-4 instead of 3.8e-5 of quantile spacing at the centre and tails ending at
+// 4.0 instead of 4.2 sigma -- immaterial for sensor noise of a few percent of the contrast threshold.
 // The table is data shared with the CPU oracle (oracle/gauss_icdf.inc holds the same text); kernels copy it to LDS once per
 // workgroup, one-off per-pixel fields may read it from global memory.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -75,13 +77,13 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 pk_splat(float v) { return f32x2{v, v}; }
 
-constexpr int kIcdfEntries = 4096, kIcdfBytes = kIcdfEntries * 8;
-static __device__ const float2 g_gauss_icdf[kIcdfEntries] = {
+constexpr int kIcdfEntries = 8192, kIcdfBytes = kIcdfEntries * 4;
+static __device__ const float g_gauss_icdf[kIcdfEntries] = {
 #include "v2v_gauss_icdf.inc"
 };
 
 // copy the table into LDS (256 work-items: 8 x 16 bytes each); the caller synchronises
-__device__ __forceinline__ void icdf_to_lds(float2 *s_icdf)
+__device__ __forceinline__ void icdf_to_lds(float *s_icdf)
 {
     const float4 *src = reinterpret_cast<const float4 *>(g_gauss_icdf);
     float4 *dst = reinterpret_cast<float4 *>(s_icdf);
@@ -90,13 +92,13 @@ __device__ __forceinline__ void icdf_to_lds(float2 *s_icdf)
 }
 
 // one word -> two deviates: g0 from the high, g1 from the low half-word
-__device__ __forceinline__ void icdf16_pair(uint32_t w, const float2 *tab, float &g0, float &g1)
+__device__ __forceinline__ void icdf_pair(uint32_t w, const float *tab, float &g0, float &g1)
 {
-    const uint32_t hi = w >> 16;
-    const float2 eh = tab[(hi & 0x7FFFu) >> 3], el = tab[(w & 0x7FFFu) >> 3];
-    const f32x2 g = pk_fma(f32x2{(float)(hi & 7u), (float)(w & 7u)}, f32x2{eh.y, el.y}, f32x2{eh.x, el.x});
-    g0 = __uint_as_float(__float_as_uint(g.x) ^ (w & 0x80000000u));
-    g1 = __uint_as_float(__float_as_uint(g.y) ^ ((w & 0x8000u) << 16));
+    const unsigned char *b = reinterpret_cast<const unsigned char *>(tab);
+    const uint32_t t0 = *reinterpret_cast<const uint32_t *>(b + ((w >> 16) & 0x7FFCu));     // byte offset = 4 * ((n >> 2) & 0x1FFF)
+    const uint32_t t1 = *reinterpret_cast<const uint32_t *>(b + (w & 0x7FFCu));
+    g0 = __uint_as_float(t0 ^ (w & 0x80000000u));
+    g1 = __uint_as_float(t1 ^ ((w << 16) & 0x80000000u));
 }
 
 // ---- per-pixel field accessors.  VEC consecutive pixels starting at p0 (p0 % VEC == 0). -------------
@@ -122,21 +124,21 @@ __device__ __forceinline__ void field_uniform53(uint64_t seed, uint32_t clip, ui
 // word in block `field`; tab = the inverse-CDF table (LDS copy in the time loops, g_gauss_icdf for one-off fields).
 template <int VEC, int ROUNDS = 10>
 __device__ __forceinline__ void field_gauss_pairs(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream,
-                                                  uint32_t p0, const float2 *tab, float (&ga)[VEC], float (&gb)[VEC])
+                                                  uint32_t p0, const float *tab, float (&ga)[VEC], float (&gb)[VEC])
 {
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     if constexpr (VEC == 1) {
         const u32x4 w = philox4x32<ROUNDS>(p0 >> 2, field, clip, stream, k0, k1);
         const uint32_t j = p0 & 3u;
-        icdf16_pair(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, tab, ga[0], gb[0]);
+        icdf_pair(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, tab, ga[0], gb[0]);
     } else {
 #pragma unroll
         for (int j = 0; j < VEC; j += 4) {
             const u32x4 w = philox4x32<ROUNDS>((p0 + j) >> 2, field, clip, stream, k0, k1);
-            icdf16_pair(w.x, tab, ga[j], gb[j]);
-            icdf16_pair(w.y, tab, ga[j + 1], gb[j + 1]);
-            icdf16_pair(w.z, tab, ga[j + 2], gb[j + 2]);
-            icdf16_pair(w.w, tab, ga[j + 3], gb[j + 3]);
+            icdf_pair(w.x, tab, ga[j], gb[j]);
+            icdf_pair(w.y, tab, ga[j + 1], gb[j + 1]);
+            icdf_pair(w.z, tab, ga[j + 2], gb[j + 2]);
+            icdf_pair(w.w, tab, ga[j + 3], gb[j + 3]);
         }
     }
 }

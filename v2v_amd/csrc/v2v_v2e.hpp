@@ -120,7 +120,7 @@ __device__ __forceinline__ float expf_det(float x)
 // ON/OFF thresholds of VEC pixels from two Gaussian fields (normal(loc,scale) = loc + scale*g), clipped at 0.01
 template <int VEC>
 __device__ __forceinline__ void v2e_native_thres(const V2eParams &P, uint64_t seed, uint32_t clip, uint32_t fa, uint32_t p0,
-                                                 const float2 *tab, double (&pt)[VEC], double (&nt)[VEC])
+                                                 const float *tab, double (&pt)[VEC], double (&nt)[VEC])
 {
     float ga[VEC], gb[VEC];                 // the two deviates of the pixel's word (block fa)
     field_gauss_pairs<VEC>(seed, clip, fa, kStreamV2e, p0, tab, ga, gb);
@@ -420,10 +420,10 @@ __device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, 
     using inten_t = typename std::conditional<IN == kInU8, V2eIntenU8, V2eIntenF32>::type;
     static_assert(sizeof(V2eFrameConst) == 32 && sizeof(inten_t) == 16, "LDS record layout");
     constexpr bool PK = !OUT64 && BIN == kBinBilinear && VEC == 4;        // packed bilinear accumulation (see the ESIM kernel)
-    // the inverse-CDF table of the Gaussian generator leads the dynamic LDS of the device-native instances
-    constexpr int kTabOff = RNG == kRngPhilox ? kIcdfBytes : 0;
-    float2 *s_icdf = reinterpret_cast<float2 *>(s_raw);
-    if constexpr (RNG == kRngPhilox) icdf_to_lds(s_icdf);
+    // the Gaussian generator's table: a static LDS array of the device-native instances (compile-time address, see v2v_esim.hpp)
+    float *s_icdf = nullptr;
+    if constexpr (RNG == kRngPhilox) { __shared__ __align__(16) float s_icdf_static[kIcdfEntries]; s_icdf = s_icdf_static; icdf_to_lds(s_icdf); }
+    constexpr int kTabOff = 0;
     inten_t *s_int = reinterpret_cast<inten_t *>(s_raw + kTabOff);                              // [256]
     V2eFrameConst *s_fc = reinterpret_cast<V2eFrameConst *>(s_raw + kTabOff + 256 * sizeof(inten_t));     // [K]
     acc_t *s_wlo = reinterpret_cast<acc_t *>(s_fc + a.K);
