@@ -192,10 +192,10 @@ int v2v_esim_voxel_padded_hip(const void *frames, int in_dtype, int64_t B, int64
     const bool noise = !(flags & V2V_FLAG_NO_NOISE);
     if (!noise && (flags & V2V_FLAG_NOISE_EXTERNAL)) return fail(V2V_ERR_PARAM, "V2V_FLAG_NO_NOISE and V2V_FLAG_NOISE_EXTERNAL are exclusive");
     if (!noise && rng_mode == V2V_RNG_REPLAY) return fail(V2V_ERR_PARAM, "V2V_FLAG_NO_NOISE is not available in replay mode");
-    const size_t lds = /* (+ 32 KB static: the Gaussian table of the device-native noise instances) */
-                       256 * 8 /* log table: float64, or {float32 value, index} */ + 32 /* thresholds + reciprocals by polarity */ +
-                       (bin_mode == V2V_BIN_BILINEAR ? (size_t)K * 2 * (out64 ? sizeof(double) : sizeof(float)) + (size_t)num_bins * sizeof(int) : 0);
-    const size_t lds_static = noise && rng_mode != V2V_RNG_REPLAY && rng_mode != V2V_RNG_NONE ? (size_t)v2v::kIcdfBytes : 0;
+    // dynamic LDS: the bilinear weights per frame pair and the segment starts per bin; static: log table, thresholds, and the
+    // Gaussian table of the instances that draw device-native noise
+    const size_t lds = bin_mode == V2V_BIN_BILINEAR ? (size_t)K * 2 * (out64 ? sizeof(double) : sizeof(float)) + (size_t)num_bins * sizeof(int) : 0;
+    const size_t lds_static = 256 * 8 + 32 + (noise && rng_mode != V2V_RNG_REPLAY && rng_mode != V2V_RNG_NONE ? (size_t)v2v::kIcdfBytes : 0);
     if (lds + lds_static > 64 * 1024) return fail(V2V_ERR_SHAPE, "too many frame pairs for the LDS tables (%zu bytes > 64 KiB): split the clip", lds + lds_static);
     hipStream_t s = static_cast<hipStream_t>(stream);
 
@@ -297,8 +297,8 @@ int v2v_v2e_voxel_hip(const void *frames, int in_dtype, int64_t B, int64_t N, in
     const int64_t nblocks = B * a.blocks_per_clip;
     if (nblocks > 0x7FFFFFFF) return fail(V2V_ERR_SHAPE, "grid too large");
     const bool out64 = out_dtype == V2V_F64;
-    const size_t lds = /* (+ 32 KB static: the Gaussian table of the device-native instances) */ 256 * 16 /* per-intensity records */ + (size_t)K * 32 /* per-frame constants */ + (bin_mode == V2V_BIN_BILINEAR ? (size_t)K * (2 * (out64 ? sizeof(double) : sizeof(float)) + sizeof(int)) : 0);
-    const size_t lds_static = rng_mode == V2V_RNG_PHILOX ? (size_t)v2v::kIcdfBytes : 0;
+    const size_t lds = /* static: per-intensity records + the Gaussian table of the device-native instances */ (size_t)K * 32 /* per-frame constants */ + (bin_mode == V2V_BIN_BILINEAR ? (size_t)K * (2 * (out64 ? sizeof(double) : sizeof(float)) + sizeof(int)) : 0);
+    const size_t lds_static = 256 * 16 + (rng_mode == V2V_RNG_PHILOX ? (size_t)v2v::kIcdfBytes : 0);
     if (lds + lds_static > 64 * 1024) return fail(V2V_ERR_SHAPE, "too many frame pairs for the LDS tables (%zu bytes > 64 KiB): split the clip", lds + lds_static);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (presum) {

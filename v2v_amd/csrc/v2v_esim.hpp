@@ -126,12 +126,12 @@ __global__ void __launch_bounds__(kBlock, V2V_MIN_WAVES) esim_voxel_kernel(const
     // compile-time constant, so the reads need no base add (-1.7 % against carving it out of the dynamic region, same box)
     float *s_icdf = nullptr;
     if constexpr (ICDF) { __shared__ __align__(16) float s_icdf_static[kIcdfEntries]; s_icdf = s_icdf_static; }
-    constexpr int kTabOff = 0;
-    ent_t *s_lut = reinterpret_cast<ent_t *>(s_raw + kTabOff);
-    // {threshold, low-biased reciprocal} of the ON and the OFF side (16 bytes each): the asymmetric step selects by polarity with
-    // ONE 16-byte LDS read per pixel (address = sign bit >> 27) instead of four v_cndmask (4 cycles each on gfx950)
-    double *s_thr = reinterpret_cast<double *>(s_raw + kTabOff + 256 * sizeof(ent_t));
-    acc_t *s_wlo = reinterpret_cast<acc_t *>(s_raw + kTabOff + 256 * sizeof(ent_t) + 32);
+    // the log table and {threshold, low-biased reciprocal} of the ON and the OFF side (16 bytes each: the asymmetric step
+    // selects by polarity with ONE 16-byte LDS read per pixel, address = sign bit >> 27, instead of four v_cndmask at 4 cycles
+    // each) are static too; only the K- and Tb-sized bilinear tables live in the dynamic region
+    __shared__ __align__(16) ent_t s_lut[256];
+    __shared__ __align__(16) double s_thr[4];
+    acc_t *s_wlo = reinterpret_cast<acc_t *>(s_raw);
     acc_t *s_whi = s_wlo + a.K;
     int *s_kb = reinterpret_cast<int *>(s_whi + a.K);      // [Tb] first pair index of each bin segment
 

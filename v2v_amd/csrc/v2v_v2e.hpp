@@ -423,9 +423,8 @@ __device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, 
     // the Gaussian generator's table: a static LDS array of the device-native instances (compile-time address, see v2v_esim.hpp)
     float *s_icdf = nullptr;
     if constexpr (RNG == kRngPhilox) { __shared__ __align__(16) float s_icdf_static[kIcdfEntries]; s_icdf = s_icdf_static; icdf_to_lds(s_icdf); }
-    constexpr int kTabOff = 0;
-    inten_t *s_int = reinterpret_cast<inten_t *>(s_raw + kTabOff);                              // [256]
-    V2eFrameConst *s_fc = reinterpret_cast<V2eFrameConst *>(s_raw + kTabOff + 256 * sizeof(inten_t));     // [K]
+    __shared__ __align__(16) inten_t s_int[256];                                                // static as well: no base add per read
+    V2eFrameConst *s_fc = reinterpret_cast<V2eFrameConst *>(s_raw);                             // [K]
     acc_t *s_wlo = reinterpret_cast<acc_t *>(s_fc + a.K);
     acc_t *s_whi = s_wlo + a.K;
     int *s_seg = reinterpret_cast<int *>(s_whi + a.K);
