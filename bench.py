@@ -426,7 +426,7 @@ def main():
                        "bin_mode": wl["bin"], "num_bins": wl["tb"], "frames_per_bin": wl["fpb"],
                        "sim_params": wl["params"], "sim_params_note": "pos_thres, neg_thres, base_noise_std, hot_pixel_fraction, hot_pixel_std"
                        + (" = EventEmulator() constructor defaults of the reference (noise on)" if wl["params"] == REF_DEFAULTS else ""),
-                       "rng": "philox4x32 on device (10 rounds per-clip fields, 7 rounds per-step noise fields)",
+                       "rng": "philox4x32 on device (10 rounds per-clip fields, 7 rounds per-step noise fields), Gaussians by direct table inversion (2 per word)",
                        "sharding": f"batch over {world} GPU(s), no collective", "grid": [wl["tb"], wl["h"], wl["w"]],
                        "launch": "hipGraph replay" if use_graph else "eager"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
