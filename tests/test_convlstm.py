@@ -42,7 +42,7 @@ def _case(b, c, h, w, seed, scale=1.0):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,tile_rows", [((2, 64, 16, 16), 0), ((2, 64, 16, 16), 128), ((2, 64, 16, 16), 64), ((1, 128, 8, 24), 0),
-                                               ((3, 64, 12, 16), 64), ((1, 256, 8, 8), 0), ((2, 64, 64, 64), 0), ((2, 64, 16, 16), 256), ((1, 128, 16, 32), 256),
+                                               ((3, 64, 12, 16), 64), ((1, 256, 8, 8), 0), ((2, 64, 64, 64), 0), ((2, 64, 16, 16), 256), ((1, 128, 16, 32), 256), ((4, 128, 32, 32), 128), ((4, 128, 32, 32), 0),
                                                ((8, 64, 64, 64), 0)])
 def test_step_matches_reference_semantics(shape, tile_rows):
     import torch

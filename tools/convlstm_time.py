@@ -64,7 +64,7 @@ def main():
             for tr in (64, 128, 256):
                 row[f"fused_step_only_t{tr}_ms"] = timeit(lambda: CL.convlstm_step(xn, hs, cs, fused._weights(), fused.Gates.bias, nchw_dtype=torch.bfloat16,
                                                                                tile_rows=tr))
-            best = min(row["fused_step_only_t64_ms"], row["fused_step_only_t128_ms"], row["fused_step_only_t256_ms"])
+            best = min(v for k, v in row.items() if k.startswith("fused_step_only_t"))
             row["fused_step_tflops"] = flops / best / 1e9
             row["conv_to_nhwc_ms"] = timeit(lambda: CL.nchw_to_nhwc_bf16(x))
         rows.append(row)

@@ -22,8 +22,10 @@
 // taps read a 128-byte zero line instead.  LDS rows are 128 B; the 16-byte slot index is XORed with (row >> 1) & 7 -- applied
 // on the SOURCE address of the LDS-DMA (its LDS destination is lane-linear) and on the ds_read_b128 address -- which makes
 // every 16-lane group of a fragment read hit 16 distinct (row parity, slot) pairs = all 64 banks once.
-// Per chunk and wave: 24 ds_read_b128, 32 MFMAs (1024 matrix-core cycles), 12 LDS-DMA instructions, one barrier.
-// The default is the 64-pixel tile (MF = 1, 80 KB of LDS): two workgroups per CU cover each other's barrier waits.
+// The launcher picks the largest tile that still gives every CU a workgroup (256 -> 128 -> 64 pixels).  Where a wave's cycles
+// go (tools/convlstm_phase_probe.py on a -DV2V_CL_TIMING build, 256-pixel tile): 7-16 % in the vmcnt wait, 16-17 % in the
+// barrier, the rest in LDS-DMA issue + fragment reads + MFMA -- the 8 LDS-DMA instructions a wave issues per chunk cost about
+// as much issue time as half of its 32 MFMAs.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,15 +36,19 @@ namespace v2v {
 
 constexpr int kClBK = 64, kClCh = 64, kClBN = 4 * kClCh;
 constexpr int kClBBytes = kClBN * kClBK * 2;
-// MF = 32-pixel accumulator blocks per wave (1 or 2), WM = wave rows (2 or 4; x 2 wave columns): the workgroup tile is
-// 32*MF*WM pixels -- 64 (4 waves, 80 KB of LDS), 128 (4 waves, 96 KB) or 256 (8 waves, 128 KB)
-constexpr int cl_lds_bytes(int mf, int wm) { return 2 * (32 * mf * wm * kClBK * 2 + kClBBytes); }
+// MF = 32-pixel accumulator blocks per wave (1 or 2), WM = wave rows (2 or 4; x 2 wave columns), STAGES = LDS buffers: the
+// workgroup tile is 32*MF*WM pixels.  Shipped: <1,2,2> 64 pixels (4 waves, 80 KB of LDS, two workgroups per CU), <1,4,3> 128
+// pixels (8 waves, 144 KB, three stages with counted vmcnt), <2,4,2> 256 pixels (8 waves, 128 KB)
+constexpr int cl_lds_bytes(int mf, int wm, int stages = 2) { return stages * (32 * mf * wm * kClBK * 2 + kClBBytes); }
 
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 cl_bf16x8;
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float cl_f32x16;
 
 
 __device__ __attribute__((aligned(128))) unsigned char g_cl_zero_line[128];      // zero-initialised: the padding source
+#ifdef V2V_CL_TIMING
+__device__ unsigned long long g_cl_dbg[4];      // EXPERIMENT: per-wave cycle totals {vmcnt wait, barrier, everything else, waves}
+#endif
 
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f)
 {
@@ -60,8 +66,8 @@ __device__ __forceinline__ void cl_glds16(const void *src, unsigned char *lds_wa
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <int MF, int WM>
-__global__ void __launch_bounds__(128 * WM, (MF == 1 || WM == 4) ? 2 : 1) convlstm_step_kernel(const ConvLstmArgs a)
+template <int MF, int WM, int STAGES = 2>
+__global__ void __launch_bounds__(128 * WM, (STAGES == 2 && MF == 1) || WM == 4 ? 2 : 1) convlstm_step_kernel(const ConvLstmArgs a)
 {
     constexpr int kClBM = 32 * MF * WM, kClABytes = kClBM * kClBK * 2, kClStage = kClABytes + kClBBytes;
     extern __shared__ __attribute__((aligned(128))) unsigned char cl_lds[];
@@ -100,7 +106,11 @@ __global__ void __launch_bounds__(128 * WM, (MF == 1 || WM == 4) ? 2 : 1) convls
     }
     const uint16_t *wtile = a.wp + (int64_t)ct * 9 * cc_all * (kClBN * kClBK);
 
-    auto stage = [&](int ck, int buf) __attribute__((always_inline)) {
+    // LDS-DMA of chunk ck into buffer buf (part / nparts: a subset of the pieces, j % nparts == part).  The main loop issues
+    // the whole chunk in front of the first k-step: spreading the pieces over the four k-steps was measured 10-15 % slower on
+    // the same box with two buffers AND with three (every piece issued between MFMAs stalls the wave's instruction stream for
+    // its turn in the address unit)
+    auto stage = [&](int ck, int buf, int part, int nparts) __attribute__((always_inline)) {
         const int tap = ck / cc_eff, cc = ck - tap * cc_eff;
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
         const uint16_t *src = cc < cc_x ? a.x : a.h_prev;
@@ -109,13 +119,17 @@ __global__ void __launch_bounds__(128 * WM, (MF == 1 || WM == 4) ? 2 : 1) convls
         const int64_t shift = ((int64_t)dy * a.W + dx) * C + c0;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
+            if (j % nparts != part) continue;
             const bool in = (unsigned)(ay[j] + dy) < (unsigned)a.H && (unsigned)(ax[j] + dx) < (unsigned)a.W;
             const void *g = in ? (const void *)(src + apix[j] + shift + aswz[j]) : (const void *)g_cl_zero_line;
             cl_glds16(g, abase + (wave * NA + j) * 1024);
         }
         const uint16_t *wchunk = wtile + (int64_t)(tap * cc_all + cc) * (kClBN * kClBK);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) cl_glds16(wchunk + boff[j], bbase + (wave * NB + j) * 1024);
+        for (int j = 0; j < NB; ++j) {
+            if (j % nparts != part) continue;
+            cl_glds16(wchunk + boff[j], bbase + (wave * NB + j) * 1024);
+        }
     };
 
     // ---- fragment read plan ------------------------------------------------------------------------------------------------
@@ -134,26 +148,77 @@ __global__ void __launch_bounds__(128 * WM, (MF == 1 || WM == 4) ? 2 : 1) convls
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][g][r] = 0.0f;
 
-    stage(0, 0);
-    for (int ck = 0; ck < n_chunks; ++ck) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                         // chunk ck has landed; everyone is done with the other buffer
-        if (ck + 1 < n_chunks) stage(ck + 1, (ck + 1) & 1);
-        const unsigned char *base = cl_lds + (ck & 1) * kClStage;
+#ifdef V2V_CL_TIMING
+    unsigned long long t_wait = 0, t_bar = 0, t_rest = 0, t_prev = __builtin_readcyclecounter();
+#define CL_STAMP(acc) { const unsigned long long t_now = __builtin_readcyclecounter(); acc += t_now - t_prev; t_prev = t_now; }
+#else
+#define CL_STAMP(acc)
+#endif
+    auto k_steps = [&](const unsigned char *base, auto &&before_step) __attribute__((always_inline)) {
+        // fragments of k-step s+1 are read before the MFMAs of k-step s are issued (two register sets: +1..3 %)
+        cl_bf16x8 af[2][MF], bf[2][4];
+        auto load = [&](int s, int slot) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i) af[slot][i] = *reinterpret_cast<const cl_bf16x8 *>(base + a_row + i * (32 * 128) + koff[s]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bf[slot][g] = *reinterpret_cast<const cl_bf16x8 *>(base + b_row + g * (32 * 128) + koff[s]);
+        };
+        before_step(0);
+        load(0, 0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            cl_bf16x8 af[MF], bf[4];
-#pragma unroll
-            for (int i = 0; i < MF; ++i) af[i] = *reinterpret_cast<const cl_bf16x8 *>(base + a_row + i * (32 * 128) + koff[s]);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bf[g] = *reinterpret_cast<const cl_bf16x8 *>(base + b_row + g * (32 * 128) + koff[s]);
+            if (s < 3) { before_step(s + 1); load(s + 1, (s + 1) & 1); }
 #pragma unroll
             for (int i = 0; i < MF; ++i)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[g], acc[i][g], 0, 0, 0);
+                for (int g = 0; g < 4; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], bf[s & 1][g], acc[i][g], 0, 0, 0);
+        }
+    };
+    if constexpr (STAGES == 2) {
+        // two LDS buffers: the whole next chunk is issued in front of the first k-step, drained (vmcnt 0) before the next barrier
+        stage(0, 0, 0, 1);
+        for (int ck = 0; ck < n_chunks; ++ck) {
+            CL_STAMP(t_rest)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            CL_STAMP(t_wait)
+            __syncthreads();                                     // chunk ck has landed; everyone is done with the other buffer
+            CL_STAMP(t_bar)
+            const bool more = ck + 1 < n_chunks;
+            k_steps(cl_lds + (ck & 1) * kClStage, [&](int s) __attribute__((always_inline)) {
+                if (more && s == 0) stage(ck + 1, (ck + 1) & 1, 0, 1);
+            });
+        }
+    } else {
+        // three LDS buffers: chunk ck+2 is issued in front of the first k-step of chunk ck and stays in flight ACROSS the next
+        // barrier -- the wait in front of a barrier is counted (the NA+NB pieces of the youngest chunk may be outstanding:
+        // LDS-DMA completes in order) and the barrier is a raw s_barrier (a __syncthreads() would drain vmcnt)
+        constexpr int kPieces = NA + NB;
+        stage(0, 0, 0, 1);
+        if (n_chunks > 1) stage(1, 1, 0, 1);
+        int buf = 0, buf2 = 2;
+        for (int ck = 0; ck < n_chunks; ++ck) {
+            CL_STAMP(t_rest)
+            if (ck + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPieces) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            CL_STAMP(t_wait)
+            __builtin_amdgcn_s_barrier();                        // chunk ck has landed for every wave; buffer buf2 is free
+            asm volatile("" ::: "memory");
+            CL_STAMP(t_bar)
+            const bool more2 = ck + 2 < n_chunks;
+            k_steps(cl_lds + buf * kClStage, [&](int s) __attribute__((always_inline)) {
+                if (more2 && s == 0) stage(ck + 2, buf2, 0, 1);
+            });
+            buf = buf == 2 ? 0 : buf + 1;
+            buf2 = buf2 == 2 ? 0 : buf2 + 1;
         }
     }
 
+#ifdef V2V_CL_TIMING
+    CL_STAMP(t_rest)
+    if (lane == 0) {
+        atomicAdd(&g_cl_dbg[0], t_wait); atomicAdd(&g_cl_dbg[1], t_bar); atomicAdd(&g_cl_dbg[2], t_rest); atomicAdd(&g_cl_dbg[3], 1ull);
+    }
+#endif
     // ---- epilogue: gates -> cell / hidden, straight from the accumulators ---------------------------------------------------
     // accumulator element r of lane l: column (channel) l & 31, row (pixel) (r & 3) + 8 (r >> 2) + 4 (l >> 5)
     const int ch = ct * kClCh + wn * 32 + fr;

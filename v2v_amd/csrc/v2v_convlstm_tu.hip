@@ -5,37 +5,40 @@
 namespace v2v {
 
 namespace {
-template <int MF, int WM>
+template <int MF, int WM, int STAGES = 2>
 hipError_t launch_step_t(const ConvLstmArgs &a, hipStream_t s)
 {
     // 80-128 KB of dynamic LDS is above the 64 KB a kernel gets by default: raise the limit once per device (kept out of the
     // launch path so that a step captures into a hipGraph as a bare kernel node)
-    constexpr int lds = cl_lds_bytes(MF, WM);
+    constexpr int lds = cl_lds_bytes(MF, WM, STAGES);
     static bool raised[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (dev < 0 || dev >= 64 || !raised[dev]) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convlstm_step_kernel<MF, WM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convlstm_step_kernel<MF, WM, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) raised[dev] = true;
     }
     const int64_t tiles = (int64_t)a.B * a.H * a.W / (32 * MF * WM) * (a.C / kClCh);
-    hipLaunchKernelGGL((convlstm_step_kernel<MF, WM>), dim3((unsigned)tiles), dim3(128 * WM), lds, s, a);
+    hipLaunchKernelGGL((convlstm_step_kernel<MF, WM, STAGES>), dim3((unsigned)tiles), dim3(128 * WM), lds, s, a);
     return hipGetLastError();
 }
 }  // namespace
 
-// tile_rows: pixels per workgroup tile (64, 128 or 256); 0 = auto.
+// tile_rows: pixels per workgroup tile (64, 128 or 256); 0 = auto: the largest tile that still gives every CU a workgroup.
+// Same box, 8 clips (ms per step; tools/ab_convlstm.sh):        64 px    128 px   256 px
+//   64 ch @128^2 / 128 ch @64^2 / 256 ch @32^2 (256^2 input)     0.119/0.100/0.094   0.114/0.096/0.089   0.101/0.083/0.126
+//   64 ch @64^2 / 128 ch @32^2 / 256 ch @16^2 (128^2 input)      0.034/0.042/0.071   0.033/0.048/0.080   0.049/0.074/0.127
 hipError_t launch_convlstm_step(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
 {
     if (tile_rows == 0) {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const int64_t m = (int64_t)a.B * a.H * a.W;
-        tile_rows = (m % 256 == 0 && m / 256 * (a.C / kClCh) >= cus) ? 256 : 64;
+        const int64_t m = (int64_t)a.B * a.H * a.W, ct = a.C / kClCh;
+        tile_rows = (m % 256 == 0 && m / 256 * ct >= cus) ? 256 : (m % 128 == 0 && m / 128 * ct >= cus) ? 128 : 64;
     }
-    if (tile_rows == 256) return launch_step_t<2, 4>(a, s);
-    return tile_rows == 128 ? launch_step_t<2, 2>(a, s) : launch_step_t<1, 2>(a, s);
+    if (tile_rows == 256) return launch_step_t<2, 4, 2>(a, s);
+    return tile_rows == 128 ? launch_step_t<1, 4, 3>(a, s) : launch_step_t<1, 2, 2>(a, s);
 }
 
 hipError_t launch_convlstm_pack(const float *w, uint16_t *wp, int C, hipStream_t s)
@@ -55,4 +58,12 @@ hipError_t launch_nchw_to_nhwc_bf16(const void *src, bool src_bf16, uint16_t *ds
     return hipGetLastError();
 }
 
+#ifdef V2V_CL_TIMING
+extern "C" int v2v_convlstm_debug_read(unsigned long long *out4, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_cl_dbg), 32);
+    if (e == hipSuccess && reset) { unsigned long long z[4] = {0, 0, 0, 0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_cl_dbg), z, 32); }
+    return (int)e;
+}
+#endif
 }  // namespace v2v
