@@ -275,6 +275,43 @@ def maybe_graph(step, torch, dev, want):
         return step, False
 
 
+BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def convlstm_roofline(torch, dev):
+    """The consumer-side matrix-core kernel at the three encoder levels of the E2VID-shaped
+    network for 8 x 256 x 256 input: per-launch HIP-event time, algorithmic FLOPs (2 * pixels * 18C * 4C), fraction of the dense
+    bf16 peak, and a parity check of the hidden state against stock PyTorch fp32 on the same bf16-rounded operands."""
+    from v2v_amd import convlstm as CL
+    out = {"bound": "mfma", "peak_TFLOPs": BF16_DENSE_PEAK_TFLOPS, "kernel": "convlstm_step_kernel", "shapes": {}}
+    for (b, c, h, w) in ((8, 64, 128, 128), (8, 128, 64, 64), (8, 256, 32, 32)):
+        g = torch.Generator(device="cpu").manual_seed(c)
+        x = torch.randn((b, c, h, w), generator=g).to(dev)
+        hp = torch.tanh(torch.randn((b, c, h, w), generator=g)).to(dev)
+        cp = torch.randn((b, c, h, w), generator=g).to(dev)
+        wgt = ((torch.rand((4 * c, 2 * c, 3, 3), generator=g) * 2 - 1) * (3.0 / (18 * c) ** 0.5)).to(dev)
+        bias = ((torch.rand((4 * c,), generator=g) * 2 - 1) * 0.5).to(dev)
+        packed = CL.pack_gate_weights(wgt)
+        xn, hn = CL.nchw_to_nhwc_bf16(x), CL.nchw_to_nhwc_bf16(hp)
+        cn = cp.permute(0, 2, 3, 1).contiguous()
+        step = lambda: CL.convlstm_step(xn, hn, cn, packed, bias, nchw_dtype=torch.float32)   # noqa: E731
+        for _ in range(3):
+            got = step()
+        ms = time_launches(step, 20, torch)
+        r16 = lambda v: v.to(torch.bfloat16).float()   # noqa: E731
+        gates = torch.nn.functional.conv2d(torch.cat([r16(x), r16(hp)], 1), r16(wgt), bias, padding=1)
+        gi, gr, go, gg = gates.chunk(4, 1)
+        c_ref = torch.sigmoid(gr) * cp + torch.sigmoid(gi) * torch.tanh(gg)
+        h_ref = torch.sigmoid(go) * torch.tanh(c_ref)
+        err = float((got[2] - h_ref).abs().max())
+        flops = 2.0 * b * h * w * (18 * c) * (4 * c)
+        avg = sum(ms) / len(ms)
+        out["shapes"][f"{b}x{c}x{h}x{w}"] = {"kernel_ms_avg": avg, "kernel_ms_p50": ms[len(ms) // 2], "algorithmic_GFLOP": flops / 1e9,
+                                           "achieved_TFLOPs": flops / (avg * 1e-3) / 1e12, "frac_of_bf16_peak": flops / (avg * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS,
+                                           "max_abs_err_vs_fp32_torch": err, "parity_check": "ok" if err < 2e-3 else "MISMATCH"}
+    return out
+
+
 def load_traffic(name):
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # rocprofv3 --pmc passes, see profiles/README.md
     try:
@@ -413,6 +450,10 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as exc:  # noqa: BLE001 - a secondary figure must not take the headline down
                 also[name] = {"error": f"{type(exc).__name__}: {exc}"}
+        try:
+            also["convlstm_step_mfma"] = convlstm_roofline(torch, dev)
+        except Exception as exc:  # noqa: BLE001
+            also["convlstm_step_mfma"] = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         achieved = W.alg_bytes / (kern_avg_ms * 1e-3) / 1e9
