@@ -486,10 +486,31 @@ def g16_monash_sequence():
     save("g16_monash_sequence.npz", **out)
 
 
+def g17_degrade_video():
+    """The reference's degrade_video (data/v2v_datasets.py:413-486) in its three NumPy modes on a small clip, gray ([H,W,1]) and
+    colour frames, after np.random.seed.  cv2 is absent: the only OpenCV call on these paths, cv2.flip(img, 1), is served by
+    its definition (mirror the columns; a [H,W,1] input comes back [H,W], which the reference itself undoes at :467-469)."""
+    cv2 = sys.modules["cv2"]
+    cv2.flip = lambda img, code: (np.ascontiguousarray(img[:, ::-1, 0]) if img.ndim == 3 and img.shape[2] == 1 else np.ascontiguousarray(img[:, ::-1]))
+    rng = np.random.default_rng(17)
+    out = {}
+    for chan in (1, 3):
+        clip = rng.integers(0, 256, size=(7, 12, 16, chan), dtype=np.uint8)
+        out[f"clip_c{chan}"] = clip
+        for mode in ("dirtyshotcut", "hdr", "ldr"):
+            for seed in (0, 1, 2):
+                inst = object.__new__(ref_ds.WebvidDatasetV2)
+                inst.video_degrade = mode
+                np.random.seed(seed)
+                got = inst.degrade_video([f.copy() for f in clip])
+                out[f"{mode}_c{chan}_s{seed}"] = np.stack([np.asarray(g) for g in got])
+    save("g17_degrade_video.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     fns = {"g1": g1_luts, "g2": g2_g3_esim_clean, "g4": g4_esim_noisy, "g5": g5_floor_divide,
-           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g15": g15_bgr_to_gray, "g16": g16_monash_sequence, "g12": g12_events_to_voxel_torch,
+           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g15": g15_bgr_to_gray, "g16": g16_monash_sequence, "g17": g17_degrade_video, "g12": g12_events_to_voxel_torch,
            "g13": g13_normalize_batch_voxel}
     for w in which:
         fns[w]()

@@ -71,3 +71,26 @@ def test_events_to_voxel_rejects_broken_reference_branch():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             voxel.make_voxel([np.zeros(0), np.zeros(0, int), np.zeros(0, int), np.zeros(0, int)], 4, 4)
+
+
+def test_degrade_video_equals_reference_golden(golden, tmp_path):
+    """The three NumPy modes of degrade_video (data/v2v_datasets.py:454-483) against golden G17, produced by the reference's own
+    method after np.random.seed: same draws, same frames.  'subtitles' needs OpenCV's font rasteriser and says so."""
+    from v2v_amd.datasets import WebvidDatasetV2
+    g = golden("g17_degrade_video.npz")
+    lst = _mk_list(tmp_path, [["a.mp4", 450, 0.2, 0.3]])
+    for chan in (1, 3):
+        clip = g[f"clip_c{chan}"]
+        for mode in ("dirtyshotcut", "hdr", "ldr"):
+            ds = WebvidDatasetV2(str(tmp_path), {"video_list_file": lst, "video_degrade": mode, "degrade_ratio": 1.0})
+            for seed in (0, 1, 2):
+                np.random.seed(seed)
+                got = np.stack(ds.degrade_video([f.copy() for f in clip]))
+                want = g[f"{mode}_c{chan}_s{seed}"]
+                assert got.shape == want.shape and got.dtype == np.uint8 and np.array_equal(got, want), (mode, chan, seed)
+    ds = WebvidDatasetV2(str(tmp_path), {"video_list_file": lst, "video_degrade": "subtitles", "degrade_ratio": 1.0})
+    try:
+        import cv2  # noqa: F401
+    except ImportError:
+        with pytest.raises(NotImplementedError):
+            ds.degrade_video([f.copy() for f in g["clip_c3"]])

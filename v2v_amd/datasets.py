@@ -215,6 +215,52 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
         cap.release()
         return size
 
+    def degrade_video(self, imgs):
+        """The reference's robustness ablations on the decoded clip (data/v2v_datasets.py:413-486): same np.random draw order,
+        same arithmetic.  'dirtyshotcut' (cut, swap the parts, mirror one), 'hdr' / 'ldr' (contrast stretch around 127.5 in
+        float64, clip, truncate to uint8) are NumPy; 'subtitles' rasterises text with OpenCV's Hershey fonts (cv2.putText) and
+        therefore needs cv2 -- without it that mode raises."""
+        t = len(imgs)
+        if self.video_degrade == "subtitles":
+            try:
+                import cv2
+            except ImportError as exc:
+                raise NotImplementedError("video_degrade 'subtitles' draws text with cv2.putText: OpenCV is required") from exc
+            fonts = [cv2.FONT_HERSHEY_SIMPLEX, cv2.FONT_HERSHEY_PLAIN, cv2.FONT_HERSHEY_DUPLEX, cv2.FONT_HERSHEY_COMPLEX,
+                     cv2.FONT_HERSHEY_TRIPLEX, cv2.FONT_HERSHEY_COMPLEX_SMALL, cv2.FONT_HERSHEY_SCRIPT_SIMPLEX, cv2.FONT_HERSHEY_SCRIPT_COMPLEX]
+            font = np.random.choice(fonts)
+            font_scale = np.random.uniform(0.5, 1.5)
+            color = (np.random.randint(0, 256), np.random.randint(0, 256), np.random.randint(0, 256))
+            thickness = np.random.randint(1, 3)
+            text_len = np.random.randint(5, 16)
+            text = "".join(np.random.choice(list("abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789 "), size=text_len))
+            h, w = imgs[0].shape[:2]
+            (text_width, text_height), baseline = cv2.getTextSize(text, font, font_scale, thickness)
+            org = (np.random.randint(0, max(1, w - text_width)), np.random.randint(text_height, max(text_height + 1, h - baseline)))
+            for i in range(t):
+                img = imgs[i].copy()
+                if img.shape[2] == 1:
+                    img = cv2.cvtColor(img, cv2.COLOR_GRAY2BGR)
+                cv2.putText(img, text, org, font, font_scale, color, thickness, cv2.LINE_AA)
+                imgs[i] = cv2.cvtColor(img, cv2.COLOR_BGR2GRAY)[..., np.newaxis] if imgs[i].shape[2] == 1 else img
+            return imgs
+        if self.video_degrade == "dirtyshotcut":
+            if t < 3:
+                return imgs
+            cut_idx = np.random.randint(1, t - 1)
+            flip_first = np.random.rand() > 0.5
+            if flip_first:
+                imgs[:cut_idx] = [img[:, ::-1] for img in imgs[:cut_idx]]          # cv2.flip(img, 1): mirror the columns
+            else:
+                imgs[cut_idx:] = [img[:, ::-1] for img in imgs[cut_idx:]]
+            return imgs[cut_idx:] + imgs[:cut_idx]
+        if self.video_degrade in ("hdr", "ldr"):
+            scale = np.random.uniform(1, 3) if self.video_degrade == "hdr" else np.random.uniform(0.3, 1)
+            for i in range(t):
+                imgs[i] = np.clip((imgs[i] - 127.5) * scale + 127.5, 0, 255).astype(np.uint8)
+            return imgs
+        raise NotImplementedError("Video degrade type not supported.")
+
     def read_video(self, video_path, start_frame, end_frame, crop_size_before_resize, min_i, min_j, flip, sample_idx=None):
         """Decode + crop + resize + flip (+ shake) like v2v_datasets.py:145-225; returns a list of [h,w,C] uint8."""
         n = end_frame - start_frame
@@ -366,8 +412,10 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
             all_imgs = gray.unsqueeze(-1) if imgs_d is None else imgs_d                                  # device [N,H,W,C] uint8
         else:
             raw_imgs = self.read_video(video_path, start_frame, end_frame, crop_before, min_i, min_j, flip, sample_idx)
-        if self.video_degrade is not None and np.random.rand() < self.degrade_ratio:
-            raise NotImplementedError("video_degrade ablations are outside the accelerated path")
+        if self.video_degrade is not None and np.random.rand() < self.degrade_ratio:                    # v2v_datasets.py:307-308
+            if self.gpu_frontend:
+                raise NotImplementedError("video_degrade acts on the decoded host frames: use gpu_frontend: false with it")
+            raw_imgs = self.degrade_video(raw_imgs)
         if not self.gpu_frontend:
             all_imgs = np.stack([raw_imgs[i] for i in img_idxes])                                       # [N,H,W,C] uint8
             gray = all_imgs[..., 0] if self.color_mode == "gray" else bgr_to_gray(all_imgs)
