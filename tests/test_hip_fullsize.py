@@ -130,3 +130,45 @@ def test_cfg4_720p_to_256_pipeline(oracle_c, luts, n, bin_mode):
         else:
             np.testing.assert_allclose(got, want[0], rtol=1e-5, atol=1e-5, err_msg=f"clip {c}")
         assert np.array_equal(counts[c].cpu().numpy(), tot[0])
+
+
+@pytest.mark.gpu
+def test_cfg5_pipeline_feeds_the_consumer():
+    """BASELINE config 5 at its per-GPU geometry: 8 clips of 41 decoded 1280x720x3 frames -> GPU front-end -> simulator (SUM, 5 bins
+    -> [8,8,5,256,256]) -> the E2VID-shaped recurrent network of tools/e2vid_consumer.py over the 8 time steps, with its three
+    ConvLSTM blocks on the fused matrix-core kernel, against the all-stock network with the same weights.  Floating point:
+    reference = the stock FP32 network; bar = what the stock network itself loses under bf16 autocast on the same input (the
+    fused blocks keep the cell state in fp32, so they must not be worse than that by more than 25 %), and half the
+    prediction's spread as an absolute sanity bound."""
+    import os
+    import sys
+    import torch
+    from v2v_amd import esim, frontend
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from e2vid_consumer import E2VIDShapedConsumer, forward_sequence
+    b, n, sh, sw, crop, tb = 8, 41, 720, 1280, 256, 5
+    g = np.random.default_rng(505)
+    base = esim.synth_clips(b, n, sh, sw, dtype=torch.uint8, seed=SEED + 9, clip_id0=0)
+    raw = torch.stack([base, base.flip(-1), 255 - base], dim=-1).contiguous()
+    keep_h = int(sh * 0.54)
+    cb = (crop / g.uniform(crop / keep_h, 1.3, size=b)).astype(np.int64)
+    table = np.stack([[g.integers(0, keep_h - c + 1), g.integers(0, sw - c + 1), c, int(g.random() > 0.5)] for c in cb]).astype(np.int32)
+    idx = np.tile(np.arange(n, dtype=np.int32), (b, 1))
+    _, gray = frontend.prepare_clips_batch(raw, table, idx, crop, "gray")
+    params = np.stack([[0.2 + 0.01 * i, 0.25, 0.05, 5e-4, 0.5] for i in range(b)])
+    voxels = esim.esim_voxel_batch(gray, params, bin_mode="sum", num_bins=tb, seed=SEED, clip_id0=0)          # [8,8,5,256,256]
+    assert voxels.shape == (b, (n - 1) // tb, tb, crop, crop) and float(voxels.abs().sum()) > 0
+    torch.manual_seed(5)
+    stock = E2VIDShapedConsumer(num_bins=tb).cuda().eval()
+    fused = E2VIDShapedConsumer(num_bins=tb, fused_convlstm=True).cuda().eval()
+    fused.load_stock_state_dict(stock.state_dict())
+    with torch.no_grad():
+        want32 = forward_sequence(stock, voxels)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            got_stock16 = forward_sequence(stock, voxels)
+            got_fused16 = forward_sequence(fused, voxels)
+    for t, (w32, s16, f16) in enumerate(zip(want32, got_stock16, got_fused16)):
+        spread = float(w32.std())
+        assert f16.shape == w32.shape == (b, 1, crop, crop)
+        err_f, err_s = float((f16.float() - w32).abs().max()), float((s16.float() - w32).abs().max())
+        assert err_f < 1.25 * err_s + 1e-3 and err_f < 0.5 * spread, f"step {t}: fused {err_f:.4g}, stock autocast {err_s:.4g}, spread {spread:.4g}"
