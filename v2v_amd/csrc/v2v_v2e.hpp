@@ -524,7 +524,8 @@ __device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, 
     };
     derive_thres();
 
-    float leak_cur[VEC];                                   // float32 product leak_rate_hz * noise_rate_array (:204)
+    float leak_cur[VEC];                                   // float32 product leak_rate_hz * noise_rate_array (:204); widening it once
+                                                           // instead of every frame (4 more VGPRs) measured flat
 #pragma unroll
     for (int j = 0; j < VEC; ++j) leak_cur[j] = (float)P.leak_rate_hz * nrate[j];
 
