@@ -1,10 +1,10 @@
 #!/bin/bash
 # Run ON THE GPU BOX: dynamic VALU instruction count of the dominant kernel per wave and 4-pixel time step, for the main
-# library and every prebuilt variant in gpurun_variants/ (one rocprofv3 --pmc pass each).  usage: valu_count.sh "<workloads>"
+# library and every prebuilt variant in gpurun_variants/ (one rocprofv3 --pmc pass each).  usage: valu_count.sh "<workloads>"   (default: the headline)
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd /tmp
-for wl in ${1:-cfg2_noise_on}; do
+for wl in ${1:-cfg2_esim_f32_256x32x256x256_bilinear5}; do
   for lib in main $REPO/gpurun_variants/lib_*.so; do
     [ -e "$lib" ] || [ "$lib" = main ] || continue
     tag=$(basename $lib .so)
