@@ -37,6 +37,19 @@ int hip_fail(hipError_t e, const char *what)
 
 bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+// SIMDs of the current device (4 per CU), cached per device; 1024 when the query fails
+int simd_count()
+{
+    static int cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1024;
+    if (!cached[dev]) {
+        int cus = 0;
+        cached[dev] = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? 4 * cus : 1024;
+    }
+    return cached[dev];
+}
+
 }  // namespace
 
 extern "C" {
@@ -156,9 +169,11 @@ int v2v_esim_voxel_padded_hip(const void *frames, int in_dtype, int64_t B, int64
     bool vec4 = (HW % 4 == 0) && (frame_stride % 4 == 0) && (B == 1 || clip_stride % 4 == 0) &&
                 aligned(frames, 4 * in_sz) && aligned(out_voxel, 16) &&
                 (out_row_pitch == W ? out_plane_size % 4 == 0 : (W % 4 == 0 && out_row_pitch % 4 == 0 && out_plane_size % 4 == 0));
-    // Small batches (the reference's training shape, 12 clips of 128x128 = 768 waves) are issue-bound on one wave per
-    // SIMD; measured: 1 pixel per work-item (4x the waves) is SLOWER (0.19 vs 0.16 ms) because the per-4-pixel RNG
-    // block is then recomputed per pixel.  Batch more clips instead.
+    // Small batches (the reference's training shape, 12 clips of 128x128 = 768 waves for 1024 SIMDs) leave SIMDs idle and run
+    // one wave per SIMD: at up to one 4-pixel wave per SIMD the 1-pixel-per-work-item instances (4x the waves; the Philox block
+    // is recomputed per pixel, affordable since the Gaussians became table reads) are faster -- 0.084 vs 0.097 ms at 12 clips,
+    // but 0.149 vs 0.138 ms at 24 (same box), hence the threshold.  Results do not depend on the mapping.
+    if (vec4 && B * ((HW + 1023) / 1024) * 4 <= (int64_t)simd_count()) vec4 = false;
 #ifdef V2V_FORCE_SCALAR_PATH       // kernel-tuning builds only: no environment lookups on the product's launch path
     vec4 = false;
 #endif
