@@ -203,10 +203,11 @@ class Workload:
             ptensor = torch.tensor(params, dtype=torch.float64, device=dev)
             self.kernel_name = "esim_voxel_kernel"
             no_noise = params[2] == 0 and params[3] <= 0
+            symmetric = params[0] == params[1]          # the workload's parameters are host constants: what EventEmulator(pos, neg) knows too
 
             def step():
                 esim.esim_voxel_batch(frames, ptensor, bin_mode=bin_mode, num_bins=tb, frames_per_bin=fpb, rng_mode=wl.get("rng", "philox"),
-                                      seed=20240001, clip_id0=clip_id0, out=out, validate=False, no_noise=no_noise)
+                                      seed=20240001, clip_id0=clip_id0, out=out, validate=False, no_noise=no_noise, symmetric=symmetric)
         else:
             from v2v_amd import v2e
             vparams = v2e.make_params(*params)

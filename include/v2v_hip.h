@@ -62,6 +62,10 @@ typedef enum v2v_bin_mode {
 #define V2V_FLAG_NOISE_EXTERNAL 0x1u /* put_noise_external (v2v_core_esim.py:46,62-65) */
 #define V2V_FLAG_NO_NOISE 0x2u       /* caller guarantees base_noise_std == 0 and hot_pixel_fraction == 0 for every  */
                                      /* clip: selects the kernel without the noise adds (same results, fewer ops)  */
+#define V2V_FLAG_SYMMETRIC 0x4u      /* caller guarantees pos_thres == neg_thres for every clip (EventEmulator's own */
+                                     /* defaults): instances without the asymmetric loop at 4 waves per SIMD; same   */
+                                     /* results; a clip that breaks the guarantee comes out as NaN.  A hint: ignored */
+                                     /* where no such instance exists (float64 output, replay, external noise ...)   */
 
 /* Replay fields, all float64 device arrays, one set per clip (clip-major). */
 typedef struct v2v_esim_replay {

@@ -161,3 +161,29 @@ def test_entry_points_capture_into_a_hip_graph():
     torch.cuda.synchronize()
     assert torch.equal(gray_keep, want[0]) and torch.equal(out_e, want[1]) and torch.equal(out_v, want[2])
     assert out_e.abs().sum() > 0 and out_v.abs().sum() > 0
+
+
+def test_symmetric_hint_is_exact_and_loud(oracle_c, luts):
+    """V2V_FLAG_SYMMETRIC (instances without the asymmetric loop, 4 waves per SIMD): bit-identical to the general kernel and to
+    the C oracle for symmetric thresholds, both bin modes and input dtypes; auto-detected from host parameters; a clip that
+    breaks the promise comes out as NaN (never as a wrong count), the other clips of the batch are unaffected."""
+    from oracle import v2v_oracle as O
+    from v2v_amd import esim
+    b, n, h, w = 5, 11, 256, 256                    # enough waves for the 4-pixel mapping (the hint has no 1-pixel instances)
+    sym = [[0.2, 0.2, 0.1, 1e-3, 0.1], [0.35, 0.35, 0.05, 0.0, 0.0], [0.2, 0.2, 0.0, 2e-3, 0.3], [0.11, 0.11, 0.07, 1e-3, 0.2], [0.5, 0.5, 0.2, 0.0, 0.0]]
+    for dt in (np.uint8, np.float32):
+        video = np.stack([O.synth_clip_s1(n, h, w, seed=70 + i, dtype=dt) for i in range(b)])
+        frames = torch.from_numpy(video).cuda()
+        ptensor = torch.tensor(sym, dtype=torch.float64, device="cuda")
+        for mode, kw in (("bilinear", dict(num_bins=5)), ("sum", dict(num_bins=5, frames_per_bin=2))):
+            general = esim.esim_voxel_batch(frames, ptensor, bin_mode=mode, seed=3, symmetric=False, **kw)     # device params: no auto-detection
+            hinted = esim.esim_voxel_batch(frames, ptensor, bin_mode=mode, seed=3, symmetric=True, **kw)
+            auto = esim.esim_voxel_batch(frames, sym, bin_mode=mode, seed=3, **kw)                              # host params: detected
+            assert torch.equal(general, hinted) and torch.equal(general, auto)
+            bm = oracle_c.BIN_BILINEAR if mode == "bilinear" else oracle_c.BIN_SUM
+            want, _ = oracle_c.esim_voxel(video, np.asarray(sym), luts, seed=3, bin_mode=bm, **kw)
+            np.testing.assert_allclose(hinted.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+            broken = [list(r) for r in sym]
+            broken[2][1] = 0.25                                                                               # clip 2 is asymmetric now
+            out = esim.esim_voxel_batch(frames, torch.tensor(broken, dtype=torch.float64, device="cuda"), bin_mode=mode, seed=3, symmetric=True, **kw)
+            assert bool(torch.isnan(out[2]).all()) and torch.equal(out[[0, 1, 3, 4]], general[[0, 1, 3, 4]])

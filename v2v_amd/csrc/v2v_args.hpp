@@ -24,6 +24,7 @@ struct EsimArgs {
     const unsigned long long *clip_keys;   // optional [B,2] per-clip {seed, clip id}: overrides seed / clip_id0 + b
     int32_t HW, K, Tb, fpb, blocks_per_clip;
     uint32_t noise_external;
+    uint32_t sym_only;                     // V2V_FLAG_SYMMETRIC: every clip has C+ == C- (instances without the asymmetric loop)
     int32_t W;                             // row length (for the padded output layout)
     int64_t out_pitch, out_plane;          // output row pitch / plane size in elements (W, H*W when unpadded)
 };

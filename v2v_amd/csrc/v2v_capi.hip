@@ -205,6 +205,7 @@ int v2v_esim_voxel_padded_hip(const void *frames, int in_dtype, int64_t B, int64
     const dim3 grid((unsigned)nblocks);
     const bool out64 = out_dtype == V2V_F64;
     const bool noise = !(flags & V2V_FLAG_NO_NOISE);
+    a.sym_only = (flags & V2V_FLAG_SYMMETRIC) ? 1u : 0u;
     if (!noise && (flags & V2V_FLAG_NOISE_EXTERNAL)) return fail(V2V_ERR_PARAM, "V2V_FLAG_NO_NOISE and V2V_FLAG_NOISE_EXTERNAL are exclusive");
     if (!noise && rng_mode == V2V_RNG_REPLAY) return fail(V2V_ERR_PARAM, "V2V_FLAG_NO_NOISE is not available in replay mode");
     // dynamic LDS: the bilinear weights per frame pair and the segment starts per bin; static: log table, thresholds, and the

@@ -41,7 +41,8 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
                      put_noise_external: bool = False, out_dtype: torch.dtype = torch.float32,
                      out: Optional[torch.Tensor] = None, counts: Optional[torch.Tensor] = None,
                      replay: Optional[Sequence[torch.Tensor]] = None, validate: bool = True,
-                     no_noise: Optional[bool] = None, clip_keys: Optional[torch.Tensor] = None, pad_to: int = 1) -> torch.Tensor:
+                     no_noise: Optional[bool] = None, clip_keys: Optional[torch.Tensor] = None, pad_to: int = 1,
+                     symmetric: Optional[bool] = None) -> torch.Tensor:
     """Simulate a batch of clips and bin the events, in one kernel launch on the current stream.
 
     frames  [B,N,H,W] uint8 or float32 CUDA tensor (grayscale; dims 2,3 contiguous).
@@ -56,6 +57,9 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
     no_noise  True asserts base_noise_std == 0 and hot_pixel_fraction == 0 for every clip, which selects the
             kernel variant without the noise adds (identical results).  Default: detected from `params` when
             they are host values, False when `params` is already a device tensor.
+    symmetric True asserts pos_thres == neg_thres for every clip (EventEmulator's own defaults): instances compiled without
+            the asymmetric loop, 4 waves per SIMD (identical results; a clip that breaks the promise comes out as NaN).
+            Default: detected from host `params`, False for a device tensor.
     """
     _lib.require_gpu()
     if frames.ndim != 4:
@@ -76,6 +80,8 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
             raise ValueError("thresholds below 1e-9 are outside the exact floor-divide domain (|potential|/C must stay < 2^40)")
         if no_noise is None:
             no_noise = bool(np.all(pa[:, 2] == 0) and np.all(pa[:, 3] <= 0))
+        if symmetric is None:
+            symmetric = bool(np.all(pa[:, 0] == pa[:, 1]))
     no_noise = bool(no_noise) and not put_noise_external and rng_mode != "replay"
     k = n - 1
     if bin_mode not in BIN_MODES:
@@ -123,7 +129,7 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
             C.c_void_p(frames.data_ptr()), _TORCH_IN[frames.dtype], b, n, h, w,
             frames.stride(0) if b > 1 else n * frames.stride(1), frames.stride(1),
             C.c_void_p(p.data_ptr()), pstride,
-            (_lib.FLAG_NOISE_EXTERNAL if put_noise_external else 0) | (_lib.FLAG_NO_NOISE if no_noise else 0),
+            (_lib.FLAG_NOISE_EXTERNAL if put_noise_external else 0) | (_lib.FLAG_NO_NOISE if no_noise else 0) | (_lib.FLAG_SYMMETRIC if symmetric else 0),
             RNG_MODES[rng_mode], C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_uint64(clip_id0),
             C.c_void_p(clip_keys.data_ptr()) if clip_keys is not None else None,
             C.byref(rp) if rp is not None else None, BIN_MODES[bin_mode], num_bins, frames_per_bin,
