@@ -469,6 +469,8 @@ def main():
                        "sim_params": wl["params"], "sim_params_note": "pos_thres, neg_thres, base_noise_std, hot_pixel_fraction, hot_pixel_std"
                        + (" = EventEmulator() constructor defaults of the reference (noise on)" if wl["params"] == REF_DEFAULTS else ""),
                        "rng": "philox4x32 on device (10 rounds per-clip fields, 7 rounds per-step noise fields), Gaussians by direct table inversion (2 per word)",
+                       "kernel_hints": (["V2V_FLAG_SYMMETRIC (pos_thres == neg_thres, known on the host as in EventEmulator(pos, neg))"] if wl["model"] == "esim" and wl["params"][0] == wl["params"][1] else [])
+                       + (["V2V_FLAG_NO_NOISE"] if wl["model"] == "esim" and wl["params"][2] == 0 and wl["params"][3] <= 0 else []),
                        "sharding": f"batch over {world} GPU(s), no collective", "grid": [wl["tb"], wl["h"], wl["w"]],
                        "launch": "hipGraph replay" if use_graph else "eager"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
