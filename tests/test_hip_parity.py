@@ -9,6 +9,14 @@ from oracle import v2v_oracle as O
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["4px", "1px"])
+def _both_mappings(request, monkeypatch):
+    """Every parity case runs through both families of instances (4 pixels / 1 pixel per work-item): left alone, shapes this
+    small would all take the 1-pixel mapping the launcher picks for small batches."""
+    from v2v_amd import esim
+    monkeypatch.setattr(esim, "DEFAULT_MAPPING", request.param)
+
 RTOL = ATOL = 1e-5   # north_star: "within 1e-5 on fp32 voxel values"
 
 

@@ -173,7 +173,8 @@ int v2v_esim_voxel_padded_hip(const void *frames, int in_dtype, int64_t B, int64
     // one wave per SIMD: at up to one 4-pixel wave per SIMD the 1-pixel-per-work-item instances (4x the waves; the Philox block
     // is recomputed per pixel, affordable since the Gaussians became table reads) are faster -- 0.084 vs 0.097 ms at 12 clips,
     // but 0.149 vs 0.138 ms at 24 (same box), hence the threshold.  Results do not depend on the mapping.
-    if (vec4 && B * ((HW + 1023) / 1024) * 4 <= (int64_t)simd_count()) vec4 = false;
+    if (flags & V2V_FLAG_MAP_1PX) vec4 = false;
+    else if (!(flags & V2V_FLAG_MAP_4PX) && vec4 && B * ((HW + 1023) / 1024) * 4 <= (int64_t)simd_count()) vec4 = false;
 #ifdef V2V_FORCE_SCALAR_PATH       // kernel-tuning builds only: no environment lookups on the product's launch path
     vec4 = false;
 #endif
@@ -382,7 +383,10 @@ static hipError_t launch_frontend(const v2v::FrontendArgs &a, int64_t B, int64_t
         for (int cpl = a.crop > 128 ? 4 : 2; cpl >= 2; cpl -= 2) {
             const int64_t span_px = (int64_t)(64 * cpl * s_max) + 3;
             const int64_t pitch = ((span_px * 3 + 12 + 15) / 16) * 16 + 16;
-            const int64_t budget = 48 * 1024 - v2v::tile_hdr_bytes(cpl);
+#ifndef V2V_FRONTEND_LDS_KB
+#define V2V_FRONTEND_LDS_KB 48
+#endif
+            const int64_t budget = V2V_FRONTEND_LDS_KB * 1024 - v2v::tile_hdr_bytes(cpl);
             int rpw_cap = (int)((a.crop + 3) / 4);                        // no point in more rows per wave than the image has
             if (rpw_cap > 4) rpw_cap = 4;
             for (int rpw = rpw_cap; rpw >= 1; rpw >>= 1) {

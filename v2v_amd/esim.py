@@ -16,6 +16,7 @@ from . import _lib
 
 _TORCH_IN = {torch.uint8: _lib.U8, torch.float32: _lib.F32}
 _OUT = {torch.float32: _lib.F32, torch.float64: _lib.F64}
+DEFAULT_MAPPING = "auto"        # work-item mapping of esim_voxel_batch when the caller does not pin it
 BIN_MODES = {"sum": _lib.BIN_SUM, "bilinear": _lib.BIN_BILINEAR}
 RNG_MODES = {"none": _lib.RNG_NONE, "philox": _lib.RNG_PHILOX, "replay": _lib.RNG_REPLAY, "philox_fast": _lib.RNG_PHILOX_FAST}
 
@@ -42,7 +43,7 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
                      out: Optional[torch.Tensor] = None, counts: Optional[torch.Tensor] = None,
                      replay: Optional[Sequence[torch.Tensor]] = None, validate: bool = True,
                      no_noise: Optional[bool] = None, clip_keys: Optional[torch.Tensor] = None, pad_to: int = 1,
-                     symmetric: Optional[bool] = None) -> torch.Tensor:
+                     symmetric: Optional[bool] = None, mapping: Optional[str] = None) -> torch.Tensor:
     """Simulate a batch of clips and bin the events, in one kernel launch on the current stream.
 
     frames  [B,N,H,W] uint8 or float32 CUDA tensor (grayscale; dims 2,3 contiguous).
@@ -60,6 +61,8 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
     symmetric True asserts pos_thres == neg_thres for every clip (EventEmulator's own defaults): instances compiled without
             the asymmetric loop, 4 waves per SIMD (identical results; a clip that breaks the promise comes out as NaN).
             Default: detected from host `params`, False for a device tensor.
+    mapping   "auto" (4 pixels per work-item for aligned layouts unless the batch is small, then 1), "4px" or "1px" to pin it;
+            results do not depend on it.  None = the module default DEFAULT_MAPPING ("auto"; the test-suite sweeps it).
     """
     _lib.require_gpu()
     if frames.ndim != 4:
@@ -129,7 +132,7 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
             C.c_void_p(frames.data_ptr()), _TORCH_IN[frames.dtype], b, n, h, w,
             frames.stride(0) if b > 1 else n * frames.stride(1), frames.stride(1),
             C.c_void_p(p.data_ptr()), pstride,
-            (_lib.FLAG_NOISE_EXTERNAL if put_noise_external else 0) | (_lib.FLAG_NO_NOISE if no_noise else 0) | (_lib.FLAG_SYMMETRIC if symmetric else 0),
+            (_lib.FLAG_NOISE_EXTERNAL if put_noise_external else 0) | (_lib.FLAG_NO_NOISE if no_noise else 0) | (_lib.FLAG_SYMMETRIC if symmetric else 0) | {"auto": 0, "4px": _lib.FLAG_MAP_4PX, "1px": _lib.FLAG_MAP_1PX}[mapping or DEFAULT_MAPPING],
             RNG_MODES[rng_mode], C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_uint64(clip_id0),
             C.c_void_p(clip_keys.data_ptr()) if clip_keys is not None else None,
             C.byref(rp) if rp is not None else None, BIN_MODES[bin_mode], num_bins, frames_per_bin,
