@@ -197,3 +197,41 @@ def test_shape_errors_are_reported_without_a_gpu():
     assert L.v2v_convlstm_step_hip(p, None, None, p, p, 1, 8, 8, 64, p, p, p, _lib.U8, 0, None) == _lib.ERR_DTYPE
     assert L.v2v_nchw_to_nhwc_bf16_hip(p, _lib.F64, 1, 64, 8, 8, 0, p, None) == _lib.ERR_DTYPE
     assert L.v2v_nchw_to_nhwc_bf16_hip(p, _lib.F32, 1, 32, 8, 8, 0, p, None) == _lib.ERR_SHAPE
+
+
+@pytest.mark.gpu
+def test_recurrence_captures_into_a_hip_graph():
+    """A three-step recurrence of the fused module (layout change, step kernel, all three tile sizes via the shapes) captured in
+    a hipGraph replays to the same bytes as the eager run: the entry points only enqueue kernels on the caller's stream."""
+    import torch
+    from v2v_amd import convlstm as CL
+    torch.manual_seed(4)
+    for c, h, w in ((64, 16, 32), (64, 64, 64), (128, 64, 64)):          # 64-, 128- and 256-pixel tiles at batch 8
+        cell = CL.ConvLSTM(c, c, 3).cuda().eval()
+        xs = torch.relu(torch.randn((3, 8, c, h, w), device="cuda"))
+        outs = [torch.empty((8, c, h, w), device="cuda") for _ in range(2)]
+
+        def run():
+            state = None
+            with torch.no_grad():
+                for t in range(3):
+                    state = cell(xs[t], state)
+            outs[0].copy_(state[0])
+            outs[1].copy_(state[1])
+
+        run()
+        torch.cuda.synchronize()
+        want = [o.clone() for o in outs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            run()
+        for o in outs:
+            o.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], want[0]) and torch.equal(outs[1], want[1]) and float(want[0].abs().sum()) > 0
