@@ -55,13 +55,19 @@ WORKLOADS = {
     # the same with the consumer's three ConvLSTM blocks on the fused matrix-core kernel
     "cfg5_fused_convlstm": dict(model="pipeline", b=8, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1,
                                 params=DATASET_STYLE, src_hw=(720, 1280), consumer="fused"),
+    # both again with the network in torch.channels_last (NHWC): MIOpen's bf16 convolutions are faster there, and the fused
+    # ConvLSTM step consumes / produces that layout in place (no layout-change kernels)
+    "cfg5_channels_last": dict(model="pipeline", b=8, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1,
+                               params=DATASET_STYLE, src_hw=(720, 1280), consumer="stock_cl"),
+    "cfg5_fused_convlstm_channels_last": dict(model="pipeline", b=8, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1,
+                                              params=DATASET_STYLE, src_hw=(720, 1280), consumer="fused_cl"),
     "train_u8_12x201x128x128_sum5": dict(model="esim", b=12, n=201, h=128, w=128, dtype="uint8", bin="sum", tb=5, fpb=1, params=DATASET_STYLE),
     "cfg1_plumbing_u8_1x8x128x128": dict(model="esim", b=1, n=8, h=128, w=128, dtype="uint8", bin="sum", tb=7, fpb=1, params=NOISE_FREE),
 }
 DEFAULT_WORKLOAD = "cfg2_esim_f32_256x32x256x256_bilinear5"
 ALSO_MEASURED = ["cfg2_noise_free", "cfg2_dataset_style", "cfg2_u8", "cfg3_v2e_f32_256x32x256x256_bilinear5", "cfg3_v2e_u8",
                  "cfg4_u8_256x41x256x256_sum5", "cfg4_pipeline_720p_to_256_41f_sum5", "train_u8_12x201x128x128_sum5",
-                 "cfg5_pipeline_plus_e2vid_bf16", "cfg5_fused_convlstm"]
+                 "cfg5_pipeline_plus_e2vid_bf16", "cfg5_fused_convlstm", "cfg5_channels_last", "cfg5_fused_convlstm_channels_last"]
 
 
 def cpu_baseline(frames_host, wl, budget_s=12.0):
@@ -189,8 +195,12 @@ class Workload:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 from e2vid_consumer import E2VIDShapedConsumer, forward_sequence
                 torch.manual_seed(0)
-                consumer = E2VIDShapedConsumer(num_bins=tb, fused_convlstm=wl["consumer"] == "fused").to(dev).eval()
-                self.kernel_name += " + E2VID-shaped UNet forward (bf16 autocast" + (", fused ConvLSTM steps)" if wl["consumer"] == "fused" else ")")
+                fused, c_last = str(wl["consumer"]).startswith("fused"), str(wl["consumer"]).endswith("_cl")
+                consumer = E2VIDShapedConsumer(num_bins=tb, fused_convlstm=fused).to(dev).eval()
+                if c_last:
+                    consumer = consumer.to(memory_format=torch.channels_last)
+                self.kernel_name += (" + E2VID-shaped UNet forward (bf16 autocast" + (", channels_last" if c_last else "")
+                                     + (", fused ConvLSTM steps)" if fused else ")"))
 
             def step():
                 gray = frontend.prepare_clips_batch(raw, table_d, idx_d, h, "gray", validate=False, max_crop_before=cb_max)[1]
@@ -198,7 +208,7 @@ class Workload:
                                       seed=20240001, clip_id0=clip_id0, out=out, validate=False, no_noise=False)
                 if consumer is not None:
                     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
-                        forward_sequence(consumer, out)
+                        forward_sequence(consumer, out, channels_last=c_last)
         elif wl["model"] == "esim":
             ptensor = torch.tensor(params, dtype=torch.float64, device=dev)
             self.kernel_name = "esim_voxel_kernel"

@@ -235,3 +235,30 @@ def test_recurrence_captures_into_a_hip_graph():
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(outs[0], want[0]) and torch.equal(outs[1], want[1]) and float(want[0].abs().sum()) > 0
+
+
+@pytest.mark.gpu
+def test_channels_last_bf16_path_is_in_place_and_equal():
+    """A bfloat16 channels-last input (torch.channels_last network under autocast) is consumed as the kernel's NHWC layout without a
+    layout-change kernel and the hidden state comes back as a channels-last view of the kernel's own buffer: same values as the
+    NCHW path, over a 4-step recurrence, including a prev_state rebuilt from clones."""
+    import torch
+    from v2v_amd import convlstm as CL
+    torch.manual_seed(21)
+    cell = CL.ConvLSTM(64, 64, 3).cuda().eval()
+    xs = torch.relu(torch.randn((4, 2, 64, 16, 32), device="cuda")).to(torch.bfloat16)
+    with torch.no_grad():
+        s_a = s_b = s_c = None
+        for t in range(4):
+            h_a, c_a = cell(xs[t], s_a)                                                        # NCHW bf16
+            x_cl = xs[t].contiguous(memory_format=torch.channels_last)
+            h_b, c_b = cell(x_cl, s_b)                                                         # channels-last bf16: in place
+            assert h_b.dtype == torch.bfloat16 and h_b.is_contiguous(memory_format=torch.channels_last) and not h_b.is_contiguous()
+            assert torch.equal(h_a, h_b.contiguous()) and torch.equal(c_a, c_b)
+            h_c, c_c = cell(x_cl, s_c)
+            assert torch.equal(h_c, h_b) and torch.equal(c_c, c_b)
+            s_a, s_b = (h_a, c_a), (h_b, c_b)
+            s_c = (h_b.clone(memory_format=torch.preserve_format), c_b.clone())                # not the cached object: re-read from its values
+        h_r, _ = cell(xs[0].contiguous(memory_format=torch.channels_last), None, input_relu=True)
+        h_n, _ = cell(xs[0], None, input_relu=True)
+        assert torch.equal(h_r.contiguous(), h_n)

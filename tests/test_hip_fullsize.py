@@ -167,8 +167,12 @@ def test_cfg5_pipeline_feeds_the_consumer():
         with torch.autocast("cuda", dtype=torch.bfloat16):
             got_stock16 = forward_sequence(stock, voxels)
             got_fused16 = forward_sequence(fused, voxels)
-    for t, (w32, s16, f16) in enumerate(zip(want32, got_stock16, got_fused16)):
+            fused_cl = fused.to(memory_format=torch.channels_last)                       # NHWC network: the step kernel works in place
+            got_fused_cl = forward_sequence(fused_cl, voxels, channels_last=True)
+    for t, (w32, s16, f16, fcl) in enumerate(zip(want32, got_stock16, got_fused16, got_fused_cl)):
         spread = float(w32.std())
         assert f16.shape == w32.shape == (b, 1, crop, crop)
         err_f, err_s = float((f16.float() - w32).abs().max()), float((s16.float() - w32).abs().max())
         assert err_f < 1.25 * err_s + 1e-3 and err_f < 0.5 * spread, f"step {t}: fused {err_f:.4g}, stock autocast {err_s:.4g}, spread {spread:.4g}"
+        err_c = float((fcl.float() - w32).abs().max())
+        assert err_c < 1.25 * err_s + 1e-3 and err_c < 0.5 * spread, f"step {t}: fused channels_last {err_c:.4g}, stock autocast {err_s:.4g}"

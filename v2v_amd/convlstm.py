@@ -87,7 +87,9 @@ class ConvLSTM(nn.Module):
     forward(input_, prev_state=None) -> (hidden, cell), both logically [B,C,H,W] as in the reference: `hidden` is a
     contiguous NCHW tensor in the input's dtype (float32, or bfloat16 under autocast -- the reference's state takes the
     input's dtype too, :202-203); `cell` is the kernel's float32 NHWC cell buffer seen through permute(0,3,1,2) (a
-    channels-last tensor; float32 even under autocast: the cell state is never rounded to bf16).  The bf16 NHWC copy of `hidden` that the next step's matrix-core GEMM reads is
+    channels-last tensor; float32 even under autocast: the cell state is never rounded to bf16).  A bfloat16 input that is
+    channels-last (torch.channels_last networks under autocast) is consumed and produced in place: `hidden` is then a
+    channels-last view of the kernel's NHWC buffer and no layout-change kernel runs.  The bf16 NHWC copy of `hidden` that the next step's matrix-core GEMM reads is
     kept beside it and reused when the (hidden, cell) pair comes back untouched (UNetRecurrent.forward, model/unet.py:293-296);
     any other prev_state (cloned, loaded, edited) is converted from its float32 values, which gives the same bits."""
 
@@ -114,18 +116,32 @@ class ConvLSTM(nn.Module):
         if torch.is_grad_enabled() and (input_.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise RuntimeError("v2v_amd.convlstm.ConvLSTM is inference-only (no autograd through the fused kernel): "
                                "call it under torch.no_grad() / in eval mode")
-        x = nchw_to_nhwc_bf16(input_, relu=input_relu)
+        # channels-last bfloat16 input (a network run in torch.channels_last under autocast): its memory IS the kernel's NHWC
+        # layout -- no layout-change kernel on the way in, and the hidden state goes out as a channels-last view of the
+        # kernel's own NHWC buffer (no NCHW copy either)
+        nhwc_io = (input_.dtype == torch.bfloat16 and input_.dim() == 4 and input_.is_contiguous(memory_format=torch.channels_last)
+                   and not input_.is_contiguous())
+        if nhwc_io:
+            x = input_.permute(0, 2, 3, 1)
+            if input_relu:
+                x = torch.relu(x)
+        else:
+            x = nchw_to_nhwc_bf16(input_, relu=input_relu)
         h_prev = c_prev = None
         if prev_state is not None:
             hidden, cell = prev_state
             cache = self._h_cache
             if cache is not None and cache[0] is hidden and cache[1] == hidden._version:
                 h_prev = cache[2]
+            elif hidden.dtype == torch.bfloat16 and hidden.is_contiguous(memory_format=torch.channels_last) and not hidden.is_contiguous():
+                h_prev = hidden.permute(0, 2, 3, 1)
             else:
                 h_prev = nchw_to_nhwc_bf16(hidden)
             c_prev = cell.permute(0, 2, 3, 1)
             if c_prev.dtype != torch.float32 or not c_prev.is_contiguous():
                 c_prev = c_prev.float().contiguous()
-        h_state, c_state, h_nchw = convlstm_step(x, h_prev, c_prev, self._weights(), self.Gates.bias.detach().float(), nchw_dtype=input_.dtype)
-        self._h_cache = (h_nchw, h_nchw._version, h_state)
-        return h_nchw, c_state.permute(0, 3, 1, 2)
+        h_state, c_state, h_nchw = convlstm_step(x, h_prev, c_prev, self._weights(), self.Gates.bias.detach().float(),
+                                                 nchw_dtype=None if nhwc_io else input_.dtype)
+        hidden_out = h_state.permute(0, 3, 1, 2) if nhwc_io else h_nchw
+        self._h_cache = (hidden_out, hidden_out._version, h_state)
+        return hidden_out, c_state.permute(0, 3, 1, 2)
