@@ -271,6 +271,17 @@ int v2v_convlstm_pack_weights_hip(const float *gates_weight, int64_t C, void *pa
 int v2v_convlstm_step_hip(const void *x, const void *h_prev, const float *c_prev, const void *packed, const float *gates_bias,
                           int64_t B, int64_t H, int64_t W, int64_t C, void *h_state, float *c_state, void *h_nchw, int h_nchw_dtype, int tile_rows,
                           void *stream);
+/* The residual blocks of the same encoder (ResidualBlock.forward, model/submodules.py:143-177, norm=None as E2VID instantiates
+ * it at model/unet.py:48): a 3x3, stride-1, pad-1 convolution on the matrix cores with the same tiles and pipeline as the
+ * ConvLSTM step -- out = [relu]( conv(x) + bias [+ residual] ), x [B,H,W,Cin] / residual, out [B,H,W,Cout] bf16 NHWC,
+ * weight = the module's conv weight fp32 [Cout,Cin,3,3] packed once by v2v_conv3x3_pack_weights_hip (Cout*Cin*9 bf16).
+ * Two calls make a block: conv1 with relu, conv2 with residual = the block's input and relu.
+ * Requirements (else V2V_ERR_SHAPE): Cin % 64 == 0, Cout % 256 == 0, (B*H*W) % 64 == 0 (% tile_rows when given); out must not
+ * alias x (neighbouring tiles read x); it may alias residual. */
+int v2v_conv3x3_pack_weights_hip(const float *weight, int64_t Cin, int64_t Cout, void *packed, void *stream);
+int v2v_conv3x3_nhwc_hip(const void *x, const void *packed, const float *bias, const void *residual, int relu, int64_t B, int64_t H,
+                         int64_t W, int64_t Cin, int64_t Cout, void *out, int tile_rows, void *stream);
+
 /* fp32 or bf16 [B,C,H,W] (src_dtype V2V_F32 / V2V_BF16) -> bf16 [B,H,W,C] (relu != 0: through max(x,0), the activation in front of the recurrent block,
  * model/submodules.py:267-271 RecurrentConvLayer = ConvLayer(relu) -> ConvLSTM).  C % 64 == 0 and (H*W) % 64 == 0. */
 int v2v_nchw_to_nhwc_bf16_hip(const void *src, int src_dtype, int64_t B, int64_t C, int64_t H, int64_t W, int relu, void *dst, void *stream);

@@ -197,6 +197,9 @@ def test_shape_errors_are_reported_without_a_gpu():
     assert L.v2v_convlstm_step_hip(p, None, None, p, p, 1, 8, 8, 64, p, p, p, _lib.U8, 0, None) == _lib.ERR_DTYPE
     assert L.v2v_nchw_to_nhwc_bf16_hip(p, _lib.F64, 1, 64, 8, 8, 0, p, None) == _lib.ERR_DTYPE
     assert L.v2v_nchw_to_nhwc_bf16_hip(p, _lib.F32, 1, 32, 8, 8, 0, p, None) == _lib.ERR_SHAPE
+    assert L.v2v_conv3x3_nhwc_hip(p, p, p, None, 1, 1, 8, 8, 64, 128, C.cast((C.c_char * 64)(), C.c_void_p), 0, None) == _lib.ERR_SHAPE    # Cout % 256
+    assert L.v2v_conv3x3_nhwc_hip(p, p, p, None, 1, 1, 8, 8, 64, 256, p, 0, None) == _lib.ERR_PARAM                                       # out aliases x
+    assert L.v2v_conv3x3_pack_weights_hip(p, 48, 256, p, None) == _lib.ERR_SHAPE
 
 
 @pytest.mark.gpu
@@ -262,3 +265,67 @@ def test_channels_last_bf16_path_is_in_place_and_equal():
         h_r, _ = cell(xs[0].contiguous(memory_format=torch.channels_last), None, input_relu=True)
         h_n, _ = cell(xs[0], None, input_relu=True)
         assert torch.equal(h_r.contiguous(), h_n)
+
+
+# ---- residual blocks on the same kernel (model/submodules.py:143-177) -----------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,tile_rows,res,relu", [((2, 256, 8, 16), 0, True, True), ((2, 64, 16, 16), 64, False, True), ((1, 128, 16, 16), 128, True, False),
+                                                        ((8, 256, 32, 32), 0, True, True), ((4, 256, 16, 16), 256, False, False)])
+def test_conv3x3_matches_reference_semantics(shape, tile_rows, res, relu):
+    """out = [relu](conv3x3(x) + bias [+ residual]) against the float64 evaluation of the same bf16-rounded operands (2e-5 before
+    the output's own bf16 rounding: compared at 1 bf16 ulp = 2^-8 relative) -- Cin from the shape, Cout = 256."""
+    import torch
+    import torch.nn.functional as F
+    from v2v_amd import convlstm as CL
+    b, cin, h, w = shape
+    cout = 256
+    g = torch.Generator().manual_seed(sum(shape) + tile_rows)
+    x = torch.randn((b, cin, h, w), generator=g)
+    r = torch.randn((b, cout, h, w), generator=g)
+    weight = (torch.rand((cout, cin, 3, 3), generator=g) * 2 - 1) * (3.0 / np.sqrt(cin * 9))
+    bias = (torch.rand((cout,), generator=g) * 2 - 1) * 0.5
+    xn = CL.nchw_to_nhwc_bf16(x.cuda())
+    rn = CL.nchw_to_nhwc_bf16(r.cuda()) if res else None
+    out = CL.conv3x3_nhwc(xn, CL.pack_conv3x3_weights(weight.cuda()), bias.cuda(), residual=rn, relu=relu, tile_rows=tile_rows)
+    want = F.conv2d(_bf16_round(x).double(), _bf16_round(weight).double(), bias.double(), padding=1)
+    if res:
+        want = want + _bf16_round(r).double()
+    if relu:
+        want = torch.relu(want)
+    got = out.permute(0, 3, 1, 2).float().cpu().double()
+    assert float(((got - want).abs() / (want.abs() + 1.0)).max()) < 2.0 ** -8
+
+
+@pytest.mark.gpu
+def test_residual_block_is_a_drop_in():
+    """Same constructor / parameter names / forward contract as the reference's ResidualBlock; against the stock fp32 block with the
+    same weights: 2e-2 absolute on unit-scale activations (bf16 operands, two convolutions); channels-last bf16 in place."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from v2v_amd import convlstm as CL
+
+    class StockRes(nn.Module):                                                      # restatement of model/submodules.py:143-177, norm=None
+        def __init__(self, c):
+            super().__init__()
+            self.conv1, self.conv2 = nn.Conv2d(c, c, 3, padding=1), nn.Conv2d(c, c, 3, padding=1)
+
+        def forward(self, x):
+            return F.relu(self.conv2(F.relu(self.conv1(x))) + x)
+
+    torch.manual_seed(8)
+    stock, fused = StockRes(256).cuda().eval(), CL.ResidualBlock(256, 256).cuda().eval()
+    fused.load_state_dict(stock.state_dict())
+    x = torch.relu(torch.randn((4, 256, 16, 32), device="cuda"))
+    with torch.no_grad():
+        want = stock(x)
+        got = fused(x)
+        assert got.dtype == torch.float32 and got.is_contiguous() and float((got - want).abs().max()) < TOL_FP32_MODULE * float(want.abs().max())
+        x_cl = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        got_cl = fused(x_cl)
+        assert got_cl.dtype == torch.bfloat16 and got_cl.is_contiguous(memory_format=torch.channels_last)
+        assert float((got_cl.float() - want).abs().max()) < 2 * TOL_FP32_MODULE * float(want.abs().max())
+    with pytest.raises(RuntimeError):
+        fused(x)
+    with pytest.raises(ValueError):
+        CL.ResidualBlock(256, 128)

@@ -3,7 +3,8 @@
 3 encoders, base 32 channels, ConvLSTM, 2 residual blocks, sum skips, bilinear-upsample decoders, 1x1 prediction).
 Stock PyTorch-ROCm ops by default -- it is NOT part of the product package (SURVEY: model families are out of scope);
 bench.py uses it to measure how fast the fused simulator can feed a consumer.  fused_convlstm=True swaps the three recurrent
-blocks for v2v_amd.convlstm.ConvLSTM (the matrix-core ConvLSTM step), everything else stays stock.
+blocks for v2v_amd.convlstm.ConvLSTM and the two residual blocks for v2v_amd.convlstm.ResidualBlock (the
+matrix-core kernels of the recurrent encoder), everything else stays stock.
 Parameter count matches the reference model: 10,710,401.
 """
 import torch
@@ -49,6 +50,18 @@ class _Res(nn.Module):
         return F.relu(self.b(F.relu(self.a(x))) + x)
 
 
+class _FusedRes(nn.Module):
+    """The residual block on the fused matrix-core convolution (v2v_amd.convlstm.ResidualBlock: conv1 / conv2 parameter names)."""
+
+    def __init__(self, ch):
+        super().__init__()
+        from v2v_amd.convlstm import ResidualBlock
+        self.block = ResidualBlock(ch, ch)
+
+    def forward(self, x):
+        return self.block(x)
+
+
 class E2VIDShapedConsumer(nn.Module):
     def __init__(self, num_bins=5, base=32, num_encoders=3, num_res=2, fused_convlstm=False):
         super().__init__()
@@ -57,7 +70,7 @@ class E2VIDShapedConsumer(nn.Module):
         chans = [base * 2 ** i for i in range(num_encoders + 1)]
         self.enc = nn.ModuleList(nn.Conv2d(a, b, 5, stride=2, padding=2) for a, b in zip(chans[:-1], chans[1:]))
         self.rec = nn.ModuleList((_FusedConvLSTM if fused_convlstm else _ConvLSTM)(b) for b in chans[1:])
-        self.res = nn.ModuleList(_Res(chans[-1]) for _ in range(num_res))
+        self.res = nn.ModuleList((_FusedRes if fused_convlstm else _Res)(chans[-1]) for _ in range(num_res))
         self.dec = nn.ModuleList(nn.Conv2d(b, a, 5, padding=2) for a, b in reversed(list(zip(chans[:-1], chans[1:]))))
         self.pred = nn.Conv2d(base, 1, 1)
         self.states = [None] * num_encoders
@@ -66,6 +79,7 @@ class E2VIDShapedConsumer(nn.Module):
         """Load the state_dict of a stock (fused_convlstm=False) consumer into this one, whichever kind it is."""
         if self.fused:
             sd = {k.replace(".gates.", ".cell.Gates.") if k.startswith("rec.") else k: v for k, v in sd.items()}
+            sd = {(k.replace(".a.", ".block.conv1.").replace(".b.", ".block.conv2.") if k.startswith("res.") else k): v for k, v in sd.items()}
         return self.load_state_dict(sd)
 
     def reset_states(self):

@@ -145,3 +145,69 @@ class ConvLSTM(nn.Module):
         hidden_out = h_state.permute(0, 3, 1, 2) if nhwc_io else h_nchw
         self._h_cache = (hidden_out, hidden_out._version, h_state)
         return hidden_out, c_state.permute(0, 3, 1, 2)
+
+
+# ---- the residual blocks of the same encoder (model/submodules.py:143-177) on the same matrix-core kernel ---------------------
+def pack_conv3x3_weights(weight: torch.Tensor) -> torch.Tensor:
+    """nn.Conv2d(Cin, Cout, 3, padding=1).weight float32 [Cout, Cin, 3, 3] -> the packed bfloat16 stream of v2v_conv3x3_nhwc_hip."""
+    _lib.require_gpu()
+    if not weight.is_cuda or weight.dtype != torch.float32 or weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3):
+        raise ValueError("weight must be a float32 CUDA tensor [Cout, Cin, 3, 3]")
+    cout, cin = weight.shape[:2]
+    packed = torch.empty((cout * cin * 9,), dtype=torch.bfloat16, device=weight.device)
+    with torch.cuda.device(weight.device):
+        _lib.check(_lib.lib().v2v_conv3x3_pack_weights_hip(_ptr(weight.detach().contiguous()), cin, cout, _ptr(packed), _lib.stream_ptr()))
+    return packed
+
+
+def conv3x3_nhwc(x, packed, bias, residual=None, relu=False, tile_rows: int = 0):
+    """out = [relu](conv3x3(x) + bias [+ residual]) on NHWC bfloat16: x [B,H,W,Cin], residual / out [B,H,W,Cout]."""
+    _lib.require_gpu()
+    if not x.is_cuda or x.dtype != torch.bfloat16 or x.dim() != 4 or not x.is_contiguous():
+        raise ValueError("x must be a contiguous bfloat16 CUDA tensor [B,H,W,Cin]")
+    b, h, w, cin = x.shape
+    cout = bias.numel()
+    if bias.dtype != torch.float32 or packed.dtype != torch.bfloat16 or packed.numel() != cout * cin * 9:
+        raise ValueError("bias must be float32 [Cout] and packed the output of pack_conv3x3_weights for the same Cin, Cout")
+    if residual is not None and (residual.dtype != torch.bfloat16 or tuple(residual.shape) != (b, h, w, cout) or not residual.is_contiguous()
+                                 or residual.device != x.device):
+        raise ValueError("residual must be a contiguous bfloat16 tensor [B,H,W,Cout] on x's device")
+    out = torch.empty((b, h, w, cout), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().v2v_conv3x3_nhwc_hip(_ptr(x), _ptr(packed), _ptr(bias.detach().contiguous()), _ptr(residual), int(bool(relu)),
+                                                   b, h, w, cin, cout, _ptr(out), tile_rows, _lib.stream_ptr()))
+    return out
+
+
+class ResidualBlock(nn.Module):
+    """Drop-in for model/submodules.py:ResidualBlock (:143-177) as E2VID instantiates it (model/unet.py:48: in == out channels,
+    stride 1, no downsample, norm=None): relu(conv2(relu(conv1(x))) + x), both convolutions on the matrix-core kernel with the
+    bias / residual / ReLU in its epilogue.  Same parameter names (conv1, conv2).  Inference only; bfloat16 operands with fp32
+    accumulation; a channels-last bfloat16 input is consumed and produced in place, anything else goes through the
+    layout-change kernel and comes back NCHW in the input's dtype."""
+
+    def __init__(self, in_channels, out_channels, stride=1, downsample=None, norm=None, BN_momentum=0.1):
+        super().__init__()
+        if stride != 1 or downsample is not None or norm is not None or in_channels != out_channels:
+            raise ValueError("the fused ResidualBlock covers the configuration E2VID instantiates "
+                             "(model/unet.py:48: in_channels == out_channels, stride 1, no downsample, norm=None)")
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=True)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=True)
+        self._packed = {}
+
+    def _weights(self, conv, name):
+        w = conv.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if self._packed.get(name, (None, None))[0] != key:
+            self._packed[name] = (key, pack_conv3x3_weights(w.detach()))
+        return self._packed[name][1]
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise RuntimeError("v2v_amd.convlstm.ResidualBlock is inference-only (no autograd through the fused kernel)")
+        nhwc_io = x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+        xn = x.permute(0, 2, 3, 1) if nhwc_io else nchw_to_nhwc_bf16(x)
+        mid = conv3x3_nhwc(xn, self._weights(self.conv1, "conv1"), self.conv1.bias.detach().float(), relu=True)
+        out = conv3x3_nhwc(mid, self._weights(self.conv2, "conv2"), self.conv2.bias.detach().float(), residual=xn, relu=True)
+        out = out.permute(0, 3, 1, 2)
+        return out if nhwc_io else out.contiguous().to(x.dtype)

@@ -81,9 +81,16 @@ struct ConvLstmArgs {
     void *h_nchw;                          // optional NCHW copy of h for the layers downstream
     int32_t h_nchw_bf16;                   // its dtype: 0 fp32, 1 bf16
     int32_t B, H, W, C;
+    // plain 3x3 convolution (EPI = 1 instances of the same kernel): x [B,H,W,C] -> out_nhwc [B,H,W,n_cols], bias + optional
+    // residual [B,H,W,n_cols] + optional ReLU; h_prev / c_prev / h_state / c_state / h_nchw unused
+    const uint16_t *residual;
+    uint16_t *out_nhwc;
+    int32_t n_cols, relu;
 };
 hipError_t launch_convlstm_step(const ConvLstmArgs &a, int tile_rows, hipStream_t s);   // tile_rows: 0 auto, 64, 128 or 256
 hipError_t launch_convlstm_pack(const float *w, uint16_t *wp, int C, hipStream_t s);
+hipError_t launch_conv3x3(const ConvLstmArgs &a, int tile_rows, hipStream_t s);
+hipError_t launch_conv3x3_pack(const float *w, uint16_t *wp, int Cin, int Cout, hipStream_t s);
 hipError_t launch_nchw_to_nhwc_bf16(const void *src, bool src_bf16, uint16_t *dst, int B, int C, int HW, int relu, hipStream_t s);
 
 }  // namespace v2v

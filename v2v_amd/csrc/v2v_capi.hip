@@ -610,6 +610,37 @@ int v2v_convlstm_step_hip(const void *x, const void *h_prev, const float *c_prev
     return e == hipSuccess ? V2V_OK : hip_fail(e, "convlstm_step_kernel launch");
 }
 
+int v2v_conv3x3_pack_weights_hip(const float *weight, int64_t Cin, int64_t Cout, void *packed, void *stream)
+{
+    if (!weight || !packed) return fail(V2V_ERR_NULL, "v2v_conv3x3_pack_weights_hip: weight/packed is NULL");
+    if (Cin < 64 || Cin % 64 != 0 || Cout < 256 || Cout % 256 != 0 || Cin > 4096 || Cout > 4096)
+        return fail(V2V_ERR_SHAPE, "conv3x3 kernel needs Cin %% 64 == 0 and Cout %% 256 == 0 (got %lld -> %lld)", (long long)Cin, (long long)Cout);
+    if (!aligned(weight, 4) || !aligned(packed, 16)) return fail(V2V_ERR_ALIGN, "weight needs 4-byte, packed 16-byte alignment");
+    const hipError_t e = v2v::launch_conv3x3_pack(weight, static_cast<uint16_t *>(packed), (int)Cin, (int)Cout, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "conv3x3_pack_kernel launch");
+}
+
+int v2v_conv3x3_nhwc_hip(const void *x, const void *packed, const float *bias, const void *residual, int relu, int64_t B, int64_t H,
+                         int64_t W, int64_t Cin, int64_t Cout, void *out, int tile_rows, void *stream)
+{
+    if (!x || !packed || !bias || !out) return fail(V2V_ERR_NULL, "v2v_conv3x3_nhwc_hip: x/packed/bias/out is NULL");
+    if (B < 1 || H < 1 || W < 1 || Cin < 64 || Cin % 64 != 0 || Cout < 256 || Cout % 256 != 0 || Cin > 4096 || Cout > 4096)
+        return fail(V2V_ERR_SHAPE, "need B,H,W >= 1, Cin %% 64 == 0, Cout %% 256 == 0");
+    if (tile_rows != 0 && tile_rows != 64 && tile_rows != 128 && tile_rows != 256) return fail(V2V_ERR_PARAM, "tile_rows must be 0 (auto), 64, 128 or 256");
+    if ((B * H * W) % (tile_rows ? tile_rows : 64) != 0 || B * H * W * (Cin > Cout ? Cin : Cout) > 0x7FFFFFFFLL)
+        return fail(V2V_ERR_SHAPE, "conv3x3 kernel needs (B*H*W) %% 64 == 0 (%% tile_rows when given) and B*H*W*C < 2^31");
+    if (out == x) return fail(V2V_ERR_PARAM, "out must not alias x (neighbouring tiles read it)");
+    if (!aligned(x, 16) || !aligned(packed, 16) || !aligned(out, 2) || !aligned(residual, 2) || !aligned(bias, 4))
+        return fail(V2V_ERR_ALIGN, "x/packed need 16-byte alignment");
+    v2v::ConvLstmArgs a{};
+    a.x = static_cast<const uint16_t *>(x); a.wp = static_cast<const uint16_t *>(packed); a.bias = bias;
+    a.residual = static_cast<const uint16_t *>(residual); a.out_nhwc = static_cast<uint16_t *>(out);
+    a.n_cols = (int)Cout; a.relu = relu ? 1 : 0;
+    a.B = (int)B; a.H = (int)H; a.W = (int)W; a.C = (int)Cin;
+    const hipError_t e = v2v::launch_conv3x3(a, tile_rows, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "conv3x3 (convlstm_step_kernel, EPI = 1) launch");
+}
+
 int v2v_nchw_to_nhwc_bf16_hip(const void *src, int src_dtype, int64_t B, int64_t C, int64_t H, int64_t W, int relu, void *dst, void *stream)
 {
     if (!src || !dst) return fail(V2V_ERR_NULL, "v2v_nchw_to_nhwc_bf16_hip: src/dst is NULL");

@@ -66,7 +66,34 @@ __device__ __forceinline__ void cl_glds16(const void *src, unsigned char *lds_wa
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <int MF, int WM, int STAGES = 2>
+// plain-convolution epilogue: accumulator g of the wave holds output channels col0 + 32 g .. + 31 (col0 = this lane's first)
+template <int MF>
+__device__ __forceinline__ void cl_epilogue_conv(const ConvLstmArgs &a, cl_f32x16 (&acc)[MF][4], int64_t mw0, int col0, int fh)
+{
+    const int N = a.n_cols;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int oc = col0 + g * 32;
+        const float bias = a.bias[oc];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = mw0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int64_t idx = m * N + oc;
+                float v = acc[i][g][r] + bias;
+                if (a.residual) v += __uint_as_float((uint32_t)a.residual[idx] << 16);
+                if (a.relu) v = v > 0.0f ? v : (v != v ? v : 0.0f);
+                a.out_nhwc[idx] = f32_to_bf16_rne(v);
+            }
+        }
+    }
+}
+
+// EPI = 0: ConvLSTM step (two inputs x|h, 4C gate columns, gate/cell epilogue).  EPI = 1: plain 3x3 convolution of x with
+// n_cols output channels (a multiple of 256), epilogue bias (+ residual) (+ ReLU) -> bf16 NHWC: the residual blocks of the same
+// encoder (model/submodules.py:143-177) on the same tiles and pipeline.
+template <int MF, int WM, int STAGES = 2, int EPI = 0>
 __global__ void __launch_bounds__(128 * WM, (STAGES == 2 && MF == 1) || WM == 4 ? 2 : 1) convlstm_step_kernel(const ConvLstmArgs a)
 {
     constexpr int kClBM = 32 * MF * WM, kClABytes = kClBM * kClBK * 2, kClStage = kClABytes + kClBBytes;
@@ -74,11 +101,11 @@ __global__ void __launch_bounds__(128 * WM, (STAGES == 2 && MF == 1) || WM == 4 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const int C = a.C, HW = a.H * a.W;
-    const int n_ct = C / kClCh;                                  // column tiles
+    const int n_ct = EPI == 0 ? C / kClCh : a.n_cols / kClBN;     // column tiles (256 columns each)
     const int ct = blockIdx.x % n_ct;
     const int64_t m0 = (int64_t)(blockIdx.x / n_ct) * kClBM;      // first pixel of the tile (flattened b,y,x)
-    const int cc_all = 2 * C / kClBK, cc_x = C / kClBK;
-    const int cc_eff = a.h_prev ? cc_all : cc_x;                  // zero state: skip h's chunks
+    const int cc_x = C / kClBK, cc_all = EPI == 0 ? 2 * cc_x : cc_x;
+    const int cc_eff = (EPI == 0 && a.h_prev) ? cc_all : cc_x;    // zero state: skip h's chunks
     const int n_chunks = 9 * cc_eff;
 
     // ---- staging plan: wave w issues A pieces NA*w.. (8 rows each) and B pieces NB*w.. per chunk ----------------------
@@ -219,6 +246,10 @@ __global__ void __launch_bounds__(128 * WM, (STAGES == 2 && MF == 1) || WM == 4 
         atomicAdd(&g_cl_dbg[0], t_wait); atomicAdd(&g_cl_dbg[1], t_bar); atomicAdd(&g_cl_dbg[2], t_rest); atomicAdd(&g_cl_dbg[3], 1ull);
     }
 #endif
+    if constexpr (EPI == 1) {
+        cl_epilogue_conv<MF>(a, acc, m0 + wm * 32 * MF, ct * kClBN + wn * 128 + fr, fh);
+        return;
+    }
     // ---- epilogue: gates -> cell / hidden, straight from the accumulators ---------------------------------------------------
     // accumulator element r of lane l: column (channel) l & 31, row (pixel) (r & 3) + 8 (r >> 2) + 4 (l >> 5)
     const int ch = ct * kClCh + wn * 32 + fr;
@@ -302,6 +333,23 @@ __global__ void __launch_bounds__(256) convlstm_pack_kernel(const float *w, uint
     const int wn = col >> 7, gate = (col >> 5) & 3, c32 = col & 31;
     const int oc = gate * C + ct * kClCh + wn * 32 + c32, ic = cc * kClBK + k;
     wp[i] = f32_to_bf16_rne(w[((int64_t)oc * 2 * C + ic) * 9 + tap]);
+}
+
+// [Cout, Cin, 3, 3] fp32 (nn.Conv2d weight) -> packed bf16 for the EPI = 1 instances:
+//   wp[col tile t = Cout/256][chunk ck = tap*(Cin/64) + cc][column n = 0..255][k = 0..63],  column n <-> output channel t*256 + n
+__global__ void __launch_bounds__(256) conv3x3_pack_kernel(const float *w, uint16_t *wp, int Cin, int Cout)
+{
+    const int64_t n = (int64_t)Cout * Cin * 9;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int cc_all = Cin / kClBK;
+    int64_t r = i;
+    const int k = (int)(r % kClBK); r /= kClBK;
+    const int col = (int)(r % kClBN); r /= kClBN;
+    const int ck = (int)(r % (9 * cc_all)); r /= 9 * cc_all;
+    const int ct = (int)r;
+    const int tap = ck / cc_all, cc = ck % cc_all;
+    wp[i] = f32_to_bf16_rne(w[((int64_t)(ct * kClBN + col) * Cin + cc * kClBK + k) * 9 + tap]);
 }
 
 }  // namespace v2v

@@ -5,7 +5,7 @@
 namespace v2v {
 
 namespace {
-template <int MF, int WM, int STAGES = 2>
+template <int MF, int WM, int STAGES = 2, int EPI = 0>
 hipError_t launch_step_t(const ConvLstmArgs &a, hipStream_t s)
 {
     // 80-128 KB of dynamic LDS is above the 64 KB a kernel gets by default: raise the limit once per device (kept out of the
@@ -15,12 +15,12 @@ hipError_t launch_step_t(const ConvLstmArgs &a, hipStream_t s)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (dev < 0 || dev >= 64 || !raised[dev]) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convlstm_step_kernel<MF, WM, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convlstm_step_kernel<MF, WM, STAGES, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) raised[dev] = true;
     }
-    const int64_t tiles = (int64_t)a.B * a.H * a.W / (32 * MF * WM) * (a.C / kClCh);
-    hipLaunchKernelGGL((convlstm_step_kernel<MF, WM, STAGES>), dim3((unsigned)tiles), dim3(128 * WM), lds, s, a);
+    const int64_t tiles = (int64_t)a.B * a.H * a.W / (32 * MF * WM) * (EPI == 0 ? a.C / kClCh : a.n_cols / kClBN);
+    hipLaunchKernelGGL((convlstm_step_kernel<MF, WM, STAGES, EPI>), dim3((unsigned)tiles), dim3(128 * WM), lds, s, a);
     return hipGetLastError();
 }
 }  // namespace
@@ -39,6 +39,25 @@ hipError_t launch_convlstm_step(const ConvLstmArgs &a, int tile_rows, hipStream_
     }
     if (tile_rows == 256) return launch_step_t<2, 4, 2>(a, s);
     return tile_rows == 128 ? launch_step_t<1, 4, 3>(a, s) : launch_step_t<1, 2, 2>(a, s);
+}
+
+hipError_t launch_conv3x3(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
+{
+    if (tile_rows == 0) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int64_t m = (int64_t)a.B * a.H * a.W, ct = a.n_cols / kClBN;
+        tile_rows = (m % 256 == 0 && m / 256 * ct >= cus) ? 256 : (m % 128 == 0 && m / 128 * ct >= cus) ? 128 : 64;
+    }
+    if (tile_rows == 256) return launch_step_t<2, 4, 2, 1>(a, s);
+    return tile_rows == 128 ? launch_step_t<1, 4, 3, 1>(a, s) : launch_step_t<1, 2, 2, 1>(a, s);
+}
+
+hipError_t launch_conv3x3_pack(const float *w, uint16_t *wp, int Cin, int Cout, hipStream_t s)
+{
+    const int64_t n = (int64_t)Cout * Cin * 9;
+    hipLaunchKernelGGL(conv3x3_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, wp, Cin, Cout);
+    return hipGetLastError();
 }
 
 hipError_t launch_convlstm_pack(const float *w, uint16_t *wp, int C, hipStream_t s)
