@@ -276,11 +276,26 @@ int v2v_convlstm_step_hip(const void *x, const void *h_prev, const float *c_prev
  * ConvLSTM step -- out = [relu]( conv(x) + bias [+ residual] ), x [B,H,W,Cin] / residual, out [B,H,W,Cout] bf16 NHWC,
  * weight = the module's conv weight fp32 [Cout,Cin,3,3] packed once by v2v_conv3x3_pack_weights_hip (Cout*Cin*9 bf16).
  * Two calls make a block: conv1 with relu, conv2 with residual = the block's input and relu.
- * Requirements (else V2V_ERR_SHAPE): Cin % 64 == 0, Cout % 256 == 0, (B*H*W) % 64 == 0 (% tile_rows when given); out must not
- * alias x (neighbouring tiles read x); it may alias residual. */
-int v2v_conv3x3_pack_weights_hip(const float *weight, int64_t Cin, int64_t Cout, void *packed, void *stream);
+ * Requirements (else V2V_ERR_SHAPE): Cin % 64 == 0, Cout % 256 == 0 (or 128 / 64 / 32), (B*H*W) % 64 == 0 (% tile_rows when given);
+ * out must not alias x (neighbouring tiles read x); it may alias residual. */
+int v2v_conv3x3_pack_weights_hip(const float *weight, int64_t Cin, int64_t Cout, void *packed, void *stream);   /* = conv_pack, ks 3 */
 int v2v_conv3x3_nhwc_hip(const void *x, const void *packed, const float *bias, const void *residual, int relu, int64_t B, int64_t H,
                          int64_t W, int64_t Cin, int64_t Cout, void *out, int tile_rows, void *stream);
+
+/* The general form: the encoder / decoder convolutions around those blocks (ConvLayer, model/submodules.py:10-50 as built at
+ * model/unet.py:34-60, 83-87: 5x5, stride 2 in the encoders, stride 1 after the bilinear upsampling in the decoders, ReLU).
+ * ks = 3 or 5 (pad ks/2), stride 1 or 2; x [B,Hin,Win,Cin] -> out [B,Hout,Wout,Cout] with Hout = (Hin-1)/stride + 1; Cin % 64 == 0;
+ * Cout a multiple of 256, or 128 / 64 / 32 (then (B*Hout*Wout) % 256 == 0); weight fp32 [Cout,Cin,ks,ks]. */
+int v2v_conv_pack_weights_hip(const float *weight, int64_t Cin, int64_t Cout, int ks, void *packed, void *stream);
+int v2v_conv_nhwc_hip(const void *x, const void *packed, const float *bias, const void *residual, int relu, int64_t B, int64_t Hin,
+                      int64_t Win, int64_t Cin, int64_t Cout, int ks, int stride, void *out, int tile_rows, void *stream);
+
+/* The bilinear x2 upsampling in front of a decoder convolution (UpsampleConvLayer.forward, model/submodules.py:86-87:
+ * f.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)) with the sum skip connection that feeds it
+ * (skip_sum, model/model_util.py:14, applied at model/unet.py:304) folded in: out = up2(x [+ skip]); x / skip [B,H,W,C], out
+ * [B,2H,2W,C], all bf16 NHWC; skip may be NULL; the sum is rounded to bf16 before the interpolation, as the stock bf16 add is.
+ * C % 8 == 0, 16-byte aligned buffers, out must not alias an input. */
+int v2v_upsample2x_nhwc_hip(const void *x, const void *skip, int64_t B, int64_t H, int64_t W, int64_t C, void *out, void *stream);
 
 /* fp32 or bf16 [B,C,H,W] (src_dtype V2V_F32 / V2V_BF16) -> bf16 [B,H,W,C] (relu != 0: through max(x,0), the activation in front of the recurrent block,
  * model/submodules.py:267-271 RecurrentConvLayer = ConvLayer(relu) -> ConvLSTM).  C % 64 == 0 and (H*W) % 64 == 0. */

@@ -329,3 +329,112 @@ def test_residual_block_is_a_drop_in():
         fused(x)
     with pytest.raises(ValueError):
         CL.ResidualBlock(256, 128)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,cout,ks,stride,tile_rows,res,relu", [
+    ((2, 64, 32, 32), 128, 5, 2, 0, False, True),       # enc2 of the recurrent UNet: 64 -> 128, 5x5 stride 2
+    ((1, 128, 32, 32), 256, 5, 2, 0, False, True),      # enc3: 128 -> 256
+    ((1, 128, 16, 32), 256, 5, 2, 64, False, False),
+    ((1, 256, 16, 16), 128, 5, 1, 0, False, True),      # dec1 after upsampling: 256 -> 128
+    ((1, 128, 16, 16), 64, 5, 1, 0, True, True),        # dec2: 128 -> 64
+    ((1, 64, 16, 32), 32, 5, 1, 0, False, True),        # dec3: 64 -> 32
+    ((1, 64, 16, 16), 32, 3, 1, 0, True, False),
+    ((2, 64, 24, 40), 64, 3, 2, 0, False, True),        # odd tile/row alignment: Wout = 20, 480 pixels -> rejected (not % 256)
+    ((2, 64, 31, 33), 256, 5, 2, 64, False, True),      # odd input size: Hout x Wout = 16 x 17 -> 544 pixels -> rejected (not % 64)
+    ((4, 64, 15, 31), 256, 5, 2, 128, True, True),      # odd input size, 4 x 8 x 16 = 512 output pixels
+])
+def test_conv_nhwc_matches_reference_semantics(shape, cout, ks, stride, tile_rows, res, relu):
+    """out = [relu](conv_ks(x, stride, pad ks // 2) + bias [+ residual]) (ConvLayer.forward, model/submodules.py:25-33) against
+    the float64 evaluation of the same bf16-rounded operands, at 1 bf16 ulp (2^-8 relative); unsupported tilings are loud."""
+    import torch
+    import torch.nn.functional as F
+    from v2v_amd import convlstm as CL
+    b, cin, h, w = shape
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    g = torch.Generator().manual_seed(sum(shape) + cout + ks + stride)
+    x = torch.randn((b, cin, h, w), generator=g)
+    r = torch.randn((b, cout, ho, wo), generator=g)
+    weight = (torch.rand((cout, cin, ks, ks), generator=g) * 2 - 1) * (3.0 / np.sqrt(cin * ks * ks))
+    bias = (torch.rand((cout,), generator=g) * 2 - 1) * 0.5
+    xn = _bf16_round(x).cuda().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
+    rn = _bf16_round(r).cuda().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous() if res else None
+    packed = CL.pack_conv_weights(weight.cuda())
+    need = 256 if cout % 256 else (tile_rows or 64)
+    if (b * ho * wo) % need:
+        with pytest.raises(ValueError):
+            CL.conv_nhwc(xn, packed, bias.cuda(), ks, stride, residual=rn, relu=relu, tile_rows=tile_rows)
+        return
+    out = CL.conv_nhwc(xn, packed, bias.cuda(), ks, stride, residual=rn, relu=relu, tile_rows=tile_rows)
+    assert tuple(out.shape) == (b, ho, wo, cout)
+    want = F.conv2d(_bf16_round(x).double(), _bf16_round(weight).double(), bias.double(), stride=stride, padding=ks // 2)
+    if res:
+        want = want + _bf16_round(r).double()
+    if relu:
+        want = torch.relu(want)
+    got = out.permute(0, 3, 1, 2).float().cpu().double()
+    assert float(((got - want).abs() / (want.abs() + 1.0)).max()) < 2.0 ** -8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,with_skip", [((2, 5, 7, 64), True), ((1, 1, 1, 8), False), ((3, 16, 8, 32), False), ((1, 9, 1, 256), True),
+                                             ((2, 32, 32, 128), True)])
+def test_upsample2x_matches_interpolate(shape, with_skip):
+    """up2(x [+ skip]) against f.interpolate(scale_factor=2, mode='bilinear', align_corners=False) of the bf16-rounded sum in
+    float32 (model/submodules.py:86-87 behind model/unet.py:304): one bf16 ulp (2^-8 relative) -- the weights are exact in
+    binary, the only difference is the summation / contraction order before the output's rounding."""
+    import torch
+    import torch.nn.functional as F
+    from v2v_amd import convlstm as CL
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g).to(torch.bfloat16).cuda()
+    s = torch.randn(shape, generator=g).to(torch.bfloat16).cuda() if with_skip else None
+    out = CL.upsample2x_nhwc(x, s)
+    b, h, w, c = shape
+    assert tuple(out.shape) == (b, 2 * h, 2 * w, c) and out.dtype == torch.bfloat16
+    src = (x + s) if with_skip else x
+    want = F.interpolate(src.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    err = ((out.float() - want).abs() / (want.abs() + 2.0 ** -6)).max()
+    assert float(err) < 2.0 ** -8
+    with pytest.raises(ValueError):
+        CL.upsample2x_nhwc(x.float())
+    with pytest.raises(ValueError):
+        CL.upsample2x_nhwc(x, torch.cat((x, x), 0))
+
+
+@pytest.mark.gpu
+def test_conv_layer_is_a_drop_in():
+    """v2v_amd.convlstm.ConvLayer against nn.Conv2d + ReLU with the same `conv2d` parameters (model/submodules.py:6-33) and, with
+    upsample=True, against UpsampleConvLayer (:68-96): 2e-2 absolute on unit-scale activations; channels-last bf16 stays in place."""
+    import torch
+    import torch.nn.functional as F
+    from v2v_amd import convlstm as CL
+    torch.manual_seed(7)
+    for cin, cout, stride, up, act in ((64, 128, 2, False, "relu"), (128, 64, 1, True, "relu"), (64, 32, 1, True, None)):
+        layer = CL.ConvLayer(cin, cout, 5, stride=stride, padding=2, activation=act, upsample=up).cuda().eval()
+        assert set(layer.state_dict()) == {"conv2d.weight", "conv2d.bias"}
+        x = torch.randn(2, cin, 32, 32, device="cuda")
+        with torch.no_grad():
+            xi = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False) if up else x
+            want = layer.conv2d(xi)
+            want = torch.relu(want) if act else want
+            got = layer(x)
+            assert got.dtype == torch.float32 and got.shape == want.shape and got.is_contiguous()
+            assert float((got - want).abs().max()) < 2e-2 * max(1.0, float(want.abs().max()))
+            xc = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            got_cl = layer(xc)
+            assert got_cl.dtype == torch.bfloat16 and got_cl.is_contiguous(memory_format=torch.channels_last)
+            assert float((got_cl.float() - want).abs().max()) < 4e-2 * max(1.0, float(want.abs().max()))
+            if up:                                                                  # the decoder's sum skip folded into the upsampling
+                half = (0.5 * xc).contiguous(memory_format=torch.channels_last)
+                assert torch.equal(layer(half, half), layer(half + half))
+                assert float((layer(0.5 * x, 0.5 * x) - want).abs().max()) < 2e-2 * max(1.0, float(want.abs().max()))
+            else:
+                with pytest.raises(ValueError):
+                    layer(x, x)
+        with pytest.raises(RuntimeError):
+            layer(x.requires_grad_())
+    with pytest.raises(ValueError):
+        CL.ConvLayer(64, 64, 5, padding=2, norm="BN")
+    with pytest.raises(ValueError):
+        CL.ConvLayer(64, 64, 7, padding=3)

@@ -3,8 +3,9 @@
 3 encoders, base 32 channels, ConvLSTM, 2 residual blocks, sum skips, bilinear-upsample decoders, 1x1 prediction).
 Stock PyTorch-ROCm ops by default -- it is NOT part of the product package (SURVEY: model families are out of scope);
 bench.py uses it to measure how fast the fused simulator can feed a consumer.  fused_convlstm=True swaps the three recurrent
-blocks for v2v_amd.convlstm.ConvLSTM and the two residual blocks for v2v_amd.convlstm.ResidualBlock (the
-matrix-core kernels of the recurrent encoder), everything else stays stock.
+blocks for v2v_amd.convlstm.ConvLSTM, the two residual blocks for v2v_amd.convlstm.ResidualBlock and the 5x5 encoder / decoder
+convolutions with >= 64 input channels for v2v_amd.convlstm.ConvLayer (the matrix-core kernels of the
+recurrent encoder); the head, the first encoder convolution (32 input channels), the upsampling and the 1x1 prediction stay stock.
 Parameter count matches the reference model: 10,710,401.
 """
 import torch
@@ -36,8 +37,8 @@ class _FusedConvLSTM(nn.Module):
         from v2v_amd.convlstm import ConvLSTM
         self.cell = ConvLSTM(ch, ch, 3)
 
-    def forward(self, x_pre_relu, state):
-        h, c = self.cell(x_pre_relu, state, input_relu=True)
+    def forward(self, x, state, input_relu=True):
+        h, c = self.cell(x, state, input_relu=input_relu)
         return h, (h, c)
 
 
@@ -62,16 +63,31 @@ class _FusedRes(nn.Module):
         return self.block(x)
 
 
+class _FusedConv(nn.Module):
+    """A 5x5 encoder (stride 2) or decoder (bilinear x2 upsample, stride 1) convolution + bias + ReLU on the matrix-core kernel
+    (v2v_amd.convlstm.ConvLayer: `conv2d` parameter name, as model/submodules.py:ConvLayer / UpsampleConvLayer)."""
+
+    def __init__(self, cin, cout, stride, upsample=False):
+        super().__init__()
+        from v2v_amd.convlstm import ConvLayer
+        self.layer = ConvLayer(cin, cout, 5, stride=stride, padding=2, activation="relu", upsample=upsample)
+
+    def forward(self, x, skip=None):
+        return self.layer(x, skip)
+
+
 class E2VIDShapedConsumer(nn.Module):
     def __init__(self, num_bins=5, base=32, num_encoders=3, num_res=2, fused_convlstm=False):
         super().__init__()
         self.fused = fused_convlstm
         self.head = nn.Conv2d(num_bins, base, 5, padding=2)
         chans = [base * 2 ** i for i in range(num_encoders + 1)]
-        self.enc = nn.ModuleList(nn.Conv2d(a, b, 5, stride=2, padding=2) for a, b in zip(chans[:-1], chans[1:]))
+        # fused: every 5x5 convolution whose input depth is a multiple of 64 runs on the matrix-core kernel too (enc1 reads 32 channels)
+        fconv = lambda a, b, s, up=False: _FusedConv(a, b, s, up) if fused_convlstm and a % 64 == 0 else None
+        self.enc = nn.ModuleList(fconv(a, b, 2) or nn.Conv2d(a, b, 5, stride=2, padding=2) for a, b in zip(chans[:-1], chans[1:]))
         self.rec = nn.ModuleList((_FusedConvLSTM if fused_convlstm else _ConvLSTM)(b) for b in chans[1:])
         self.res = nn.ModuleList((_FusedRes if fused_convlstm else _Res)(chans[-1]) for _ in range(num_res))
-        self.dec = nn.ModuleList(nn.Conv2d(b, a, 5, padding=2) for a, b in reversed(list(zip(chans[:-1], chans[1:]))))
+        self.dec = nn.ModuleList(fconv(b, a, 1, True) or nn.Conv2d(b, a, 5, padding=2) for a, b in reversed(list(zip(chans[:-1], chans[1:]))))
         self.pred = nn.Conv2d(base, 1, 1)
         self.states = [None] * num_encoders
 
@@ -80,6 +96,8 @@ class E2VIDShapedConsumer(nn.Module):
         if self.fused:
             sd = {k.replace(".gates.", ".cell.Gates.") if k.startswith("rec.") else k: v for k, v in sd.items()}
             sd = {(k.replace(".a.", ".block.conv1.").replace(".b.", ".block.conv2.") if k.startswith("res.") else k): v for k, v in sd.items()}
+            fused_convs = {f"{n}.{i}" for n, ml in (("enc", self.enc), ("dec", self.dec)) for i, m in enumerate(ml) if isinstance(m, _FusedConv)}
+            sd = {(k.rsplit(".", 1)[0] + ".layer.conv2d." + k.rsplit(".", 1)[1] if k.rsplit(".", 1)[0] in fused_convs else k): v for k, v in sd.items()}
         return self.load_state_dict(sd)
 
     def reset_states(self):
@@ -89,13 +107,19 @@ class E2VIDShapedConsumer(nn.Module):
         x = F.relu(self.head(x))
         head, blocks = x, []
         for i, (conv, rec) in enumerate(zip(self.enc, self.rec)):
-            x, self.states[i] = rec(conv(x) if self.fused else F.relu(conv(x)), self.states[i])
+            if isinstance(conv, _FusedConv):
+                x, self.states[i] = rec(conv(x), self.states[i], input_relu=False)         # ReLU already applied in the conv's epilogue
+            else:
+                x, self.states[i] = rec(conv(x) if self.fused else F.relu(conv(x)), self.states[i])
             blocks.append(x)
         for r in self.res:
             x = r(x)
         for i, conv in enumerate(self.dec):
-            x = x + blocks[len(blocks) - 1 - i]                                        # skip_type: sum
-            x = F.relu(conv(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)))
+            if isinstance(conv, _FusedConv):
+                x = conv(x, blocks[len(blocks) - 1 - i])                               # skip sum + upsample, conv + bias + ReLU
+            else:
+                x = x + blocks[len(blocks) - 1 - i]                                    # skip_type: sum
+                x = F.relu(conv(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)))
         return self.pred(x + head)
 
 

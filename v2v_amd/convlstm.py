@@ -211,3 +211,100 @@ class ResidualBlock(nn.Module):
         out = conv3x3_nhwc(mid, self._weights(self.conv2, "conv2"), self.conv2.bias.detach().float(), residual=xn, relu=True)
         out = out.permute(0, 3, 1, 2)
         return out if nhwc_io else out.contiguous().to(x.dtype)
+
+
+# ---- the encoder / decoder convolutions around those blocks (ConvLayer / UpsampleConvLayer, model/submodules.py:6-96) -----------
+def pack_conv_weights(weight: torch.Tensor) -> torch.Tensor:
+    """nn.Conv2d(Cin, Cout, ks, padding=ks//2).weight float32 [Cout, Cin, ks, ks] (ks 3 or 5) -> the packed bfloat16 stream."""
+    _lib.require_gpu()
+    if not weight.is_cuda or weight.dtype != torch.float32 or weight.dim() != 4 or weight.shape[2] != weight.shape[3]:
+        raise ValueError("weight must be a float32 CUDA tensor [Cout, Cin, ks, ks]")
+    cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
+    packed = torch.empty((cout * cin * ks * ks,), dtype=torch.bfloat16, device=weight.device)
+    with torch.cuda.device(weight.device):
+        _lib.check(_lib.lib().v2v_conv_pack_weights_hip(_ptr(weight.detach().contiguous()), cin, cout, ks, _ptr(packed), _lib.stream_ptr()))
+    return packed
+
+
+def conv_nhwc(x, packed, bias, ks: int, stride: int = 1, residual=None, relu=False, tile_rows: int = 0):
+    """out = [relu](conv_ks(x, stride, pad ks//2) + bias [+ residual]) on NHWC bfloat16: x [B,Hin,Win,Cin] -> [B,Hout,Wout,Cout]."""
+    _lib.require_gpu()
+    if not x.is_cuda or x.dtype != torch.bfloat16 or x.dim() != 4 or not x.is_contiguous():
+        raise ValueError("x must be a contiguous bfloat16 CUDA tensor [B,H,W,Cin]")
+    b, hin, win, cin = x.shape
+    cout = bias.numel()
+    if bias.dtype != torch.float32 or packed.dtype != torch.bfloat16 or packed.numel() != cout * cin * ks * ks:
+        raise ValueError("bias must be float32 [Cout] and packed the output of pack_conv_weights for the same Cin, Cout, ks")
+    h, w = (hin - 1) // stride + 1, (win - 1) // stride + 1
+    if residual is not None and (residual.dtype != torch.bfloat16 or tuple(residual.shape) != (b, h, w, cout) or not residual.is_contiguous()
+                                 or residual.device != x.device):
+        raise ValueError("residual must be a contiguous bfloat16 tensor [B,Hout,Wout,Cout] on x's device")
+    out = torch.empty((b, h, w, cout), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().v2v_conv_nhwc_hip(_ptr(x), _ptr(packed), _ptr(bias.detach().contiguous()), _ptr(residual), int(bool(relu)),
+                                                b, hin, win, cin, cout, ks, stride, _ptr(out), tile_rows, _lib.stream_ptr()))
+    return out
+
+
+def upsample2x_nhwc(x, skip=None):
+    """out = bilinear_x2(x [+ skip]) on NHWC bfloat16 ([B,H,W,C] -> [B,2H,2W,C]): f.interpolate(scale_factor=2, mode='bilinear',
+    align_corners=False) of UpsampleConvLayer.forward (model/submodules.py:86-87) behind the sum skip (model/unet.py:304)."""
+    _lib.require_gpu()
+    for name, v in (("x", x), ("skip", skip)):
+        if v is not None and (not v.is_cuda or v.dtype != torch.bfloat16 or v.dim() != 4 or not v.is_contiguous()):
+            raise ValueError(f"{name} must be a contiguous bfloat16 CUDA tensor [B,H,W,C]")
+    if skip is not None and (skip.shape != x.shape or skip.device != x.device):
+        raise ValueError("skip must have x's shape and device")
+    b, h, w, c = x.shape
+    out = torch.empty((b, 2 * h, 2 * w, c), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().v2v_upsample2x_nhwc_hip(_ptr(x), _ptr(skip), b, h, w, c, _ptr(out), _lib.stream_ptr()))
+    return out
+
+
+class ConvLayer(nn.Module):
+    """Drop-in for model/submodules.py:ConvLayer (:6-33) as the recurrent UNet builds its encoder / decoder convolutions
+    (model/unet.py: kernel_size 5, padding 2, stride 2 or 1, activation 'relu' or None, norm=None): same constructor, same
+    `conv2d` parameter, convolution + bias + ReLU in one matrix-core kernel.  upsample=True puts the bilinear x2 upsampling
+    (f.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False), its own bfloat16 NHWC kernel) in front, i.e.
+    UpsampleConvLayer (:68-96).  Inference only; bfloat16 operands, fp32 accumulation; channels-last bfloat16
+    inputs are consumed and produced in place, anything else goes through the layout-change kernel and comes back NCHW in the
+    input's dtype.  in_channels % 64 == 0 and out_channels in {32, 64, 128, 256k}, else ValueError (no fallback)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, activation="relu", norm=None, BN_momentum=0.1,
+                 upsample=False):
+        super().__init__()
+        if norm is not None or activation not in ("relu", None) or kernel_size not in (3, 5) or padding != kernel_size // 2 or stride not in (1, 2):
+            raise ValueError("the fused ConvLayer covers norm=None, activation 'relu' or None, kernel_size 3 or 5 with padding "
+                             "kernel_size // 2, stride 1 or 2 (what model/unet.py builds)")
+        self.conv2d = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=True)
+        self.relu, self.upsample = activation == "relu", upsample
+        self._packed = (None, None)
+
+    def _weights(self):
+        w = self.conv2d.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if self._packed[0] != key:
+            self._packed = (key, pack_conv_weights(w.detach()))
+        return self._packed[1]
+
+    def forward(self, x, skip=None):
+        """skip (upsample=True only): the sum skip connection model/unet.py:304 adds in front of the decoder, folded into the
+        upsampling kernel -- layer(x, skip) == layer(x + skip)."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise RuntimeError("v2v_amd.convlstm.ConvLayer is inference-only (no autograd through the fused kernel)")
+        if skip is not None and not self.upsample:
+            raise ValueError("skip is the decoder's (upsample=True) sum skip connection")
+
+        def is_nhwc(v):
+            return v.dtype == torch.bfloat16 and v.dim() == 4 and v.is_contiguous(memory_format=torch.channels_last) and not v.is_contiguous()
+        nhwc_io = is_nhwc(x)
+        if skip is not None and not (nhwc_io and is_nhwc(skip)):
+            x, skip = x + skip, None
+            nhwc_io = is_nhwc(x)
+        xn = x.permute(0, 2, 3, 1) if nhwc_io else nchw_to_nhwc_bf16(x)
+        if self.upsample:
+            xn = upsample2x_nhwc(xn, None if skip is None else skip.permute(0, 2, 3, 1))
+        out = conv_nhwc(xn, self._weights(), self.conv2d.bias.detach().float(), self.conv2d.kernel_size[0], self.conv2d.stride[0],
+                        relu=self.relu).permute(0, 3, 1, 2)
+        return out if nhwc_io else out.contiguous().to(x.dtype)

@@ -610,35 +610,62 @@ int v2v_convlstm_step_hip(const void *x, const void *h_prev, const float *c_prev
     return e == hipSuccess ? V2V_OK : hip_fail(e, "convlstm_step_kernel launch");
 }
 
-int v2v_conv3x3_pack_weights_hip(const float *weight, int64_t Cin, int64_t Cout, void *packed, void *stream)
+int v2v_conv_pack_weights_hip(const float *weight, int64_t Cin, int64_t Cout, int ks, void *packed, void *stream)
 {
-    if (!weight || !packed) return fail(V2V_ERR_NULL, "v2v_conv3x3_pack_weights_hip: weight/packed is NULL");
-    if (Cin < 64 || Cin % 64 != 0 || Cout < 256 || Cout % 256 != 0 || Cin > 4096 || Cout > 4096)
-        return fail(V2V_ERR_SHAPE, "conv3x3 kernel needs Cin %% 64 == 0 and Cout %% 256 == 0 (got %lld -> %lld)", (long long)Cin, (long long)Cout);
+    if (!weight || !packed) return fail(V2V_ERR_NULL, "v2v_conv_pack_weights_hip: weight/packed is NULL");
+    if (Cin < 64 || Cin % 64 != 0 || Cin > 4096 || Cout > 4096 || v2v::conv_tile_cols((int)Cout) == 0 || (ks != 3 && ks != 5))
+        return fail(V2V_ERR_SHAPE, "conv kernel needs Cin %% 64 == 0, Cout in {32, 64, 128} or a multiple of 256, ks 3 or 5 (got %lld -> %lld, ks %d)",
+                    (long long)Cin, (long long)Cout, ks);
     if (!aligned(weight, 4) || !aligned(packed, 16)) return fail(V2V_ERR_ALIGN, "weight needs 4-byte, packed 16-byte alignment");
-    const hipError_t e = v2v::launch_conv3x3_pack(weight, static_cast<uint16_t *>(packed), (int)Cin, (int)Cout, static_cast<hipStream_t>(stream));
-    return e == hipSuccess ? V2V_OK : hip_fail(e, "conv3x3_pack_kernel launch");
+    const hipError_t e = v2v::launch_conv_pack(weight, static_cast<uint16_t *>(packed), (int)Cin, (int)Cout, ks, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "conv_pack_kernel launch");
 }
 
-int v2v_conv3x3_nhwc_hip(const void *x, const void *packed, const float *bias, const void *residual, int relu, int64_t B, int64_t H,
-                         int64_t W, int64_t Cin, int64_t Cout, void *out, int tile_rows, void *stream)
+int v2v_conv_nhwc_hip(const void *x, const void *packed, const float *bias, const void *residual, int relu, int64_t B, int64_t Hin,
+                      int64_t Win, int64_t Cin, int64_t Cout, int ks, int stride, void *out, int tile_rows, void *stream)
 {
-    if (!x || !packed || !bias || !out) return fail(V2V_ERR_NULL, "v2v_conv3x3_nhwc_hip: x/packed/bias/out is NULL");
-    if (B < 1 || H < 1 || W < 1 || Cin < 64 || Cin % 64 != 0 || Cout < 256 || Cout % 256 != 0 || Cin > 4096 || Cout > 4096)
-        return fail(V2V_ERR_SHAPE, "need B,H,W >= 1, Cin %% 64 == 0, Cout %% 256 == 0");
+    if (!x || !packed || !bias || !out) return fail(V2V_ERR_NULL, "v2v_conv_nhwc_hip: x/packed/bias/out is NULL");
+    if ((ks != 3 && ks != 5) || (stride != 1 && stride != 2)) return fail(V2V_ERR_PARAM, "ks must be 3 or 5, stride 1 or 2");
+    if (B < 1 || Hin < 1 || Win < 1 || Cin < 64 || Cin % 64 != 0 || Cin > 4096 || Cout > 4096 || v2v::conv_tile_cols((int)Cout) == 0)
+        return fail(V2V_ERR_SHAPE, "need B,H,W >= 1, Cin %% 64 == 0, Cout in {32, 64, 128} or a multiple of 256");
+    const int64_t H = (Hin - 1) / stride + 1, W = (Win - 1) / stride + 1;          // output size for pad = ks / 2
     if (tile_rows != 0 && tile_rows != 64 && tile_rows != 128 && tile_rows != 256) return fail(V2V_ERR_PARAM, "tile_rows must be 0 (auto), 64, 128 or 256");
-    if ((B * H * W) % (tile_rows ? tile_rows : 64) != 0 || B * H * W * (Cin > Cout ? Cin : Cout) > 0x7FFFFFFFLL)
-        return fail(V2V_ERR_SHAPE, "conv3x3 kernel needs (B*H*W) %% 64 == 0 (%% tile_rows when given) and B*H*W*C < 2^31");
+    const int64_t need = Cout % 256 == 0 ? (tile_rows ? tile_rows : 64) : 256;
+    if ((B * H * W) % need != 0 || B * Hin * Win * Cin > 0x7FFFFFFFLL || B * H * W * Cout > 0x7FFFFFFFLL)
+        return fail(V2V_ERR_SHAPE, "conv kernel needs (B*Hout*Wout) %% %lld == 0 and tensors below 2^31 elements", (long long)need);
     if (out == x) return fail(V2V_ERR_PARAM, "out must not alias x (neighbouring tiles read it)");
     if (!aligned(x, 16) || !aligned(packed, 16) || !aligned(out, 2) || !aligned(residual, 2) || !aligned(bias, 4))
         return fail(V2V_ERR_ALIGN, "x/packed need 16-byte alignment");
     v2v::ConvLstmArgs a{};
     a.x = static_cast<const uint16_t *>(x); a.wp = static_cast<const uint16_t *>(packed); a.bias = bias;
     a.residual = static_cast<const uint16_t *>(residual); a.out_nhwc = static_cast<uint16_t *>(out);
-    a.n_cols = (int)Cout; a.relu = relu ? 1 : 0;
+    a.n_cols = (int)Cout; a.relu = relu ? 1 : 0; a.ks = ks; a.stride = stride; a.Hin = (int)Hin; a.Win = (int)Win;
     a.B = (int)B; a.H = (int)H; a.W = (int)W; a.C = (int)Cin;
-    const hipError_t e = v2v::launch_conv3x3(a, tile_rows, static_cast<hipStream_t>(stream));
-    return e == hipSuccess ? V2V_OK : hip_fail(e, "conv3x3 (convlstm_step_kernel, EPI = 1) launch");
+    const hipError_t e = v2v::launch_conv_nhwc(a, tile_rows, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "conv (convlstm_step_kernel, EPI = 1) launch");
+}
+
+int v2v_upsample2x_nhwc_hip(const void *x, const void *skip, int64_t B, int64_t H, int64_t W, int64_t C, void *out, void *stream)
+{
+    if (!x || !out) return fail(V2V_ERR_NULL, "v2v_upsample2x_nhwc_hip: x/out is NULL");
+    if (B < 1 || H < 1 || W < 1 || C < 8 || C % 8 != 0 || B * H * W * C > (1LL << 36))
+        return fail(V2V_ERR_SHAPE, "need B,H,W >= 1, C %% 8 == 0 and an input below 2^36 elements");
+    if (!aligned(x, 16) || !aligned(out, 16) || !aligned(skip, 16)) return fail(V2V_ERR_ALIGN, "x/skip/out need 16-byte alignment");
+    if (out == x || out == skip) return fail(V2V_ERR_PARAM, "out must not alias x or skip");
+    const hipError_t e = v2v::launch_upsample2x_nhwc(static_cast<const uint16_t *>(x), static_cast<const uint16_t *>(skip), static_cast<uint16_t *>(out),
+                                                     (int)B, (int)H, (int)W, (int)C, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "upsample2x_nhwc_bf16_kernel launch");
+}
+
+int v2v_conv3x3_pack_weights_hip(const float *weight, int64_t Cin, int64_t Cout, void *packed, void *stream)
+{
+    return v2v_conv_pack_weights_hip(weight, Cin, Cout, 3, packed, stream);
+}
+
+int v2v_conv3x3_nhwc_hip(const void *x, const void *packed, const float *bias, const void *residual, int relu, int64_t B, int64_t H,
+                         int64_t W, int64_t Cin, int64_t Cout, void *out, int tile_rows, void *stream)
+{
+    return v2v_conv_nhwc_hip(x, packed, bias, residual, relu, B, H, W, Cin, Cout, 3, 1, out, tile_rows, stream);
 }
 
 int v2v_nchw_to_nhwc_bf16_hip(const void *src, int src_dtype, int64_t B, int64_t C, int64_t H, int64_t W, int relu, void *dst, void *stream)

@@ -39,7 +39,7 @@ constexpr int kClBBytes = kClBN * kClBK * 2;
 // MF = 32-pixel accumulator blocks per wave (1 or 2), WM = wave rows (2 or 4; x 2 wave columns), STAGES = LDS buffers: the
 // workgroup tile is 32*MF*WM pixels.  Shipped: <1,2,2> 64 pixels (4 waves, 80 KB of LDS, two workgroups per CU), <1,4,3> 128
 // pixels (8 waves, 144 KB, three stages with counted vmcnt), <2,4,2> 256 pixels (8 waves, 128 KB)
-constexpr int cl_lds_bytes(int mf, int wm, int stages = 2) { return stages * (32 * mf * wm * kClBK * 2 + kClBBytes); }
+constexpr int cl_lds_bytes(int mf, int wm, int stages = 2, int bn = kClBN) { return stages * (32 * mf * wm * kClBK * 2 + bn * kClBK * 2); }
 
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 cl_bf16x8;
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float cl_f32x16;
@@ -50,13 +50,14 @@ __device__ __attribute__((aligned(128))) unsigned char g_cl_zero_line[128];     
 __device__ unsigned long long g_cl_dbg[4];      // EXPERIMENT: per-wave cycle totals {vmcnt wait, barrier, everything else, waves}
 #endif
 
-__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f)
+// float -> bf16, round to nearest even, NaN stays NaN: gfx950's v_cvt_pk_bf16_f32 (two values per instruction)
+typedef __bf16 cl_hwbf16x2 __attribute__((ext_vector_type(2)));
+typedef float cl_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cl_pack_bf16(float lo, float hi)
 {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);   // NaN stays NaN
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(cl_f32x2{lo, hi}, cl_hwbf16x2));
 }
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) { return (uint16_t)cl_pack_bf16(f, f); }
 __device__ __forceinline__ float cl_sigmoid(float v) { return __frcp_rn(1.0f + __expf(-v)); }
 __device__ __forceinline__ float cl_tanh(float v) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * v)) - 1.0f; }
 
@@ -67,12 +68,12 @@ __device__ __forceinline__ void cl_glds16(const void *src, unsigned char *lds_wa
 }
 
 // plain-convolution epilogue: accumulator g of the wave holds output channels col0 + 32 g .. + 31 (col0 = this lane's first)
-template <int MF>
-__device__ __forceinline__ void cl_epilogue_conv(const ConvLstmArgs &a, cl_f32x16 (&acc)[MF][4], int64_t mw0, int col0, int fh)
+template <int MF, int NF>
+__device__ __forceinline__ void cl_epilogue_conv(const ConvLstmArgs &a, cl_f32x16 (&acc)[MF][NF], int64_t mw0, int col0, int fh)
 {
     const int N = a.n_cols;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < NF; ++g) {
         const int oc = col0 + g * 32;
         const float bias = a.bias[oc];
 #pragma unroll
@@ -93,24 +94,33 @@ __device__ __forceinline__ void cl_epilogue_conv(const ConvLstmArgs &a, cl_f32x1
 // EPI = 0: ConvLSTM step (two inputs x|h, 4C gate columns, gate/cell epilogue).  EPI = 1: plain 3x3 convolution of x with
 // n_cols output channels (a multiple of 256), epilogue bias (+ residual) (+ ReLU) -> bf16 NHWC: the residual blocks of the same
 // encoder (model/submodules.py:143-177) on the same tiles and pipeline.
-template <int MF, int WM, int STAGES = 2, int EPI = 0>
-__global__ void __launch_bounds__(128 * WM, (STAGES == 2 && MF == 1) || WM == 4 ? 2 : 1) convlstm_step_kernel(const ConvLstmArgs a)
+// WN x NF: wave columns x 32-column B fragments per wave = the tile's columns (2 x 4 = 256 for the gates; 1 x {4,2,1} = 128 / 64 /
+// 32 output channels for the narrower plain convolutions).  EPI = 1 also takes the tap count (ks x ks, pad ks/2) and the stride
+// from the arguments (5x5 and stride-2 encoder / decoder convolutions of model/unet.py).
+template <int MF, int WM, int STAGES = 2, int EPI = 0, int WN = 2, int NF = 4>
+__global__ void __launch_bounds__(64 * WM * WN, (STAGES == 2 && MF == 1) || WM * WN == 8 || NF < 4 ? 2 : 1) convlstm_step_kernel(const ConvLstmArgs a)
 {
-    constexpr int kClBM = 32 * MF * WM, kClABytes = kClBM * kClBK * 2, kClStage = kClABytes + kClBBytes;
+    static_assert(EPI == 1 || (WN == 2 && NF == 4), "the gate epilogue needs the four gates of a channel in one wave");
+    constexpr int kBN = WN * NF * 32, kBBytes = kBN * kClBK * 2;
+    constexpr int kClBM = 32 * MF * WM, kClABytes = kClBM * kClBK * 2, kClStage = kClABytes + kBBytes;
+    constexpr int NS = WM * WN;                                   // waves (all of them stage)
     extern __shared__ __attribute__((aligned(128))) unsigned char cl_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const int C = a.C, HW = a.H * a.W;
-    const int n_ct = EPI == 0 ? C / kClCh : a.n_cols / kClBN;     // column tiles (256 columns each)
+    const int ks = EPI == 0 ? 3 : a.ks, pad = ks >> 1, n_taps = ks * ks, stride = EPI == 0 ? 1 : a.stride;
+    const int Hin = EPI == 0 ? a.H : a.Hin, Win = EPI == 0 ? a.W : a.Win;
+    const int n_ct = EPI == 0 ? C / kClCh : a.n_cols / kBN;       // column tiles
     const int ct = blockIdx.x % n_ct;
     const int64_t m0 = (int64_t)(blockIdx.x / n_ct) * kClBM;      // first pixel of the tile (flattened b,y,x)
     const int cc_x = C / kClBK, cc_all = EPI == 0 ? 2 * cc_x : cc_x;
     const int cc_eff = (EPI == 0 && a.h_prev) ? cc_all : cc_x;    // zero state: skip h's chunks
-    const int n_chunks = 9 * cc_eff;
+    const int n_chunks = n_taps * cc_eff;
 
     // ---- staging plan: wave w issues A pieces NA*w.. (8 rows each) and B pieces NB*w.. per chunk ----------------------
     const int srow = lane >> 3, sslot = lane & 7;                 // this lane's (row in piece, LDS slot)
-    constexpr int NA = 2 * MF;                                    // A pieces per wave
+    constexpr int NA = kClBM / 8 / NS;                            // A pieces per wave
+    static_assert(NA >= 1 && (kBN / 8) % NS == 0, "every wave stages whole pieces");
     int ay[NA], ax[NA];
     int64_t apix[NA];
     uint32_t aswz[NA];
@@ -118,20 +128,20 @@ __global__ void __launch_bounds__(128 * WM, (STAGES == 2 && MF == 1) || WM == 4 
     for (int j = 0; j < NA; ++j) {
         const int row = (wave * NA + j) * 8 + srow;
         const int64_t m = m0 + row;
-        const int p = (int)(m % HW);
-        ay[j] = p / a.W;
-        ax[j] = p % a.W;
-        apix[j] = m * C;                                          // element offset of the pixel's channel vector
+        const int p = (int)(m % HW), bimg = (int)(m / HW);
+        ay[j] = (p / a.W) * stride;                               // the tap centre in INPUT coordinates
+        ax[j] = (p % a.W) * stride;
+        apix[j] = (((int64_t)bimg * Hin + ay[j]) * Win + ax[j]) * C;    // element offset of the centre pixel's channel vector
         aswz[j] = (uint32_t)((sslot ^ ((row >> 1) & 7)) * 8);     // source channel offset inside the 64-channel chunk
     }
-    constexpr int NB = 16 / WM;                                   // B pieces per wave
+    constexpr int NB = kBN / 8 / NS;                              // B pieces per wave
     uint32_t boff[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int row = (wave * NB + j) * 8 + srow;
         boff[j] = (uint32_t)(row * kClBK + (sslot ^ ((row >> 1) & 7)) * 8);
     }
-    const uint16_t *wtile = a.wp + (int64_t)ct * 9 * cc_all * (kClBN * kClBK);
+    const uint16_t *wtile = a.wp + (int64_t)ct * n_taps * cc_all * (kBN * kClBK);
 
     // LDS-DMA of chunk ck into buffer buf (part / nparts: a subset of the pieces, j % nparts == part).  The main loop issues
     // the whole chunk in front of the first k-step: spreading the pieces over the four k-steps was measured 10-15 % slower on
@@ -139,19 +149,19 @@ __global__ void __launch_bounds__(128 * WM, (STAGES == 2 && MF == 1) || WM == 4 
     // its turn in the address unit)
     auto stage = [&](int ck, int buf, int part, int nparts) __attribute__((always_inline)) {
         const int tap = ck / cc_eff, cc = ck - tap * cc_eff;
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int dy = tap / ks - pad, dx = tap % ks - pad;
         const uint16_t *src = cc < cc_x ? a.x : a.h_prev;
         const int c0 = (cc < cc_x ? cc : cc - cc_x) * kClBK;
         unsigned char *abase = cl_lds + buf * kClStage, *bbase = abase + kClABytes;
-        const int64_t shift = ((int64_t)dy * a.W + dx) * C + c0;
+        const int64_t shift = ((int64_t)dy * Win + dx) * C + c0;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             if (j % nparts != part) continue;
-            const bool in = (unsigned)(ay[j] + dy) < (unsigned)a.H && (unsigned)(ax[j] + dx) < (unsigned)a.W;
+            const bool in = (unsigned)(ay[j] + dy) < (unsigned)Hin && (unsigned)(ax[j] + dx) < (unsigned)Win;
             const void *g = in ? (const void *)(src + apix[j] + shift + aswz[j]) : (const void *)g_cl_zero_line;
             cl_glds16(g, abase + (wave * NA + j) * 1024);
         }
-        const uint16_t *wchunk = wtile + (int64_t)(tap * cc_all + cc) * (kClBN * kClBK);
+        const uint16_t *wchunk = wtile + (int64_t)(tap * cc_all + cc) * (kBN * kClBK);
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if (j % nparts != part) continue;
@@ -165,13 +175,13 @@ __global__ void __launch_bounds__(128 * WM, (STAGES == 2 && MF == 1) || WM == 4 
     uint32_t koff[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) koff[s] = ((uint32_t)(2 * s + fh) ^ fsw) << 4;
-    const uint32_t a_row = (uint32_t)((wm * 32 * MF + fr) * 128), b_row = (uint32_t)(kClABytes + (wn * 128 + fr) * 128);
+    const uint32_t a_row = (uint32_t)((wm * 32 * MF + fr) * 128), b_row = (uint32_t)(kClABytes + (wn * 32 * NF + fr) * 128);
 
-    cl_f32x16 acc[MF][4];
+    cl_f32x16 acc[MF][NF];
 #pragma unroll
     for (int i = 0; i < MF; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < NF; ++g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][g][r] = 0.0f;
 
@@ -183,12 +193,12 @@ __global__ void __launch_bounds__(128 * WM, (STAGES == 2 && MF == 1) || WM == 4 
 #endif
     auto k_steps = [&](const unsigned char *base, auto &&before_step) __attribute__((always_inline)) {
         // fragments of k-step s+1 are read before the MFMAs of k-step s are issued (two register sets: +1..3 %)
-        cl_bf16x8 af[2][MF], bf[2][4];
+        cl_bf16x8 af[2][MF], bf[2][NF];
         auto load = [&](int s, int slot) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < MF; ++i) af[slot][i] = *reinterpret_cast<const cl_bf16x8 *>(base + a_row + i * (32 * 128) + koff[s]);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bf[slot][g] = *reinterpret_cast<const cl_bf16x8 *>(base + b_row + g * (32 * 128) + koff[s]);
+            for (int g = 0; g < NF; ++g) bf[slot][g] = *reinterpret_cast<const cl_bf16x8 *>(base + b_row + g * (32 * 128) + koff[s]);
         };
         before_step(0);
         load(0, 0);
@@ -198,7 +208,7 @@ __global__ void __launch_bounds__(128 * WM, (STAGES == 2 && MF == 1) || WM == 4 
 #pragma unroll
             for (int i = 0; i < MF; ++i)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], bf[s & 1][g], acc[i][g], 0, 0, 0);
+                for (int g = 0; g < NF; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], bf[s & 1][g], acc[i][g], 0, 0, 0);
         }
     };
     if constexpr (STAGES == 2) {
@@ -247,9 +257,10 @@ __global__ void __launch_bounds__(128 * WM, (STAGES == 2 && MF == 1) || WM == 4 
     }
 #endif
     if constexpr (EPI == 1) {
-        cl_epilogue_conv<MF>(a, acc, m0 + wm * 32 * MF, ct * kClBN + wn * 128 + fr, fh);
+        cl_epilogue_conv<MF, NF>(a, acc, m0 + wm * 32 * MF, ct * kBN + wn * 32 * NF + fr, fh);
         return;
     }
+    if constexpr (EPI == 0) {
     // ---- epilogue: gates -> cell / hidden, straight from the accumulators ---------------------------------------------------
     // accumulator element r of lane l: column (channel) l & 31, row (pixel) (r & 3) + 8 (r >> 2) + 4 (l >> 5)
     const int ch = ct * kClCh + wn * 32 + fr;
@@ -277,14 +288,14 @@ __global__ void __launch_bounds__(128 * WM, (STAGES == 2 && MF == 1) || WM == 4 
                 const int64_t b = mq / HW, p = mq - b * HW;                  // HW % 4 == 0: the 4 pixels share an image
                 const int64_t o = (b * C + ch) * HW + p;
                 if (a.h_nchw_bf16) {
-                    const uint32_t lo = (uint32_t)f32_to_bf16_rne(hv[0]) | ((uint32_t)f32_to_bf16_rne(hv[1]) << 16);
-                    const uint32_t hi = (uint32_t)f32_to_bf16_rne(hv[2]) | ((uint32_t)f32_to_bf16_rne(hv[3]) << 16);
+                    const uint32_t lo = cl_pack_bf16(hv[0], hv[1]), hi = cl_pack_bf16(hv[2], hv[3]);
                     *reinterpret_cast<uint2 *>(static_cast<uint16_t *>(a.h_nchw) + o) = make_uint2(lo, hi);
                 } else {
                     *reinterpret_cast<float4 *>(static_cast<float *>(a.h_nchw) + o) = make_float4(hv[0], hv[1], hv[2], hv[3]);
                 }
             }
         }
+    }
     }
 }
 
@@ -317,6 +328,70 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_bf16_kernel(const SRC *src, 
     }
 }
 
+// out = bilinear_x2(x [+ skip]) on NHWC bf16 (f.interpolate(scale_factor=2, mode='bilinear', align_corners=False) of
+// UpsampleConvLayer.forward, model/submodules.py:86-87, with the sum skip of model/unet.py:304 in front).  One work-item per INPUT
+// pixel and 8 channels (16 bytes): it reads the clamped 3x3 neighbourhood once and writes the 2x2 output quad.  For scale 2 the
+// source index (dst + 0.5) / 2 - 0.5 (clamped at 0) gives output 2k the neighbours (k-1, k) with weights (0.25, 0.75) and output
+// 2k+1 the neighbours (k, k+1) with (0.75, 0.25), edge neighbours clamped -- torch's upsample_bilinear2d weights and its order
+// (rows first, then columns: h0 (w0 v00 + w1 v01) + h1 (w0 v10 + w1 v11)) in float; x + skip rounds to bf16 first, as the
+// stock bf16 add does.  HBM-bound: 2 bytes written per output element, a quarter (half with skip) of that read.
+__device__ __forceinline__ void cl_unpack8(const uint4 v, float (&f)[8])
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u); }
+}
+
+__global__ void __launch_bounds__(256) upsample2x_nhwc_bf16_kernel(const uint16_t *x, const uint16_t *skip, uint16_t *out, int B, int H, int W, int C)
+{
+    const int c8n = C >> 3;
+    const int64_t n = (int64_t)B * H * W * c8n;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c8 = (int)(i % c8n);
+    int64_t r = i / c8n;
+    const int ix = (int)(r % W); r /= W;
+    const int iy = (int)(r % H);
+    const int b = (int)(r / H);
+    const int ys[3] = {iy > 0 ? iy - 1 : 0, iy, iy < H - 1 ? iy + 1 : iy}, xs[3] = {ix > 0 ? ix - 1 : 0, ix, ix < W - 1 ? ix + 1 : ix};
+    float L[3][8], R[3][8];                                       // per input row: the left (2 ix) and right (2 ix + 1) output column
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float v[3][8];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int64_t o = (((int64_t)b * H + ys[j]) * W + xs[k]) * C + c8 * 8;
+            cl_unpack8(*reinterpret_cast<const uint4 *>(x + o), v[k]);
+            if (skip) {
+                float s[8];
+                cl_unpack8(*reinterpret_cast<const uint4 *>(skip + o), s);
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const uint32_t pk = cl_pack_bf16(v[k][e] + s[e], v[k][e + 1] + s[e + 1]);
+                    v[k][e] = __uint_as_float(pk << 16);
+                    v[k][e + 1] = __uint_as_float(pk & 0xFFFF0000u);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float mid = 0.75f * v[1][e];
+            L[j][e] = 0.25f * v[0][e] + mid;
+            R[j][e] = mid + 0.25f * v[2][e];
+        }
+    }
+    auto put = [&](int oy, int ox, const float (&top)[8], float wt, const float (&bot)[8], float wb) __attribute__((always_inline)) {
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) w[e >> 1] = cl_pack_bf16(wt * top[e] + wb * bot[e], wt * top[e + 1] + wb * bot[e + 1]);
+        *reinterpret_cast<uint4 *>(out + ((((int64_t)b * 2 * H + oy) * 2 * W + ox) * C + c8 * 8)) = make_uint4(w[0], w[1], w[2], w[3]);
+    };
+    put(2 * iy, 2 * ix, L[0], 0.25f, L[1], 0.75f);
+    put(2 * iy, 2 * ix + 1, R[0], 0.25f, R[1], 0.75f);
+    put(2 * iy + 1, 2 * ix, L[1], 0.75f, L[2], 0.25f);
+    put(2 * iy + 1, 2 * ix + 1, R[1], 0.75f, R[2], 0.25f);
+}
+
 // [4C, 2C, 3, 3] fp32 (nn.Conv2d weight of ConvLSTM.Gates) -> packed bf16 (layout at the top of this file); one thread per element
 __global__ void __launch_bounds__(256) convlstm_pack_kernel(const float *w, uint16_t *wp, int C)
 {
@@ -335,21 +410,22 @@ __global__ void __launch_bounds__(256) convlstm_pack_kernel(const float *w, uint
     wp[i] = f32_to_bf16_rne(w[((int64_t)oc * 2 * C + ic) * 9 + tap]);
 }
 
-// [Cout, Cin, 3, 3] fp32 (nn.Conv2d weight) -> packed bf16 for the EPI = 1 instances:
-//   wp[col tile t = Cout/256][chunk ck = tap*(Cin/64) + cc][column n = 0..255][k = 0..63],  column n <-> output channel t*256 + n
-__global__ void __launch_bounds__(256) conv3x3_pack_kernel(const float *w, uint16_t *wp, int Cin, int Cout)
+// [Cout, Cin, ks, ks] fp32 (nn.Conv2d weight) -> packed bf16 for the EPI = 1 instances, bn = the instance's tile columns:
+//   wp[col tile t = Cout/bn][chunk ck = tap*(Cin/64) + cc][column n = 0..bn-1][k = 0..63],  column n <-> output channel t*bn + n
+__global__ void __launch_bounds__(256) conv_pack_kernel(const float *w, uint16_t *wp, int Cin, int Cout, int ks, int bn)
 {
-    const int64_t n = (int64_t)Cout * Cin * 9;
+    const int taps = ks * ks;
+    const int64_t n = (int64_t)Cout * Cin * taps;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int cc_all = Cin / kClBK;
     int64_t r = i;
     const int k = (int)(r % kClBK); r /= kClBK;
-    const int col = (int)(r % kClBN); r /= kClBN;
-    const int ck = (int)(r % (9 * cc_all)); r /= 9 * cc_all;
+    const int col = (int)(r % bn); r /= bn;
+    const int ck = (int)(r % (taps * cc_all)); r /= taps * cc_all;
     const int ct = (int)r;
     const int tap = ck / cc_all, cc = ck % cc_all;
-    wp[i] = f32_to_bf16_rne(w[((int64_t)(ct * kClBN + col) * Cin + cc * kClBK + k) * 9 + tap]);
+    wp[i] = f32_to_bf16_rne(w[((int64_t)(ct * bn + col) * Cin + cc * kClBK + k) * taps + tap]);
 }
 
 }  // namespace v2v

@@ -5,22 +5,22 @@
 namespace v2v {
 
 namespace {
-template <int MF, int WM, int STAGES = 2, int EPI = 0>
+template <int MF, int WM, int STAGES = 2, int EPI = 0, int WN = 2, int NF = 4>
 hipError_t launch_step_t(const ConvLstmArgs &a, hipStream_t s)
 {
     // 80-128 KB of dynamic LDS is above the 64 KB a kernel gets by default: raise the limit once per device (kept out of the
     // launch path so that a step captures into a hipGraph as a bare kernel node)
-    constexpr int lds = cl_lds_bytes(MF, WM, STAGES);
+    constexpr int lds = cl_lds_bytes(MF, WM, STAGES, WN * NF * 32);
     static bool raised[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (dev < 0 || dev >= 64 || !raised[dev]) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convlstm_step_kernel<MF, WM, STAGES, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convlstm_step_kernel<MF, WM, STAGES, EPI, WN, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) raised[dev] = true;
     }
-    const int64_t tiles = (int64_t)a.B * a.H * a.W / (32 * MF * WM) * (EPI == 0 ? a.C / kClCh : a.n_cols / kClBN);
-    hipLaunchKernelGGL((convlstm_step_kernel<MF, WM, STAGES, EPI>), dim3((unsigned)tiles), dim3(128 * WM), lds, s, a);
+    const int64_t tiles = (int64_t)a.B * a.H * a.W / (32 * MF * WM) * (EPI == 0 ? a.C / kClCh : a.n_cols / (WN * NF * 32));
+    hipLaunchKernelGGL((convlstm_step_kernel<MF, WM, STAGES, EPI, WN, NF>), dim3((unsigned)tiles), dim3(64 * WM * WN), lds, s, a);
     return hipGetLastError();
 }
 }  // namespace
@@ -41,22 +41,34 @@ hipError_t launch_convlstm_step(const ConvLstmArgs &a, int tile_rows, hipStream_
     return tile_rows == 128 ? launch_step_t<1, 4, 3>(a, s) : launch_step_t<1, 2, 2>(a, s);
 }
 
-hipError_t launch_conv3x3(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
+// plain convolution (EPI = 1): Cout % 256 == 0 takes the 256-column tiles of the gate kernel (three pixel-tile sizes), Cout =
+// 128 / 64 / 32 a 256-pixel tile of 4 waves with 4 / 2 / 1 column fragments per wave
+int conv_tile_cols(int Cout) { return Cout % 256 == 0 ? 256 : (Cout == 128 || Cout == 64 || Cout == 32) ? Cout : 0; }
+
+hipError_t launch_conv_nhwc(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
 {
+    const int64_t m = (int64_t)a.B * a.H * a.W;
+    if (a.n_cols % 256 != 0) {
+        if (m % 256 != 0) return hipErrorInvalidValue;
+        if (a.n_cols == 128) return launch_step_t<2, 4, 2, 1, 1, 4>(a, s);
+        if (a.n_cols == 64) return launch_step_t<2, 4, 2, 1, 1, 2>(a, s);
+        if (a.n_cols == 32) return launch_step_t<2, 4, 2, 1, 1, 1>(a, s);
+        return hipErrorInvalidValue;
+    }
     if (tile_rows == 0) {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const int64_t m = (int64_t)a.B * a.H * a.W, ct = a.n_cols / kClBN;
+        const int64_t ct = a.n_cols / kClBN;
         tile_rows = (m % 256 == 0 && m / 256 * ct >= cus) ? 256 : (m % 128 == 0 && m / 128 * ct >= cus) ? 128 : 64;
     }
     if (tile_rows == 256) return launch_step_t<2, 4, 2, 1>(a, s);
     return tile_rows == 128 ? launch_step_t<1, 4, 3, 1>(a, s) : launch_step_t<1, 2, 2, 1>(a, s);
 }
 
-hipError_t launch_conv3x3_pack(const float *w, uint16_t *wp, int Cin, int Cout, hipStream_t s)
+hipError_t launch_conv_pack(const float *w, uint16_t *wp, int Cin, int Cout, int ks, hipStream_t s)
 {
-    const int64_t n = (int64_t)Cout * Cin * 9;
-    hipLaunchKernelGGL(conv3x3_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, wp, Cin, Cout);
+    const int64_t n = (int64_t)Cout * Cin * ks * ks;
+    hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, wp, Cin, Cout, ks, conv_tile_cols(Cout));
     return hipGetLastError();
 }
 
@@ -74,6 +86,13 @@ hipError_t launch_nchw_to_nhwc_bf16(const void *src, bool src_bf16, uint16_t *ds
         hipLaunchKernelGGL(nchw_to_nhwc_bf16_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint16_t *>(src), dst, C, HW, relu);
     else
         hipLaunchKernelGGL(nchw_to_nhwc_bf16_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float *>(src), dst, C, HW, relu);
+    return hipGetLastError();
+}
+
+hipError_t launch_upsample2x_nhwc(const uint16_t *x, const uint16_t *skip, uint16_t *out, int B, int H, int W, int C, hipStream_t s)
+{
+    const int64_t n = (int64_t)B * H * W * (C / 8);                  // one work-item per input pixel and 8 channels
+    hipLaunchKernelGGL(upsample2x_nhwc_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, skip, out, B, H, W, C);
     return hipGetLastError();
 }
 
