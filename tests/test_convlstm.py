@@ -343,6 +343,9 @@ def test_residual_block_is_a_drop_in():
     ((2, 64, 24, 40), 64, 3, 2, 0, False, True),        # odd tile/row alignment: Wout = 20, 480 pixels -> rejected (not % 256)
     ((2, 64, 31, 33), 256, 5, 2, 64, False, True),      # odd input size: Hout x Wout = 16 x 17 -> 544 pixels -> rejected (not % 64)
     ((4, 64, 15, 31), 256, 5, 2, 128, True, True),      # odd input size, 4 x 8 x 16 = 512 output pixels
+    ((2, 64, 31, 33), 256, 5, 2, 0, True, True),        # 544 = 17 x 32 output pixels: the 32-pixel tile
+    ((1, 256, 16, 16), 256, 3, 1, 32, True, True),      # residual-block shape on the 32-pixel tile
+    ((1, 128, 32, 32), 512, 5, 2, 0, False, True),      # two column tiles
 ])
 def test_conv_nhwc_matches_reference_semantics(shape, cout, ks, stride, tile_rows, res, relu):
     """out = [relu](conv_ks(x, stride, pad ks // 2) + bias [+ residual]) (ConvLayer.forward, model/submodules.py:25-33) against
@@ -360,7 +363,7 @@ def test_conv_nhwc_matches_reference_semantics(shape, cout, ks, stride, tile_row
     xn = _bf16_round(x).cuda().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
     rn = _bf16_round(r).cuda().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous() if res else None
     packed = CL.pack_conv_weights(weight.cuda())
-    need = 256 if cout % 256 else (tile_rows or 64)
+    need = 256 if cout % 256 else (tile_rows or 32)
     if (b * ho * wo) % need:
         with pytest.raises(ValueError):
             CL.conv_nhwc(xn, packed, bias.cuda(), ks, stride, residual=rn, relu=relu, tile_rows=tile_rows)

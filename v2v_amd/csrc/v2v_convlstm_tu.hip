@@ -59,9 +59,13 @@ hipError_t launch_conv_nhwc(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const int64_t ct = a.n_cols / kClBN;
-        tile_rows = (m % 256 == 0 && m / 256 * ct >= cus) ? 256 : (m % 128 == 0 && m / 128 * ct >= cus) ? 128 : 64;
+        // 32-pixel tiles when even 64-pixel ones leave CUs idle (8 clips at 32^2, same box: residual-block convolution 36.7 ->
+        // 30.0 us, 5x5 stride-2 128 -> 256 48.0 -> 39.1 us; a third stage on the 64-pixel tile measured no gain)
+        tile_rows = (m % 256 == 0 && m / 256 * ct >= cus) ? 256 : (m % 128 == 0 && m / 128 * ct >= cus) ? 128
+                    : (m % 64 != 0 || m / 64 * ct < cus) ? 32 : 64;
     }
     if (tile_rows == 256) return launch_step_t<2, 4, 2, 1>(a, s);
+    if (tile_rows == 32) return launch_step_t<1, 1, 3, 1, 4, 2>(a, s); // 4 waves of 32 px x 64 columns, three stages
     return tile_rows == 128 ? launch_step_t<1, 4, 3, 1>(a, s) : launch_step_t<1, 2, 2, 1>(a, s);
 }
 
