@@ -52,11 +52,12 @@ WORKLOADS = {
     # tools/e2vid_consumer.py) -- end-to-end "dataloader -> model forward" throughput.
     "cfg5_pipeline_plus_e2vid_bf16": dict(model="pipeline", b=8, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1,
                                           params=DATASET_STYLE, src_hw=(720, 1280), consumer=True),
-    # the same with the consumer's three ConvLSTM blocks on the fused matrix-core kernel
+    # the same with the consumer's ConvLSTM blocks, residual blocks, >=64-channel 5x5 convolutions and upsampling on the device
+    # kernels
     "cfg5_fused_convlstm": dict(model="pipeline", b=8, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1,
                                 params=DATASET_STYLE, src_hw=(720, 1280), consumer="fused"),
-    # both again with the network in torch.channels_last (NHWC): MIOpen's bf16 convolutions are faster there, and the fused
-    # ConvLSTM step consumes / produces that layout in place (no layout-change kernels)
+    # both again with the network in torch.channels_last (NHWC): MIOpen's bf16 convolutions are faster there, and the device
+    # kernels consume / produce that layout in place (no layout-change kernels)
     "cfg5_channels_last": dict(model="pipeline", b=8, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1,
                                params=DATASET_STYLE, src_hw=(720, 1280), consumer="stock_cl"),
     "cfg5_fused_convlstm_channels_last": dict(model="pipeline", b=8, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1,
@@ -200,7 +201,7 @@ class Workload:
                 if c_last:
                     consumer = consumer.to(memory_format=torch.channels_last)
                 self.kernel_name += (" + E2VID-shaped UNet forward (bf16 autocast" + (", channels_last" if c_last else "")
-                                     + (", fused ConvLSTM steps)" if fused else ")"))
+                                     + (", ConvLSTM / residual / 5x5 convolutions / upsampling on the device kernels)" if fused else ")"))
 
             def step():
                 gray = frontend.prepare_clips_batch(raw, table_d, idx_d, h, "gray", validate=False, max_crop_before=cb_max)[1]
