@@ -276,8 +276,9 @@ int v2v_convlstm_step_hip(const void *x, const void *h_prev, const float *c_prev
  * ConvLSTM step -- out = [relu]( conv(x) + bias [+ residual] ), x [B,H,W,Cin] / residual, out [B,H,W,Cout] bf16 NHWC,
  * weight = the module's conv weight fp32 [Cout,Cin,3,3] packed once by v2v_conv3x3_pack_weights_hip (Cout*Cin*9 bf16).
  * Two calls make a block: conv1 with relu, conv2 with residual = the block's input and relu.
- * Requirements (else V2V_ERR_SHAPE): Cin % 64 == 0, Cout % 256 == 0 (or 128 / 64 / 32), (B*H*W) % 32 == 0 (% tile_rows when given:
- * 32, 64, 128 or 256 pixels per workgroup; 0 = the largest tile that still fills the CUs; 256 for Cout 128 / 64 / 32);
+ * Requirements (else V2V_ERR_SHAPE): Cin % 64 == 0, Cout % 256 == 0 (or 128 / 64 / 32), (B*H*W) % 32 == 0 (% 128 for Cout 128 /
+ * 64 / 32; % tile_rows when given: 32, 64, 128 or 256 pixels per workgroup, the first two for Cout % 256 == 0 only; 0 = the
+ * largest tile that still fills the CUs);
  * out must not alias x (neighbouring tiles read x); it may alias residual. */
 int v2v_conv3x3_pack_weights_hip(const float *weight, int64_t Cin, int64_t Cout, void *packed, void *stream);   /* = conv_pack, ks 3 */
 int v2v_conv3x3_nhwc_hip(const void *x, const void *packed, const float *bias, const void *residual, int relu, int64_t B, int64_t H,
@@ -286,7 +287,7 @@ int v2v_conv3x3_nhwc_hip(const void *x, const void *packed, const float *bias, c
 /* The general form: the encoder / decoder convolutions around those blocks (ConvLayer, model/submodules.py:10-50 as built at
  * model/unet.py:34-60, 83-87: 5x5, stride 2 in the encoders, stride 1 after the bilinear upsampling in the decoders, ReLU).
  * ks = 3 or 5 (pad ks/2), stride 1 or 2; x [B,Hin,Win,Cin] -> out [B,Hout,Wout,Cout] with Hout = (Hin-1)/stride + 1; Cin % 64 == 0;
- * Cout a multiple of 256, or 128 / 64 / 32 (then (B*Hout*Wout) % 256 == 0); weight fp32 [Cout,Cin,ks,ks]. */
+ * Cout a multiple of 256, or 128 / 64 / 32 (then (B*Hout*Wout) % 128 == 0); weight fp32 [Cout,Cin,ks,ks]. */
 int v2v_conv_pack_weights_hip(const float *weight, int64_t Cin, int64_t Cout, int ks, void *packed, void *stream);
 int v2v_conv_nhwc_hip(const void *x, const void *packed, const float *bias, const void *residual, int relu, int64_t B, int64_t Hin,
                       int64_t Win, int64_t Cin, int64_t Cout, int ks, int stride, void *out, int tile_rows, void *stream);

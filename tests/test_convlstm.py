@@ -340,7 +340,10 @@ def test_residual_block_is_a_drop_in():
     ((1, 128, 16, 16), 64, 5, 1, 0, True, True),        # dec2: 128 -> 64
     ((1, 64, 16, 32), 32, 5, 1, 0, False, True),        # dec3: 64 -> 32
     ((1, 64, 16, 16), 32, 3, 1, 0, True, False),
-    ((2, 64, 24, 40), 64, 3, 2, 0, False, True),        # odd tile/row alignment: Wout = 20, 480 pixels -> rejected (not % 256)
+    ((2, 64, 24, 40), 64, 3, 2, 0, False, True),        # Wout = 20, 480 pixels -> rejected (not % 128)
+    ((2, 64, 32, 24), 64, 3, 2, 0, True, True),         # 2 x 16 x 12 = 384 pixels: three 128-pixel tiles
+    ((1, 128, 16, 16), 32, 5, 1, 256, False, True),     # pinned 256-pixel tile
+    ((1, 64, 32, 32), 128, 5, 1, 128, True, False),     # pinned 128-pixel tile
     ((2, 64, 31, 33), 256, 5, 2, 64, False, True),      # odd input size: Hout x Wout = 16 x 17 -> 544 pixels -> rejected (not % 64)
     ((4, 64, 15, 31), 256, 5, 2, 128, True, True),      # odd input size, 4 x 8 x 16 = 512 output pixels
     ((2, 64, 31, 33), 256, 5, 2, 0, True, True),        # 544 = 17 x 32 output pixels: the 32-pixel tile
@@ -363,7 +366,7 @@ def test_conv_nhwc_matches_reference_semantics(shape, cout, ks, stride, tile_row
     xn = _bf16_round(x).cuda().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
     rn = _bf16_round(r).cuda().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous() if res else None
     packed = CL.pack_conv_weights(weight.cuda())
-    need = 256 if cout % 256 else (tile_rows or 32)
+    need = tile_rows or (128 if cout % 256 else 32)
     if (b * ho * wo) % need:
         with pytest.raises(ValueError):
             CL.conv_nhwc(xn, packed, bias.cuda(), ks, stride, residual=rn, relu=relu, tile_rows=tile_rows)

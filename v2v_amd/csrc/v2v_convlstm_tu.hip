@@ -48,16 +48,26 @@ int conv_tile_cols(int Cout) { return Cout % 256 == 0 ? 256 : (Cout == 128 || Co
 hipError_t launch_conv_nhwc(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
 {
     const int64_t m = (int64_t)a.B * a.H * a.W;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (a.n_cols % 256 != 0) {
-        if (m % 256 != 0) return hipErrorInvalidValue;
-        if (a.n_cols == 128) return launch_step_t<2, 4, 2, 1, 1, 4>(a, s);
-        if (a.n_cols == 64) return launch_step_t<2, 4, 2, 1, 1, 2>(a, s);
-        if (a.n_cols == 32) return launch_step_t<2, 4, 2, 1, 1, 1>(a, s);
+        // one column tile of 4 / 2 / 1 B fragments per wave: 256 pixels (8 fragment rows of 4 waves x MF 2), or 128 pixels on
+        // three stages when 256-pixel tiles leave CUs idle (8 clips at 64^2, same box: 5x5 256 -> 128 121 -> 88 us, 5x5
+        // stride-2 64 -> 128 41 -> 30 us).  Measured and not kept for 32 columns: 512- and 256-pixel tiles of MF 4 (+26 / +41 %)
+        if (tile_rows == 0) tile_rows = (m % 256 == 0 && m / 256 >= cus) ? 256 : 128;
+        if (m % tile_rows != 0) return hipErrorInvalidValue;
+        if (tile_rows == 256) {
+            if (a.n_cols == 128) return launch_step_t<2, 4, 2, 1, 1, 4>(a, s);
+            if (a.n_cols == 64) return launch_step_t<2, 4, 2, 1, 1, 2>(a, s);
+            if (a.n_cols == 32) return launch_step_t<2, 4, 2, 1, 1, 1>(a, s);
+        } else if (tile_rows == 128) {
+            if (a.n_cols == 128) return launch_step_t<1, 4, 3, 1, 1, 4>(a, s);
+            if (a.n_cols == 64) return launch_step_t<1, 4, 3, 1, 1, 2>(a, s);
+            if (a.n_cols == 32) return launch_step_t<1, 4, 3, 1, 1, 1>(a, s);
+        }
         return hipErrorInvalidValue;
     }
     if (tile_rows == 0) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const int64_t ct = a.n_cols / kClBN;
         // 32-pixel tiles when even 64-pixel ones leave CUs idle (8 clips at 32^2, same box: residual-block convolution 36.7 ->
         // 30.0 us, 5x5 stride-2 128 -> 256 48.0 -> 39.1 us; a third stage on the 64-pixel tile measured no gain)
