@@ -444,3 +444,49 @@ def test_conv_layer_is_a_drop_in():
         CL.ConvLayer(64, 64, 5, padding=2, norm="BN")
     with pytest.raises(ValueError):
         CL.ConvLayer(64, 64, 7, padding=3)
+
+
+@pytest.mark.gpu
+def test_conv_nhwc_random_shapes():
+    """Seeded sweep over (batch, input size, Cin, Cout tile, kernel size, stride, pixel tile, residual, relu): every shape the
+    entry point takes is within 1 bf16 ulp of the float64 convolution of the same bf16 operands; every shape it does not take
+    (pixel count not a multiple of the tile) raises ValueError instead of computing something else."""
+    import torch
+    import torch.nn.functional as F
+    from v2v_amd import convlstm as CL
+    rng = np.random.default_rng(20261003)
+    ran = rejected = 0
+    for case in range(60):
+        cin = int(rng.choice([64, 128, 192, 256]))
+        cout = int(rng.choice([32, 64, 128, 256, 512]))
+        ks, stride = int(rng.choice([3, 5])), int(rng.choice([1, 2]))
+        b, h, w = int(rng.integers(1, 4)), int(rng.integers(4, 41)), int(rng.integers(4, 41))
+        if rng.random() < 0.6:                                                     # steer most cases onto a shape the tiles take
+            h, w = int(rng.choice([8, 16, 24, 32])) * stride, int(rng.choice([8, 16, 32])) * stride
+        tiles = [0, 32, 64, 128, 256] if cout % 256 == 0 else [0, 128, 256]
+        tile = int(rng.choice(tiles))
+        res, relu = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+        g = torch.Generator().manual_seed(case)
+        x = torch.randn((b, cin, h, w), generator=g)
+        r = torch.randn((b, cout, ho, wo), generator=g)
+        weight = (torch.rand((cout, cin, ks, ks), generator=g) * 2 - 1) * (3.0 / np.sqrt(cin * ks * ks))
+        bias = (torch.rand((cout,), generator=g) * 2 - 1) * 0.5
+        xn = _bf16_round(x).cuda().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
+        rn = _bf16_round(r).cuda().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous() if res else None
+        packed = CL.pack_conv_weights(weight.cuda())
+        need = tile or (128 if cout % 256 else 32)
+        if (b * ho * wo) % need:
+            with pytest.raises(ValueError):
+                CL.conv_nhwc(xn, packed, bias.cuda(), ks, stride, residual=rn, relu=relu, tile_rows=tile)
+            rejected += 1
+            continue
+        out = CL.conv_nhwc(xn, packed, bias.cuda(), ks, stride, residual=rn, relu=relu, tile_rows=tile)
+        want = F.conv2d(_bf16_round(x).double(), _bf16_round(weight).double(), bias.double(), stride=stride, padding=ks // 2)
+        want = want + _bf16_round(r).double() if res else want
+        want = torch.relu(want) if relu else want
+        got = out.permute(0, 3, 1, 2).float().cpu().double()
+        err = float(((got - want).abs() / (want.abs() + 1.0)).max())
+        assert err < 2.0 ** -8, (case, (b, cin, h, w), cout, ks, stride, tile, res, relu, err)
+        ran += 1
+    assert ran >= 25 and rejected >= 5, (ran, rejected)
