@@ -349,6 +349,11 @@ def test_residual_block_is_a_drop_in():
     ((2, 64, 31, 33), 256, 5, 2, 0, True, True),        # 544 = 17 x 32 output pixels: the 32-pixel tile
     ((1, 256, 16, 16), 256, 3, 1, 32, True, True),      # residual-block shape on the 32-pixel tile
     ((1, 128, 32, 32), 512, 5, 2, 0, False, True),      # two column tiles
+    ((1, 64, 16, 16), 32, 3, 1, 16, True, False),       # halo tiles (16 x 16 patch + halo staged once per channel chunk), pinned
+    ((1, 128, 32, 16), 128, 3, 1, 16, False, True),     # halo tiles, 3x3, 128 columns, two channel chunks
+    ((2, 192, 16, 32), 64, 5, 1, 16, True, True),       # halo tiles, 5x5, three channel chunks, one tap per weight group
+    ((1, 64, 48, 16), 32, 5, 1, 0, False, True),        # halo tiles picked by the launcher (5x5, 32 columns)
+    ((1, 64, 24, 16), 32, 5, 1, 128, False, True),      # same layer on the 128-pixel tile when H is not a multiple of 16
 ])
 def test_conv_nhwc_matches_reference_semantics(shape, cout, ks, stride, tile_rows, res, relu):
     """out = [relu](conv_ks(x, stride, pad ks // 2) + bias [+ residual]) (ConvLayer.forward, model/submodules.py:25-33) against
@@ -366,7 +371,7 @@ def test_conv_nhwc_matches_reference_semantics(shape, cout, ks, stride, tile_row
     xn = _bf16_round(x).cuda().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
     rn = _bf16_round(r).cuda().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous() if res else None
     packed = CL.pack_conv_weights(weight.cuda())
-    need = tile_rows or (128 if cout % 256 else 32)
+    need = (128 if cout % 256 else 32) if tile_rows in (0, 16) else tile_rows     # halo tiles (16) need H, W % 16 == 0: chosen so here
     if (b * ho * wo) % need:
         with pytest.raises(ValueError):
             CL.conv_nhwc(xn, packed, bias.cuda(), ks, stride, residual=rn, relu=relu, tile_rows=tile_rows)
@@ -464,6 +469,8 @@ def test_conv_nhwc_random_shapes():
         if rng.random() < 0.6:                                                     # steer most cases onto a shape the tiles take
             h, w = int(rng.choice([8, 16, 24, 32])) * stride, int(rng.choice([8, 16, 32])) * stride
         tiles = [0, 32, 64, 128, 256] if cout % 256 == 0 else [0, 128, 256]
+        if cout % 256 and stride == 1 and h % 16 == 0 and w % 16 == 0 and (ks == 3 or cout <= 64):
+            tiles.append(16)                                                       # halo tiles
         tile = int(rng.choice(tiles))
         res, relu = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
         ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
@@ -475,7 +482,7 @@ def test_conv_nhwc_random_shapes():
         xn = _bf16_round(x).cuda().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
         rn = _bf16_round(r).cuda().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous() if res else None
         packed = CL.pack_conv_weights(weight.cuda())
-        need = tile or (128 if cout % 256 else 32)
+        need = (128 if cout % 256 else 32) if tile in (0, 16) else tile
         if (b * ho * wo) % need:
             with pytest.raises(ValueError):
                 CL.conv_nhwc(xn, packed, bias.cuda(), ks, stride, residual=rn, relu=relu, tile_rows=tile)

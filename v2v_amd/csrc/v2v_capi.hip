@@ -629,9 +629,12 @@ int v2v_conv_nhwc_hip(const void *x, const void *packed, const float *bias, cons
     if (B < 1 || Hin < 1 || Win < 1 || Cin < 64 || Cin % 64 != 0 || Cin > 4096 || Cout > 4096 || v2v::conv_tile_cols((int)Cout) == 0)
         return fail(V2V_ERR_SHAPE, "need B,H,W >= 1, Cin %% 64 == 0, Cout in {32, 64, 128} or a multiple of 256");
     const int64_t H = (Hin - 1) / stride + 1, W = (Win - 1) / stride + 1;          // output size for pad = ks / 2
-    if (tile_rows != 0 && tile_rows != 128 && tile_rows != 256 && (Cout % 256 != 0 || (tile_rows != 32 && tile_rows != 64)))
+    if (tile_rows != 0 && tile_rows != 128 && tile_rows != 256 && tile_rows != 16 && (Cout % 256 != 0 || (tile_rows != 32 && tile_rows != 64)))
         return fail(V2V_ERR_PARAM, "tile_rows must be 0 (auto), 128 or 256 (and 32 or 64 for Cout %% 256 == 0)");
-    const int64_t need = tile_rows ? tile_rows : Cout % 256 == 0 ? 32 : 128;
+    const bool halo_fits = Cout % 256 != 0 && stride == 1 && H % 16 == 0 && W % 16 == 0 && (ks == 3 || Cout <= 64);   // see launch_conv_nhwc
+    const bool halo = halo_fits && (tile_rows == 16 || (tile_rows == 0 && ks == 5));
+    if (tile_rows == 16 && !halo) return fail(V2V_ERR_PARAM, "tile_rows 16 (halo tiles) needs stride 1, H and W multiples of 16 and Cout 32 / 64 (128 for 3x3)");
+    const int64_t need = halo ? 256 : tile_rows ? tile_rows : Cout % 256 == 0 ? 32 : 128;
     if ((B * H * W) % need != 0 || B * Hin * Win * Cin > 0x7FFFFFFFLL || B * H * W * Cout > 0x7FFFFFFFLL)
         return fail(V2V_ERR_SHAPE, "conv kernel needs (B*Hout*Wout) %% %lld == 0 and tensors below 2^31 elements", (long long)need);
     if (out == x) return fail(V2V_ERR_PARAM, "out must not alias x (neighbouring tiles read it)");

@@ -392,6 +392,161 @@ __global__ void __launch_bounds__(256) upsample2x_nhwc_bf16_kernel(const uint16_
     put(2 * iy + 1, 2 * ix + 1, R[1], 0.75f, R[2], 0.25f);
 }
 
+// ---- stride-1 convolutions with few output channels (the decoders: 5x5, 32 / 64 / 128 columns): HALO tiles ------------------
+// With one column tile of NF <= 4 fragments the kernel above is LDS-DMA-bound: every tap re-stages the 256 activations of the
+// tile for 8 NF MFMAs per wave.  Here the workgroup owns a 16 x 16 pixel patch of one image and stages, once per 64-channel
+// chunk, the patch WITH its halo ((16 + 2 pad)^2 pixels, out-of-image ones from the zero line) -- all ks^2 taps then read
+// their A fragments from it at shifted rows.  Weights stream through LDS in groups of `tps` taps (two buffers); one barrier
+// per group.  4 waves x 64 pixels (MF = 2: fragment row f = image rows 2f, 2f + 1 of the patch) x 32 NF columns.
+// LDS rows are 128 B with the slot XOR (row >> 1) & 7 as above, row = pixel index inside the halo patch.
+// Same packed weights as the kernel above ([tap * cc_all + cc][column][k]).
+struct ConvHaloLds { int a_bytes, b_bytes; };                     // one A patch buffer, one weight-group buffer
+__host__ __device__ constexpr int conv_halo_pw(int ks) { return 16 + 2 * (ks >> 1); }
+__host__ __device__ constexpr int conv_halo_pieces(int ks) { return (conv_halo_pw(ks) * conv_halo_pw(ks) + 7) / 8; }
+
+template <int NF>
+__global__ void __launch_bounds__(256, 2) conv_halo_kernel(const ConvLstmArgs a, int tps, int a_bufs)
+{
+    constexpr int kBN = NF * 32;
+    extern __shared__ __attribute__((aligned(128))) unsigned char cl_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;            // wave = wm: fragment rows 2 wm, 2 wm + 1
+    const int C = a.C, H = a.H, W = a.W, ks = a.ks, pad = ks >> 1, n_taps = ks * ks;
+    const int PW = 16 + 2 * pad, NP = PW * PW, n_pa = (NP + 7) >> 3;
+    const int a_bytes = n_pa * 1024, b_bytes = tps * kBN * 128;
+    unsigned char *const a_lds = cl_lds, *const b_lds = cl_lds + a_bufs * a_bytes;
+    const int tiles_x = W >> 4, tiles_y = H >> 4;
+    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, bimg = blockIdx.x / (tiles_x * tiles_y);
+    const int cc_x = C / kClBK, n_groups = (n_taps + tps - 1) / tps, n_chunks = cc_x * n_groups;
+    const int srow = lane >> 3, sslot = lane & 7;
+
+    // ---- A staging plan: wave w stages patch pieces w, w + 4, ... (8 patch pixels each) ----------------------------------
+    constexpr int kMaxPa = 13;                                            // ceil(50 / 4)
+    uint32_t a_off[kMaxPa];
+    uint32_t a_in = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxPa; ++j) {
+        const int pa = wave + 4 * j, hr = pa * 8 + srow;
+        const int hy = hr / PW, hx = hr - hy * PW;
+        const int iy = ty * 16 + hy - pad, ix = tx * 16 + hx - pad;
+        const bool in = pa < n_pa && hr < NP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        a_off[j] = in ? (uint32_t)((((int64_t)bimg * H + iy) * W + ix) * C) + (uint32_t)((sslot ^ ((hr >> 1) & 7)) * 8) : 0u;
+        a_in |= in ? (1u << j) : 0u;
+    }
+    auto stage_a = [&](int cc) __attribute__((always_inline)) {
+        unsigned char *dst = a_lds + (a_bufs == 2 ? (cc & 1) : 0) * a_bytes;
+        const uint16_t *src = a.x + cc * kClBK;
+#pragma unroll
+        for (int j = 0; j < kMaxPa; ++j) {
+            const int pa = wave + 4 * j;
+            if (pa < n_pa) {
+                const void *g = (a_in >> j) & 1u ? (const void *)(src + a_off[j]) : (const void *)g_cl_zero_line;
+                cl_glds16(g, dst + pa * 1024);
+            }
+        }
+    };
+    // weights of chunk (cc, tap group g) -> buffer `buf`: pieces of 8 columns, tap-major
+    auto stage_b = [&](int ck, int buf) __attribute__((always_inline)) {
+        const int cc = ck / n_groups, g = ck - cc * n_groups;
+        const int tap0 = g * tps, nt = min(tps, n_taps - tap0), n_pb = nt * (kBN / 8);
+        unsigned char *dst = b_lds + buf * b_bytes;
+        for (int pb = wave; pb < n_pb; pb += 4) {
+            const int tig = pb / (kBN / 8), brow0 = (pb - tig * (kBN / 8)) * 8, brow = brow0 + srow;
+            const uint16_t *wsrc = a.wp + (int64_t)((tap0 + tig) * cc_x + cc) * (kBN * kClBK) + brow * kClBK + (sslot ^ ((brow >> 1) & 7)) * 8;
+            cl_glds16(wsrc, dst + (tig * kBN + brow0) * 128);
+        }
+    };
+
+    // ---- fragment read plan ----------------------------------------------------------------------------------------------
+    const int fr = lane & 31, fh = lane >> 5;
+    int hr_base[2];                                                       // patch pixel of this lane's A row for tap (-pad, -pad)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) hr_base[i] = ((wave * 2 + i) * 2 + (fr >> 4)) * PW + (fr & 15);
+    const uint32_t b_sw = (uint32_t)((fr >> 1) & 7);
+
+    cl_f32x16 acc[2][NF];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < NF; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][g][r] = 0.0f;
+
+    stage_a(0);
+    stage_b(0, 0);
+    for (int ck = 0; ck < n_chunks; ++ck) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                  // chunk ck has landed; everyone is done with the other buffers
+        const int cc = ck / n_groups, g = ck - cc * n_groups;
+        if (ck + 1 < n_chunks) stage_b(ck + 1, (ck + 1) & 1);
+        if (g == 0 && cc + 1 < cc_x && a_bufs == 2) stage_a(cc + 1);      // the other patch buffer was last read in chunk ck - 1
+        const unsigned char *ab = a_lds + (a_bufs == 2 ? (cc & 1) : 0) * a_bytes, *bb = b_lds + (ck & 1) * b_bytes;
+        const int tap0 = g * tps, nt = min(tps, n_taps - tap0);
+        // 32 columns: fragments of tap t + 1 are read before the MFMAs of tap t are issued (two register sets)
+        cl_bf16x8 af0[2][4], bf0[NF][4], af1[2][4], bf1[NF][4];
+        auto load = [&](int tig, cl_bf16x8 (&af)[2][4], cl_bf16x8 (&bf)[NF][4]) __attribute__((always_inline)) {
+            const int tap = tap0 + tig, dy = tap / ks, dx = tap - dy * ks;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int hr = hr_base[i] + dy * PW + dx;
+                const uint32_t sw = (uint32_t)((hr >> 1) & 7);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) af[i][s] = *reinterpret_cast<const cl_bf16x8 *>(ab + hr * 128 + (((uint32_t)(2 * s + fh) ^ sw) << 4));
+            }
+#pragma unroll
+            for (int q = 0; q < NF; ++q)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    bf[q][s] = *reinterpret_cast<const cl_bf16x8 *>(bb + (tig * kBN + q * 32 + fr) * 128 + (((uint32_t)(2 * s + fh) ^ b_sw) << 4));
+        };
+        auto mma = [&](const cl_bf16x8 (&af)[2][4], const cl_bf16x8 (&bf)[NF][4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int q = 0; q < NF; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][s], bf[q][s], acc[i][q], 0, 0, 0);
+        };
+        if constexpr (NF == 1) {                                          // wider column tiles run one tap per group: nothing to prefetch
+            load(0, af0, bf0);
+            int tig = 0;
+            for (; tig + 1 < nt; tig += 2) {
+                load(tig + 1, af1, bf1);
+                mma(af0, bf0);
+                if (tig + 2 < nt) load(tig + 2, af0, bf0);
+                mma(af1, bf1);
+            }
+            if (tig < nt) mma(af0, bf0);
+        } else {
+            for (int tig = 0; tig < nt; ++tig) { load(tig, af0, bf0); mma(af0, bf0); }
+        }
+        if (a_bufs == 1 && g == n_groups - 1 && cc + 1 < cc_x) {         // single patch buffer: restage between the chunks of two cc
+            __syncthreads();
+            stage_a(cc + 1);
+        }
+    }
+
+    // ---- epilogue: bias (+ residual) (+ ReLU) -> bf16 NHWC ---------------------------------------------------------------------
+    const int N = a.n_cols;
+#pragma unroll
+    for (int q = 0; q < NF; ++q) {
+        const int oc = q * 32 + fr;
+        const float bias = a.bias[oc];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;                   // pixel inside the 32-pixel fragment row
+                const int py = (wave * 2 + i) * 2 + (row >> 4), px = row & 15;
+                const int64_t idx = ((((int64_t)bimg * H + ty * 16 + py) * W) + tx * 16 + px) * N + oc;
+                float v = acc[i][q][r] + bias;
+                if (a.residual) v += __uint_as_float((uint32_t)a.residual[idx] << 16);
+                if (a.relu) v = v > 0.0f ? v : (v != v ? v : 0.0f);
+                a.out_nhwc[idx] = f32_to_bf16_rne(v);
+            }
+        }
+    }
+}
+
 // [4C, 2C, 3, 3] fp32 (nn.Conv2d weight of ConvLSTM.Gates) -> packed bf16 (layout at the top of this file); one thread per element
 __global__ void __launch_bounds__(256) convlstm_pack_kernel(const float *w, uint16_t *wp, int C)
 {

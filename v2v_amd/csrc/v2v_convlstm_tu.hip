@@ -1,4 +1,5 @@
 // v2v_convlstm_tu.hip -- translation unit of the fused ConvLSTM step: launchers.
+#include <cstdlib>
 #include "v2v_convlstm.hpp"
 #include "v2v_args.hpp"
 
@@ -50,6 +51,34 @@ hipError_t launch_conv_nhwc(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
     const int64_t m = (int64_t)a.B * a.H * a.W;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    // halo tiles (conv_halo_kernel): the 16 x 16 patch with its halo staged once per 64-channel chunk.  One patch buffer + two
+    // weight-group buffers must leave room for TWO workgroups per CU (<= 80 KB): 8 clips of 256^2, same box, 5x5: 64 -> 32
+    // columns 0.117 -> 0.085 ms (3 taps per group), 128 -> 64 columns 0.079 -> 0.071 ms (1 tap); 256 -> 128 columns does not fit
+    // twice and measured 0.126-0.137 against 0.090 ms on the 128-pixel tile; with one workgroup per CU (two patch buffers or
+    // 5-tap groups) the same kernel is slower than the tiles above.  tile_rows 16 forces it (tests), 0 takes it where measured.
+    const int halo_a = conv_halo_pieces(a.ks) * 1024;
+    const int halo_tps = a.n_cols % 256 != 0 ? (80 * 1024 - halo_a) / (2 * a.n_cols * 128) : 0;
+    const bool halo_ok = a.n_cols % 256 != 0 && a.stride == 1 && a.H % 16 == 0 && a.W % 16 == 0 && halo_tps >= 1;
+    if (halo_ok && (tile_rows == 16 || (tile_rows == 0 && a.ks == 5 && a.n_cols <= 64))) {
+        const int nf = a.n_cols / 32;
+        const int tps = halo_tps < a.ks ? halo_tps : a.ks, a_bufs = 1;
+        const int lds = a_bufs * halo_a + 2 * tps * a.n_cols * 128;
+        const void *fn = nf == 4 ? (const void *)&conv_halo_kernel<4> : nf == 2 ? (const void *)&conv_halo_kernel<2> : (const void *)&conv_halo_kernel<1>;
+        static bool raised[3][64] = {};                              // once per instance and device (not in a captured launch path)
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        const int inst = nf == 4 ? 2 : nf - 1;
+        if (dev < 0 || dev >= 64 || !raised[inst][dev]) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            if (dev >= 0 && dev < 64) raised[inst][dev] = true;
+        }
+        const unsigned tiles = (unsigned)(a.B * (a.H / 16) * (a.W / 16));
+        if (nf == 4) hipLaunchKernelGGL(conv_halo_kernel<4>, dim3(tiles), dim3(256), lds, s, a, tps, a_bufs);
+        else if (nf == 2) hipLaunchKernelGGL(conv_halo_kernel<2>, dim3(tiles), dim3(256), lds, s, a, tps, a_bufs);
+        else hipLaunchKernelGGL(conv_halo_kernel<1>, dim3(tiles), dim3(256), lds, s, a, tps, a_bufs);
+        return hipGetLastError();
+    }
     if (a.n_cols % 256 != 0) {
         // one column tile of 4 / 2 / 1 B fragments per wave: 256 pixels (8 fragment rows of 4 waves x MF 2), or 128 pixels on
         // three stages when 256-pixel tiles leave CUs idle (8 clips at 64^2, same box: 5x5 256 -> 128 121 -> 88 us, 5x5
