@@ -397,15 +397,14 @@ __global__ void __launch_bounds__(256) upsample2x_nhwc_bf16_kernel(const uint16_
 // tile for 8 NF MFMAs per wave.  Here the workgroup owns a 16 x 16 pixel patch of one image and stages, once per 64-channel
 // chunk, the patch WITH its halo ((16 + 2 pad)^2 pixels, out-of-image ones from the zero line) -- all ks^2 taps then read
 // their A fragments from it at shifted rows.  Weights stream through LDS in groups of `tps` taps (two buffers); one barrier
-// per group.  4 waves x 64 pixels (MF = 2: fragment row f = image rows 2f, 2f + 1 of the patch) x 32 NF columns.
+// per group; one patch buffer, restaged between channel chunks, so that two workgroups fit a CU.  4 waves x 64 pixels (MF = 2: fragment row f = image rows 2f, 2f + 1 of the patch) x 32 NF columns.
 // LDS rows are 128 B with the slot XOR (row >> 1) & 7 as above, row = pixel index inside the halo patch.
 // Same packed weights as the kernel above ([tap * cc_all + cc][column][k]).
-struct ConvHaloLds { int a_bytes, b_bytes; };                     // one A patch buffer, one weight-group buffer
 __host__ __device__ constexpr int conv_halo_pw(int ks) { return 16 + 2 * (ks >> 1); }
 __host__ __device__ constexpr int conv_halo_pieces(int ks) { return (conv_halo_pw(ks) * conv_halo_pw(ks) + 7) / 8; }
 
 template <int NF>
-__global__ void __launch_bounds__(256, 2) conv_halo_kernel(const ConvLstmArgs a, int tps, int a_bufs)
+__global__ void __launch_bounds__(256, 2) conv_halo_kernel(const ConvLstmArgs a, int tps)
 {
     constexpr int kBN = NF * 32;
     extern __shared__ __attribute__((aligned(128))) unsigned char cl_lds[];
@@ -413,7 +412,7 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const ConvLstmArgs a,
     const int C = a.C, H = a.H, W = a.W, ks = a.ks, pad = ks >> 1, n_taps = ks * ks;
     const int PW = 16 + 2 * pad, NP = PW * PW, n_pa = (NP + 7) >> 3;
     const int a_bytes = n_pa * 1024, b_bytes = tps * kBN * 128;
-    unsigned char *const a_lds = cl_lds, *const b_lds = cl_lds + a_bufs * a_bytes;
+    unsigned char *const a_lds = cl_lds, *const b_lds = cl_lds + a_bytes;    // ONE patch buffer (two workgroups per CU), two weight-group buffers
     const int tiles_x = W >> 4, tiles_y = H >> 4;
     const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, bimg = blockIdx.x / (tiles_x * tiles_y);
     const int cc_x = C / kClBK, n_groups = (n_taps + tps - 1) / tps, n_chunks = cc_x * n_groups;
@@ -433,7 +432,7 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const ConvLstmArgs a,
         a_in |= in ? (1u << j) : 0u;
     }
     auto stage_a = [&](int cc) __attribute__((always_inline)) {
-        unsigned char *dst = a_lds + (a_bufs == 2 ? (cc & 1) : 0) * a_bytes;
+        unsigned char *dst = a_lds;
         const uint16_t *src = a.x + cc * kClBK;
 #pragma unroll
         for (int j = 0; j < kMaxPa; ++j) {
@@ -478,8 +477,7 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const ConvLstmArgs a,
         __syncthreads();                                                  // chunk ck has landed; everyone is done with the other buffers
         const int cc = ck / n_groups, g = ck - cc * n_groups;
         if (ck + 1 < n_chunks) stage_b(ck + 1, (ck + 1) & 1);
-        if (g == 0 && cc + 1 < cc_x && a_bufs == 2) stage_a(cc + 1);      // the other patch buffer was last read in chunk ck - 1
-        const unsigned char *ab = a_lds + (a_bufs == 2 ? (cc & 1) : 0) * a_bytes, *bb = b_lds + (ck & 1) * b_bytes;
+        const unsigned char *ab = a_lds, *bb = b_lds + (ck & 1) * b_bytes;
         const int tap0 = g * tps, nt = min(tps, n_taps - tap0);
         // 32 columns: fragments of tap t + 1 are read before the MFMAs of tap t are issued (two register sets)
         cl_bf16x8 af0[2][4], bf0[NF][4], af1[2][4], bf1[NF][4];
@@ -519,7 +517,7 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const ConvLstmArgs a,
         } else {
             for (int tig = 0; tig < nt; ++tig) { load(tig, af0, bf0); mma(af0, bf0); }
         }
-        if (a_bufs == 1 && g == n_groups - 1 && cc + 1 < cc_x) {         // single patch buffer: restage between the chunks of two cc
+        if (g == n_groups - 1 && cc + 1 < cc_x) {                        // restage the patch between two channel chunks (the CU's other workgroup covers the wait)
             __syncthreads();
             stage_a(cc + 1);
         }

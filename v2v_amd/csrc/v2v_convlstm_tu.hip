@@ -1,5 +1,4 @@
 // v2v_convlstm_tu.hip -- translation unit of the fused ConvLSTM step: launchers.
-#include <cstdlib>
 #include "v2v_convlstm.hpp"
 #include "v2v_args.hpp"
 
@@ -61,12 +60,10 @@ hipError_t launch_conv_nhwc(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
     const bool halo_ok = a.n_cols % 256 != 0 && a.stride == 1 && a.H % 16 == 0 && a.W % 16 == 0 && halo_tps >= 1;
     if (halo_ok && (tile_rows == 16 || (tile_rows == 0 && a.ks == 5 && a.n_cols <= 64))) {
         const int nf = a.n_cols / 32;
-        const int tps = halo_tps < a.ks ? halo_tps : a.ks, a_bufs = 1;
-        const int lds = a_bufs * halo_a + 2 * tps * a.n_cols * 128;
+        const int tps = halo_tps < a.ks ? halo_tps : a.ks;
+        const int lds = halo_a + 2 * tps * a.n_cols * 128;
         const void *fn = nf == 4 ? (const void *)&conv_halo_kernel<4> : nf == 2 ? (const void *)&conv_halo_kernel<2> : (const void *)&conv_halo_kernel<1>;
         static bool raised[3][64] = {};                              // once per instance and device (not in a captured launch path)
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
         const int inst = nf == 4 ? 2 : nf - 1;
         if (dev < 0 || dev >= 64 || !raised[inst][dev]) {
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -74,9 +71,9 @@ hipError_t launch_conv_nhwc(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
             if (dev >= 0 && dev < 64) raised[inst][dev] = true;
         }
         const unsigned tiles = (unsigned)(a.B * (a.H / 16) * (a.W / 16));
-        if (nf == 4) hipLaunchKernelGGL(conv_halo_kernel<4>, dim3(tiles), dim3(256), lds, s, a, tps, a_bufs);
-        else if (nf == 2) hipLaunchKernelGGL(conv_halo_kernel<2>, dim3(tiles), dim3(256), lds, s, a, tps, a_bufs);
-        else hipLaunchKernelGGL(conv_halo_kernel<1>, dim3(tiles), dim3(256), lds, s, a, tps, a_bufs);
+        if (nf == 4) hipLaunchKernelGGL(conv_halo_kernel<4>, dim3(tiles), dim3(256), lds, s, a, tps);
+        else if (nf == 2) hipLaunchKernelGGL(conv_halo_kernel<2>, dim3(tiles), dim3(256), lds, s, a, tps);
+        else hipLaunchKernelGGL(conv_halo_kernel<1>, dim3(tiles), dim3(256), lds, s, a, tps);
         return hipGetLastError();
     }
     if (a.n_cols % 256 != 0) {
