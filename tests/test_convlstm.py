@@ -348,7 +348,8 @@ def test_residual_block_is_a_drop_in():
     ((4, 64, 15, 31), 256, 5, 2, 128, True, True),      # odd input size, 4 x 8 x 16 = 512 output pixels
     ((2, 64, 31, 33), 256, 5, 2, 0, True, True),        # 544 = 17 x 32 output pixels: the 32-pixel tile
     ((1, 256, 16, 16), 256, 3, 1, 32, True, True),      # residual-block shape on the 32-pixel tile
-    ((1, 128, 32, 32), 512, 5, 2, 0, False, True),      # two column tiles
+    ((1, 128, 32, 32), 512, 5, 2, 0, False, True),      # two packed column tiles, four 64 px x 128 column workgroup tiles each
+    ((2, 256, 16, 16), 256, 3, 1, 0, True, True),       # small layer: 64 px x 128 columns (half a packed column tile per workgroup)
     ((1, 64, 16, 16), 32, 3, 1, 16, True, False),       # halo tiles (16 x 16 patch + halo staged once per channel chunk), pinned
     ((1, 128, 32, 16), 128, 3, 1, 16, False, True),     # halo tiles, 3x3, 128 columns, two channel chunks
     ((2, 192, 16, 32), 64, 5, 1, 16, True, True),       # halo tiles, 5x5, three channel chunks, one tap per weight group

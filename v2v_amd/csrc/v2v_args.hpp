@@ -87,6 +87,7 @@ struct ConvLstmArgs {
     uint16_t *out_nhwc;
     int32_t n_cols, relu;
     int32_t ks, stride, Hin, Win;          // taps per side (3 or 5, pad ks/2), stride (1 or 2), input size (H, W = the OUTPUT size)
+    int32_t pack_cols;                     // columns per PACKED weight tile when the instance's tile is narrower (0: the same)
 };
 hipError_t launch_convlstm_step(const ConvLstmArgs &a, int tile_rows, hipStream_t s);   // tile_rows: 0 auto, 64, 128 or 256
 hipError_t launch_convlstm_pack(const float *w, uint16_t *wp, int C, hipStream_t s);

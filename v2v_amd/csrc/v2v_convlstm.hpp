@@ -141,7 +141,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (STAGES == 2 && MF == 1) || WM *
         const int row = (wave * NB + j) * 8 + srow;
         boff[j] = (uint32_t)(row * kClBK + (sslot ^ ((row >> 1) & 7)) * 8);
     }
-    const uint16_t *wtile = a.wp + (int64_t)ct * n_taps * cc_all * (kBN * kClBK);
+    // a column tile narrower than the packed one (EPI = 1, 128-column instances on 256-column packing): sub-tile `ct % per`
+    const int pcols = (EPI == 1 && a.pack_cols) ? a.pack_cols : kBN, per = pcols / kBN;
+    const uint16_t *wtile = a.wp + (int64_t)(ct / per) * n_taps * cc_all * (pcols * kClBK) + (ct % per) * (kBN * kClBK);
 
     // LDS-DMA of chunk ck into buffer buf (part / nparts: a subset of the pieces, j % nparts == part).  The main loop issues
     // the whole chunk in front of the first k-step: spreading the pieces over the four k-steps was measured 10-15 % slower on
@@ -161,7 +163,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (STAGES == 2 && MF == 1) || WM *
             const void *g = in ? (const void *)(src + apix[j] + shift + aswz[j]) : (const void *)g_cl_zero_line;
             cl_glds16(g, abase + (wave * NA + j) * 1024);
         }
-        const uint16_t *wchunk = wtile + (int64_t)(tap * cc_all + cc) * (kBN * kClBK);
+        const uint16_t *wchunk = wtile + (int64_t)(tap * cc_all + cc) * (pcols * kClBK);
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if (j % nparts != part) continue;
