@@ -1,10 +1,16 @@
-"""Fused ConvLSTM step of the consumer side: host side of v2v_convlstm_step_hip.
+"""The recurrent UNet's layers on the matrix cores: host side of v2v_convlstm_step_hip, v2v_conv_nhwc_hip and
+v2v_upsample2x_nhwc_hip.
 
     ConvLSTM(input_size, hidden_size, kernel_size)        model/submodules.py:179-235 -- same constructor, same `Gates`
                                                           parameter names (state_dicts load unchanged), same
                                                           forward(input_, prev_state=None) -> (hidden, cell)
-    convlstm_step(...)                                    the raw NHWC step
-    nchw_to_nhwc_bf16(x, relu=False)                      layout change in front of it
+    ResidualBlock(in_channels, out_channels)              model/submodules.py:143-177 (norm=None): `conv1` / `conv2`
+    ConvLayer(in, out, kernel_size, stride, padding, activation, norm=None, upsample=False)
+                                                          model/submodules.py:6-33, and :68-96 (UpsampleConvLayer) with
+                                                          upsample=True; `conv2d`; forward(x, skip=None) folds the sum skip
+    convlstm_step / conv_nhwc / conv3x3_nhwc / upsample2x_nhwc     the raw NHWC bfloat16 operators
+    pack_gate_weights / pack_conv_weights                  one-off weight packing
+    nchw_to_nhwc_bf16(x, relu=False)                      layout change in front of them (not needed for channels-last bf16 input)
 
 The 3x3 gate convolution runs as an implicit GEMM on the bf16 matrix cores with fp32 accumulation and the gate / cell / hidden
 update fused on the accumulators (v2v_amd/csrc/v2v_convlstm.hpp).  Inference only (no autograd through the kernel: a call
