@@ -213,6 +213,23 @@ __global__ void __launch_bounds__(64 * WM * WN, (STAGES == 2 && MF == 1) || WM *
                 for (int g = 0; g < NF; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], bf[s & 1][g], acc[i][g], 0, 0, 0);
         }
     };
+    // 64- and 128-pixel tiles (MF = 1): the previous cell state of this lane's outputs is fetched while the LAST chunk's MFMAs
+    // run, so the epilogue does not start with a round trip to HBM (-1...-4 % on the same box; the 256-pixel tile has no
+    // registers left for it: 104 spilled, +30 %)
+    constexpr bool kCpre = EPI == 0 && MF == 1;
+    float cpre[kCpre ? MF : 1][16];
+    auto prefetch_c = [&]() __attribute__((always_inline)) {
+        if constexpr (kCpre) {
+            const int ch = ct * kClCh + wn * 32 + fr;
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t mrow = m0 + wm * 32 * MF + i * 32 + (r >> 2) * 8 + fh * 4 + (r & 3);
+                    cpre[i][r] = a.c_prev ? a.c_prev[mrow * C + ch] : 0.0f;
+                }
+        }
+    };
     if constexpr (STAGES == 2) {
         // two LDS buffers: the whole next chunk is issued in front of the first k-step, drained (vmcnt 0) before the next barrier
         stage(0, 0, 0, 1);
@@ -223,6 +240,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (STAGES == 2 && MF == 1) || WM *
             __syncthreads();                                     // chunk ck has landed; everyone is done with the other buffer
             CL_STAMP(t_bar)
             const bool more = ck + 1 < n_chunks;
+            if (!more) prefetch_c();
             k_steps(cl_lds + (ck & 1) * kClStage, [&](int s) __attribute__((always_inline)) {
                 if (more && s == 0) stage(ck + 1, (ck + 1) & 1, 0, 1);
             });
@@ -244,6 +262,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (STAGES == 2 && MF == 1) || WM *
             asm volatile("" ::: "memory");
             CL_STAMP(t_bar)
             const bool more2 = ck + 2 < n_chunks;
+            if (ck + 1 == n_chunks) prefetch_c();
             k_steps(cl_lds + buf * kClStage, [&](int s) __attribute__((always_inline)) {
                 if (more2 && s == 0) stage(ck + 2, buf2, 0, 1);
             });
@@ -279,7 +298,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (STAGES == 2 && MF == 1) || WM *
                 const int64_t idx = (mq + e) * C + ch;
                 const float gi = cl_sigmoid(acc[i][0][r] + b_i), gr = cl_sigmoid(acc[i][1][r] + b_r);
                 const float go = cl_sigmoid(acc[i][2][r] + b_o), gg = cl_tanh(acc[i][3][r] + b_g);
-                const float cp = a.c_prev ? a.c_prev[idx] : 0.0f;
+                float cp;
+                if constexpr (kCpre) cp = cpre[i][r];
+                else cp = a.c_prev ? a.c_prev[idx] : 0.0f;
                 const float cn = gr * cp + gi * gg;
                 const float hn = go * cl_tanh(cn);
                 a.c_state[idx] = cn;
