@@ -301,6 +301,14 @@ int v2v_conv_nhwc_hip(const void *x, const void *packed, const float *bias, cons
  * C % 8 == 0, 16-byte aligned buffers, out must not alias an input. */
 int v2v_upsample2x_nhwc_hip(const void *x, const void *skip, int64_t B, int64_t H, int64_t W, int64_t C, void *out, void *stream);
 
+/* The prediction layer: ConvLayer(base_num_channels, out, kernel_size=1, activation=None) (model/unet.py:58-64) applied to
+ * skip_sum(x, head) (model/unet.py:307): out[m][o] = bias[o] + sum_c w[o][c] * (x[m][c] + skip[m][c]); x / skip [M, C] bf16
+ * (NHWC with M = B*H*W; skip may be NULL; the sum is rounded to bf16 first, the weights to bf16, as bf16 autocast does), weight
+ * fp32 [Cout, C], out [M, Cout] fp32 or bf16 (out_dtype) -- for Cout = 1 that is the NCHW image.  C a power of two in 8..512,
+ * Cout 1..3. */
+int v2v_conv1x1_nhwc_hip(const void *x, const void *skip, const float *weight, const float *bias, int64_t M, int64_t C, int64_t Cout,
+                         void *out, int out_dtype, void *stream);
+
 /* fp32 or bf16 [B,C,H,W] (src_dtype V2V_F32 / V2V_BF16) -> bf16 [B,H,W,C] (relu != 0: through max(x,0), the activation in front of the recurrent block,
  * model/submodules.py:267-271 RecurrentConvLayer = ConvLayer(relu) -> ConvLSTM).  C % 64 == 0 and (H*W) % 64 == 0. */
 int v2v_nchw_to_nhwc_bf16_hip(const void *src, int src_dtype, int64_t B, int64_t C, int64_t H, int64_t W, int relu, void *dst, void *stream);

@@ -498,3 +498,33 @@ def test_conv_nhwc_random_shapes():
         assert err < 2.0 ** -8, (case, (b, cin, h, w), cout, ks, stride, tile, res, relu, err)
         ran += 1
     assert ran >= 25 and rejected >= 5, (ran, rejected)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,cout,with_skip,out_dtype", [((2, 16, 16, 32), 1, True, "bfloat16"), ((1, 5, 7, 64), 3, False, "float32"),
+                                                            ((1, 1, 3, 8), 2, True, "float32"), ((2, 32, 32, 512), 1, True, "bfloat16")])
+def test_conv1x1_prediction_layer(shape, cout, with_skip, out_dtype):
+    """pred(skip_sum(x, head)) (model/unet.py:58-64, :307) against the float64 evaluation of the same bf16 operands (sum and
+    weights rounded to bf16 as bf16 autocast does): 1e-5 relative for float32 output, 1 bf16 ulp for bfloat16."""
+    import torch
+    from v2v_amd import convlstm as CL
+    g = torch.Generator().manual_seed(sum(shape) + cout)
+    x = torch.randn(shape, generator=g).to(torch.bfloat16).cuda()
+    s = torch.randn(shape, generator=g).to(torch.bfloat16).cuda() if with_skip else None
+    w = (torch.rand((cout, shape[-1], 1, 1), generator=g) - 0.5).cuda()
+    b = torch.randn((cout,), generator=g).cuda()
+    out = CL.conv1x1_nhwc(x, w, b, s, out_dtype=getattr(torch, out_dtype))
+    src = (x + s) if with_skip else x
+    want = src.double() @ w.reshape(cout, -1).to(torch.bfloat16).double().t() + b.double()
+    assert out.shape == shape[:-1] + (cout,) and out.dtype == getattr(torch, out_dtype)
+    tol = 2.0 ** -8 if out_dtype == "bfloat16" else 1e-5
+    assert float(((out.double() - want).abs() / (want.abs() + 1.0)).max()) < tol
+    layer = CL.ConvLayer(shape[-1], cout, 1, activation=None).cuda().eval()            # the drop-in form, NCHW float32 in / out
+    xn = x.permute(0, 3, 1, 2).float().contiguous()
+    if (shape[1] * shape[2]) % 64 == 0 and shape[-1] % 64 == 0:
+        with torch.no_grad():
+            got = layer(xn)
+            ref = layer.conv2d(xn)
+        assert got.shape == ref.shape and float((got - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max()))
+    with pytest.raises(ValueError):
+        CL.ConvLayer(32, 8, 1, activation=None)

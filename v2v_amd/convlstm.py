@@ -9,6 +9,7 @@ v2v_upsample2x_nhwc_hip.
                                                           model/submodules.py:6-33, and :68-96 (UpsampleConvLayer) with
                                                           upsample=True; `conv2d`; forward(x, skip=None) folds the sum skip
     convlstm_step / conv_nhwc / conv3x3_nhwc / upsample2x_nhwc     the raw NHWC bfloat16 operators
+    conv1x1_nhwc                                           the 1x1 prediction layer on skip_sum(x, head) (ConvLayer with kernel_size 1)
     pack_gate_weights / pack_conv_weights                  one-off weight packing
     nchw_to_nhwc_bf16(x, relu=False)                      layout change in front of them (not needed for channels-last bf16 input)
 
@@ -268,6 +269,26 @@ def upsample2x_nhwc(x, skip=None):
     return out
 
 
+def conv1x1_nhwc(x, weight, bias, skip=None, out_dtype=torch.bfloat16):
+    """out[..., o] = bias[o] + sum_c weight[o, c] * (x[..., c] + skip[..., c]) on NHWC bfloat16 ([B,H,W,C] -> [B,H,W,Cout], Cout <= 3):
+    the prediction layer ConvLayer(base, out, 1, activation=None) on skip_sum(x, head) (model/unet.py:58-64, :307)."""
+    _lib.require_gpu()
+    for name, v in (("x", x), ("skip", skip)):
+        if v is not None and (not v.is_cuda or v.dtype != torch.bfloat16 or v.dim() != 4 or not v.is_contiguous()):
+            raise ValueError(f"{name} must be a contiguous bfloat16 CUDA tensor [B,H,W,C]")
+    if skip is not None and (skip.shape != x.shape or skip.device != x.device):
+        raise ValueError("skip must have x's shape and device")
+    b, h, w, c = x.shape
+    weight = weight.detach().reshape(weight.shape[0], -1).float().contiguous()
+    if weight.shape[1] != c or bias.numel() != weight.shape[0] or out_dtype not in _DTYPES:
+        raise ValueError("weight must be [Cout, C(,1,1)], bias [Cout], out_dtype float32 or bfloat16")
+    out = torch.empty((b, h, w, weight.shape[0]), dtype=out_dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().v2v_conv1x1_nhwc_hip(_ptr(x), _ptr(skip), _ptr(weight), _ptr(bias.detach().float().contiguous()), b * h * w, c,
+                                                   weight.shape[0], _ptr(out), _DTYPES[out_dtype], _lib.stream_ptr()))
+    return out
+
+
 class ConvLayer(nn.Module):
     """Drop-in for model/submodules.py:ConvLayer (:6-33) as the recurrent UNet builds its encoder / decoder convolutions
     (model/unet.py: kernel_size 5, padding 2, stride 2 or 1, activation 'relu' or None, norm=None): same constructor, same
@@ -280,9 +301,10 @@ class ConvLayer(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, activation="relu", norm=None, BN_momentum=0.1,
                  upsample=False):
         super().__init__()
-        if norm is not None or activation not in ("relu", None) or kernel_size not in (3, 5) or padding != kernel_size // 2 or stride not in (1, 2):
+        if norm is not None or activation not in ("relu", None) or kernel_size not in (1, 3, 5) or padding != kernel_size // 2 or stride not in (1, 2) \
+                or (kernel_size == 1 and (stride != 1 or activation is not None or upsample or out_channels > 3)):
             raise ValueError("the fused ConvLayer covers norm=None, activation 'relu' or None, kernel_size 3 or 5 with padding "
-                             "kernel_size // 2, stride 1 or 2 (what model/unet.py builds)")
+                             "kernel_size // 2, stride 1 or 2, and the 1x1 prediction layer (stride 1, no activation, <= 3 outputs)")
         self.conv2d = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=True)
         self.relu, self.upsample = activation == "relu", upsample
         self._packed = (None, None)
@@ -299,6 +321,20 @@ class ConvLayer(nn.Module):
         upsampling kernel -- layer(x, skip) == layer(x + skip)."""
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise RuntimeError("v2v_amd.convlstm.ConvLayer is inference-only (no autograd through the fused kernel)")
+        if self.conv2d.kernel_size[0] == 1:                                           # prediction layer: pred(skip_sum(x, head)), model/unet.py:307
+            nhwc = all(v is None or (v.dtype == torch.bfloat16 and v.dim() == 4 and v.is_contiguous(memory_format=torch.channels_last)
+                                     and not v.is_contiguous()) for v in (x, skip))
+            if not nhwc:
+                x, skip = (x if skip is None else x + skip), None
+            if nhwc:
+                xn = x.permute(0, 2, 3, 1)
+            elif x.shape[1] % 64 == 0 and (x.shape[2] * x.shape[3]) % 64 == 0:
+                xn = nchw_to_nhwc_bf16(x)
+            else:                                                                     # 32 channels: below the layout kernel's 64-channel tile
+                xn = x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
+            out = conv1x1_nhwc(xn, self.conv2d.weight, self.conv2d.bias, None if skip is None else skip.permute(0, 2, 3, 1),
+                               out_dtype=torch.bfloat16 if nhwc else x.dtype).permute(0, 3, 1, 2)
+            return out if nhwc else out.contiguous()
         if skip is not None and not self.upsample:
             raise ValueError("skip is the decoder's (upsample=True) sum skip connection")
 

@@ -649,6 +649,19 @@ int v2v_conv_nhwc_hip(const void *x, const void *packed, const float *bias, cons
     return e == hipSuccess ? V2V_OK : hip_fail(e, "conv (convlstm_step_kernel, EPI = 1) launch");
 }
 
+int v2v_conv1x1_nhwc_hip(const void *x, const void *skip, const float *weight, const float *bias, int64_t M, int64_t C, int64_t Cout,
+                         void *out, int out_dtype, void *stream)
+{
+    if (!x || !weight || !bias || !out) return fail(V2V_ERR_NULL, "v2v_conv1x1_nhwc_hip: x/weight/bias/out is NULL");
+    if (out_dtype != V2V_F32 && out_dtype != V2V_BF16) return fail(V2V_ERR_DTYPE, "out_dtype must be V2V_F32 or V2V_BF16");
+    if (M < 1 || C < 8 || C > 512 || (C & (C - 1)) != 0 || Cout < 1 || Cout > 3 || M * (C / 8) > 0x7FFFFFFFLL * 256)
+        return fail(V2V_ERR_SHAPE, "need M >= 1, C a power of two in 8..512, Cout 1..3");
+    if (!aligned(x, 16) || !aligned(skip, 16) || !aligned(out, out_dtype == V2V_F32 ? 4 : 2)) return fail(V2V_ERR_ALIGN, "x/skip need 16-byte alignment");
+    const hipError_t e = v2v::launch_conv1x1_nhwc(static_cast<const uint16_t *>(x), static_cast<const uint16_t *>(skip), weight, bias, out,
+                                                  out_dtype == V2V_BF16, M, (int)C, (int)Cout, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "conv1x1_nhwc_kernel launch");
+}
+
 int v2v_upsample2x_nhwc_hip(const void *x, const void *skip, int64_t B, int64_t H, int64_t W, int64_t C, void *out, void *stream)
 {
     if (!x || !out) return fail(V2V_ERR_NULL, "v2v_upsample2x_nhwc_hip: x/out is NULL");

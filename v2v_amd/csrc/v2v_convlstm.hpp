@@ -568,6 +568,55 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const ConvLstmArgs a,
     }
 }
 
+// The prediction layer (ConvLayer(base, out, kernel_size 1, activation None), model/unet.py:58-64, applied to skip_sum(x, head) at
+// :307): out[m][o] = bias[o] + sum_c bf16(w[o][c]) * bf16(x[m][c] + skip[m][c]) on NHWC bf16 -- HBM-bound (C x 2 (x 4 with the
+// skip) bytes read per pixel, COUT x 2 written).  C / 8 lanes share a pixel (16 bytes each, power of two <= 64), partial sums
+// meet by xor-shuffles; fp32 accumulation, one rounding of the result (bf16 or fp32 output).
+template <int COUT>
+__global__ void __launch_bounds__(256) conv1x1_nhwc_kernel(const uint16_t *x, const uint16_t *skip, const float *w, const float *bias,
+                                                           void *out, int out_bf16, int64_t M, int C)
+{
+    const int lpp = C >> 3;                                       // lanes per pixel
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t m = i / lpp;
+    const int g = (int)(i - m * lpp);
+    float part[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) part[o] = 0.0f;
+    if (m < M) {
+        float v[8];
+        cl_unpack8(*reinterpret_cast<const uint4 *>(x + m * C + g * 8), v);
+        if (skip) {
+            float s[8];
+            cl_unpack8(*reinterpret_cast<const uint4 *>(skip + m * C + g * 8), s);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const uint32_t pk = cl_pack_bf16(v[e] + s[e], v[e + 1] + s[e + 1]);
+                v[e] = __uint_as_float(pk << 16);
+                v[e + 1] = __uint_as_float(pk & 0xFFFF0000u);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < COUT; ++o)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float wv = __uint_as_float((uint32_t)f32_to_bf16_rne(w[o * C + g * 8 + e]) << 16);
+                part[o] = __builtin_fmaf(wv, v[e], part[o]);
+            }
+    }
+    for (int d = 1; d < lpp; d <<= 1)
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) part[o] += __shfl_xor(part[o], d);
+    if (m < M && g == 0) {
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            const float r = part[o] + bias[o];
+            if (out_bf16) static_cast<uint16_t *>(out)[m * COUT + o] = f32_to_bf16_rne(r);
+            else static_cast<float *>(out)[m * COUT + o] = r;
+        }
+    }
+}
+
 // [4C, 2C, 3, 3] fp32 (nn.Conv2d weight of ConvLSTM.Gates) -> packed bf16 (layout at the top of this file); one thread per element
 __global__ void __launch_bounds__(256) convlstm_pack_kernel(const float *w, uint16_t *wp, int C)
 {

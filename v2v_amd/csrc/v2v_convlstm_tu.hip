@@ -136,6 +136,20 @@ hipError_t launch_nchw_to_nhwc_bf16(const void *src, bool src_bf16, uint16_t *ds
     return hipGetLastError();
 }
 
+hipError_t launch_conv1x1_nhwc(const uint16_t *x, const uint16_t *skip, const float *w, const float *bias, void *out, int out_bf16, int64_t M,
+                               int C, int Cout, hipStream_t s)
+{
+    const int64_t n = M * (C / 8);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    switch (Cout) {
+    case 1: hipLaunchKernelGGL(conv1x1_nhwc_kernel<1>, grid, block, 0, s, x, skip, w, bias, out, out_bf16, M, C); break;
+    case 2: hipLaunchKernelGGL(conv1x1_nhwc_kernel<2>, grid, block, 0, s, x, skip, w, bias, out, out_bf16, M, C); break;
+    case 3: hipLaunchKernelGGL(conv1x1_nhwc_kernel<3>, grid, block, 0, s, x, skip, w, bias, out, out_bf16, M, C); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_upsample2x_nhwc(const uint16_t *x, const uint16_t *skip, uint16_t *out, int B, int H, int W, int C, hipStream_t s)
 {
     const int64_t n = (int64_t)B * H * W * (C / 8);                  // one work-item per input pixel and 8 channels
