@@ -301,6 +301,17 @@ int v2v_conv_nhwc_hip(const void *x, const void *packed, const float *bias, cons
  * C % 8 == 0, 16-byte aligned buffers, out must not alias an input. */
 int v2v_upsample2x_nhwc_hip(const void *x, const void *skip, int64_t B, int64_t H, int64_t W, int64_t C, void *out, void *stream);
 
+/* The head of the recurrent UNet: ConvLayer(num_bins, base_num_channels = 32, kernel_size 5, stride 1, padding 2, relu)
+ * (model/unet.py:77-78 / :265-266, ConvLayer.forward model/submodules.py:25-33) -- few input channels (<= 8: the voxel bins),
+ * 32 output channels.  x8 = the input as bf16 NHWC with the channels padded to 8 (v2v_to_nhwc8_bf16_hip makes it from a float32
+ * [B,C,H,W] tensor of any element strides); weight fp32 [32,Cin,ks,ks] packed once (v2v_conv_head_packed_elems(ks) bf16
+ * elements); out bf16 [B,H,W,32] = [relu](conv + bias).  ks 3 or 5 (pad ks/2), H and W multiples of 16. */
+int64_t v2v_conv_head_packed_elems(int ks);
+int v2v_conv_head_pack_weights_hip(const float *weight, int64_t Cin, int ks, void *packed, void *stream);
+int v2v_to_nhwc8_bf16_hip(const float *src, int64_t stride_b, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t B, int64_t C,
+                          int64_t H, int64_t W, void *dst, void *stream);
+int v2v_conv_head_nhwc_hip(const void *x8, const void *packed, const float *bias, int relu, int64_t B, int64_t H, int64_t W, int ks, void *out, void *stream);
+
 /* The prediction layer: ConvLayer(base_num_channels, out, kernel_size=1, activation=None) (model/unet.py:58-64) applied to
  * skip_sum(x, head) (model/unet.py:307): out[m][o] = bias[o] + sum_c w[o][c] * (x[m][c] + skip[m][c]); x / skip [M, C] bf16
  * (NHWC with M = B*H*W; skip may be NULL; the sum is rounded to bf16 first, the weights to bf16, as bf16 autocast does), weight

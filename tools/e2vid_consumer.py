@@ -92,7 +92,7 @@ class E2VIDShapedConsumer(nn.Module):
     def __init__(self, num_bins=5, base=32, num_encoders=3, num_res=2, fused_convlstm=False):
         super().__init__()
         self.fused = fused_convlstm
-        self.head = nn.Conv2d(num_bins, base, 5, padding=2)
+        self.head = _FusedConv(num_bins, base, 1) if fused_convlstm and base == 32 and num_bins <= 8 else nn.Conv2d(num_bins, base, 5, padding=2)
         chans = [base * 2 ** i for i in range(num_encoders + 1)]
         # fused: every 5x5 convolution whose input depth is a multiple of 64 runs on the matrix-core kernel too (enc1 reads 32 channels)
         fconv = lambda a, b, s, up=False: _FusedConv(a, b, s, up) if fused_convlstm and a % 64 == 0 else None
@@ -110,6 +110,8 @@ class E2VIDShapedConsumer(nn.Module):
             sd = {(k.replace(".a.", ".block.conv1.").replace(".b.", ".block.conv2.") if k.startswith("res.") else k): v for k, v in sd.items()}
             fused_convs = {f"{n}.{i}" for n, ml in (("enc", self.enc), ("dec", self.dec)) for i, m in enumerate(ml) if isinstance(m, _FusedConv)}
             fused_convs.add("pred")
+            if isinstance(self.head, _FusedConv):
+                fused_convs.add("head")
             sd = {(k.rsplit(".", 1)[0] + ".layer.conv2d." + k.rsplit(".", 1)[1] if k.rsplit(".", 1)[0] in fused_convs else k): v for k, v in sd.items()}
         return self.load_state_dict(sd)
 
@@ -117,7 +119,7 @@ class E2VIDShapedConsumer(nn.Module):
         self.states = [None] * len(self.enc)
 
     def forward(self, x):
-        x = F.relu(self.head(x))
+        x = self.head(x) if isinstance(self.head, _FusedConv) else F.relu(self.head(x))        # fused: conv + bias + ReLU in one kernel
         head, blocks = x, []
         for i, (conv, rec) in enumerate(zip(self.enc, self.rec)):
             if isinstance(conv, _FusedConv):

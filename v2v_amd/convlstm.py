@@ -10,6 +10,7 @@ v2v_upsample2x_nhwc_hip.
                                                           upsample=True; `conv2d`; forward(x, skip=None) folds the sum skip
     convlstm_step / conv_nhwc / conv3x3_nhwc / upsample2x_nhwc     the raw NHWC bfloat16 operators
     conv1x1_nhwc                                           the 1x1 prediction layer on skip_sum(x, head) (ConvLayer with kernel_size 1)
+    conv_head_nhwc / to_nhwc8_bf16 / pack_head_weights     the head (voxel bins -> 32 channels; ConvLayer with <= 8 input channels)
     pack_gate_weights / pack_conv_weights                  one-off weight packing
     nchw_to_nhwc_bf16(x, relu=False)                      layout change in front of them (not needed for channels-last bf16 input)
 
@@ -289,6 +290,47 @@ def conv1x1_nhwc(x, weight, bias, skip=None, out_dtype=torch.bfloat16):
     return out
 
 
+def to_nhwc8_bf16(x):
+    """float32 [B, C <= 8, H, W] of any strides -> bfloat16 [B, H, W, 8] with the channels zero-padded to 8: the head's input layout."""
+    _lib.require_gpu()
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] > 8:
+        raise ValueError("x must be a float32 CUDA tensor [B, C <= 8, H, W]")
+    b, c, h, w = x.shape
+    out = torch.empty((b, h, w, 8), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().v2v_to_nhwc8_bf16_hip(_ptr(x), *x.stride(), b, c, h, w, _ptr(out), _lib.stream_ptr()))
+    return out
+
+
+def pack_head_weights(weight):
+    """nn.Conv2d(Cin <= 8, 32, ks, padding=ks//2).weight float32 -> the head kernel's packed bfloat16 stream (taps along K)."""
+    _lib.require_gpu()
+    if not weight.is_cuda or weight.dtype != torch.float32 or weight.dim() != 4 or weight.shape[0] != 32 or weight.shape[1] > 8 \
+            or weight.shape[2] != weight.shape[3] or weight.shape[2] not in (3, 5):
+        raise ValueError("weight must be a float32 CUDA tensor [32, Cin <= 8, ks, ks], ks 3 or 5")
+    ks = weight.shape[2]
+    packed = torch.empty((_lib.lib().v2v_conv_head_packed_elems(ks),), dtype=torch.bfloat16, device=weight.device)
+    with torch.cuda.device(weight.device):
+        _lib.check(_lib.lib().v2v_conv_head_pack_weights_hip(_ptr(weight.detach().contiguous()), weight.shape[1], ks, _ptr(packed), _lib.stream_ptr()))
+    return packed
+
+
+def conv_head_nhwc(x8, packed, bias, ks: int, relu=True):
+    """out = [relu](conv_ks(x, stride 1, pad ks//2) + bias): x8 [B,H,W,8] bfloat16 (to_nhwc8_bf16) -> [B,H,W,32] bfloat16; the UNet's
+    head ConvLayer(num_bins, 32, 5, stride 1, padding 2) (model/unet.py:77-78).  H and W multiples of 16."""
+    _lib.require_gpu()
+    if not x8.is_cuda or x8.dtype != torch.bfloat16 or x8.dim() != 4 or x8.shape[3] != 8 or not x8.is_contiguous():
+        raise ValueError("x8 must be a contiguous bfloat16 CUDA tensor [B,H,W,8]")
+    if bias.numel() != 32 or packed.dtype != torch.bfloat16 or packed.numel() != _lib.lib().v2v_conv_head_packed_elems(ks):
+        raise ValueError("bias must be [32] and packed the output of pack_head_weights for the same ks")
+    b, h, w, _ = x8.shape
+    out = torch.empty((b, h, w, 32), dtype=torch.bfloat16, device=x8.device)
+    with torch.cuda.device(x8.device):
+        _lib.check(_lib.lib().v2v_conv_head_nhwc_hip(_ptr(x8), _ptr(packed), _ptr(bias.detach().float().contiguous()), int(bool(relu)), b, h, w, ks,
+                                                     _ptr(out), _lib.stream_ptr()))
+    return out
+
+
 class ConvLayer(nn.Module):
     """Drop-in for model/submodules.py:ConvLayer (:6-33) as the recurrent UNet builds its encoder / decoder convolutions
     (model/unet.py: kernel_size 5, padding 2, stride 2 or 1, activation 'relu' or None, norm=None): same constructor, same
@@ -307,13 +349,16 @@ class ConvLayer(nn.Module):
                              "kernel_size // 2, stride 1 or 2, and the 1x1 prediction layer (stride 1, no activation, <= 3 outputs)")
         self.conv2d = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=True)
         self.relu, self.upsample = activation == "relu", upsample
+        self.head = in_channels <= 8 and kernel_size in (3, 5)                  # the UNet's head: voxel bins -> 32 channels
+        if self.head and (out_channels != 32 or stride != 1 or upsample):
+            raise ValueError("with <= 8 input channels the fused ConvLayer is the UNet's head: 32 output channels, stride 1")
         self._packed = (None, None)
 
     def _weights(self):
         w = self.conv2d.weight
         key = (w.data_ptr(), w._version, w.device)
         if self._packed[0] != key:
-            self._packed = (key, pack_conv_weights(w.detach()))
+            self._packed = (key, (pack_head_weights if self.head else pack_conv_weights)(w.detach()))
         return self._packed[1]
 
     def forward(self, x, skip=None):
@@ -337,6 +382,12 @@ class ConvLayer(nn.Module):
             return out if nhwc else out.contiguous()
         if skip is not None and not self.upsample:
             raise ValueError("skip is the decoder's (upsample=True) sum skip connection")
+        if self.head:                                                                  # model/unet.py:77-78: any float layout in, bf16 out
+            low = x.dtype == torch.bfloat16 or (x.is_cuda and torch.is_autocast_enabled())
+            cl = x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+            out = conv_head_nhwc(to_nhwc8_bf16(x.float()), self._weights(), self.conv2d.bias, self.conv2d.kernel_size[0], relu=self.relu).permute(0, 3, 1, 2)
+            out = out if cl else out.contiguous()
+            return out if low else out.to(x.dtype)
 
         def is_nhwc(v):
             return v.dtype == torch.bfloat16 and v.dim() == 4 and v.is_contiguous(memory_format=torch.channels_last) and not v.is_contiguous()

@@ -93,6 +93,9 @@ hipError_t launch_convlstm_step(const ConvLstmArgs &a, int tile_rows, hipStream_
 hipError_t launch_convlstm_pack(const float *w, uint16_t *wp, int C, hipStream_t s);
 hipError_t launch_conv_nhwc(const ConvLstmArgs &a, int tile_rows, hipStream_t s);
 int conv_tile_cols(int Cout);             // columns per tile of the instance launch_conv_nhwc takes for Cout (0: unsupported)
+hipError_t launch_conv_head(const uint16_t *x8, const uint16_t *wp, const float *bias, uint16_t *out, int B, int H, int W, int ks, int relu, hipStream_t s);
+hipError_t launch_conv_head_pack(const float *w, uint16_t *wp, int Cin, int ks, hipStream_t s);
+hipError_t launch_to_nhwc8_bf16(const float *src, int64_t sb, int64_t sc, int64_t sh, int64_t sw, uint16_t *dst, int B, int C, int H, int W, hipStream_t s);
 hipError_t launch_conv1x1_nhwc(const uint16_t *x, const uint16_t *skip, const float *w, const float *bias, void *out, int out_bf16, int64_t M,
                                int C, int Cout, hipStream_t s);
 hipError_t launch_upsample2x_nhwc(const uint16_t *x, const uint16_t *skip, uint16_t *out, int B, int H, int W, int C, hipStream_t s);

@@ -649,6 +649,40 @@ int v2v_conv_nhwc_hip(const void *x, const void *packed, const float *bias, cons
     return e == hipSuccess ? V2V_OK : hip_fail(e, "conv (convlstm_step_kernel, EPI = 1) launch");
 }
 
+int64_t v2v_conv_head_packed_elems(int ks) { return (ks == 3 || ks == 5) ? (int64_t)((ks * ks + 7) / 8) * 32 * 64 : -1; }
+
+int v2v_conv_head_pack_weights_hip(const float *weight, int64_t Cin, int ks, void *packed, void *stream)
+{
+    if (!weight || !packed) return fail(V2V_ERR_NULL, "v2v_conv_head_pack_weights_hip: weight/packed is NULL");
+    if (Cin < 1 || Cin > 8 || (ks != 3 && ks != 5)) return fail(V2V_ERR_SHAPE, "need 1 <= Cin <= 8 and ks 3 or 5 (32 output channels)");
+    if (!aligned(packed, 16)) return fail(V2V_ERR_ALIGN, "packed needs 16-byte alignment");
+    const hipError_t e = v2v::launch_conv_head_pack(weight, static_cast<uint16_t *>(packed), (int)Cin, ks, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "conv_head_pack_kernel launch");
+}
+
+int v2v_to_nhwc8_bf16_hip(const float *src, int64_t stride_b, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t B, int64_t C,
+                          int64_t H, int64_t W, void *dst, void *stream)
+{
+    if (!src || !dst) return fail(V2V_ERR_NULL, "v2v_to_nhwc8_bf16_hip: src/dst is NULL");
+    if (B < 1 || C < 1 || C > 8 || H < 1 || W < 1 || B * H * W > 0x7FFFFFFFLL) return fail(V2V_ERR_SHAPE, "need B,H,W >= 1, 1 <= C <= 8, B*H*W < 2^31");
+    if (!aligned(dst, 16) || !aligned(src, 4)) return fail(V2V_ERR_ALIGN, "dst needs 16-byte alignment");
+    const hipError_t e = v2v::launch_to_nhwc8_bf16(src, stride_b, stride_c, stride_h, stride_w, static_cast<uint16_t *>(dst), (int)B, (int)C, (int)H, (int)W,
+                                                   static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "to_nhwc8_bf16_kernel launch");
+}
+
+int v2v_conv_head_nhwc_hip(const void *x8, const void *packed, const float *bias, int relu, int64_t B, int64_t H, int64_t W, int ks, void *out, void *stream)
+{
+    if (!x8 || !packed || !bias || !out) return fail(V2V_ERR_NULL, "v2v_conv_head_nhwc_hip: x8/packed/bias/out is NULL");
+    if (ks != 3 && ks != 5) return fail(V2V_ERR_PARAM, "ks must be 3 or 5");
+    if (B < 1 || H < 16 || W < 16 || H % 16 != 0 || W % 16 != 0 || B * H * W * 32 > 0x7FFFFFFFLL)
+        return fail(V2V_ERR_SHAPE, "need B >= 1, H and W multiples of 16, output below 2^31 elements");
+    if (!aligned(x8, 16) || !aligned(packed, 16) || !aligned(out, 2) || !aligned(bias, 4)) return fail(V2V_ERR_ALIGN, "x8/packed need 16-byte alignment");
+    const hipError_t e = v2v::launch_conv_head(static_cast<const uint16_t *>(x8), static_cast<const uint16_t *>(packed), bias, static_cast<uint16_t *>(out),
+                                               (int)B, (int)H, (int)W, ks, relu ? 1 : 0, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "conv_head_kernel launch");
+}
+
 int v2v_conv1x1_nhwc_hip(const void *x, const void *skip, const float *weight, const float *bias, int64_t M, int64_t C, int64_t Cout,
                          void *out, int out_dtype, void *stream)
 {

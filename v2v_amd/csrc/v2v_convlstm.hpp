@@ -617,6 +617,97 @@ __global__ void __launch_bounds__(256) conv1x1_nhwc_kernel(const uint16_t *x, co
     }
 }
 
+// ---- the head of the UNet: few input channels (the voxel bins, <= 8), 32 output channels, stride 1 (ConvLayer, model/unet.py:77) ----
+// Input NHWC with the channels padded to 8 (one 16-byte slot per pixel).  K is packed TAP-major: k = 8 slot + c of chunk ck is
+// channel c of tap 8 ck + slot (25 taps -> 4 chunks of 64, the 7 spare slots are zero weights and read a zero slot), so a lane's
+// A fragment of one k-step is ONE 16-byte LDS read of the halo patch at its tap's pixel -- no im2col copy anywhere.  A 16 x 16
+// pixel patch per workgroup (4 waves x 64 pixels), patch + halo (6.4 KB) and ALL weights (ceil(taps / 8) x 32 x 128 B) staged once:
+// one barrier in the kernel.  Output bias (+ ReLU) -> bf16 NHWC [B,H,W,32].  HBM-bound on the output write.
+__global__ void __launch_bounds__(256) conv_head_kernel(const uint16_t *x8, const uint16_t *wp, const float *bias, uint16_t *out, int B, int H, int W, int ks, int relu)
+{
+    extern __shared__ __attribute__((aligned(128))) unsigned char cl_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pad = ks >> 1, n_taps = ks * ks, n_ck = (n_taps + 7) >> 3;
+    const int PW = 16 + 2 * pad, NP = PW * PW;
+    unsigned char *const patch = cl_lds;                              // NP pixels x 16 B, then one zero slot
+    unsigned char *const wl = cl_lds + ((NP * 16 + 16 + 127) & ~127);  // n_ck x 32 columns x 128 B, slot-swizzled rows
+    const int tiles_x = W >> 4, tiles_y = H >> 4;
+    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, bimg = blockIdx.x / (tiles_x * tiles_y);
+    for (int i = threadIdx.x; i <= NP; i += 256) {                    // patch (+ the zero slot at index NP)
+        const int hy = i / PW, hx = i - hy * PW;
+        const int iy = ty * 16 + hy - pad, ix = tx * 16 + hx - pad;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (i < NP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+            v = *reinterpret_cast<const uint4 *>(x8 + (((int64_t)bimg * H + iy) * W + ix) * 8);
+        *reinterpret_cast<uint4 *>(patch + i * 16) = v;
+    }
+    for (int i = threadIdx.x; i < n_ck * 32 * 8; i += 256) {          // weights: 16-byte slots, XOR swizzle on the slot as everywhere
+        const int row = i >> 3, slot = i & 7, col = row & 31;
+        *reinterpret_cast<uint4 *>(wl + row * 128 + ((slot ^ ((col >> 1) & 7)) << 4)) = *reinterpret_cast<const uint4 *>(wp + (int64_t)row * 64 + slot * 8);
+    }
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;
+    int hr_base[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) hr_base[i] = ((wave * 2 + i) * 2 + (fr >> 4)) * PW + (fr & 15);
+    const uint32_t b_sw = (uint32_t)((fr >> 1) & 7);
+    cl_f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    for (int ck = 0; ck < n_ck; ++ck) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int tap = ck * 8 + 2 * s + fh;                      // this lane's tap in k-step s
+            const int dy = tap / ks, dx = tap - dy * ks;
+            const bool live = tap < n_taps;
+            const cl_bf16x8 bf = *reinterpret_cast<const cl_bf16x8 *>(wl + (ck * 32 + fr) * 128 + (((uint32_t)(2 * s + fh) ^ b_sw) << 4));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int hr = live ? hr_base[i] + dy * PW + dx : NP;
+                const cl_bf16x8 af = *reinterpret_cast<const cl_bf16x8 *>(patch + hr * 16);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[i], 0, 0, 0);
+            }
+        }
+    }
+    const float bv = bias[fr];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+            const int py = (wave * 2 + i) * 2 + (row >> 4), px = row & 15;
+            float v = acc[i][r] + bv;
+            if (relu) v = v > 0.0f ? v : (v != v ? v : 0.0f);
+            out[((((int64_t)bimg * H + ty * 16 + py) * W) + tx * 16 + px) * 32 + fr] = f32_to_bf16_rne(v);
+        }
+    }
+}
+
+// nn.Conv2d weight fp32 [32, Cin <= 8, ks, ks] -> [chunk][32 columns][64 k], k = 8 slot + c <-> tap 8 chunk + slot, channel c (zero beyond)
+__global__ void __launch_bounds__(256) conv_head_pack_kernel(const float *w, uint16_t *wp, int Cin, int ks)
+{
+    const int n_taps = ks * ks, n_ck = (n_taps + 7) >> 3;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_ck * 32 * 64) return;
+    const int k = i & 63, col = (i >> 6) & 31, ck = i >> 11;
+    const int tap = ck * 8 + (k >> 3), c = k & 7;
+    wp[i] = (tap < n_taps && c < Cin) ? f32_to_bf16_rne(w[((int64_t)col * Cin + c) * n_taps + tap]) : (uint16_t)0;
+}
+
+// float32 [B, C <= 8, H, W] with arbitrary element strides -> bf16 [B, H, W, 8], channels C..7 zero (the head's input layout)
+__global__ void __launch_bounds__(256) to_nhwc8_bf16_kernel(const float *src, int64_t sb, int64_t sc, int64_t sh, int64_t sw, uint16_t *dst, int B, int C, int H, int W)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * H * W) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H), b = (int)(i / ((int64_t)W * H));
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = c < C ? src[b * sb + c * sc + y * sh + x * sw] : 0.0f;
+    *reinterpret_cast<uint4 *>(dst + i * 8) = make_uint4(cl_pack_bf16(v[0], v[1]), cl_pack_bf16(v[2], v[3]), cl_pack_bf16(v[4], v[5]), cl_pack_bf16(v[6], v[7]));
+}
+
 // [4C, 2C, 3, 3] fp32 (nn.Conv2d weight of ConvLSTM.Gates) -> packed bf16 (layout at the top of this file); one thread per element
 __global__ void __launch_bounds__(256) convlstm_pack_kernel(const float *w, uint16_t *wp, int C)
 {

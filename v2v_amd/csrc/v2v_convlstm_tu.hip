@@ -136,6 +136,27 @@ hipError_t launch_nchw_to_nhwc_bf16(const void *src, bool src_bf16, uint16_t *ds
     return hipGetLastError();
 }
 
+hipError_t launch_conv_head(const uint16_t *x8, const uint16_t *wp, const float *bias, uint16_t *out, int B, int H, int W, int ks, int relu, hipStream_t s)
+{
+    const int pw = 16 + 2 * (ks >> 1), lds = ((pw * pw * 16 + 16 + 127) & ~127) + ((ks * ks + 7) / 8) * 32 * 128;
+    hipLaunchKernelGGL(conv_head_kernel, dim3((unsigned)(B * (H / 16) * (W / 16))), dim3(256), lds, s, x8, wp, bias, out, B, H, W, ks, relu);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_head_pack(const float *w, uint16_t *wp, int Cin, int ks, hipStream_t s)
+{
+    const int n = ((ks * ks + 7) / 8) * 32 * 64;
+    hipLaunchKernelGGL(conv_head_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, wp, Cin, ks);
+    return hipGetLastError();
+}
+
+hipError_t launch_to_nhwc8_bf16(const float *src, int64_t sb, int64_t sc, int64_t sh, int64_t sw, uint16_t *dst, int B, int C, int H, int W, hipStream_t s)
+{
+    const int64_t n = (int64_t)B * H * W;
+    hipLaunchKernelGGL(to_nhwc8_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, sb, sc, sh, sw, dst, B, C, H, W);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv1x1_nhwc(const uint16_t *x, const uint16_t *skip, const float *w, const float *bias, void *out, int out_bf16, int64_t M,
                                int C, int Cout, hipStream_t s)
 {
