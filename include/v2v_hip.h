@@ -288,8 +288,10 @@ int v2v_conv3x3_nhwc_hip(const void *x, const void *packed, const float *bias, c
  * model/unet.py:34-60, 83-87: 5x5, stride 2 in the encoders, stride 1 after the bilinear upsampling in the decoders, ReLU).
  * ks = 3 or 5 (pad ks/2), stride 1 or 2; x [B,Hin,Win,Cin] -> out [B,Hout,Wout,Cout] with Hout = (Hin-1)/stride + 1; Cin % 64 == 0;
  * Cout a multiple of 256, or 128 / 64 / 32 (then (B*Hout*Wout) % 128 == 0); weight fp32 [Cout,Cin,ks,ks].
+ * Cin = 32 with Cout 64 / 128 (the UNet's first encoder, model/unet.py:34-44 with base 32) packs two taps per 64-wide K chunk.
  * tile_rows 16 = halo tiles (a 16x16 pixel patch staged once per channel chunk with its halo; stride 1, H and W multiples of
  * 16, Cout 32 / 64, or 128 for 3x3): what 0 picks for the 5x5 decoders with 32 / 64 output channels. */
+int64_t v2v_conv_packed_elems(int64_t Cin, int64_t Cout, int ks);      /* bf16 elements of the packed stream; -1: shape not taken */
 int v2v_conv_pack_weights_hip(const float *weight, int64_t Cin, int64_t Cout, int ks, void *packed, void *stream);
 int v2v_conv_nhwc_hip(const void *x, const void *packed, const float *bias, const void *residual, int relu, int64_t B, int64_t Hin,
                       int64_t Win, int64_t Cin, int64_t Cout, int ks, int stride, void *out, int tile_rows, void *stream);

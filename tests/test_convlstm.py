@@ -354,6 +354,9 @@ def test_residual_block_is_a_drop_in():
     ((1, 256, 16, 16), 256, 3, 1, 32, True, True),      # residual-block shape on the 32-pixel tile
     ((1, 128, 32, 32), 512, 5, 2, 0, False, True),      # two packed column tiles, four 64 px x 128 column workgroup tiles each
     ((2, 256, 16, 16), 256, 3, 1, 0, True, True),       # small layer: 64 px x 128 columns (half a packed column tile per workgroup)
+    ((2, 32, 32, 32), 64, 5, 2, 0, False, True),        # 32 input channels (enc1): two taps per K chunk, 25 taps -> the last half chunk is zero
+    ((1, 32, 16, 16), 128, 3, 1, 256, True, False),     # 32 input channels, 3x3, 128 columns, pinned 256-pixel tile
+    ((1, 32, 33, 31), 64, 5, 2, 128, True, True),       # 32 input channels, odd input size, 17 x 16 = 272 pixels -> rejected on the 128-pixel tile
     ((1, 64, 16, 16), 32, 3, 1, 16, True, False),       # halo tiles (16 x 16 patch + halo staged once per channel chunk), pinned
     ((1, 128, 32, 16), 128, 3, 1, 16, False, True),     # halo tiles, 3x3, 128 columns, two channel chunks
     ((2, 192, 16, 32), 64, 5, 1, 16, True, True),       # halo tiles, 5x5, three channel chunks, one tap per weight group

@@ -5,7 +5,7 @@ Stock PyTorch-ROCm ops by default -- it is NOT part of the product package (SURV
 bench.py uses it to measure how fast the fused simulator can feed a consumer.  fused_convlstm=True swaps the three recurrent
 blocks for v2v_amd.convlstm.ConvLSTM, the two residual blocks for v2v_amd.convlstm.ResidualBlock and the 5x5 encoder / decoder
 convolutions with >= 64 input channels for v2v_amd.convlstm.ConvLayer (the matrix-core kernels of the
-recurrent encoder); the head, the first encoder convolution (32 input channels), the upsampling and the 1x1 prediction stay stock.
+recurrent encoder), as do the head, the upsampling and the 1x1 prediction: no stock layer is left on the forward path.
 Parameter count matches the reference model: 10,710,401.
 """
 import torch
@@ -94,8 +94,8 @@ class E2VIDShapedConsumer(nn.Module):
         self.fused = fused_convlstm
         self.head = _FusedConv(num_bins, base, 1) if fused_convlstm and base == 32 and num_bins <= 8 else nn.Conv2d(num_bins, base, 5, padding=2)
         chans = [base * 2 ** i for i in range(num_encoders + 1)]
-        # fused: every 5x5 convolution whose input depth is a multiple of 64 runs on the matrix-core kernel too (enc1 reads 32 channels)
-        fconv = lambda a, b, s, up=False: _FusedConv(a, b, s, up) if fused_convlstm and a % 64 == 0 else None
+        # fused: every 5x5 convolution runs on the matrix-core kernel too (enc1 with its 32 input channels: two taps per K chunk)
+        fconv = lambda a, b, s, up=False: _FusedConv(a, b, s, up) if fused_convlstm and (a % 64 == 0 or (a == 32 and b in (64, 128))) else None
         self.enc = nn.ModuleList(fconv(a, b, 2) or nn.Conv2d(a, b, 5, stride=2, padding=2) for a, b in zip(chans[:-1], chans[1:]))
         self.rec = nn.ModuleList((_FusedConvLSTM if fused_convlstm else _ConvLSTM)(b) for b in chans[1:])
         self.res = nn.ModuleList((_FusedRes if fused_convlstm else _Res)(chans[-1]) for _ in range(num_res))

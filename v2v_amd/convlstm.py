@@ -228,7 +228,10 @@ def pack_conv_weights(weight: torch.Tensor) -> torch.Tensor:
     if not weight.is_cuda or weight.dtype != torch.float32 or weight.dim() != 4 or weight.shape[2] != weight.shape[3]:
         raise ValueError("weight must be a float32 CUDA tensor [Cout, Cin, ks, ks]")
     cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
-    packed = torch.empty((cout * cin * ks * ks,), dtype=torch.bfloat16, device=weight.device)
+    n = _lib.lib().v2v_conv_packed_elems(cin, cout, ks)
+    if n < 0:
+        raise ValueError(f"the convolution kernel does not take {cin} -> {cout} channels, {ks}x{ks}")
+    packed = torch.empty((n,), dtype=torch.bfloat16, device=weight.device)
     with torch.cuda.device(weight.device):
         _lib.check(_lib.lib().v2v_conv_pack_weights_hip(_ptr(weight.detach().contiguous()), cin, cout, ks, _ptr(packed), _lib.stream_ptr()))
     return packed
@@ -241,7 +244,7 @@ def conv_nhwc(x, packed, bias, ks: int, stride: int = 1, residual=None, relu=Fal
         raise ValueError("x must be a contiguous bfloat16 CUDA tensor [B,H,W,Cin]")
     b, hin, win, cin = x.shape
     cout = bias.numel()
-    if bias.dtype != torch.float32 or packed.dtype != torch.bfloat16 or packed.numel() != cout * cin * ks * ks:
+    if bias.dtype != torch.float32 or packed.dtype != torch.bfloat16 or packed.numel() != _lib.lib().v2v_conv_packed_elems(cin, cout, ks):
         raise ValueError("bias must be float32 [Cout] and packed the output of pack_conv_weights for the same Cin, Cout, ks")
     h, w = (hin - 1) // stride + 1, (win - 1) // stride + 1
     if residual is not None and (residual.dtype != torch.bfloat16 or tuple(residual.shape) != (b, h, w, cout) or not residual.is_contiguous()
@@ -338,7 +341,8 @@ class ConvLayer(nn.Module):
     (f.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False), its own bfloat16 NHWC kernel) in front, i.e.
     UpsampleConvLayer (:68-96).  Inference only; bfloat16 operands, fp32 accumulation; channels-last bfloat16
     inputs are consumed and produced in place, anything else goes through the layout-change kernel and comes back NCHW in the
-    input's dtype.  in_channels % 64 == 0 and out_channels in {32, 64, 128, 256k}, else ValueError (no fallback)."""
+    input's dtype.  in_channels % 64 == 0 and out_channels in {32, 64, 128, 256k}; in_channels 32 with 64 / 128 outputs (the first
+    encoder); <= 8 input channels with 32 outputs = the head; kernel_size 1 = the prediction layer; else ValueError (no fallback)."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, activation="relu", norm=None, BN_momentum=0.1,
                  upsample=False):
@@ -376,7 +380,7 @@ class ConvLayer(nn.Module):
             elif x.shape[1] % 64 == 0 and (x.shape[2] * x.shape[3]) % 64 == 0:
                 xn = nchw_to_nhwc_bf16(x)
             else:                                                                     # 32 channels: below the layout kernel's 64-channel tile
-                xn = x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
+                xn = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)     # one copy; a contiguous NHWC view
             out = conv1x1_nhwc(xn, self.conv2d.weight, self.conv2d.bias, None if skip is None else skip.permute(0, 2, 3, 1),
                                out_dtype=torch.bfloat16 if nhwc else x.dtype).permute(0, 3, 1, 2)
             return out if nhwc else out.contiguous()
@@ -395,7 +399,12 @@ class ConvLayer(nn.Module):
         if skip is not None and not (nhwc_io and is_nhwc(skip)):
             x, skip = x + skip, None
             nhwc_io = is_nhwc(x)
-        xn = x.permute(0, 2, 3, 1) if nhwc_io else nchw_to_nhwc_bf16(x)
+        if nhwc_io:
+            xn = x.permute(0, 2, 3, 1)
+        elif x.shape[1] % 64 == 0:
+            xn = nchw_to_nhwc_bf16(x)
+        else:                                                                         # 32 input channels: below the layout kernel's 64-channel tile
+            xn = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)     # one copy; a contiguous NHWC view
         if self.upsample:
             xn = upsample2x_nhwc(xn, None if skip is None else skip.permute(0, 2, 3, 1))
         out = conv_nhwc(xn, self._weights(), self.conv2d.bias.detach().float(), self.conv2d.kernel_size[0], self.conv2d.stride[0],

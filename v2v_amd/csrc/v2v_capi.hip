@@ -610,11 +610,19 @@ int v2v_convlstm_step_hip(const void *x, const void *h_prev, const float *c_prev
     return e == hipSuccess ? V2V_OK : hip_fail(e, "convlstm_step_kernel launch");
 }
 
+int64_t v2v_conv_packed_elems(int64_t Cin, int64_t Cout, int ks)
+{
+    if ((ks != 3 && ks != 5) || Cout < 1 || Cout > 4096 || v2v::conv_tile_cols((int)Cout) == 0) return -1;
+    if (Cin == 32) return (Cout == 64 || Cout == 128) ? Cout * ((ks * ks + 1) / 2) * 64 : -1;      // two taps per 64-wide chunk
+    if (Cin < 64 || Cin % 64 != 0 || Cin > 4096) return -1;
+    return Cout * Cin * ks * ks;
+}
+
 int v2v_conv_pack_weights_hip(const float *weight, int64_t Cin, int64_t Cout, int ks, void *packed, void *stream)
 {
     if (!weight || !packed) return fail(V2V_ERR_NULL, "v2v_conv_pack_weights_hip: weight/packed is NULL");
-    if (Cin < 64 || Cin % 64 != 0 || Cin > 4096 || Cout > 4096 || v2v::conv_tile_cols((int)Cout) == 0 || (ks != 3 && ks != 5))
-        return fail(V2V_ERR_SHAPE, "conv kernel needs Cin %% 64 == 0, Cout in {32, 64, 128} or a multiple of 256, ks 3 or 5 (got %lld -> %lld, ks %d)",
+    if (v2v_conv_packed_elems(Cin, Cout, ks) < 0)
+        return fail(V2V_ERR_SHAPE, "conv kernel needs Cin %% 64 == 0 (or Cin 32 with Cout 64 / 128), Cout in {32, 64, 128} or a multiple of 256, ks 3 or 5 (got %lld -> %lld, ks %d)",
                     (long long)Cin, (long long)Cout, ks);
     if (!aligned(weight, 4) || !aligned(packed, 16)) return fail(V2V_ERR_ALIGN, "weight needs 4-byte, packed 16-byte alignment");
     const hipError_t e = v2v::launch_conv_pack(weight, static_cast<uint16_t *>(packed), (int)Cin, (int)Cout, ks, static_cast<hipStream_t>(stream));
@@ -626,12 +634,12 @@ int v2v_conv_nhwc_hip(const void *x, const void *packed, const float *bias, cons
 {
     if (!x || !packed || !bias || !out) return fail(V2V_ERR_NULL, "v2v_conv_nhwc_hip: x/packed/bias/out is NULL");
     if ((ks != 3 && ks != 5) || (stride != 1 && stride != 2)) return fail(V2V_ERR_PARAM, "ks must be 3 or 5, stride 1 or 2");
-    if (B < 1 || Hin < 1 || Win < 1 || Cin < 64 || Cin % 64 != 0 || Cin > 4096 || Cout > 4096 || v2v::conv_tile_cols((int)Cout) == 0)
-        return fail(V2V_ERR_SHAPE, "need B,H,W >= 1, Cin %% 64 == 0, Cout in {32, 64, 128} or a multiple of 256");
+    if (B < 1 || Hin < 1 || Win < 1 || v2v_conv_packed_elems(Cin, Cout, ks) < 0)
+        return fail(V2V_ERR_SHAPE, "need B,H,W >= 1, Cin %% 64 == 0 (or Cin 32 with Cout 64 / 128), Cout in {32, 64, 128} or a multiple of 256");
     const int64_t H = (Hin - 1) / stride + 1, W = (Win - 1) / stride + 1;          // output size for pad = ks / 2
     if (tile_rows != 0 && tile_rows != 128 && tile_rows != 256 && tile_rows != 16 && (Cout % 256 != 0 || (tile_rows != 32 && tile_rows != 64)))
         return fail(V2V_ERR_PARAM, "tile_rows must be 0 (auto), 128 or 256 (and 32 or 64 for Cout %% 256 == 0)");
-    const bool halo_fits = Cout % 256 != 0 && stride == 1 && H % 16 == 0 && W % 16 == 0 && (ks == 3 || Cout <= 64);   // see launch_conv_nhwc
+    const bool halo_fits = Cin % 64 == 0 && Cout % 256 != 0 && stride == 1 && H % 16 == 0 && W % 16 == 0 && (ks == 3 || Cout <= 64);   // see launch_conv_nhwc
     const bool halo = halo_fits && (tile_rows == 16 || (tile_rows == 0 && ks == 5));
     if (tile_rows == 16 && !halo) return fail(V2V_ERR_PARAM, "tile_rows 16 (halo tiles) needs stride 1, H and W multiples of 16 and Cout 32 / 64 (128 for 3x3)");
     const int64_t need = halo ? 256 : tile_rows ? tile_rows : Cout % 256 == 0 ? 32 : 128;

@@ -97,10 +97,14 @@ __device__ __forceinline__ void cl_epilogue_conv(const ConvLstmArgs &a, cl_f32x1
 // WN x NF: wave columns x 32-column B fragments per wave = the tile's columns (2 x 4 = 256 for the gates; 1 x {4,2,1} = 128 / 64 /
 // 32 output channels for the narrower plain convolutions).  EPI = 1 also takes the tap count (ks x ks, pad ks/2) and the stride
 // from the arguments (5x5 and stride-2 encoder / decoder convolutions of model/unet.py).
-template <int MF, int WM, int STAGES = 2, int EPI = 0, int WN = 2, int NF = 4>
+// TPC = 2 (EPI = 1, Cin = 32: the first encoder of the UNet): TWO taps per 64-wide K chunk, k = 32 idx + c <-> tap 2 ck + idx,
+// channel c -- a lane's 16-byte LDS-DMA source belongs to the tap its (swizzled) slot falls in; an odd tap count leaves the last
+// half chunk to zero weights and the zero line.
+template <int MF, int WM, int STAGES = 2, int EPI = 0, int WN = 2, int NF = 4, int TPC = 1>
 __global__ void __launch_bounds__(64 * WM * WN, (STAGES == 2 && MF == 1) || WM * WN == 8 || NF < 4 ? 2 : 1) convlstm_step_kernel(const ConvLstmArgs a)
 {
     static_assert(EPI == 1 || (WN == 2 && NF == 4), "the gate epilogue needs the four gates of a channel in one wave");
+    static_assert(TPC == 1 || (TPC == 2 && EPI == 1), "two taps per chunk: plain convolution of 32 input channels");
     constexpr int kBN = WN * NF * 32, kBBytes = kBN * kClBK * 2;
     constexpr int kClBM = 32 * MF * WM, kClABytes = kClBM * kClBK * 2, kClStage = kClABytes + kBBytes;
     constexpr int NS = WM * WN;                                   // waves (all of them stage)
@@ -113,9 +117,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (STAGES == 2 && MF == 1) || WM *
     const int n_ct = EPI == 0 ? C / kClCh : a.n_cols / kBN;       // column tiles
     const int ct = blockIdx.x % n_ct;
     const int64_t m0 = (int64_t)(blockIdx.x / n_ct) * kClBM;      // first pixel of the tile (flattened b,y,x)
-    const int cc_x = C / kClBK, cc_all = EPI == 0 ? 2 * cc_x : cc_x;
+    const int cc_x = TPC == 2 ? 1 : C / kClBK, cc_all = EPI == 0 ? 2 * cc_x : cc_x;
     const int cc_eff = (EPI == 0 && a.h_prev) ? cc_all : cc_x;    // zero state: skip h's chunks
-    const int n_chunks = n_taps * cc_eff;
+    const int n_chunks = TPC == 2 ? (n_taps + 1) / 2 : n_taps * cc_eff;
 
     // ---- staging plan: wave w issues A pieces NA*w.. (8 rows each) and B pieces NB*w.. per chunk ----------------------
     const int srow = lane >> 3, sslot = lane & 7;                 // this lane's (row in piece, LDS slot)
@@ -133,6 +137,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (STAGES == 2 && MF == 1) || WM *
         ax[j] = (p % a.W) * stride;
         apix[j] = (((int64_t)bimg * Hin + ay[j]) * Win + ax[j]) * C;    // element offset of the centre pixel's channel vector
         aswz[j] = (uint32_t)((sslot ^ ((row >> 1) & 7)) * 8);     // source channel offset inside the 64-channel chunk
+        if constexpr (TPC == 2) aswz[j] = (aswz[j] & 24u) | (aswz[j] >> 5 << 31);   // channel offset in the tap's 32 | which tap (bit 31)
     }
     constexpr int NB = kBN / 8 / NS;                              // B pieces per wave
     uint32_t boff[NB];
@@ -143,13 +148,36 @@ __global__ void __launch_bounds__(64 * WM * WN, (STAGES == 2 && MF == 1) || WM *
     }
     // a column tile narrower than the packed one (EPI = 1, 128-column instances on 256-column packing): sub-tile `ct % per`
     const int pcols = (EPI == 1 && a.pack_cols) ? a.pack_cols : kBN, per = pcols / kBN;
-    const uint16_t *wtile = a.wp + (int64_t)(ct / per) * n_taps * cc_all * (pcols * kClBK) + (ct % per) * (kBN * kClBK);
+    const uint16_t *wtile = a.wp + (int64_t)(ct / per) * (TPC == 2 ? n_chunks : n_taps * cc_all) * (pcols * kClBK) + (ct % per) * (kBN * kClBK);
 
     // LDS-DMA of chunk ck into buffer buf (part / nparts: a subset of the pieces, j % nparts == part).  The main loop issues
     // the whole chunk in front of the first k-step: spreading the pieces over the four k-steps was measured 10-15 % slower on
     // the same box with two buffers AND with three (every piece issued between MFMAs stalls the wave's instruction stream for
     // its turn in the address unit)
     auto stage = [&](int ck, int buf, int part, int nparts) __attribute__((always_inline)) {
+        if constexpr (TPC == 2) {
+            const int t0 = 2 * ck, t1 = 2 * ck + 1;
+            const int dy0 = t0 / ks - pad, dx0 = t0 % ks - pad, dy1 = t1 / ks - pad, dx1 = t1 % ks - pad;
+            const bool live1 = t1 < n_taps;
+            const int sh0 = (dy0 * Win + dx0) * C, sh1 = (dy1 * Win + dx1) * C;          // tensors are below 2^31 elements
+            unsigned char *abase = cl_lds + buf * kClStage, *bbase = abase + kClABytes;
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                if (j % nparts != part) continue;
+                const bool second = (int32_t)aswz[j] < 0;
+                const int dy = second ? dy1 : dy0, dx = second ? dx1 : dx0;
+                const bool in = (!second || live1) && (unsigned)(ay[j] + dy) < (unsigned)Hin && (unsigned)(ax[j] + dx) < (unsigned)Win;
+                const void *g = in ? (const void *)(a.x + apix[j] + (second ? sh1 : sh0) + (aswz[j] & 24u)) : (const void *)g_cl_zero_line;
+                cl_glds16(g, abase + (wave * NA + j) * 1024);
+            }
+            const uint16_t *wchunk = wtile + (int64_t)ck * (pcols * kClBK);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (j % nparts != part) continue;
+                cl_glds16(wchunk + boff[j], bbase + (wave * NB + j) * 1024);
+            }
+            return;
+        }
         const int tap = ck / cc_eff, cc = ck - tap * cc_eff;
         const int dy = tap / ks - pad, dx = tap % ks - pad;
         const uint16_t *src = cc < cc_x ? a.x : a.h_prev;
@@ -706,6 +734,21 @@ __global__ void __launch_bounds__(256) to_nhwc8_bf16_kernel(const float *src, in
 #pragma unroll
     for (int c = 0; c < 8; ++c) v[c] = c < C ? src[b * sb + c * sc + y * sh + x * sw] : 0.0f;
     *reinterpret_cast<uint4 *>(dst + i * 8) = make_uint4(cl_pack_bf16(v[0], v[1]), cl_pack_bf16(v[2], v[3]), cl_pack_bf16(v[4], v[5]), cl_pack_bf16(v[6], v[7]));
+}
+
+// Cin = 32 (two taps per chunk): wp[col tile][chunk ck = 0 .. ceil(taps / 2) - 1][column][k], k = 32 idx + c <-> tap 2 ck + idx, channel c
+__global__ void __launch_bounds__(256) conv_pack32_kernel(const float *w, uint16_t *wp, int Cout, int ks, int bn)
+{
+    const int taps = ks * ks, n_ck = (taps + 1) / 2;
+    const int64_t n = (int64_t)Cout * n_ck * kClBK;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int64_t r = i;
+    const int k = (int)(r % kClBK); r /= kClBK;
+    const int col = (int)(r % bn); r /= bn;
+    const int ck = (int)(r % n_ck); r /= n_ck;
+    const int ct = (int)r, tap = 2 * ck + (k >> 5), c = k & 31;
+    wp[i] = tap < taps ? f32_to_bf16_rne(w[((int64_t)(ct * bn + col) * 32 + c) * taps + tap]) : (uint16_t)0;
 }
 
 // [4C, 2C, 3, 3] fp32 (nn.Conv2d weight of ConvLSTM.Gates) -> packed bf16 (layout at the top of this file); one thread per element

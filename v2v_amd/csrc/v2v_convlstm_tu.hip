@@ -5,7 +5,7 @@
 namespace v2v {
 
 namespace {
-template <int MF, int WM, int STAGES = 2, int EPI = 0, int WN = 2, int NF = 4>
+template <int MF, int WM, int STAGES = 2, int EPI = 0, int WN = 2, int NF = 4, int TPC = 1>
 hipError_t launch_step_t(const ConvLstmArgs &a, hipStream_t s)
 {
     // 80-128 KB of dynamic LDS is above the 64 KB a kernel gets by default: raise the limit once per device (kept out of the
@@ -15,12 +15,12 @@ hipError_t launch_step_t(const ConvLstmArgs &a, hipStream_t s)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (dev < 0 || dev >= 64 || !raised[dev]) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convlstm_step_kernel<MF, WM, STAGES, EPI, WN, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convlstm_step_kernel<MF, WM, STAGES, EPI, WN, NF, TPC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) raised[dev] = true;
     }
     const int64_t tiles = (int64_t)a.B * a.H * a.W / (32 * MF * WM) * (EPI == 0 ? a.C / kClCh : a.n_cols / (WN * NF * 32));
-    hipLaunchKernelGGL((convlstm_step_kernel<MF, WM, STAGES, EPI, WN, NF>), dim3((unsigned)tiles), dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL((convlstm_step_kernel<MF, WM, STAGES, EPI, WN, NF, TPC>), dim3((unsigned)tiles), dim3(64 * WM * WN), lds, s, a);
     return hipGetLastError();
 }
 }  // namespace
@@ -57,7 +57,7 @@ hipError_t launch_conv_nhwc(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
     // 5-tap groups) the same kernel is slower than the tiles above.  tile_rows 16 forces it (tests), 0 takes it where measured.
     const int halo_a = conv_halo_pieces(a.ks) * 1024;
     const int halo_tps = a.n_cols % 256 != 0 ? (80 * 1024 - halo_a) / (2 * a.n_cols * 128) : 0;
-    const bool halo_ok = a.n_cols % 256 != 0 && a.stride == 1 && a.H % 16 == 0 && a.W % 16 == 0 && halo_tps >= 1;
+    const bool halo_ok = a.C % 64 == 0 && a.n_cols % 256 != 0 && a.stride == 1 && a.H % 16 == 0 && a.W % 16 == 0 && halo_tps >= 1;
     if (halo_ok && (tile_rows == 16 || (tile_rows == 0 && a.ks == 5 && a.n_cols <= 64))) {
         const int nf = a.n_cols / 32;
         const int tps = halo_tps < a.ks ? halo_tps : a.ks;
@@ -75,6 +75,13 @@ hipError_t launch_conv_nhwc(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
         else if (nf == 2) hipLaunchKernelGGL(conv_halo_kernel<2>, dim3(tiles), dim3(256), lds, s, a, tps);
         else hipLaunchKernelGGL(conv_halo_kernel<1>, dim3(tiles), dim3(256), lds, s, a, tps);
         return hipGetLastError();
+    }
+    if (a.C == 32) {                                                 // two taps per chunk (the UNet's first encoder: 32 -> 64, 5x5, stride 2)
+        if (tile_rows == 0) tile_rows = (m % 256 == 0 && m / 256 >= cus) ? 256 : 128;
+        if (m % tile_rows != 0) return hipErrorInvalidValue;
+        if (a.n_cols == 64) return tile_rows == 256 ? launch_step_t<2, 4, 2, 1, 1, 2, 2>(a, s) : tile_rows == 128 ? launch_step_t<1, 4, 3, 1, 1, 2, 2>(a, s) : hipErrorInvalidValue;
+        if (a.n_cols == 128) return tile_rows == 256 ? launch_step_t<2, 4, 2, 1, 1, 4, 2>(a, s) : tile_rows == 128 ? launch_step_t<1, 4, 3, 1, 1, 4, 2>(a, s) : hipErrorInvalidValue;
+        return hipErrorInvalidValue;
     }
     if (a.n_cols % 256 != 0) {
         // one column tile of 4 / 2 / 1 B fragments per wave: 256 pixels (8 fragment rows of 4 waves x MF 2), or 128 pixels on
@@ -114,6 +121,11 @@ hipError_t launch_conv_nhwc(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
 
 hipError_t launch_conv_pack(const float *w, uint16_t *wp, int Cin, int Cout, int ks, hipStream_t s)
 {
+    if (Cin == 32) {
+        const int64_t n32 = (int64_t)Cout * ((ks * ks + 1) / 2) * kClBK;
+        hipLaunchKernelGGL(conv_pack32_kernel, dim3((unsigned)((n32 + 255) / 256)), dim3(256), 0, s, w, wp, Cout, ks, conv_tile_cols(Cout));
+        return hipGetLastError();
+    }
     const int64_t n = (int64_t)Cout * Cin * ks * ks;
     hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, wp, Cin, Cout, ks, conv_tile_cols(Cout));
     return hipGetLastError();
