@@ -54,7 +54,8 @@ hipError_t launch_conv_nhwc(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
     // weight-group buffers must leave room for TWO workgroups per CU (<= 80 KB): 8 clips of 256^2, same box, 5x5: 64 -> 32
     // columns 0.117 -> 0.085 ms (3 taps per group), 128 -> 64 columns 0.079 -> 0.071 ms (1 tap); 256 -> 128 columns does not fit
     // twice and measured 0.126-0.137 against 0.090 ms on the 128-pixel tile; with one workgroup per CU (two patch buffers or
-    // 5-tap groups) the same kernel is slower than the tiles above.  tile_rows 16 forces it (tests), 0 takes it where measured.
+    // 5-tap groups) the same kernel is slower than the tiles above; an 8-row patch (30 KB, so that 128 columns fit twice) measured
+    // 0.109 against 0.090 ms as well.  tile_rows 16 forces it (tests), 0 takes it where measured.
     const int halo_a = conv_halo_pieces(a.ks) * 1024;
     const int halo_tps = a.n_cols % 256 != 0 ? (80 * 1024 - halo_a) / (2 * a.n_cols * 128) : 0;
     const bool halo_ok = a.C % 64 == 0 && a.n_cols % 256 != 0 && a.stride == 1 && a.H % 16 == 0 && a.W % 16 == 0 && halo_tps >= 1;
