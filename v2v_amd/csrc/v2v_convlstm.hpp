@@ -1,4 +1,9 @@
-// v2v_convlstm.hpp -- fused ConvLSTM step of the consumer side (gfx950 MFMA).
+// v2v_convlstm.hpp -- the recurrent UNet of the consumer side on the matrix cores (gfx950 MFMA).
+//
+// Kernels in this file:  convlstm_step_kernel (the ConvLSTM step, below; its EPI = 1 instances are the plain convolutions: residual
+// blocks, stride-2 encoders, wide decoders; TPC = 2 = 32 input channels) | conv_halo_kernel (5x5 decoders with 32 / 64 columns) |
+// conv_head_kernel (voxel bins -> 32 channels) | conv1x1_nhwc_kernel (prediction layer) | upsample2x_nhwc_bf16_kernel |
+// layout / packing helpers (nchw_to_nhwc_bf16, to_nhwc8_bf16, *_pack_kernel).  Everything below this paragraph describes the step.
 //
 // Replaces one ConvLSTM.forward of the reference's recurrent encoders (model/submodules.py:179-235):
 //     gates = Conv2d(2C -> 4C, 3x3, pad 1)(cat(x, h_prev));  i, r, o, g = gates.chunk(4, 1)
@@ -15,9 +20,9 @@
 //   column n = wn*128 + gate*32 + c32  <->  output channel gate*C + t*64 + wn*32 + c32,   k <-> input channel cc*64 + k
 // i.e. every (tile, chunk) is one contiguous 32 KB block and a wave's four B fragments are the four gates of ITS 32 channels.
 //
-// Tiling.  A workgroup (4 waves) owns 128 consecutive pixels x 64 hidden channels (x 4 gates = 256 columns); wave (wm, wn)
-// owns 64 pixels x 32 channels x 4 gates = 2 x 4 accumulators of v_mfma_f32_32x32x16_bf16 (128 VGPRs).  K is walked in chunks
-// of 64 (one tap, 64 channels): the A tile (128 px x 64 k, 16 KB) and the B tile (256 cols x 64 k, 32 KB) of chunk k+1 are
+// Tiling.  A workgroup (WM x 2 waves) owns 32 MF WM consecutive pixels x 64 hidden channels (x 4 gates = 256 columns); wave (wm, wn)
+// owns 32 MF pixels x 32 channels x 4 gates = MF x 4 accumulators of v_mfma_f32_32x32x16_bf16 (128 VGPRs).  K is walked in chunks
+// of 64 (one tap, 64 channels): the A tile (pixels x 64 k) and the B tile (256 cols x 64 k, 32 KB) of chunk k+1 are
 // brought into the other LDS buffer by global_load_lds_dwordx4 (no VGPR staging) while the MFMAs run on chunk k; out-of-image
 // taps read a 128-byte zero line instead.  LDS rows are 128 B; the 16-byte slot index is XORed with (row >> 1) & 7 -- applied
 // on the SOURCE address of the LDS-DMA (its LDS destination is lane-linear) and on the ds_read_b128 address -- which makes
