@@ -568,3 +568,38 @@ def test_head_convolution(b, cin, h, w, ks, relu):
         CL.ConvLayer(5, 64, 5, padding=2)
     with pytest.raises(ValueError):
         CL.conv_head_nhwc(CL.to_nhwc8_bf16(x[:, :, :15]), CL.pack_head_weights(weight), bias, ks)
+
+
+@pytest.mark.gpu
+def test_whole_consumer_captures_into_a_hip_graph():
+    """Every layer of the E2VID-shaped consumer on the device kernels, channels-last, bf16 autocast: a 3-step forward captured
+    into one hipGraph (after a warm-up that packs the weights and raises the kernels' LDS limits) replays to the eager result
+    bit for bit, also on new input written into the captured buffer."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from e2vid_consumer import E2VIDShapedConsumer, forward_sequence
+    torch.manual_seed(5)
+    model = E2VIDShapedConsumer(fused_convlstm=True).cuda().eval().to(memory_format=torch.channels_last)
+    events = torch.round(torch.randn((2, 3, 5, 64, 64), device="cuda") * 2)
+
+    def run():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return torch.stack([o.float() for o in forward_sequence(model, events, channels_last=True)])
+    eager = run()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = run()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    events.copy_(torch.round(torch.randn(events.shape, device="cuda") * 2))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, run()) and not torch.equal(out, eager)
