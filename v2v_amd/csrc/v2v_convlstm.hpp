@@ -105,16 +105,23 @@ __device__ __forceinline__ void cl_epilogue_conv(const ConvLstmArgs &a, cl_f32x1
 // TPC = 2 (EPI = 1, Cin = 32: the first encoder of the UNet): TWO taps per 64-wide K chunk, k = 32 idx + c <-> tap 2 ck + idx,
 // channel c -- a lane's 16-byte LDS-DMA source belongs to the tap its (swizzled) slot falls in; an odd tap count leaves the last
 // half chunk to zero weights and the zero line.
-template <int MF, int WM, int STAGES = 2, int EPI = 0, int WN = 2, int NF = 4, int TPC = 1>
-__global__ void __launch_bounds__(64 * WM * WN, (STAGES == 2 && MF == 1) || WM * WN == 8 || NF < 4 ? 2 : 1) convlstm_step_kernel(const ConvLstmArgs a)
+// KS = 2 (EPI = 1, three stages): the workgroup is TWO wave groups that walk alternate K chunks of the SAME tile (each with its own
+// LDS stages), i.e. twice the waves, LDS-DMA in flight and MFMA issue per CU for the small layers that cannot fill the chip with
+// more tiles; group 1's accumulators meet group 0's through LDS before the epilogue.
+template <int MF, int WM, int STAGES = 2, int EPI = 0, int WN = 2, int NF = 4, int TPC = 1, int KS = 1>
+__global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 ? 1 : (STAGES == 2 && MF == 1) || WM * WN == 8 || NF < 4 ? 2 : 1) convlstm_step_kernel(const ConvLstmArgs a)
 {
+    static_assert(KS == 1 || (KS == 2 && EPI == 1 && STAGES == 3), "split K: plain convolution on the three-stage loop");
     static_assert(EPI == 1 || (WN == 2 && NF == 4), "the gate epilogue needs the four gates of a channel in one wave");
     static_assert(TPC == 1 || (TPC == 2 && EPI == 1), "two taps per chunk: plain convolution of 32 input channels");
     constexpr int kBN = WN * NF * 32, kBBytes = kBN * kClBK * 2;
     constexpr int kClBM = 32 * MF * WM, kClABytes = kClBM * kClBK * 2, kClStage = kClABytes + kBBytes;
     constexpr int NS = WM * WN;                                   // waves (all of them stage)
-    extern __shared__ __attribute__((aligned(128))) unsigned char cl_lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ __attribute__((aligned(128))) unsigned char cl_lds_all[];
+    // wave: inside its K group; kgrp wave-uniform in an SGPR (it feeds the chunk -> tap arithmetic), the constant 0 without the split
+    const int lane = threadIdx.x & 63, wave = KS == 1 ? (int)(threadIdx.x >> 6) : (int)(threadIdx.x >> 6) % NS;
+    const int kgrp = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) / NS);
+    unsigned char *const cl_lds = cl_lds_all + kgrp * (STAGES * kClStage);
     const int wm = wave % WM, wn = wave / WM;
     const int C = a.C, HW = a.H * a.W;
     const int ks = EPI == 0 ? 3 : a.ks, pad = ks >> 1, n_taps = ks * ks, stride = EPI == 0 ? 1 : a.stride;
@@ -283,27 +290,50 @@ __global__ void __launch_bounds__(64 * WM * WN, (STAGES == 2 && MF == 1) || WM *
         // barrier -- the wait in front of a barrier is counted (the NA+NB pieces of the youngest chunk may be outstanding:
         // LDS-DMA completes in order) and the barrier is a raw s_barrier (a __syncthreads() would drain vmcnt)
         constexpr int kPieces = NA + NB;
-        stage(0, 0, 0, 1);
-        if (n_chunks > 1) stage(1, 1, 0, 1);
+        // K group g walks chunks g, g + KS, ...; every wave runs the same number of iterations (and barriers)
+        const int n_it = (n_chunks + KS - 1) / KS;
+        auto chunk_of = [&](int it) __attribute__((always_inline)) { return it * KS + kgrp; };
+        if (chunk_of(0) < n_chunks) stage(chunk_of(0), 0, 0, 1);
+        if (chunk_of(1) < n_chunks) stage(chunk_of(1), 1, 0, 1);
         int buf = 0, buf2 = 2;
-        for (int ck = 0; ck < n_chunks; ++ck) {
+        for (int it = 0; it < n_it; ++it) {
             CL_STAMP(t_rest)
-            if (ck + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPieces) : "memory");
+            if (chunk_of(it + 1) < n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPieces) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             CL_STAMP(t_wait)
-            __builtin_amdgcn_s_barrier();                        // chunk ck has landed for every wave; buffer buf2 is free
+            __builtin_amdgcn_s_barrier();                        // chunk `it` has landed for every wave; buffer buf2 is free
             asm volatile("" ::: "memory");
             CL_STAMP(t_bar)
-            const bool more2 = ck + 2 < n_chunks;
-            if (ck + 1 == n_chunks) prefetch_c();
-            k_steps(cl_lds + buf * kClStage, [&](int s) __attribute__((always_inline)) {
-                if (more2 && s == 0) stage(ck + 2, buf2, 0, 1);
-            });
+            const bool more2 = chunk_of(it + 2) < n_chunks;
+            if (it + 1 == n_it) prefetch_c();
+            if (chunk_of(it) < n_chunks)
+                k_steps(cl_lds + buf * kClStage, [&](int s) __attribute__((always_inline)) {
+                    if (more2 && s == 0) stage(chunk_of(it + 2), buf2, 0, 1);
+                });
             buf = buf == 2 ? 0 : buf + 1;
             buf2 = buf2 == 2 ? 0 : buf2 + 1;
         }
     }
-
+    if constexpr (KS == 2) {                                      // group 1's partial sums -> group 0 (through the stage buffers, now idle)
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(cl_lds_all) + (size_t)wave * (MF * NF * 16 * 64) + lane;
+        if (kgrp == 1) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int g = 0; g < NF; ++g)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((i * NF + g) * 16 + r) * 64] = acc[i][g][r];
+        }
+        __syncthreads();
+        if (kgrp == 1) return;
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int g = 0; g < NF; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][g][r] += red[((i * NF + g) * 16 + r) * 64];
+    }
 #ifdef V2V_CL_TIMING
     CL_STAMP(t_rest)
     if (lane == 0) {

@@ -5,22 +5,22 @@
 namespace v2v {
 
 namespace {
-template <int MF, int WM, int STAGES = 2, int EPI = 0, int WN = 2, int NF = 4, int TPC = 1>
+template <int MF, int WM, int STAGES = 2, int EPI = 0, int WN = 2, int NF = 4, int TPC = 1, int KS = 1>
 hipError_t launch_step_t(const ConvLstmArgs &a, hipStream_t s)
 {
     // 80-128 KB of dynamic LDS is above the 64 KB a kernel gets by default: raise the limit once per device (kept out of the
     // launch path so that a step captures into a hipGraph as a bare kernel node)
-    constexpr int lds = cl_lds_bytes(MF, WM, STAGES, WN * NF * 32);
+    constexpr int lds = KS * cl_lds_bytes(MF, WM, STAGES, WN * NF * 32);
     static bool raised[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (dev < 0 || dev >= 64 || !raised[dev]) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convlstm_step_kernel<MF, WM, STAGES, EPI, WN, NF, TPC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convlstm_step_kernel<MF, WM, STAGES, EPI, WN, NF, TPC, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) raised[dev] = true;
     }
     const int64_t tiles = (int64_t)a.B * a.H * a.W / (32 * MF * WM) * (EPI == 0 ? a.C / kClCh : a.n_cols / (WN * NF * 32));
-    hipLaunchKernelGGL((convlstm_step_kernel<MF, WM, STAGES, EPI, WN, NF, TPC>), dim3((unsigned)tiles), dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL((convlstm_step_kernel<MF, WM, STAGES, EPI, WN, NF, TPC, KS>), dim3((unsigned)tiles), dim3(64 * WM * WN * KS), lds, s, a);
     return hipGetLastError();
 }
 }  // namespace
@@ -106,7 +106,8 @@ hipError_t launch_conv_nhwc(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
         // 32-pixel tiles when even 64-pixel ones leave CUs idle (8 clips at 32^2, same box: residual-block convolution 36.7 ->
         // 30.0 us, 5x5 stride-2 128 -> 256 48.0 -> 39.1 us; a third stage on the 64-pixel tile measured no gain)
         // ... and better still 64 px x 128 columns, i.e. half a packed column tile per workgroup (4 waves of 32 x 64, three
-        // stages, 72 KB): a third fewer LDS-DMA pieces per MFMA than 32 px x 256 columns (30.1 -> 27.4 us, 39.2 -> 36.0 us)
+        // stages): a third fewer LDS-DMA pieces per MFMA than 32 px x 256 columns (30.1 -> 27.4 us, 39.2 -> 36.0 us), and with the
+        // workgroup as two K groups of 4 waves (KS = 2: 8 waves, 144 KB) 31.0 -> 24.3 us and 39.7 -> 30.2 us on the same box
         tile_rows = (m % 256 == 0 && m / 256 * ct >= cus) ? 256 : (m % 128 == 0 && m / 128 * ct >= cus) ? 128
                     : (m % 64 != 0) ? 32 : (m / 64 * ct < cus) ? 66 : 64;
     }
@@ -115,7 +116,7 @@ hipError_t launch_conv_nhwc(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
     if (tile_rows == 66) {                                             // 64 px x HALF a packed column tile (internal code, see above)
         ConvLstmArgs b = a;
         b.pack_cols = kClBN;
-        return launch_step_t<1, 2, 3, 1, 2, 2>(b, s);
+        return launch_step_t<1, 2, 3, 1, 2, 2, 1, 2>(b, s);            // ... as two K groups of 4 waves (see the kernel's KS)
     }
     return tile_rows == 128 ? launch_step_t<1, 4, 3, 1>(a, s) : launch_step_t<1, 2, 2, 1>(a, s);
 }
