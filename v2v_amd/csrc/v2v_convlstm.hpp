@@ -111,7 +111,7 @@ __device__ __forceinline__ void cl_epilogue_conv(const ConvLstmArgs &a, cl_f32x1
 template <int MF, int WM, int STAGES = 2, int EPI = 0, int WN = 2, int NF = 4, int TPC = 1, int KS = 1>
 __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 ? 1 : (STAGES == 2 && MF == 1) || WM * WN == 8 || NF < 4 ? 2 : 1) convlstm_step_kernel(const ConvLstmArgs a)
 {
-    static_assert(KS == 1 || (KS == 2 && EPI == 1 && STAGES == 3), "split K: plain convolution on the three-stage loop");
+    static_assert(KS == 1 || (KS == 2 && EPI == 1), "split K: plain convolutions only");
     static_assert(EPI == 1 || (WN == 2 && NF == 4), "the gate epilogue needs the four gates of a channel in one wave");
     static_assert(TPC == 1 || (TPC == 2 && EPI == 1), "two taps per chunk: plain convolution of 32 input channels");
     constexpr int kBN = WN * NF * 32, kBBytes = kBN * kClBK * 2;
@@ -272,18 +272,22 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 ? 1 : (STAGES == 2 
     };
     if constexpr (STAGES == 2) {
         // two LDS buffers: the whole next chunk is issued in front of the first k-step, drained (vmcnt 0) before the next barrier
-        stage(0, 0, 0, 1);
-        for (int ck = 0; ck < n_chunks; ++ck) {
+        // (K group g walks chunks g, g + KS, ...: the same number of iterations and barriers for every wave)
+        const int n_it = (n_chunks + KS - 1) / KS;
+        if (kgrp < n_chunks) stage(kgrp, 0, 0, 1);
+        for (int it = 0; it < n_it; ++it) {
+            const int ck = it * KS + kgrp;
             CL_STAMP(t_rest)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             CL_STAMP(t_wait)
             __syncthreads();                                     // chunk ck has landed; everyone is done with the other buffer
             CL_STAMP(t_bar)
-            const bool more = ck + 1 < n_chunks;
-            if (!more) prefetch_c();
-            k_steps(cl_lds + (ck & 1) * kClStage, [&](int s) __attribute__((always_inline)) {
-                if (more && s == 0) stage(ck + 1, (ck + 1) & 1, 0, 1);
-            });
+            const bool more = ck + KS < n_chunks;
+            if (it + 1 == n_it) prefetch_c();
+            if (ck < n_chunks)
+                k_steps(cl_lds + (it & 1) * kClStage, [&](int s) __attribute__((always_inline)) {
+                    if (more && s == 0) stage(ck + KS, (it + 1) & 1, 0, 1);
+                });
         }
     } else {
         // three LDS buffers: chunk ck+2 is issued in front of the first k-step of chunk ck and stays in flight ACROSS the next

@@ -95,7 +95,9 @@ hipError_t launch_conv_nhwc(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
             if (a.n_cols == 64) return launch_step_t<2, 4, 2, 1, 1, 2>(a, s);
             if (a.n_cols == 32) return launch_step_t<2, 4, 2, 1, 1, 1>(a, s);
         } else if (tile_rows == 128) {
-            if (a.n_cols == 128) return launch_step_t<1, 4, 3, 1, 1, 4>(a, s);
+            // 128 columns: two K groups of 4 waves on two stages each (128 KB) instead of 4 waves on three: same box, 8 clips at
+            // 64^2, 5x5 256 -> 128 87.7 -> 72.4 us, stride-2 64 -> 128 29.4 -> 26.1 us
+            if (a.n_cols == 128) return launch_step_t<1, 4, 2, 1, 1, 4, 1, 2>(a, s);
             if (a.n_cols == 64) return launch_step_t<1, 4, 3, 1, 1, 2>(a, s);
             if (a.n_cols == 32) return launch_step_t<1, 4, 3, 1, 1, 1>(a, s);
         }
