@@ -75,7 +75,10 @@ def test_zero_state_and_in_place_cell():
     zh, zc = torch.zeros_like(xn), torch.zeros(xn.shape, dtype=torch.float32, device=dev)
     a = CL.convlstm_step(xn, None, None, packed, bias.to(dev))                      # prev_state=None (:196-209): K over x only
     bb = CL.convlstm_step(xn, zh, zc, packed, bias.to(dev))
-    assert torch.equal(a[0], bb[0]) and torch.equal(a[1], bb[1]) and torch.equal(a[2], bb[2])
+    # same sums in another order (on small inputs the workgroup is two K groups walking alternate chunks): fp32 rounding apart --
+    # 2e-6 on the fp32 outputs, one bf16 ulp of a value in [-1, 1] on the bf16 hidden state
+    assert float((a[1] - bb[1]).abs().max()) < 2e-6 and float((a[2] - bb[2]).abs().max()) < 2e-6
+    assert float((a[0].float() - bb[0].float()).abs().max()) <= 2.0 ** -8
     c_buf = torch.randn(xn.shape, dtype=torch.float32, device=dev)
     keep = c_buf.clone()
     out_of_place = CL.convlstm_step(xn, a[0], keep, packed, bias.to(dev))

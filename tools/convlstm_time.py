@@ -61,7 +61,7 @@ def main():
             row["fused_module_bf16io_ms"] = timeit(lambda: fused(xb, stateb))
             xn = CL.nchw_to_nhwc_bf16(x)
             hs, cs, _ = CL.convlstm_step(xn, None, None, fused._weights(), fused.Gates.bias)
-            for tr in (64, 128, 256):
+            for tr in (0, 64, 128, 256):
                 row[f"fused_step_only_t{tr}_ms"] = timeit(lambda: CL.convlstm_step(xn, hs, cs, fused._weights(), fused.Gates.bias, nchw_dtype=torch.bfloat16,
                                                                                tile_rows=tr))
             best = min(v for k, v in row.items() if k.startswith("fused_step_only_t"))

@@ -111,7 +111,7 @@ __device__ __forceinline__ void cl_epilogue_conv(const ConvLstmArgs &a, cl_f32x1
 template <int MF, int WM, int STAGES = 2, int EPI = 0, int WN = 2, int NF = 4, int TPC = 1, int KS = 1>
 __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 ? 1 : (STAGES == 2 && MF == 1) || WM * WN == 8 || NF < 4 ? 2 : 1) convlstm_step_kernel(const ConvLstmArgs a)
 {
-    static_assert(KS == 1 || (KS == 2 && EPI == 1), "split K: plain convolutions only");
+    static_assert(KS == 1 || KS == 2, "one or two K groups");
     static_assert(EPI == 1 || (WN == 2 && NF == 4), "the gate epilogue needs the four gates of a channel in one wave");
     static_assert(TPC == 1 || (TPC == 2 && EPI == 1), "two taps per chunk: plain convolution of 32 input channels");
     constexpr int kBN = WN * NF * 32, kBBytes = kBN * kClBK * 2;

@@ -36,7 +36,11 @@ hipError_t launch_convlstm_step(const ConvLstmArgs &a, int tile_rows, hipStream_
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const int64_t m = (int64_t)a.B * a.H * a.W, ct = a.C / kClCh;
         tile_rows = (m % 256 == 0 && m / 256 * ct >= cus) ? 256 : (m % 128 == 0 && m / 128 * ct >= cus) ? 128 : 64;
+        // when even 64-pixel tiles give a CU at most one workgroup: that workgroup as two K groups (KS = 2; same box, 8 clips:
+        // 128 ch @32^2 0.039 -> 0.033 ms, 256 ch @16^2 0.067 -> 0.053 ms; slower where more tiles exist: 0.115 -> 0.144 ms)
+        if (tile_rows == 64 && m / 64 * ct <= cus) tile_rows = 65;
     }
+    if (tile_rows == 65) return launch_step_t<1, 2, 2, 0, 2, 4, 1, 2>(a, s);   // 64 px as two K groups of 4 waves (160 KB, internal code)
     if (tile_rows == 256) return launch_step_t<2, 4, 2>(a, s);
     return tile_rows == 128 ? launch_step_t<1, 4, 3>(a, s) : launch_step_t<1, 2, 2>(a, s);
 }
