@@ -388,7 +388,9 @@ class ConvLayer(nn.Module):
             raise ValueError("skip is the decoder's (upsample=True) sum skip connection")
         if self.head:                                                                  # model/unet.py:77-78: any float layout in, bf16 out
             low = x.dtype == torch.bfloat16 or (x.is_cuda and torch.is_autocast_enabled())
-            cl = x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+            # channels-last out when the input or (as torch's own convolution decides) the weight is channels-last
+            w = self.conv2d.weight
+            cl = any(v.is_contiguous(memory_format=torch.channels_last) and not v.is_contiguous() for v in (x, w))
             out = conv_head_nhwc(to_nhwc8_bf16(x.float()), self._weights(), self.conv2d.bias, self.conv2d.kernel_size[0], relu=self.relu).permute(0, 3, 1, 2)
             out = out if cl else out.contiguous()
             return out if low else out.to(x.dtype)
