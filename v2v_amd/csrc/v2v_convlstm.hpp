@@ -42,8 +42,8 @@ namespace v2v {
 constexpr int kClBK = 64, kClCh = 64, kClBN = 4 * kClCh;
 constexpr int kClBBytes = kClBN * kClBK * 2;
 // MF = 32-pixel accumulator blocks per wave (1 or 2), WM = wave rows (2 or 4; x 2 wave columns), STAGES = LDS buffers: the
-// workgroup tile is 32*MF*WM pixels.  Shipped: <1,2,2> 64 pixels (4 waves, 80 KB of LDS, two workgroups per CU), <1,4,3> 128
-// pixels (8 waves, 144 KB, three stages with counted vmcnt), <2,4,2> 256 pixels (8 waves, 128 KB)
+// workgroup tile is 32*MF*WM pixels.  Shipped for the step: <1,2,2> 64 pixels (4 waves, 80 KB of LDS, two workgroups per CU; as two K
+// groups when a CU gets one), <1,4,3> 128 pixels (8 waves, 144 KB, three stages with counted vmcnt), <1,8,2> 256 pixels (16 waves, 128 KB)
 constexpr int cl_lds_bytes(int mf, int wm, int stages = 2, int bn = kClBN) { return stages * (32 * mf * wm * kClBK * 2 + bn * kClBK * 2); }
 
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 cl_bf16x8;
@@ -109,7 +109,7 @@ __device__ __forceinline__ void cl_epilogue_conv(const ConvLstmArgs &a, cl_f32x1
 // LDS stages), i.e. twice the waves, LDS-DMA in flight and MFMA issue per CU for the small layers that cannot fill the chip with
 // more tiles; group 1's accumulators meet group 0's through LDS before the epilogue.
 template <int MF, int WM, int STAGES = 2, int EPI = 0, int WN = 2, int NF = 4, int TPC = 1, int KS = 1>
-__global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 ? 1 : (STAGES == 2 && MF == 1) || WM * WN == 8 || NF < 4 ? 2 : 1) convlstm_step_kernel(const ConvLstmArgs a)
+__global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 1 : (STAGES == 2 && MF == 1) || WM * WN == 8 || NF < 4 ? 2 : 1) convlstm_step_kernel(const ConvLstmArgs a)
 {
     static_assert(KS == 1 || KS == 2, "one or two K groups");
     static_assert(EPI == 1 || (WN == 2 && NF == 4), "the gate epilogue needs the four gates of a channel in one wave");

@@ -41,7 +41,8 @@ hipError_t launch_convlstm_step(const ConvLstmArgs &a, int tile_rows, hipStream_
         if (tile_rows == 64 && m / 64 * ct <= cus) tile_rows = 65;
     }
     if (tile_rows == 65) return launch_step_t<1, 2, 2, 0, 2, 4, 1, 2>(a, s);   // 64 px as two K groups of 4 waves (160 KB, internal code)
-    if (tile_rows == 256) return launch_step_t<2, 4, 2>(a, s);
+    // 256 px as 16 waves of 32 px x 128 columns (4 per SIMD, 114 VGPRs) instead of 8 of 64 x 128: bit-identical, -2...-4 % same box
+    if (tile_rows == 256) return launch_step_t<1, 8, 2>(a, s);
     return tile_rows == 128 ? launch_step_t<1, 4, 3>(a, s) : launch_step_t<1, 2, 2>(a, s);
 }
 
