@@ -230,13 +230,13 @@ class Workload:
         self.step = step
 
     def parity(self):
-        """Light guard outside the timed region: clip 0 AND the last clip of this rank against the C oracle."""
+        """Light guard outside the timed region: the first, a middle and the last clip of this rank against the C oracle."""
         import numpy as np
         from oracle import clib, v2v_oracle as O
         wl = self.wl
         bm = clib.BIN_BILINEAR if wl["bin"] == "bilinear" else clib.BIN_SUM
         verdicts = []
-        for c in sorted({0, self.b - 1}):
+        for c in sorted({0, self.b // 2, self.b - 1}):
             host = self.frames[c:c + 1].cpu().numpy()
             if wl["model"] in ("esim", "pipeline"):
                 want, _ = clib.esim_voxel(host, wl["params"], O.load_luts(), rng_mode=clib.RNG_PHILOX, seed=20240001,
@@ -332,6 +332,21 @@ def load_traffic(name):
         return None
 
 
+def self_launch(n_gpus):
+    """Re-run this script as `n_gpus` ranks under torch.distributed.run (child process; this one never initialises the GPU)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n_gpus} without WORLD_SIZE: launching {' '.join(cmd[1:9])} ...", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -348,11 +363,17 @@ def main():
                     help="replay the step from a captured hipGraph (auto: multi-launch pipeline workloads only)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU under
+        # torch.distributed.run) BEFORE anything in this process touches the GPU, relay rank 0's JSON line and exit with the
+        # launcher's code.  A --gpus N request never quietly measures one GPU.
+        sys.exit(self_launch(args.gpus))
+
     import torch
     from v2v_amd import sharding
     rank, local_rank, world = sharding.env_rank_world()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or plain `python bench.py --gpus {args.gpus}`)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
     if args.share_gpu:
@@ -372,7 +393,9 @@ def main():
     t0 = time.perf_counter()
     kern_ms = time_launches(step, args.steps, torch)
     sharding.barrier(dist, local_rank)
-    elapsed = sharding.max_over_ranks(dist, time.perf_counter() - t0, dev)
+    my_elapsed = time.perf_counter() - t0
+    elapsed = sharding.max_over_ranks(dist, my_elapsed, dev)
+    per_rank_ms = sharding.gather_floats(dist, my_elapsed / args.steps * 1e3, dev)        # every rank's own ms per step
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
 
     # parity guard outside the timed region (first + last clip of rank 0 against the C oracle) + the CPU baseline
@@ -473,7 +496,8 @@ def main():
             "metric": "voxel grids/sec", "value": W.grids_per_step * world * args.steps / elapsed, "unit": "voxel grids/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic", "dist_backend": backend,
+            "data": "synthetic", "dist_backend": backend, "dist_world_size": (dist.get_world_size() if dist is not None else 1),
+            "ms_per_step_per_rank": per_rank_ms,
             "config": {"workload": args.workload, "model": wl["model"], "clips_per_gpu": W.b, "frames": wl["n"], "height": wl["h"], "width": wl["w"],
                        "input_dtype": wl["dtype"], "output_dtype": "float32", "state_dtype": "float64 (potential, floor-divide)",
                        "bin_mode": wl["bin"], "num_bins": wl["tb"], "frames_per_bin": wl["fpb"],
@@ -486,6 +510,8 @@ def main():
                        "launch": "hipGraph replay" if use_graph else "eager"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(args.workload),
+                         "traffic_source": "static: profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
+                                           "collected separately; not re-measured in this run)",
                          "kernel": W.kernel_name, "algorithmic_bytes_per_launch": W.alg_bytes,
                          "measured_ceilings_GBps": MEASURED_CEILINGS_GBPS,
                          "kernel_ms_avg": kern_avg_ms, "kernel_ms_p10": kern_ms[len(kern_ms) // 10],

@@ -25,7 +25,12 @@
 extern "C" {
 #endif
 
-#define V2V_ABI_VERSION 1
+/* 2: every device-native (V2V_RNG_PHILOX) random stream differs from ABI 1 for the same (seed, clip id): Gaussians by
+ *    table inversion (was Box-Muller), Philox4x32-7 for per-step fields, two time steps per Gaussian field id; the v2e
+ *    shot-noise sampler and its fields changed again in round 3; v2v_v2e_workspace_bytes and v2v_postops_workspace_bytes
+ *    grew; v2v_lut_set acts on the current device only.  A client must re-query workspace sizes and cannot replay ABI-1
+ *    native noise.  Replay-mode (V2V_RNG_REPLAY) results are unchanged. */
+#define V2V_ABI_VERSION 2
 
 typedef enum v2v_status {
     V2V_OK = 0,
@@ -48,9 +53,13 @@ typedef enum v2v_rng_mode {
                         /* do not depend on batch size or on how the batch is sharded over GPUs        */
     V2V_RNG_REPLAY = 2, /* caller supplies the fields (e.g. drawn from np.random in the reference's    */
                         /* order): bit-exact replay of a reference run                                 */
-    V2V_RNG_PHILOX_FAST = 3 /* accepted as an alias of V2V_RNG_PHILOX: the exact generator (one Philox word per */
-                        /* Box-Muller pair, packed float32 polynomials) runs as fast as the round-1 variant on */
-                        /* the hardware transcendental units did, so that non-reproducible variant is gone      */
+    V2V_RNG_PHILOX_FAST = 3 /* accepted as an alias of V2V_RNG_PHILOX.  The round-1 variant on the hardware         */
+                        /* transcendental units (not reproducible on a CPU) is gone: the exact generator is as  */
+                        /* fast.  Gaussians are drawn by TABLE INVERSION: each 16-bit half n of a Philox4x32    */
+                        /* word is one deviate, sign = n >> 15, magnitude = table[(n >> 2) & 0x1FFF] = float32  */
+                        /* Phi^-1(1/2 + (i + 1/2) / 2^14) (8192 entries, 2^14 distinct values, |g| <= 4.009:    */
+                        /* tails end at 4 sigma; variance 0.99992).  Philox4x32-7 for per-time-step fields, -10 */
+                        /* for per-clip fields.  ABI 2 changed every native stream (see V2V_ABI_VERSION).       */
 } v2v_rng_mode;
 
 typedef enum v2v_bin_mode {
@@ -89,7 +98,7 @@ int v2v_device_count(void);            /* number of visible HIP devices, 0 if no
  * float32.  The library ships NumPy's values (golden G1); set lets a deployment re-pin them.
  * `which`: 0 = ESIM float64, 1 = ESIM float32, 2 = v2e lin_log float32.  Host pointers, 256 entries. */
 int v2v_lut_get(int which, void *dst_host);
-int v2v_lut_set(int which, const void *src_host);
+int v2v_lut_set(int which, const void *src_host);     /* the CURRENT device's table; call once per device a process drives */
 
 /* ---- fused ESIM simulator + voxel binning ---------------------------------------------------------
  * Replaces EventEmulator.video_to_voxel (data/v2v_core_esim.py:26-69) fused with the binning of

@@ -342,3 +342,29 @@ def test_host_stager_double_buffers_keep_batches_apart():
     for a, b in zip(got, want):
         assert torch.equal(a, b)
     assert len(st._slots) == 1 and len(next(iter(st._slots.values()))) == 2
+
+
+@pytest.mark.gpu
+def test_host_stager_does_not_overwrite_a_pinned_buffer_whose_dma_is_still_queued():
+    """A host that runs ahead of the GPU: a long kernel occupies the compute stream, then depth + 1 pageable batches are staged
+    back to back.  The H2D copy of batch 0 is queued behind the long kernel (copy_stream.wait_stream is a GPU-side dependency
+    only), so staging batch `depth` re-uses batch 0's page-locked buffer while its DMA may not have run yet: stage() must wait
+    for that DMA on the host before the memcpy, or batch 0 arrives with batch `depth`'s bytes (advisor finding, round 2)."""
+    from v2v_amd.staging import HostStager
+    st = HostStager("cuda", depth=2)
+    g = torch.Generator().manual_seed(5)
+    batches = [torch.randint(0, 256, (8, 16, 256, 256), dtype=torch.uint8, generator=g) for _ in range(3)]     # 8 MiB each
+    busy = torch.randn((4096, 4096), device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(60):                                   # ~100+ ms of queued work on the compute (current) stream
+        busy = busy @ busy
+        busy = busy / busy.abs().max()
+    h0, h1 = st.stage(batches[0]), st.stage(batches[1])   # no host synchronisation anywhere below
+    got0 = st.ready(h0).clone()                           # batch 0's consumer, enqueued (not run: the stream is busy)
+    h2 = st.stage(batches[2])                             # recycles batch 0's slot while its DMA is still queued
+    got1 = st.ready(h1).clone()
+    got2 = st.ready(h2).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(got1.cpu(), batches[1])
+    assert torch.equal(got0.cpu(), batches[0]), "batch 0 was overwritten in its page-locked buffer before its DMA ran"
+    assert torch.equal(got2.cpu(), batches[2])

@@ -18,9 +18,12 @@ def _sample_ids(b):
 
 @gpu
 @pytest.mark.parametrize("dt_name", ["float32", "uint8"])
-@pytest.mark.parametrize("params", [[0.2, 0.2, 0.0, 0.0, 0.0], [0.2, 0.3, 0.05, 5e-4, 1.0]], ids=["fixedC_clean", "asym_noisy"])
+@pytest.mark.parametrize("params", [[0.2, 0.2, 0.0, 0.0, 0.0], [0.2, 0.3, 0.05, 5e-4, 1.0], [0.2, 0.2, 0.1, 1e-3, 0.1]],
+                         ids=["fixedC_clean", "asym_noisy", "ref_defaults"])
 def test_cfg2_full_batch_256x32x256x256(oracle_c, luts, dt_name, params):
-    """BASELINE config 2: 256 clips of 32x256x256, 5 temporal-bilinear bins, one launch."""
+    """BASELINE config 2: 256 clips of 32x256x256, 5 temporal-bilinear bins, one launch.  `ref_defaults` = the reference's own
+    EventEmulator() constructor defaults (data/v2v_core_esim.py:8-16) = bench.py's headline parameter set: the host list has
+    pos == neg, so the launch takes the symmetric-only noise instance (V2V_FLAG_SYMMETRIC), exactly the instance bench.py times."""
     import torch
     from v2v_amd import esim
     b, n, h, w, tb = 256, 32, 256, 256, 5
@@ -59,6 +62,35 @@ def test_cfg2_full_batch_sum_mode_exact(oracle_c, luts):
         want, _ = oracle_c.esim_voxel(frames[c:c + 1].cpu().numpy(), p, luts, seed=SEED, clip_id0=c, bin_mode=oracle_c.BIN_SUM, num_bins=5,
                                       frames_per_bin=3)
         assert np.array_equal(out[c].cpu().numpy().astype(np.float64), want[0]), f"clip {c}"
+
+
+@gpu
+def test_cfg4_shape_sum_mode_per_clip_device_params(oracle_c, luts):
+    """The config-4 shape (256 clips x 41 uint8 frames -> 8 grids of 5 SUM bins) with PER-CLIP parameters resident on the
+    device as a [B,5] tensor, drawn as imgs_to_voxels draws them (data/v2v_datasets.py:368-386): what SimulatingCollator hands
+    the kernel.  A device tensor gives the launcher no host knowledge (no symmetric / no-noise hint): the general instance."""
+    import torch
+    from v2v_amd import esim
+    b, n, h, w = 256, 41, 256, 256
+    frames = esim.synth_clips(b, n, h, w, dtype=torch.uint8, seed=SEED, clip_id0=0)
+    g = np.random.default_rng(41)
+    pos = g.uniform(0.05, 2.0, b)
+    gap = g.uniform(1.0, 1.5, b)
+    neg = np.clip(np.where(g.random(b) > 0.5, pos * gap, pos / gap), 0.05, 2.0)
+    params = np.stack([pos, neg, g.uniform(0, 0.2, b), g.uniform(0, 1e-3, b), g.uniform(0, 0.2, b)], axis=1)
+    params[7, 1] = params[7, 0]                                  # one clip with equal thresholds inside an asymmetric batch
+    params[11, 2:] = 0.0                                         # and one noise-free clip
+    pdev = torch.tensor(params, dtype=torch.float64, device="cuda")
+    counts = torch.zeros((b, 2), dtype=torch.int64, device="cuda")
+    out = esim.esim_voxel_batch(frames, pdev, bin_mode="sum", num_bins=5, frames_per_bin=1, seed=SEED, clip_id0=0, counts=counts)
+    torch.cuda.synchronize()
+    assert out.shape == (b, 8, 5, h, w)
+    for c in sorted({0, 7, 11, b // 2, b - 1}):
+        want, tot = oracle_c.esim_voxel(frames[c:c + 1].cpu().numpy(), params[c], luts, seed=SEED, clip_id0=c, bin_mode=oracle_c.BIN_SUM,
+                                        num_bins=5, frames_per_bin=1)
+        assert np.array_equal(out[c].cpu().numpy().astype(np.float64), want[0]), f"clip {c}"
+        assert np.array_equal(counts[c].cpu().numpy(), tot[0]), f"clip {c} totals"
+    assert float(out.sum()) == float((counts[:, 0] - counts[:, 1]).sum())          # SUM grids are the signed counts: totals agree exactly
 
 
 V2E_NOISY = [24, "pn_related", 0.5, 0.1, 0.0, 0.1, 30, 0.1, 0, 5.0, 0.1, 0.1]     # SURVEY §8d S3

@@ -187,3 +187,18 @@ def test_symmetric_hint_is_exact_and_loud(oracle_c, luts):
             broken[2][1] = 0.25                                                                               # clip 2 is asymmetric now
             out = esim.esim_voxel_batch(frames, torch.tensor(broken, dtype=torch.float64, device="cuda"), bin_mode=mode, seed=3, symmetric=True, **kw)
             assert bool(torch.isnan(out[2]).all()) and torch.equal(out[[0, 1, 3, 4]], general[[0, 1, 3, 4]])
+
+
+def test_bench_gpus_n_without_a_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE must not measure one GPU and call it two: bench.py starts the
+    two ranks itself (torch.distributed.run child, before any GPU call in the parent) and relays rank 0's line.  Here both ranks
+    share the box's one GPU over gloo; n_gpus, the world size the process group reports and one time per rank are in the line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8",
+                          "--share-gpu", "--backend", "gloo"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dist_world_size"] == 2 and len(d["ms_per_step_per_rank"]) == 2 and d["dist_backend"] == "gloo"
+    assert max(d["ms_per_step_per_rank"]) <= d["ms_per_step"] * 1.0001 and d["parity_check"] == "ok"

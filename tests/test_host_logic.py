@@ -1,6 +1,12 @@
 """Host-side logic of the drop-in surface that needs no GPU: config defaults, sample indexing, parameter draws."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _mk_list(tmp_path, rows):
@@ -94,3 +100,11 @@ def test_degrade_video_equals_reference_golden(golden, tmp_path):
     except ImportError:
         with pytest.raises(NotImplementedError):
             ds.degrade_video([f.copy() for f in g["clip_c3"]])
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """WORLD_SIZE=1 from a launcher but --gpus 2 asked: an error, never a 1-GPU number labelled n_gpus 2 (runs without a GPU)."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert res.returncode != 0 and "WORLD_SIZE=1" in (res.stderr + res.stdout)

@@ -49,6 +49,18 @@ def nchw_to_nhwc_bf16(x: torch.Tensor, relu: bool = False) -> torch.Tensor:
     return out
 
 
+
+def _to_nhwc_bf16(x: torch.Tensor, relu: bool = False) -> torch.Tensor:
+    """[B,C,H,W] float32 / bfloat16 -> a contiguous bfloat16 [B,H,W,C] tensor: the layout kernel where it applies (64-channel x
+    64-pixel tiles: C % 64 == 0 and H*W % 64 == 0), one torch copy otherwise -- the same guard for every layer, so an odd
+    spatial size does not surface as an opaque V2V_ERR_SHAPE from the kernel."""
+    if x.shape[1] % 64 == 0 and (x.shape[2] * x.shape[3]) % 64 == 0:
+        return nchw_to_nhwc_bf16(x, relu=relu)
+    if relu:
+        x = torch.relu(x)
+    return x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+
+
 def pack_gate_weights(weight: torch.Tensor) -> torch.Tensor:
     """Gates.weight float32 [4C, 2C, 3, 3] -> the packed bfloat16 stream the kernel reads (flat tensor)."""
     _lib.require_gpu()
@@ -134,7 +146,7 @@ class ConvLSTM(nn.Module):
             if input_relu:
                 x = torch.relu(x)
         else:
-            x = nchw_to_nhwc_bf16(input_, relu=input_relu)
+            x = _to_nhwc_bf16(input_, relu=input_relu)
         h_prev = c_prev = None
         if prev_state is not None:
             hidden, cell = prev_state
@@ -144,7 +156,7 @@ class ConvLSTM(nn.Module):
             elif hidden.dtype == torch.bfloat16 and hidden.is_contiguous(memory_format=torch.channels_last) and not hidden.is_contiguous():
                 h_prev = hidden.permute(0, 2, 3, 1)
             else:
-                h_prev = nchw_to_nhwc_bf16(hidden)
+                h_prev = _to_nhwc_bf16(hidden)
             c_prev = cell.permute(0, 2, 3, 1)
             if c_prev.dtype != torch.float32 or not c_prev.is_contiguous():
                 c_prev = c_prev.float().contiguous()
@@ -214,7 +226,7 @@ class ResidualBlock(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise RuntimeError("v2v_amd.convlstm.ResidualBlock is inference-only (no autograd through the fused kernel)")
         nhwc_io = x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
-        xn = x.permute(0, 2, 3, 1) if nhwc_io else nchw_to_nhwc_bf16(x)
+        xn = x.permute(0, 2, 3, 1) if nhwc_io else _to_nhwc_bf16(x)
         mid = conv3x3_nhwc(xn, self._weights(self.conv1, "conv1"), self.conv1.bias.detach().float(), relu=True)
         out = conv3x3_nhwc(mid, self._weights(self.conv2, "conv2"), self.conv2.bias.detach().float(), residual=xn, relu=True)
         out = out.permute(0, 3, 1, 2)
@@ -377,10 +389,8 @@ class ConvLayer(nn.Module):
                 x, skip = (x if skip is None else x + skip), None
             if nhwc:
                 xn = x.permute(0, 2, 3, 1)
-            elif x.shape[1] % 64 == 0 and (x.shape[2] * x.shape[3]) % 64 == 0:
-                xn = nchw_to_nhwc_bf16(x)
-            else:                                                                     # 32 channels: below the layout kernel's 64-channel tile
-                xn = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)     # one copy; a contiguous NHWC view
+            else:
+                xn = _to_nhwc_bf16(x)                    # layout kernel, or one torch copy below its 64-channel x 64-pixel tile
             out = conv1x1_nhwc(xn, self.conv2d.weight, self.conv2d.bias, None if skip is None else skip.permute(0, 2, 3, 1),
                                out_dtype=torch.bfloat16 if nhwc else x.dtype).permute(0, 3, 1, 2)
             return out if nhwc else out.contiguous()
@@ -403,10 +413,8 @@ class ConvLayer(nn.Module):
             nhwc_io = is_nhwc(x)
         if nhwc_io:
             xn = x.permute(0, 2, 3, 1)
-        elif x.shape[1] % 64 == 0:
-            xn = nchw_to_nhwc_bf16(x)
-        else:                                                                         # 32 input channels: below the layout kernel's 64-channel tile
-            xn = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)     # one copy; a contiguous NHWC view
+        else:
+            xn = _to_nhwc_bf16(x)                        # layout kernel, or one torch copy below its 64-channel x 64-pixel tile
         if self.upsample:
             xn = upsample2x_nhwc(xn, None if skip is None else skip.permute(0, 2, 3, 1))
         out = conv_nhwc(xn, self._weights(), self.conv2d.bias.detach().float(), self.conv2d.kernel_size[0], self.conv2d.stride[0],

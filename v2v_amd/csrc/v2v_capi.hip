@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -40,14 +41,16 @@ bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) %
 // SIMDs of the current device (4 per CU), cached per device; 1024 when the query fails
 int simd_count()
 {
-    static int cached[64] = {};
+    static std::atomic<int> cached[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1024;
-    if (!cached[dev]) {
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (!v) {
         int cus = 0;
-        cached[dev] = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? 4 * cus : 1024;
+        v = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? 4 * cus : 1024;
+        cached[dev].store(v, std::memory_order_relaxed);       // every thread computes the same value
     }
-    return cached[dev];
+    return v;
 }
 
 }  // namespace
@@ -77,17 +80,11 @@ int v2v_lut_set(int which, const void *src)
 {
     if (!src) return fail(V2V_ERR_NULL, "v2v_lut_set: src is NULL");
     if (which < 0 || which > 2) return fail(V2V_ERR_PARAM, "v2v_lut_set: which=%d", which);
-    // the tables are per-device symbols: a host that drives several GPUs from one process gets the same table on all of them
+    // The tables are per-device symbols and this call sets the one of the CURRENT device only: under one process per GPU a rank
+    // must not create HIP contexts (VRAM + start-up cost) on the devices of its peers.  A process that drives several GPUs
+    // calls it once per device (hipSetDevice first).
     void *p = const_cast<void *>(src);
-    int ndev = 0, cur = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return hip_fail(hipGetLastError(), "v2v_lut_set: no device");
-    (void)hipGetDevice(&cur);
-    hipError_t e = hipSuccess;
-    for (int d = 0; d < ndev && e == hipSuccess; ++d) {
-        e = hipSetDevice(d);
-        if (e == hipSuccess) e = which == 2 ? v2v::lut_v2e_copy(p, true) : which == 1 ? v2v::lut_esim32_copy(p, true) : v2v::lut_esim64_copy(p, true);
-    }
-    (void)hipSetDevice(cur);
+    const hipError_t e = which == 2 ? v2v::lut_v2e_copy(p, true) : which == 1 ? v2v::lut_esim32_copy(p, true) : v2v::lut_esim64_copy(p, true);
     return e == hipSuccess ? V2V_OK : hip_fail(e, "v2v_lut_set");
 }
 

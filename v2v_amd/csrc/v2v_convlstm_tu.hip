@@ -1,4 +1,6 @@
 // v2v_convlstm_tu.hip -- translation unit of the fused ConvLSTM step: launchers.
+#include <atomic>
+
 #include "v2v_convlstm.hpp"
 #include "v2v_args.hpp"
 
@@ -11,13 +13,13 @@ hipError_t launch_step_t(const ConvLstmArgs &a, hipStream_t s)
     // 80-128 KB of dynamic LDS is above the 64 KB a kernel gets by default: raise the limit once per device (kept out of the
     // launch path so that a step captures into a hipGraph as a bare kernel node)
     constexpr int lds = KS * cl_lds_bytes(MF, WM, STAGES, WN * NF * 32);
-    static bool raised[64] = {};
+    static std::atomic<bool> raised[64];              // idempotent attribute call: a benign repeat, but no data race
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    if (dev < 0 || dev >= 64 || !raised[dev]) {
+    if (dev < 0 || dev >= 64 || !raised[dev].load(std::memory_order_acquire)) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convlstm_step_kernel<MF, WM, STAGES, EPI, WN, NF, TPC, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) raised[dev] = true;
+        if (dev >= 0 && dev < 64) raised[dev].store(true, std::memory_order_release);
     }
     const int64_t tiles = (int64_t)a.B * a.H * a.W / (32 * MF * WM) * (EPI == 0 ? a.C / kClCh : a.n_cols / (WN * NF * 32));
     hipLaunchKernelGGL((convlstm_step_kernel<MF, WM, STAGES, EPI, WN, NF, TPC, KS>), dim3((unsigned)tiles), dim3(64 * WM * WN * KS), lds, s, a);
@@ -69,12 +71,12 @@ hipError_t launch_conv_nhwc(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
         const int tps = halo_tps < a.ks ? halo_tps : a.ks;
         const int lds = halo_a + 2 * tps * a.n_cols * 128;
         const void *fn = nf == 4 ? (const void *)&conv_halo_kernel<4> : nf == 2 ? (const void *)&conv_halo_kernel<2> : (const void *)&conv_halo_kernel<1>;
-        static bool raised[3][64] = {};                              // once per instance and device (not in a captured launch path)
+        static std::atomic<bool> raised[3][64];                              // once per instance and device (not in a captured launch path)
         const int inst = nf == 4 ? 2 : nf - 1;
-        if (dev < 0 || dev >= 64 || !raised[inst][dev]) {
+        if (dev < 0 || dev >= 64 || !raised[inst][dev].load(std::memory_order_acquire)) {
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
-            if (dev >= 0 && dev < 64) raised[inst][dev] = true;
+            if (dev >= 0 && dev < 64) raised[inst][dev].store(true, std::memory_order_release);
         }
         const unsigned tiles = (unsigned)(a.B * (a.H / 16) * (a.W / 16));
         if (nf == 4) hipLaunchKernelGGL(conv_halo_kernel<4>, dim3(tiles), dim3(256), lds, s, a, tps);

@@ -481,7 +481,7 @@ class SimulatingCollator:
     voxels the per-sample path (`defer_sim: false`, sim_rng 'philox') produces for the same draws."""
 
     def __init__(self, num_bins=5, frames_per_bin=1, put_noise_external=False, output_additional_evs=False,
-                 device="cuda", output_device=None, rng_mode="philox", pad_to=1, normalize=False):
+                 device="cuda", output_device=None, rng_mode="philox", pad_to=1, normalize=False, stager=None):
         self.num_bins, self.frames_per_bin = num_bins, frames_per_bin
         self.put_noise_external = put_noise_external
         self.output_additional_evs = output_additional_evs
@@ -492,7 +492,7 @@ class SimulatingCollator:
         # into the x`pad_to`-padded layout, and `normalize` applies normalize_batch_voxel in place (exact counting select on the
         # integer SUM-mode grids; radix select when the noise is external).  Then run the model with normalize_voxels: false.
         self.pad_to, self.normalize = int(pad_to), bool(normalize)
-        self._stager = None
+        self._stager = stager                     # a shared v2v_amd.staging.HostStager; one is created on first use otherwise
 
     @property
     def stager(self):
@@ -533,7 +533,13 @@ class SimulatingCollator:
         if self.normalize:
             from . import postops
             h, w = clips.shape[-2:]
-            if self.put_noise_external:                       # non-integer voxels: exact radix select on the unpadded interior
+            # The counting select is exact for integer grids with |v| <= 255 and turns any other sample into NaN.  A SUM bin holds
+            # at most frames_per_bin * (log-intensity range 6.91 + noise excursion) / C events: when the batch's own parameters
+            # cannot rule out |v| > 255 (several frames per bin, very small thresholds), take the radix select instead of
+            # handing NaN samples to training (advisor finding, round 2).
+            noise_span = 8.1 * float(pa[:, 2].max() + pa[:, 4].max())       # table Gaussians end at 4.009 sigma, both signs
+            count_bound = self.frames_per_bin * (6.91 + noise_span) / max(float(pa[:, :2].min()), 1e-12) + 1
+            if self.put_noise_external or count_bound > 255:  # non-integer or possibly large voxels: exact radix select on the unpadded interior
                 vox = postops.normalize_and_pad(vox[..., :h, :w], True, self.pad_to, method="radix")
             else:
                 vox = postops.normalize_and_pad(vox, True, self.pad_to, method="count", valid_hw=(h, w), inplace=True)

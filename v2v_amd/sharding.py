@@ -94,3 +94,14 @@ def max_over_ranks(dist, value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_floats(dist, value: float, device=None) -> list:
+    """Every rank's `value`, in rank order, on every rank (timing bookkeeping only; the data path exchanges nothing)."""
+    if dist is None:
+        return [value]
+    dev = device if dist.get_backend() == "nccl" else "cpu"
+    mine = torch.tensor([value], dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]

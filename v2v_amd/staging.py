@@ -23,10 +23,10 @@ class HostStager:
         if key not in self._slots:
             try:
                 mk_pin = lambda: torch.empty(t.shape, dtype=t.dtype).pin_memory()   # noqa: E731
-                self._slots[key] = [[mk_pin(), torch.empty(t.shape, dtype=t.dtype, device=self.device), torch.cuda.Event()]
+                self._slots[key] = [[mk_pin(), torch.empty(t.shape, dtype=t.dtype, device=self.device), torch.cuda.Event(), False]
                                     for _ in range(self.depth)]
             except RuntimeError:                       # RLIMIT_MEMLOCK too small for page-locked memory: pageable copies
-                self._slots[key] = [[None, torch.empty(t.shape, dtype=t.dtype, device=self.device), torch.cuda.Event()]
+                self._slots[key] = [[None, torch.empty(t.shape, dtype=t.dtype, device=self.device), torch.cuda.Event(), False]
                                     for _ in range(self.depth)]
             self._turn[key] = 0
         i = self._turn[key]
@@ -39,16 +39,23 @@ class HostStager:
         consumes batch k before staging batch k+depth)."""
         if host.is_cuda:
             return (host, None)
-        pinned, dev, ev = self._slot(host)
+        slot = self._slot(host)
+        pinned, dev, ev, used = slot
         cur = torch.cuda.current_stream(self.device)
         self.copy_stream.wait_stream(cur)              # the slot's last consumer (enqueued on `cur`) must be done with `dev`
         with torch.cuda.stream(self.copy_stream):
             if host.is_pinned() or pinned is None:
                 dev.copy_(host, non_blocking=True)
             else:
+                # The DMA out of this page-locked buffer that was queued `depth` calls ago sits behind the compute stream's
+                # backlog (wait_stream above is a GPU-side dependency: it does not hold the host back).  A host that runs
+                # ahead of the GPU would overwrite the buffer before that DMA has read it -- wait for it ON THE HOST first.
+                if used:
+                    ev.synchronize()
                 pinned.copy_(host)                     # host memcpy into the page-locked buffer (overlaps the GPU's work)
                 dev.copy_(pinned, non_blocking=True)
             ev.record(self.copy_stream)
+            slot[3] = True
         return (dev, ev)
 
     def ready(self, handle) -> torch.Tensor:
