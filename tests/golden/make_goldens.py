@@ -366,6 +366,70 @@ def g14_v2e_native():
     save("g14_v2e_native.npz", **out)
 
 
+def g18_unet_modules():
+    """The reference's own consumer modules run in float32 on seeded weights (tests/seeded_weights.py: the recipe, not the
+    10.7 M values, is what the fixture shares with the GPU tests): model/submodules.py ConvLSTM (:179-235, two steps incl.
+    prev_state=None), ResidualBlock (:143-177), ConvLayer 5x5 stride 2 (:6-33), UpsampleConvLayer (:68-96), and
+    model/unet.py UNetRecurrent (:252-310) with the kwargs of config/train_v2v_e2vid_10k.yaml:21-30 over 3 time steps at 64x64.
+    Stored: inputs, outputs, the seeds / gains, and the reference modules' state_dict keys + shapes (so the package module's
+    key compatibility is checked without a GPU)."""
+    import contextlib
+    import io
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from seeded_weights import load_seeded
+    import model.submodules as sm          # the reference's modules (REF is on sys.path)
+    import model.unet as un
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    g = np.random.Generator(np.random.PCG64(1818))
+    rnd = lambda *shape: g.standard_normal(shape).astype(np.float32)      # noqa: E731
+    out = {}
+    with torch.no_grad():
+        # ConvLSTM, C = 64, 16x16, two steps: prev_state None, then the returned state
+        m = sm.ConvLSTM(64, 64, 3).eval()
+        load_seeded(m, 1801, gain=1.0)
+        x0, x1 = rnd(1, 64, 16, 16), rnd(1, 64, 16, 16)
+        h1, c1 = m(torch.from_numpy(x0), None)
+        h2, c2 = m(torch.from_numpy(x1), (h1, c1))
+        out.update(convlstm__x0=x0, convlstm__x1=x1, convlstm__h1=h1.numpy(), convlstm__c1=c1.numpy(), convlstm__h2=h2.numpy(),
+                   convlstm__c2=c2.numpy(), convlstm__seed=np.array(1801))
+        # ResidualBlock 256 -> 256 at 8x8 (the bottleneck of the 64x64 network)
+        m = sm.ResidualBlock(256, 256).eval()
+        load_seeded(m, 1802, gain=1.0)
+        x = rnd(1, 256, 8, 8)
+        out.update(resblock__x=x, resblock__y=m(torch.from_numpy(x.copy())).numpy(), resblock__seed=np.array(1802))
+        # ConvLayer 5x5 stride 2, 64 -> 128 (the second encoder's convolution)
+        m = sm.ConvLayer(64, 128, 5, stride=2, padding=2).eval()
+        load_seeded(m, 1803, gain=1.0)
+        x = rnd(1, 64, 16, 16)
+        out.update(convlayer__x=x, convlayer__y=m(torch.from_numpy(x)).numpy(), convlayer__seed=np.array(1803))
+        # UpsampleConvLayer 128 -> 64 (the second decoder)
+        m = sm.UpsampleConvLayer(128, 64, 5, padding=2).eval()
+        load_seeded(m, 1804, gain=1.0)
+        x = rnd(1, 128, 8, 8)
+        out.update(upsample__x=x, upsample__y=m(torch.from_numpy(x)).numpy(), upsample__seed=np.array(1804))
+        # UNetRecurrent, the training configuration, three time steps of integer voxel grids
+        kwargs = dict(num_bins=5, skip_type="sum", recurrent_block_type="convlstm", num_encoders=3, base_num_channels=32,
+                      num_residual_blocks=2, use_upsample_conv=True, final_activation="", norm=None)
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = un.UNetRecurrent(dict(kwargs)).eval()
+        gain = 1.7                                              # keeps the random-init activations O(1) through the depth of the net
+        probe = load_seeded(net, 1805, gain=gain)
+        out["unet__weight_probe"] = np.concatenate([probe[k].ravel()[:3] for k in list(probe)[::5]])   # the recipe must reproduce these bits
+        vox = g.integers(-3, 4, size=(3, 1, 5, 64, 64)).astype(np.float32)
+        vox[g.random(vox.shape) < 0.6] = 0.0                    # sparse, like event counts
+        imgs = [net(torch.from_numpy(vox[t]))["image"].numpy() for t in range(3)]
+        sd = net.state_dict()
+        out.update(unet__vox=vox.astype(np.int8), unet__images=np.stack(imgs), unet__seed=np.array(1805), unet__gain=np.array(gain),
+                   unet__keys=np.array(list(sd.keys())), unet__shapes=np.array([",".join(map(str, v.shape)) for v in sd.values()]),
+                   unet__hidden0_absmax=np.array([float(s[0].abs().max()) for s in net.states]),
+                   unet__n_params=np.array(sum(v.numel() for v in sd.values())))
+        print(f"  g18 unet: {int(out['unet__n_params'])} parameters, image range {np.stack(imgs).min():.3f} .. {np.stack(imgs).max():.3f}, "
+              f"std {np.stack(imgs).std():.3f}")
+    save("g18_unet_modules.npz", **out)
+
+
 def g15_bgr_to_gray():
     """The reference's bgr_to_gray (data/v2v_datasets.py:19-22) on ALL 2^24 colours, passed as the 4-D [N,H,W,3] stack the
     reference passes (np.dot's evaluation order depends on the array's dimensionality): sha256 of the full [256,256,256]
@@ -508,9 +572,9 @@ def g17_degrade_video():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
     fns = {"g1": g1_luts, "g2": g2_g3_esim_clean, "g4": g4_esim_noisy, "g5": g5_floor_divide,
-           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g15": g15_bgr_to_gray, "g16": g16_monash_sequence, "g17": g17_degrade_video, "g12": g12_events_to_voxel_torch,
+           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g15": g15_bgr_to_gray, "g16": g16_monash_sequence, "g17": g17_degrade_video, "g18": g18_unet_modules, "g12": g12_events_to_voxel_torch,
            "g13": g13_normalize_batch_voxel}
     for w in which:
         fns[w]()

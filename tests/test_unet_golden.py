@@ -1,0 +1,123 @@
+"""Golden G18: the device-kernel consumer (v2v_amd/unet.py, v2v_amd/convlstm.py) against outputs of the REFERENCE'S OWN modules
+(model/submodules.py:6-33,68-96,143-235; model/unet.py:252-310) run in float32 on seeded weights by tests/golden/make_goldens.py.
+
+Tolerances are ABSOLUTE and written here.  The kernels compute on bfloat16 operands with float32 accumulation; the reference
+ran in float32.  For the values in this fixture (inputs ~N(0,1), activations O(1)):
+    single layers   |err| <= 3e-2 max, 6e-3 rms   (one bf16 rounding of inputs + weights, K up to 2304, one bf16 rounding of the output)
+    ConvLSTM        |err| <= 1e-2 max on hidden (|h| < 0.4) and cell (float32, never rounded to bf16)
+    UNetRecurrent   |err| <= 4e-2 max, 8e-3 rms on the prediction (std 0.78, range -3.9..2.8) at every one of 3 time steps
+(the reference's own network under CPU bf16 autocast lands at 1.5e-2 max / 3.4e-3 rms against its float32 self.)
+"""
+import os
+
+import numpy as np
+import pytest
+
+from seeded_weights import load_seeded, seeded_state
+
+gpu = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+KW = dict(num_bins=5, skip_type="sum", recurrent_block_type="convlstm", num_encoders=3, base_num_channels=32,
+          num_residual_blocks=2, use_upsample_conv=True, final_activation="", norm=None)
+
+
+@pytest.fixture(scope="module")
+def g18():
+    return np.load(os.path.join(HERE, "golden", "g18_unet_modules.npz"))
+
+
+def _err(got, want):
+    d = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    return float(d.max()), float(np.sqrt((d ** 2).mean()))
+
+
+# ---- no GPU needed: the package modules carry the reference's state_dict keys and shapes -------------------------------------
+def test_package_unet_has_the_reference_state_dict_keys(g18):
+    from v2v_amd.unet import E2VIDRecurrent, UNetRecurrent
+    net = UNetRecurrent(dict(KW))
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g18["unet__keys"]]
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in g18["unet__shapes"]]
+    assert sum(v.numel() for v in sd.values()) == int(g18["unet__n_params"]) == 10710401
+    wrapped = E2VIDRecurrent(dict(KW))
+    assert list(wrapped.state_dict().keys()) == ["unetrecurrent." + str(k) for k in g18["unet__keys"]]       # model/model.py:203
+    assert wrapped.states == [None, None, None]
+    wrapped.reset_states()
+    for bad in (dict(KW, skip_type="concat"), dict(KW, use_upsample_conv=False), dict(KW, norm="BN"), dict(KW, recurrent_block_type="convgru")):
+        with pytest.raises(ValueError):
+            UNetRecurrent(bad)
+
+
+def test_seeded_weight_recipe_reproduces_the_generators_bits(g18):
+    shapes = {str(k): tuple(int(x) for x in str(s).split(",")) for k, s in zip(g18["unet__keys"], g18["unet__shapes"])}
+    vals = seeded_state(shapes, int(g18["unet__seed"]), float(g18["unet__gain"]))
+    probe = np.concatenate([vals[k].ravel()[:3] for k in list(vals)[::5]])
+    assert np.array_equal(probe, g18["unet__weight_probe"])
+
+
+# ---- GPU: device kernels vs the reference's outputs ---------------------------------------------------------------------------
+@gpu
+def test_convlstm_two_steps_vs_reference(g18):
+    import torch
+    from v2v_amd.convlstm import ConvLSTM
+    m = ConvLSTM(64, 64, 3).cuda().eval()
+    load_seeded(m, int(g18["convlstm__seed"]))
+    with torch.no_grad():
+        h1, c1 = m(torch.from_numpy(g18["convlstm__x0"]).cuda(), None)
+        h2, c2 = m(torch.from_numpy(g18["convlstm__x1"]).cuda(), (h1, c1))
+    for name, got in (("h1", h1), ("c1", c1), ("h2", h2), ("c2", c2)):
+        mx, rms = _err(got.float().cpu().numpy(), g18["convlstm__" + name])
+        assert mx <= 1e-2 and rms <= 2e-3, (name, mx, rms)
+
+
+@gpu
+@pytest.mark.parametrize("layout", ["nchw_f32", "channels_last_bf16"])
+def test_single_layers_vs_reference(g18, layout):
+    import torch
+    from v2v_amd.convlstm import ConvLayer, ResidualBlock
+    from v2v_amd.unet import UpsampleConvLayer
+    cases = [("resblock", ResidualBlock(256, 256)), ("convlayer", ConvLayer(64, 128, 5, stride=2, padding=2)),
+             ("upsample", UpsampleConvLayer(128, 64, 5, padding=2))]
+    for name, mod in cases:
+        mod = mod.cuda().eval()
+        load_seeded(mod, int(g18[name + "__seed"]))
+        x = torch.from_numpy(g18[name + "__x"]).cuda()
+        if layout == "channels_last_bf16":
+            x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            y = mod(x)
+        assert tuple(y.shape) == g18[name + "__y"].shape
+        mx, rms = _err(y.float().cpu().numpy(), g18[name + "__y"])
+        assert mx <= 3e-2 and rms <= 6e-3, (name, layout, mx, rms)
+
+
+@gpu
+def test_unet_recurrent_three_steps_vs_reference(g18):
+    """UNetRecurrent(num_bins 5, base 32, 3 encoders, 2 residual blocks, sum skips) loaded through the REFERENCE'S state_dict keys,
+    3 time steps at 64x64 with the recurrent state carried, float32 NCHW voxel grids in, float32 prediction out."""
+    import torch
+    from v2v_amd.unet import E2VIDRecurrent
+    net = E2VIDRecurrent(dict(KW)).cuda().eval()
+    shapes = {str(k): tuple(int(x) for x in str(s).split(",")) for k, s in zip(g18["unet__keys"], g18["unet__shapes"])}
+    vals = seeded_state(shapes, int(g18["unet__seed"]), float(g18["unet__gain"]))
+    missing = net.load_state_dict({"unetrecurrent." + k: torch.from_numpy(v) for k, v in vals.items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    vox = torch.from_numpy(g18["unet__vox"].astype(np.float32)).cuda()
+    net.reset_states()
+    with torch.no_grad():
+        for t in range(3):
+            img = net(vox[t])["image"]
+            assert img.dtype == torch.float32 and tuple(img.shape) == (1, 1, 64, 64)
+            mx, rms = _err(img.cpu().numpy(), g18["unet__images"][t])
+            assert mx <= 4e-2 and rms <= 8e-3, (t, mx, rms)
+    st = net.states                                                   # model/model.py:205-207: a copy, (hidden, cell) per encoder
+    assert len(st) == 3 and all(isinstance(s, tuple) and len(s) == 2 for s in st)
+    for s, want in zip(st, g18["unet__hidden0_absmax"]):
+        assert abs(float(s[0].float().abs().max()) - float(want)) <= 2e-2
+    # the same network fed channels-last bfloat16 under autocast (how bench.py's config 5 runs it) gives the same prediction
+    net.reset_states()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        for t in range(3):
+            img = net(vox[t].contiguous(memory_format=torch.channels_last))["image"]
+            mx, rms = _err(img.float().cpu().numpy(), g18["unet__images"][t])
+            assert img.dtype == torch.bfloat16 and mx <= 6e-2 and rms <= 1.2e-2, (t, mx, rms)     # + one bf16 rounding of the output (|img| < 4)

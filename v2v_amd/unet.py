@@ -1,0 +1,142 @@
+"""The recurrent UNet that consumes the voxel grids (BASELINE config 5), assembled from the device kernels of
+v2v_amd/convlstm.py under the REFERENCE'S OWN module tree, so that a reference checkpoint loads unchanged:
+
+    E2VIDRecurrent(unet_kwargs)            model/model.py:194-223          keys  unetrecurrent.*
+    UNetRecurrent(unet_kwargs)             model/unet.py:252-310           keys  head.conv2d.*, encoders.N.conv.conv2d.*,
+                                                                                 encoders.N.recurrent_block.Gates.*,
+                                                                                 resblocks.N.conv1.* / conv2.*,
+                                                                                 decoders.N.conv2d.*, pred.conv2d.*
+    RecurrentConvLayer / UpsampleConvLayer model/submodules.py:99-119 / :68-96
+
+Configuration covered = what config/train_v2v_e2vid_10k.yaml:21-30 instantiates: skip_type 'sum', recurrent_block_type
+'convlstm', use_upsample_conv true, norm none, kernel_size 5, base_num_channels 32, channel_multiplier 2 (anything else raises:
+there is no stock-layer fallback inside this module).  Inference only (the kernels have no backward).
+
+Inside forward() everything runs in bfloat16 NHWC (torch.channels_last views of the kernels' own buffers): the head takes
+the float voxel grid in any layout, every later layer consumes and produces NHWC in place, the cell states stay float32, and
+the prediction comes back in the input's dtype.  Parity: golden G18 = the reference's modules run in float32 on seeded
+weights (tests/test_unet_golden.py; tolerance stated there).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .convlstm import ConvLayer, ConvLSTM, ResidualBlock
+
+
+class UpsampleConvLayer(ConvLayer):
+    """model/submodules.py:68-96: bilinear x2 upsampling + convolution + ReLU; forward(x, skip) == forward(skip_sum(x, skip))."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, activation="relu", norm=None):
+        super().__init__(in_channels, out_channels, kernel_size, stride=stride, padding=padding, activation=activation, norm=norm,
+                         upsample=True)
+
+
+class RecurrentConvLayer(nn.Module):
+    """model/submodules.py:99-119: ConvLayer followed by the ConvLSTM; same attribute names (`conv`, `recurrent_block`)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=0, recurrent_block_type="convlstm",
+                 activation="relu", norm=None, BN_momentum=0.1):
+        super().__init__()
+        if recurrent_block_type != "convlstm":
+            raise ValueError("only recurrent_block_type 'convlstm' runs on the device kernels")
+        self.recurrent_block_type = recurrent_block_type
+        self.conv = ConvLayer(in_channels, out_channels, kernel_size, stride, padding, activation, norm)
+        self.recurrent_block = ConvLSTM(input_size=out_channels, hidden_size=out_channels, kernel_size=3)
+
+    def forward(self, x, prev_state):
+        x = self.conv(x)                                   # ReLU in the convolution's epilogue
+        state = self.recurrent_block(x, prev_state)
+        return state[0], state
+
+
+class UNetRecurrent(nn.Module):
+    """model/unet.py:252-310 (+ BaseUNet :13-64).  `unet_kwargs` as the reference's YAML gives them."""
+
+    def __init__(self, unet_kwargs):
+        super().__init__()
+        kw = dict(unet_kwargs)
+        final_activation = kw.pop("final_activation", "none")
+        self.final_activation = getattr(torch, final_activation, None) if final_activation else None
+        kw["num_output_channels"] = 1                      # :263
+        self.base_num_channels = kw["base_num_channels"]
+        self.num_encoders = kw["num_encoders"]
+        self.num_residual_blocks = kw["num_residual_blocks"]
+        self.num_output_channels = kw["num_output_channels"]
+        self.kernel_size = kw.get("kernel_size", 5)
+        self.skip_type = kw["skip_type"]
+        self.norm = kw.get("norm", None)
+        self.num_bins = kw["num_bins"]
+        self.recurrent_block_type = kw.get("recurrent_block_type", None)
+        mult = kw.get("channel_multiplier", 2)
+        if self.norm in ("none", "None", ""):
+            self.norm = None
+        if self.skip_type != "sum" or not kw.get("use_upsample_conv", True) or self.norm is not None:
+            raise ValueError("the device kernels cover skip_type 'sum', use_upsample_conv true, norm none "
+                             "(config/train_v2v_e2vid_10k.yaml:21-30)")
+        self.encoder_input_sizes = [int(self.base_num_channels * pow(mult, i)) for i in range(self.num_encoders)]
+        self.encoder_output_sizes = [int(self.base_num_channels * pow(mult, i + 1)) for i in range(self.num_encoders)]
+        self.max_num_channels = self.encoder_output_sizes[-1]
+        k = self.kernel_size
+        self.head = ConvLayer(self.num_bins, self.base_num_channels, kernel_size=k, stride=1, padding=k // 2)
+        self.encoders = nn.ModuleList(
+            RecurrentConvLayer(i, o, kernel_size=k, stride=2, padding=k // 2, recurrent_block_type=self.recurrent_block_type, norm=self.norm)
+            for i, o in zip(self.encoder_input_sizes, self.encoder_output_sizes))
+        self.resblocks = nn.ModuleList(ResidualBlock(self.max_num_channels, self.max_num_channels, norm=self.norm)
+                                       for _ in range(self.num_residual_blocks))
+        self.decoders = nn.ModuleList(UpsampleConvLayer(i, o, kernel_size=k, padding=k // 2, norm=self.norm)
+                                      for i, o in zip(reversed(self.encoder_output_sizes), reversed(self.encoder_input_sizes)))
+        self.pred = ConvLayer(self.base_num_channels, self.num_output_channels, 1, activation=None, norm=self.norm)
+        self.states = [None] * self.num_encoders
+
+    def forward(self, x):
+        """x: [N, num_bins, H, W] float voxel grid (any layout), H and W multiples of 2^num_encoders -> {'image': [N,1,H,W]}."""
+        out_dtype = torch.bfloat16 if (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()) else x.dtype
+        with torch.autocast("cuda", dtype=torch.bfloat16):      # the head hands out bfloat16; every later layer keeps it
+            x = self.head(x if x.dim() != 4 else x.contiguous(memory_format=torch.channels_last))
+        head = x
+        blocks = []
+        for i, encoder in enumerate(self.encoders):
+            x, state = encoder(x, self.states[i])
+            blocks.append(x)
+            self.states[i] = state
+        for resblock in self.resblocks:
+            x = resblock(x)
+        for i, decoder in enumerate(self.decoders):
+            x = decoder(x, blocks[self.num_encoders - i - 1])   # skip_sum folded into the upsampling kernel (:304)
+        img = self.pred(x, head)                                 # pred(skip_sum(x, head)) in one pass (:307)
+        if self.final_activation is not None:
+            img = self.final_activation(img)
+        return {"image": img.to(out_dtype)}
+
+
+def copy_states(states):
+    """model/model.py:17-24 copy_states: clone every state tensor (a list of None stays a list of None)."""
+    if states[0] is None:
+        return list(states)
+    return [tuple(s.detach().clone() for s in st) if isinstance(st, tuple) else st.detach().clone() for st in states]
+
+
+class E2VIDRecurrent(nn.Module):
+    """model/model.py:194-223: `unetrecurrent` + the states property / reset_states the training loop uses."""
+
+    def __init__(self, unet_kwargs):
+        super().__init__()
+        self.num_bins = unet_kwargs["num_bins"]
+        self.num_encoders = unet_kwargs["num_encoders"]
+        self.unetrecurrent = UNetRecurrent(unet_kwargs)
+
+    @property
+    def states(self):
+        return copy_states(self.unetrecurrent.states)
+
+    @states.setter
+    def states(self, states):
+        self.unetrecurrent.states = states
+
+    def reset_states(self):
+        self.unetrecurrent.states = [None] * self.unetrecurrent.num_encoders
+
+    def forward(self, event_tensor):
+        return self.unetrecurrent.forward(event_tensor)
