@@ -197,9 +197,27 @@ class Workload:
                 from e2vid_consumer import E2VIDShapedConsumer, forward_sequence
                 torch.manual_seed(0)
                 fused, c_last = str(wl["consumer"]).startswith("fused"), str(wl["consumer"]).endswith("_cl")
-                consumer = E2VIDShapedConsumer(num_bins=tb, fused_convlstm=fused).to(dev).eval()
-                if c_last:
-                    consumer = consumer.to(memory_format=torch.channels_last)
+                if fused and c_last:
+                    # the PRODUCT's network: v2v_amd.unet.E2VIDRecurrent (the reference's module tree and state_dict keys, every
+                    # layer on the device kernels, bfloat16 NHWC inside); random init, as the reference starts training
+                    from v2v_amd.unet import E2VIDRecurrent
+                    net = E2VIDRecurrent(dict(num_bins=tb, skip_type="sum", recurrent_block_type="convlstm", num_encoders=3,
+                                              base_num_channels=32, num_residual_blocks=2, use_upsample_conv=True,
+                                              final_activation="", norm=None)).to(dev).eval()
+
+                    class _Seq:                                              # forward_sequence's protocol
+                        reads_any_layout = True
+
+                        def reset_states(self):
+                            net.reset_states()
+
+                        def __call__(self, x):
+                            return net(x)["image"]
+                    consumer = _Seq()
+                else:
+                    consumer = E2VIDShapedConsumer(num_bins=tb, fused_convlstm=fused).to(dev).eval()
+                    if c_last:
+                        consumer = consumer.to(memory_format=torch.channels_last)
                 self.kernel_name += (" + E2VID-shaped UNet forward (bf16 autocast" + (", channels_last" if c_last else "")
                                      + (", ConvLSTM / residual / 5x5 convolutions / upsampling on the device kernels)" if fused else ")"))
 

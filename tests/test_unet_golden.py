@@ -55,6 +55,29 @@ def test_seeded_weight_recipe_reproduces_the_generators_bits(g18):
     assert np.array_equal(probe, g18["unet__weight_probe"])
 
 
+def test_stock_restatement_of_the_network_equals_the_reference_on_cpu(g18):
+    """tools/e2vid_consumer.py (the stock-PyTorch network bench.py and the full-size config-5 test use as float32 yardstick) is a
+    restatement: this pins it to the reference's UNetRecurrent outputs -- float32 on the CPU, same seeded weights through the key
+    map, 3 recurrent steps; float32 summation order is the only freedom (1e-4 absolute on values up to 3.9)."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    from e2vid_consumer import E2VIDShapedConsumer, forward_sequence, reference_to_stock_keys, stock_to_reference_keys
+    torch.set_num_threads(4)
+    net = E2VIDShapedConsumer(num_bins=5).eval()
+    shapes = {str(k): tuple(int(x) for x in str(s).split(",")) for k, s in zip(g18["unet__keys"], g18["unet__shapes"])}
+    vals = seeded_state(shapes, int(g18["unet__seed"]), float(g18["unet__gain"]))
+    sd = reference_to_stock_keys({k: torch.from_numpy(v) for k, v in vals.items()})
+    assert set(stock_to_reference_keys(sd)) == set(vals)
+    net.load_state_dict(sd, strict=True)
+    vox = torch.from_numpy(g18["unet__vox"].astype(np.float32)).permute(1, 0, 2, 3, 4)          # [B=1, T=3, 5, 64, 64]
+    with torch.no_grad():
+        imgs = forward_sequence(net, vox)
+    for t in range(3):
+        mx, _ = _err(imgs[t].numpy(), g18["unet__images"][t])
+        assert mx <= 1e-4, (t, mx)
+
+
 # ---- GPU: device kernels vs the reference's outputs ---------------------------------------------------------------------------
 @gpu
 def test_convlstm_two_steps_vs_reference(g18):

@@ -142,11 +142,56 @@ def forward_sequence(model, events, channels_last=False):
     """events [B,T,C,H,W] -> list of T predictions (the time loop of model/train_utils.py:339-345).  channels_last=True feeds
     every time step in torch.channels_last (the model should have been moved with .to(memory_format=torch.channels_last))."""
     model.reset_states()
-    if channels_last and isinstance(getattr(model, "head", None), _FusedConv):
+    if channels_last and (isinstance(getattr(model, "head", None), _FusedConv) or getattr(model, "reads_any_layout", False)):
         return [model(events[:, t]) for t in range(events.shape[1])]       # the fused head reads any strides (its own layout kernel)
     if channels_last:
         return [model(events[:, t].contiguous(memory_format=torch.channels_last)) for t in range(events.shape[1])]
     return [model(events[:, t]) for t in range(events.shape[1])]
+
+
+def stock_to_reference_keys(sd):
+    """state_dict of a stock E2VIDShapedConsumer -> the reference UNetRecurrent's keys (model/unet.py:252-310), and back with
+    reference_to_stock_keys: head.conv2d.*, encoders.N.conv.conv2d.*, encoders.N.recurrent_block.Gates.*, resblocks.N.conv1/2.*,
+    decoders.N.conv2d.*, pred.conv2d.*."""
+    out = {}
+    for k, v in sd.items():
+        top, rest = k.split(".", 1)
+        if top in ("head", "pred"):
+            out[f"{top}.conv2d.{rest}"] = v
+        elif top == "enc":
+            i, leaf = rest.split(".", 1)
+            out[f"encoders.{i}.conv.conv2d.{leaf}"] = v
+        elif top == "rec":
+            i, _, leaf = rest.split(".", 2)
+            out[f"encoders.{i}.recurrent_block.Gates.{leaf}"] = v
+        elif top == "res":
+            i, ab, leaf = rest.split(".", 2)
+            out[f"resblocks.{i}.{'conv1' if ab == 'a' else 'conv2'}.{leaf}"] = v
+        elif top == "dec":
+            i, leaf = rest.split(".", 1)
+            out[f"decoders.{i}.conv2d.{leaf}"] = v
+        else:
+            raise KeyError(k)
+    return out
+
+
+def reference_to_stock_keys(sd):
+    out = {}
+    for k, v in sd.items():
+        p = k.split(".")
+        if p[0] in ("head", "pred"):
+            out[f"{p[0]}.{p[-1]}"] = v
+        elif p[0] == "encoders" and p[2] == "conv":
+            out[f"enc.{p[1]}.{p[-1]}"] = v
+        elif p[0] == "encoders":
+            out[f"rec.{p[1]}.gates.{p[-1]}"] = v
+        elif p[0] == "resblocks":
+            out[f"res.{p[1]}.{'a' if p[2] == 'conv1' else 'b'}.{p[-1]}"] = v
+        elif p[0] == "decoders":
+            out[f"dec.{p[1]}.{p[-1]}"] = v
+        else:
+            raise KeyError(k)
+    return out
 
 
 if __name__ == "__main__":

@@ -368,6 +368,7 @@ class ConvLayer(nn.Module):
         self.head = in_channels <= 8 and kernel_size in (3, 5)                  # the UNet's head: voxel bins -> 32 channels
         if self.head and (out_channels != 32 or stride != 1 or upsample):
             raise ValueError("with <= 8 input channels the fused ConvLayer is the UNet's head: 32 output channels, stride 1")
+        self.force_channels_last = False          # head only: hand out the kernel's NHWC buffer as a channels-last view whatever came in
         self._packed = (None, None)
 
     def _weights(self):
@@ -400,7 +401,7 @@ class ConvLayer(nn.Module):
             low = x.dtype == torch.bfloat16 or (x.is_cuda and torch.is_autocast_enabled())
             # channels-last out when the input or (as torch's own convolution decides) the weight is channels-last
             w = self.conv2d.weight
-            cl = any(v.is_contiguous(memory_format=torch.channels_last) and not v.is_contiguous() for v in (x, w))
+            cl = self.force_channels_last or any(v.is_contiguous(memory_format=torch.channels_last) and not v.is_contiguous() for v in (x, w))
             out = conv_head_nhwc(to_nhwc8_bf16(x.float()), self._weights(), self.conv2d.bias, self.conv2d.kernel_size[0], relu=self.relu).permute(0, 3, 1, 2)
             out = out if cl else out.contiguous()
             return out if low else out.to(x.dtype)

@@ -80,6 +80,7 @@ class UNetRecurrent(nn.Module):
         self.max_num_channels = self.encoder_output_sizes[-1]
         k = self.kernel_size
         self.head = ConvLayer(self.num_bins, self.base_num_channels, kernel_size=k, stride=1, padding=k // 2)
+        self.head.force_channels_last = True               # NHWC from the first layer on, whatever layout the voxel grid arrives in
         self.encoders = nn.ModuleList(
             RecurrentConvLayer(i, o, kernel_size=k, stride=2, padding=k // 2, recurrent_block_type=self.recurrent_block_type, norm=self.norm)
             for i, o in zip(self.encoder_input_sizes, self.encoder_output_sizes))
@@ -94,7 +95,7 @@ class UNetRecurrent(nn.Module):
         """x: [N, num_bins, H, W] float voxel grid (any layout), H and W multiples of 2^num_encoders -> {'image': [N,1,H,W]}."""
         out_dtype = torch.bfloat16 if (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()) else x.dtype
         with torch.autocast("cuda", dtype=torch.bfloat16):      # the head hands out bfloat16; every later layer keeps it
-            x = self.head(x if x.dim() != 4 else x.contiguous(memory_format=torch.channels_last))
+            x = self.head(x)                                    # reads any strides (its own layout kernel), bfloat16 NHWC out
         head = x
         blocks = []
         for i, encoder in enumerate(self.encoders):
