@@ -215,9 +215,12 @@ int v2v_events_to_voxel_hip(const double *ts, const int64_t *xs, const int64_t *
  * __getitem__ (:311-316) for frames that are already decoded and on the device.
  * src [T,Hs,Ws,Cs] uint8 (Cs = 3 BGR or 1); frame_idx [N] int32 = decoded frame shown by each simulator frame;
  * shake_di/dj [T] int32 (>= 0) or NULL; out_gray [N,crop,crop] uint8 (simulator input); out_imgs [N,crop,crop,C]
- * uint8 or NULL.  gray_first != 0: color_mode 'gray' (cvtColor before the resize); 0 with Cs == 3:
- * 'gray_in_bgr_out' (resize BGR, gray = bgr_to_gray, v2v_datasets.py:19-22).
- * PARITY UNPINNED against OpenCV (absent here): bit-exact against the restatement in oracle/frontend_oracle.py. */
+ * uint8 or NULL.  gray_first: color_mode 'gray' (cvtColor BGR2GRAY before the resize) = 1 with the 15-bit weights of
+ * OpenCV >= 4.0 (3735/19235/9798, +2^14, >> 15: what an unpinned opencv-python installs), 2 with the 14-bit weights of
+ * OpenCV 2.x/3.x (1868/9617/4899, +2^13, >> 14); 0 with Cs == 3: 'gray_in_bgr_out' (resize BGR, gray = bgr_to_gray,
+ * v2v_datasets.py:19-22).
+ * PARITY UNPINNED against OpenCV (absent here): bit-exact against the restatement of the OpenCV 4.x 8-bit algorithms in
+ * oracle/frontend_oracle.py. */
 int v2v_frontend_hip(const uint8_t *src, int64_t T, int64_t Hs, int64_t Ws, int64_t Cs, int64_t min_i, int64_t min_j,
                      int64_t crop_before, int64_t need_h, int64_t need_w, int64_t crop, int flip, int gray_first,
                      const int32_t *frame_idx, int64_t N, const int32_t *shake_di, const int32_t *shake_dj, uint8_t *out_imgs,

@@ -4,11 +4,17 @@ Reference flow: data/v2v_datasets.py:191-224 (per decoded frame: [cvtColor BGR2G
 INTER_LINEAR -> [flip] ; then per-frame shake crop), :311-316 (pause-index gather, gray = channel 0 or bgr_to_gray).
 
 PARITY UNPINNED for the OpenCV pieces: cv2 is a third-party dependency that is absent from /root/reference and from
-this image (requirements.txt lists opencv-python unpinned), so cv2.resize / cv2.cvtColor cannot be run here and no
-golden vectors exist.  What is restated below is OpenCV's published 8-bit algorithm (modules/imgproc/src/resize.cpp:
-float source coordinate (dx+0.5)*scale-0.5, 11-bit fixed-point weights, two-pass int32 accumulation with the
-(>>4, >>16, +2, >>2) vertical rounding; exact 2x2 box average when both scales are exactly 2; color.cpp: BGR2GRAY
-with 14-bit coefficients 1868/9617/4899).  bgr_to_gray (np.dot + truncation, v2v_datasets.py:19-22) is the reference's
+this image, so cv2.resize / cv2.cvtColor cannot be run here and no golden vectors exist.  The reference's
+requirements.txt:11 lists `opencv-python` UNPINNED, i.e. a current 4.x wheel: the version restated here is
+**OpenCV 4.x (4.5 - 4.10 sources; the 8-bit paths below have not changed across them)**:
+  * modules/imgproc/src/resize.cpp, INTER_LINEAR, 8u: float source coordinate (dx+0.5)*scale-0.5, 11-bit fixed-point
+    weights (INTER_RESIZE_COEF_BITS), two-pass int32 accumulation with the (>>4, >>16, +2, >>2) vertical rounding of
+    VResizeLinear<uchar,...>; exact 2x2 box average when both scales are exactly 2 (the INTER_LINEAR -> INTER_AREA shortcut).
+  * modules/imgproc/src/color_rgb.simd.hpp, RGB2Gray<uchar>: since OpenCV 4.0 the 8-bit path uses the 15-BIT weights
+    BY15 = 3735, GY15 = 19235, RY15 = 9798 with gray_shift = 15: (B*3735 + G*19235 + R*9798 + 2^14) >> 15.
+    OpenCV 2.x / 3.x (color.cpp) used the 14-bit weights 1868 / 9617 / 4899 with (+2^13) >> 14 -- round 2 of this build
+    restated THAT form by mistake.  Both are selectable (`version`); the default everywhere is the 4.x form.
+  Known answers worked by hand from the two formulas are in tests/test_frontend.py::test_bgr2gray_known_answers.  bgr_to_gray (np.dot + truncation, v2v_datasets.py:19-22) is the reference's
 own NumPy code and IS pinned: golden G15 holds its output on all 2^24 colours (see bgr_to_gray_scalar).
 """
 from __future__ import annotations
@@ -60,10 +66,17 @@ def cv_resize_linear_u8(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
     return out[..., 0] if squeeze else out
 
 
-def cv_bgr2gray_u8(img: np.ndarray) -> np.ndarray:
-    """cv2.cvtColor(img, COLOR_BGR2GRAY) for uint8 (14-bit fixed point)."""
+GRAY_VERSIONS = {"cv4": 1, "cv3": 2}          # the C ABI's gray_first values
+
+
+def cv_bgr2gray_u8(img: np.ndarray, version: str = "cv4") -> np.ndarray:
+    """cv2.cvtColor(img, COLOR_BGR2GRAY) for uint8: "cv4" = OpenCV >= 4.0 (15-bit fixed point), "cv3" = OpenCV 2.x / 3.x (14-bit)."""
     b, g, r = (img[..., k].astype(np.int64) for k in range(3))
-    return ((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+    if version == "cv4":
+        return ((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15).astype(np.uint8)
+    if version == "cv3":
+        return ((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+    raise ValueError("version must be 'cv4' or 'cv3'")
 
 
 def bgr_to_gray_scalar(img: np.ndarray) -> np.ndarray:
@@ -74,7 +87,7 @@ def bgr_to_gray_scalar(img: np.ndarray) -> np.ndarray:
     return clib.bgr_to_gray(img)
 
 
-def frontend(raw, crop_before, min_i, min_j, flip, crop_size, img_idxes, all_di=None, all_dj=None, color_mode="gray"):
+def frontend(raw, crop_before, min_i, min_j, flip, crop_size, img_idxes, all_di=None, all_dj=None, color_mode="gray", cv_version="cv4"):
     """raw: list/array of decoded frames [T,Hs,Ws,3] uint8 (BGR).  Returns (all_imgs [N,crop,crop,C], gray [N,crop,crop]).
     Mirrors read_video (:145-225) + the gather of __getitem__ (:311-316)."""
     t = len(raw)
@@ -86,7 +99,7 @@ def frontend(raw, crop_before, min_i, min_j, flip, crop_size, img_idxes, all_di=
     for k in range(t):
         f = raw[k]
         if color_mode == "gray":
-            f = cv_bgr2gray_u8(f)
+            f = cv_bgr2gray_u8(f, cv_version)
         f = f[min_i:min_i + crop_before, min_j:min_j + crop_before, ...]
         f = cv_resize_linear_u8(f, need_w, need_h)
         if flip:

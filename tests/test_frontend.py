@@ -146,3 +146,57 @@ def test_hip_frontend_tiled_batch_mixed_rectangles():
     for c in range(b):
         _, want = F.frontend(raw[c], int(table[c, 2]), int(table[c, 0]), int(table[c, 1]), bool(table[c, 3]), crop, idx[c], None, None, "gray")
         assert np.array_equal(gray[c].cpu().numpy(), want), c
+
+
+def test_bgr2gray_known_answers():
+    """Hand-worked known answers of the two fixed-point BGR2GRAY forms (oracle/frontend_oracle.py header): OpenCV >= 4.0
+    (B*3735 + G*19235 + R*9798 + 16384) >> 15 and OpenCV 2.x/3.x (B*1868 + G*9617 + R*4899 + 8192) >> 14.
+        (B,G,R) = (255,0,0):  cv4 (952425 + 16384) >> 15 = 968809 >> 15 = 29          cv3 (476340 + 8192) >> 14 = 484532 >> 14 = 29
+        (0,255,0):            cv4 (4904925 + 16384) >> 15 = 4921309 >> 15 = 150        cv3 (2452335 + 8192) >> 14 = 2460527 >> 14 = 150
+        (0,0,255):            cv4 (2498490 + 16384) >> 15 = 2514874 >> 15 = 76         cv3 (1249245 + 8192) >> 14 = 1257437 >> 14 = 76
+        (255,255,255):        weights sum to 32768 / 16384 -> 255 in both
+        (0,5,0):              cv4 (96175 + 16384) >> 15 = 112559 >> 15 = 3             cv3 (48085 + 8192) >> 14 = 56277 >> 14 = 3
+        (1,1,0):              cv4 (22970 + 16384) >> 15 = 39354 >> 15 = 1              cv3 (11485 + 8192) >> 14 = 19677 >> 14 = 1
+        (0,23,0):             cv4 (442405 + 16384) >> 15 = 458789 >> 15 = 14 (14.0011) cv3 (221191 + 8192) >> 14 = 229383 >> 14 = 14 (14.0004)
+        (203,0,0):            cv4 (758205 + 16384) >> 15 = 774589 >> 15 = 23 (23.64)   cv3 (379204 + 8192) >> 14 = 387396 >> 14 = 23 (23.64)
+        (20,4,2):             cv4 (74700 + 76940 + 19596 + 16384) >> 15 = 187620 >> 15 = 5 (5.73)
+                              cv3 (37360 + 38468 + 9798 + 8192) >> 14 = 93818 >> 14 = 5 (5.73)
+    and the two forms DIFFER on some colours (that is why the version matters): the test finds them and checks one by hand:
+        (B,G,R) = (0,0,3):    cv4 (29394 + 16384) >> 15 = 45778 >> 15 = 1 (1.397)      cv3 (14697 + 8192) >> 14 = 22889 >> 14 = 1 -> equal;
+        (125,0,0):            cv4 (466875 + 16384) >> 15 = 483259 >> 15 = 14 (14.748)  cv3 (233500 + 8192) >> 14 = 241692 >> 14 = 14 (14.752)"""
+    px = np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 5, 0], [1, 1, 0], [0, 23, 0], [203, 0, 0], [20, 4, 2],
+                   [0, 0, 3], [125, 0, 0]], dtype=np.uint8)
+    want = np.array([29, 150, 76, 255, 3, 1, 14, 23, 5, 1, 14], dtype=np.uint8)
+    assert np.array_equal(F.cv_bgr2gray_u8(px, "cv4"), want) and np.array_equal(F.cv_bgr2gray_u8(px, "cv3"), want)
+    # all 2^24 colours: the forms agree except where the weighted sum sits within 2^-15 of a rounding boundary
+    v = np.arange(256, dtype=np.uint8)
+    b, g, r = np.meshgrid(v, v, v, indexing="ij")
+    allc = np.stack([b.ravel(), g.ravel(), r.ravel()], axis=1)
+    g4, g3 = F.cv_bgr2gray_u8(allc, "cv4"), F.cv_bgr2gray_u8(allc, "cv3")
+    diff = np.flatnonzero(g4 != g3)
+    assert 0 < diff.size < allc.shape[0] // 100 and int(np.abs(g4.astype(int) - g3.astype(int)).max()) == 1
+    bb, gg, rr = (int(x) for x in allc[diff[0]])
+    assert ((bb * 3735 + gg * 19235 + rr * 9798 + 16384) >> 15) == int(g4[diff[0]])
+    assert ((bb * 1868 + gg * 9617 + rr * 4899 + 8192) >> 14) == int(g3[diff[0]])
+    with pytest.raises(ValueError):
+        F.cv_bgr2gray_u8(px, "cv2")
+
+
+@pytest.mark.gpu
+def test_hip_frontend_gray_versions():
+    """The kernel's two BGR2GRAY forms (gather kernel and LDS-tiled kernel) against the restatement, default = OpenCV 4.x."""
+    import torch
+    from v2v_amd import frontend as FE
+    g = np.random.default_rng(44)
+    raw = g.integers(0, 256, size=(3, 96, 160, 3), dtype=np.uint8)
+    raw_d = torch.from_numpy(raw).cuda()
+    idx = [0, 1, 1, 2]
+    for ver in ("cv4", "cv3"):
+        _, want = F.frontend(raw, 80, 7, 21, True, 64, idx, None, None, "gray", cv_version=ver)
+        _, got = FE.prepare_clip(raw_d, 80, 7, 21, True, 64, idx, color_mode="gray", want_imgs=False, cv_version=ver)      # tiled kernel
+        assert np.array_equal(got.cpu().numpy(), want), ver
+        imgs, got2 = FE.prepare_clip(raw_d, 80, 7, 21, True, 64, idx, color_mode="gray", want_imgs=True, cv_version=ver)    # gather kernel
+        assert np.array_equal(got2.cpu().numpy(), want) and np.array_equal(imgs.cpu().numpy()[..., 0], want), ver
+    _, default = FE.prepare_clip(raw_d, 80, 7, 21, True, 64, idx, color_mode="gray", want_imgs=False)
+    _, want4 = F.frontend(raw, 80, 7, 21, True, 64, idx, None, None, "gray")
+    assert np.array_equal(default.cpu().numpy(), want4)

@@ -417,6 +417,7 @@ int v2v_frontend_hip(const uint8_t *src, int64_t T, int64_t Hs, int64_t Ws, int6
     if (!src || !frame_idx || !out_gray) return fail(V2V_ERR_NULL, "v2v_frontend_hip: src/frame_idx/out_gray is NULL");
     if (T < 1 || N < 0 || Hs < 1 || Ws < 1 || (Cs != 1 && Cs != 3)) return fail(V2V_ERR_SHAPE, "need T>=1, N>=0, Hs,Ws>=1, Cs in {1,3}");
     if (crop_before < 1 || crop < 1 || need_h < crop || need_w < crop) return fail(V2V_ERR_SHAPE, "need crop_before>=1 and need_h,need_w >= crop >= 1");
+    if (gray_first < 0 || gray_first > 2) return fail(V2V_ERR_MODE, "gray_first: 0 none, 1 BGR2GRAY as OpenCV >= 4.0 (15-bit), 2 as OpenCV 2.x/3.x (14-bit)");
     if (min_i < 0 || min_j < 0 || min_i + crop_before > Hs || min_j + crop_before > Ws) return fail(V2V_ERR_SHAPE, "crop rectangle outside the frame");
     if ((shake_di == nullptr) != (shake_dj == nullptr)) return fail(V2V_ERR_NULL, "shake_di and shake_dj must both be given or both be NULL");
     if (!shake_di && (need_h != crop || need_w != crop)) return fail(V2V_ERR_SHAPE, "need_h/need_w differ from crop but no shake offsets");
@@ -426,7 +427,7 @@ int v2v_frontend_hip(const uint8_t *src, int64_t T, int64_t Hs, int64_t Ws, int6
     a.src = src; a.T = (int32_t)T; a.Hs = (int32_t)Hs; a.Ws = (int32_t)Ws; a.Cs = (int32_t)Cs;
     a.min_i = (int32_t)min_i; a.min_j = (int32_t)min_j; a.crop_before = (int32_t)crop_before;
     a.need_h = (int32_t)need_h; a.need_w = (int32_t)need_w; a.crop = (int32_t)crop;
-    a.flip = flip ? 1 : 0; a.gray_first = gray_first ? 1 : 0;
+    a.flip = flip ? 1 : 0; a.gray_first = gray_first;
     a.frame_idx = frame_idx; a.di = shake_di; a.dj = shake_dj; a.N = (int32_t)N;
     a.Cout = (gray_first || Cs == 1) ? 1 : 3;
     a.out_imgs = out_imgs; a.out_gray = out_gray;
@@ -444,11 +445,12 @@ int v2v_frontend_batch_hip(const uint8_t *src, int64_t B, int64_t T, int64_t Hs,
     if (!src || !frame_idx || !out_gray || !clip_table) return fail(V2V_ERR_NULL, "v2v_frontend_batch_hip: src/clip_table/frame_idx/out_gray is NULL");
     if (B < 0 || T < 1 || N < 0 || Hs < 1 || Ws < 1 || (Cs != 1 && Cs != 3) || crop < 1) return fail(V2V_ERR_SHAPE, "need B>=0, T>=1, N>=0, Hs,Ws,crop>=1, Cs in {1,3}");
     if (!aligned(frame_idx, 4) || !aligned(clip_table, 4)) return fail(V2V_ERR_ALIGN, "index arrays must be 4-byte aligned");
+    if (gray_first < 0 || gray_first > 2) return fail(V2V_ERR_MODE, "gray_first: 0 none, 1 BGR2GRAY as OpenCV >= 4.0 (15-bit), 2 as OpenCV 2.x/3.x (14-bit)");
     if (B == 0 || N == 0) return V2V_OK;
     v2v::FrontendArgs a{};
     a.src = src; a.T = (int32_t)T; a.Hs = (int32_t)Hs; a.Ws = (int32_t)Ws; a.Cs = (int32_t)Cs;
     a.need_h = a.need_w = a.crop = (int32_t)crop;
-    a.gray_first = gray_first ? 1 : 0;
+    a.gray_first = gray_first;
     a.frame_idx = frame_idx; a.N = (int32_t)N;
     a.Cout = (gray_first || Cs == 1) ? 1 : 3;
     a.out_imgs = out_imgs; a.out_gray = out_gray;

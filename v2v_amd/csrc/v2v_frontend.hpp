@@ -19,7 +19,7 @@ struct FrontendArgs {
     int32_t T, Hs, Ws, Cs;
     int32_t min_i, min_j, crop_before;      // crop rectangle in the source frame (square)
     int32_t need_h, need_w, crop;           // resize target (crop + shake extent), final crop size
-    int32_t flip, gray_first;               // gray_first: cvtColor BGR2GRAY before the resize (color_mode 'gray')
+    int32_t flip, gray_first;               // gray_first: cvtColor BGR2GRAY before the resize (color_mode 'gray'): 1 = OpenCV >= 4.0's 15-bit form, 2 = the 14-bit form of 2.x / 3.x
     const int32_t *frame_idx;               // [N] decoded-frame index of every simulator frame (pause schedule)
     const int32_t *di, *dj;                 // [T] shake offsets (already shifted to >= 0) or nullptr
     int32_t N, Cout;                        // Cout = 1 (gray_first or Cs == 1) or 3
@@ -58,9 +58,27 @@ __device__ __forceinline__ int resize_src_lo(int d, int ssize, double scale)
     return s;
 }
 
-__device__ __forceinline__ int bgr2gray_cv(const uint8_t *p)
+// cv2.cvtColor(BGR2GRAY) on 8-bit data, in the two fixed-point forms OpenCV has shipped (wave-uniform choice, scalar registers):
+//   gray_first == 1  OpenCV >= 4.0 (color_rgb.simd.hpp, RGB2Gray<uchar>): 15-bit weights B 3735, G 19235, R 9798, (+2^14) >> 15
+//                    -- what an unpinned `opencv-python` (requirements.txt:11) installs; the default
+//   gray_first == 2  OpenCV 2.x / 3.x (color.cpp): 14-bit weights 1868 / 9617 / 4899, (+2^13) >> 14
+struct GrayCoef {
+    int cb, cg, cr, half, shift;
+    uint32_t lo, hi;              // the weights split into bytes for v_dot4_u32_u8: w = hi * 256 + lo per channel
+};
+__device__ __forceinline__ GrayCoef gray_coef(int mode)
 {
-    return ((int)p[0] * 1868 + (int)p[1] * 9617 + (int)p[2] * 4899 + (1 << 13)) >> 14;
+    GrayCoef k;
+    const bool v4 = mode != 2;
+    k.cb = v4 ? 3735 : 1868; k.cg = v4 ? 19235 : 9617; k.cr = v4 ? 9798 : 4899;
+    k.shift = v4 ? 15 : 14; k.half = 1 << (k.shift - 1);
+    k.lo = (uint32_t)(k.cb & 255) | ((uint32_t)(k.cg & 255) << 8) | ((uint32_t)(k.cr & 255) << 16);
+    k.hi = (uint32_t)(k.cb >> 8) | ((uint32_t)(k.cg >> 8) << 8) | ((uint32_t)(k.cr >> 8) << 16);
+    return k;
+}
+__device__ __forceinline__ int bgr2gray_cv(const uint8_t *p, const GrayCoef &k)
+{
+    return ((int)p[0] * k.cb + (int)p[1] * k.cg + (int)p[2] * k.cr + k.half) >> k.shift;
 }
 
 constexpr int kFrontPx = 4;    // horizontally adjacent output pixels per work-item (one packed 4-byte gray store)
@@ -68,6 +86,7 @@ constexpr int kFrontPx = 4;    // horizontally adjacent output pixels per work-i
 __global__ void __launch_bounds__(256) frontend_kernel(const FrontendArgs a_in)
 {
     FrontendArgs a = a_in;
+    const GrayCoef gk = gray_coef(a.gray_first);
     const int qpr = (a.crop + kFrontPx - 1) / kFrontPx;          // work-items per output row
     const int64_t per_frame = (int64_t)a.crop * a.crop;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -94,7 +113,7 @@ __global__ void __launch_bounds__(256) frontend_kernel(const FrontendArgs a_in)
     const bool gray3 = a.gray_first && a.Cs == 3;
     auto src_px = [&](const uint8_t *row, int sx, int c) -> int {
         const uint8_t *p = row + (int64_t)sx * a.Cs;
-        return gray3 ? bgr2gray_cv(p) : (int)p[c];
+        return gray3 ? bgr2gray_cv(p, gk) : (int)p[c];
     };
     const bool area2 = (a.crop_before == 2 * a.need_w) && (a.crop_before == 2 * a.need_h);
     const double scale_x = 1.0 / ((double)a.need_w / (double)a.crop_before);
@@ -124,8 +143,8 @@ __global__ void __launch_bounds__(256) frontend_kernel(const FrontendArgs a_in)
                 uint64_t w0, w1;
                 __builtin_memcpy(&w0, p0, 8);
                 __builtin_memcpy(&w1, p1, 8);
-                auto g2 = [](uint64_t w, int sh) -> int {
-                    return ((int)((w >> sh) & 255) * 1868 + (int)((w >> (sh + 8)) & 255) * 9617 + (int)((w >> (sh + 16)) & 255) * 4899 + (1 << 13)) >> 14;
+                auto g2 = [&gk](uint64_t w, int sh) -> int {
+                    return ((int)((w >> sh) & 255) * gk.cb + (int)((w >> (sh + 8)) & 255) * gk.cg + (int)((w >> (sh + 16)) & 255) * gk.cr + gk.half) >> gk.shift;
                 };
                 const int r0 = g2(w0, 0) * cx.a0 + g2(w0, 24) * cx.a1;
                 const int r1 = g2(w1, 0) * cx.a0 + g2(w1, 24) * cx.a1;
@@ -201,26 +220,26 @@ __device__ __forceinline__ int vblend_cv(int h0, int h1, int ya0, int ya1)
     return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
-// cv2's BGR2GRAY of the pixel in the three low bytes of p (byte 3 is ignored): (B*1868 + G*9617 + R*4899 + 2^13) >> 14 with
-// the 14-bit weights split into bytes for v_dot4_u32_u8 -- 1868 = 7*256 + 76, 9617 = 37*256 + 145, 4899 = 19*256 + 35;
-// the same integer sum, 4 instructions instead of three extracts + three multiply-adds
-__device__ __forceinline__ int bgr2gray_dot4(uint32_t p)
+// cv2's BGR2GRAY of the pixel in the three low bytes of p (byte 3 is ignored): (B*wb + G*wg + R*wr + half) >> shift with
+// the weights split into bytes for v_dot4_u32_u8 (e.g. 19235 = 75*256 + 35): the same integer sum, 4 instructions
+// instead of three extracts + three multiply-adds
+__device__ __forceinline__ int bgr2gray_dot4(uint32_t p, const GrayCoef &k)
 {
-    const uint32_t lo = __builtin_amdgcn_udot4(p, 76u | (145u << 8) | (35u << 16), 1u << 13, false);
-    const uint32_t hi = __builtin_amdgcn_udot4(p, 7u | (37u << 8) | (19u << 16), 0u, false);
-    return (int)((lo + (hi << 8)) >> 14);
+    const uint32_t lo = __builtin_amdgcn_udot4(p, k.lo, (uint32_t)k.half, false);
+    const uint32_t hi = __builtin_amdgcn_udot4(p, k.hi, 0u, false);
+    return (int)((lo + (hi << 8)) >> k.shift);
 }
 
 // bytes [o, o+6) of an LDS row (o = byte offset from the 4-byte-aligned row start) -> gray of the two BGR pixels
-__device__ __forceinline__ void lds_gray_pair(const unsigned char *row, uint32_t o, int &g0, int &g1)
+__device__ __forceinline__ void lds_gray_pair(const unsigned char *row, uint32_t o, const GrayCoef &k, int &g0, int &g1)
 {
     const uint32_t *w = reinterpret_cast<const uint32_t *>(row + (o & ~3u));
     const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
     const uint32_t sh = o & 3u;
     const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);       // bytes o .. o+3
     const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);       // bytes o+4 .. o+7
-    g0 = bgr2gray_dot4(lo);
-    g1 = bgr2gray_dot4(__builtin_amdgcn_alignbyte(hi, lo, 3));        // bytes o+3 .. o+6
+    g0 = bgr2gray_dot4(lo, k);
+    g1 = bgr2gray_dot4(__builtin_amdgcn_alignbyte(hi, lo, 3), k);        // bytes o+3 .. o+6
 }
 
 template <int CPL>
@@ -232,6 +251,7 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
     RowC *s_row = reinterpret_cast<RowC *>(s_mem + kCols * 8);
     unsigned char *s_rows = s_mem + tile_hdr_bytes(CPL);
     const FrontendArgs &a = ta.f;
+    const GrayCoef gk = gray_coef(a.gray_first);
     const int clip = blockIdx.y;
     const int tiles = ta.tiles_x * ta.tiles_y;
     const int n = blockIdx.x / tiles;
@@ -326,7 +346,7 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
                 int g0, g1;
-                lds_gray_pair(lrow, off[j] + mis, g0, g1);
+                lds_gray_pair(lrow, off[j] + mis, gk, g0, g1);
                 h_cur[j] = (g0 * cc[j].a0 + g1 * cc[j].a1) >> 4;
             }
             // vertical pass of every output row whose lower tap is sr
@@ -356,13 +376,13 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
                 int v;
                 if (area2) {
                     const uint8_t *p0 = frame + ((int64_t)(2 * (y0 + y)) * a.Ws + 2 * X) * 3, *p1 = p0 + (int64_t)a.Ws * 3;
-                    v = (bgr2gray_cv(p0) + bgr2gray_cv(p0 + 3) + bgr2gray_cv(p1) + bgr2gray_cv(p1 + 3) + 2) >> 2;
+                    v = (bgr2gray_cv(p0, gk) + bgr2gray_cv(p0 + 3, gk) + bgr2gray_cv(p1, gk) + bgr2gray_cv(p1 + 3, gk) + 2) >> 2;
                 } else {
                     const ColC c1 = s_col[cg + j];
                     const int s1 = c1.single ? c1.s0 : c1.s0 + 1;      // (a1 is 0 for a clamped tap: either pixel gives the same sum)
                     const uint8_t *p0 = frame + (int64_t)rc.s0 * a.Ws * 3, *p1 = frame + (int64_t)rc.s1 * a.Ws * 3;
-                    const int h0 = (bgr2gray_cv(p0 + c1.s0 * 3) * c1.a0 + bgr2gray_cv(p0 + s1 * 3) * c1.a1) >> 4;
-                    const int h1 = (bgr2gray_cv(p1 + c1.s0 * 3) * c1.a0 + bgr2gray_cv(p1 + s1 * 3) * c1.a1) >> 4;
+                    const int h0 = (bgr2gray_cv(p0 + c1.s0 * 3, gk) * c1.a0 + bgr2gray_cv(p0 + s1 * 3, gk) * c1.a1) >> 4;
+                    const int h1 = (bgr2gray_cv(p1 + c1.s0 * 3, gk) * c1.a0 + bgr2gray_cv(p1 + s1 * 3, gk) * c1.a1) >> 4;
                     v = vblend_cv(h0, h1, rc.a0, rc.a1);
                 }
                 packed |= (uint32_t)v << (8 * j);

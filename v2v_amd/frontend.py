@@ -3,7 +3,9 @@
 `prepare_clip` takes decoded frames that are already on the device and does what WebvidDatasetV2.read_video +
 the gather in __getitem__ do on the host (data/v2v_datasets.py:191-224, :311-316): [BGR->gray] -> crop ->
 bilinear resize -> [flip] -> shake crop -> pause-index gather -> gray.  Output feeds esim_voxel_batch directly.
-PARITY UNPINNED against OpenCV (not available here); bit-exact against oracle/frontend_oracle.py's restatement.
+PARITY UNPINNED against OpenCV (not available here); bit-exact against oracle/frontend_oracle.py's restatement of the
+OpenCV 4.x 8-bit algorithms.  `cv_version`: "cv4" (default; cvtColor BGR2GRAY with the 15-bit weights 3735/19235/9798 every
+OpenCV >= 4.0 uses -- what the reference's unpinned `opencv-python` installs) or "cv3" (the 14-bit weights of OpenCV 2.x/3.x).
 """
 from __future__ import annotations
 
@@ -14,9 +16,11 @@ import torch
 
 from . import _lib
 
+GRAY_VERSIONS = {"cv4": 1, "cv3": 2}       # C ABI gray_first: BGR2GRAY as OpenCV >= 4.0 (15-bit weights) / as 2.x-3.x (14-bit)
+
 
 def prepare_clip(raw: torch.Tensor, crop_before: int, min_i: int, min_j: int, flip: bool, crop_size: int, img_idxes,
-                 all_di=None, all_dj=None, color_mode: str = "gray", want_imgs: bool = True):
+                 all_di=None, all_dj=None, color_mode: str = "gray", want_imgs: bool = True, cv_version: str = "cv4"):
     """raw [T,Hs,Ws,C] uint8 CUDA (C = 3 BGR or 1).  Returns (all_imgs [N,crop,crop,Cout] uint8 or None,
     gray [N,crop,crop] uint8), both CUDA tensors."""
     _lib.require_gpu()
@@ -38,7 +42,7 @@ def prepare_clip(raw: torch.Tensor, crop_before: int, min_i: int, min_j: int, fl
         need_h, need_w = crop_size + int(di_h.max()), crop_size + int(dj_h.max())
         di = torch.as_tensor(di_h.astype(np.int32), device=dev)
         dj = torch.as_tensor(dj_h.astype(np.int32), device=dev)
-    gray_first = color_mode == "gray"
+    gray_first = GRAY_VERSIONS[cv_version] if color_mode == "gray" else 0
     cout = 1 if (gray_first or cs == 1) else 3
     imgs = torch.empty((n, crop_size, crop_size, cout), dtype=torch.uint8, device=dev) if want_imgs else None
     gray = torch.empty((n, crop_size, crop_size), dtype=torch.uint8, device=dev)
@@ -53,7 +57,7 @@ def prepare_clip(raw: torch.Tensor, crop_before: int, min_i: int, min_j: int, fl
 
 
 def prepare_clips_batch(raw: torch.Tensor, clip_table, img_idxes, crop_size: int, color_mode: str = "gray",
-                        want_imgs: bool = False, validate: bool = True, max_crop_before: int = 0):
+                        want_imgs: bool = False, validate: bool = True, max_crop_before: int = 0, cv_version: str = "cv4"):
     """Batch form of prepare_clip (no shake): raw [B,T,Hs,Ws,C] uint8 CUDA; clip_table [B,4] int = {min_i, min_j,
     crop_before, flip}; img_idxes [B,N].  Returns (imgs [B,N,crop,crop,Cout] or None, gray [B,N,crop,crop]) -- ONE launch.
     max_crop_before: optional upper bound of crop_before for device-resident tables (taken from the table when it is on
@@ -84,7 +88,7 @@ def prepare_clips_batch(raw: torch.Tensor, clip_table, img_idxes, crop_size: int
         if b:
             max_crop_before = int(tab_h[:, 2].max())
     n = idx.shape[1]
-    gray_first = color_mode == "gray"
+    gray_first = GRAY_VERSIONS[cv_version] if color_mode == "gray" else 0
     cout = 1 if (gray_first or cs == 1) else 3
     imgs = torch.empty((b, n, crop_size, crop_size, cout), dtype=torch.uint8, device=dev) if want_imgs else None
     gray = torch.empty((b, n, crop_size, crop_size), dtype=torch.uint8, device=dev)
