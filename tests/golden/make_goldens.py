@@ -382,33 +382,36 @@ def g18_unet_modules():
     import model.unet as un
     torch.manual_seed(0)
     torch.set_num_threads(4)
+    from seeded_weights import seeded_input as rnd          # inputs are a recipe too (NEP 19 streams): only OUTPUTS are stored
     g = np.random.Generator(np.random.PCG64(1818))
-    rnd = lambda *shape: g.standard_normal(shape).astype(np.float32)      # noqa: E731
     out = {}
     with torch.no_grad():
         # ConvLSTM, C = 64, 16x16, two steps: prev_state None, then the returned state
         m = sm.ConvLSTM(64, 64, 3).eval()
         load_seeded(m, 1801, gain=1.0)
-        x0, x1 = rnd(1, 64, 16, 16), rnd(1, 64, 16, 16)
+        x0, x1 = rnd(18010, 1, 64, 16, 16), rnd(18011, 1, 64, 16, 16)
         h1, c1 = m(torch.from_numpy(x0), None)
         h2, c2 = m(torch.from_numpy(x1), (h1, c1))
-        out.update(convlstm__x0=x0, convlstm__x1=x1, convlstm__h1=h1.numpy(), convlstm__c1=c1.numpy(), convlstm__h2=h2.numpy(),
+        out.update(convlstm__x_seeds=np.array([18010, 18011]), convlstm__x_shape=np.array(x0.shape), convlstm__h1=h1.numpy(), convlstm__c1=c1.numpy(), convlstm__h2=h2.numpy(),
                    convlstm__c2=c2.numpy(), convlstm__seed=np.array(1801))
-        # ResidualBlock 256 -> 256 at 8x8 (the bottleneck of the 64x64 network)
+        # ResidualBlock 256 -> 256 at 2 x 8x8 (the bottleneck of the 64x64 network; the kernels want >= 128 pixels per launch)
         m = sm.ResidualBlock(256, 256).eval()
         load_seeded(m, 1802, gain=1.0)
-        x = rnd(1, 256, 8, 8)
-        out.update(resblock__x=x, resblock__y=m(torch.from_numpy(x.copy())).numpy(), resblock__seed=np.array(1802))
+        x = rnd(18020, 2, 256, 8, 8)
+        out.update(resblock__x_seed=np.array(18020), resblock__x_shape=np.array(x.shape), resblock__y=m(torch.from_numpy(x.copy())).numpy(),
+                   resblock__seed=np.array(1802))
         # ConvLayer 5x5 stride 2, 64 -> 128 (the second encoder's convolution)
         m = sm.ConvLayer(64, 128, 5, stride=2, padding=2).eval()
         load_seeded(m, 1803, gain=1.0)
-        x = rnd(1, 64, 16, 16)
-        out.update(convlayer__x=x, convlayer__y=m(torch.from_numpy(x)).numpy(), convlayer__seed=np.array(1803))
+        x = rnd(18030, 2, 64, 16, 16)
+        out.update(convlayer__x_seed=np.array(18030), convlayer__x_shape=np.array(x.shape), convlayer__y=m(torch.from_numpy(x)).numpy(),
+                   convlayer__seed=np.array(1803))
         # UpsampleConvLayer 128 -> 64 (the second decoder)
         m = sm.UpsampleConvLayer(128, 64, 5, padding=2).eval()
         load_seeded(m, 1804, gain=1.0)
-        x = rnd(1, 128, 8, 8)
-        out.update(upsample__x=x, upsample__y=m(torch.from_numpy(x)).numpy(), upsample__seed=np.array(1804))
+        x = rnd(18040, 2, 128, 8, 8)
+        out.update(upsample__x_seed=np.array(18040), upsample__x_shape=np.array(x.shape), upsample__y=m(torch.from_numpy(x)).numpy(),
+                   upsample__seed=np.array(1804))
         # UNetRecurrent, the training configuration, three time steps of integer voxel grids
         kwargs = dict(num_bins=5, skip_type="sum", recurrent_block_type="convlstm", num_encoders=3, base_num_channels=32,
                       num_residual_blocks=2, use_upsample_conv=True, final_activation="", norm=None)
@@ -417,7 +420,7 @@ def g18_unet_modules():
         gain = 1.7                                              # keeps the random-init activations O(1) through the depth of the net
         probe = load_seeded(net, 1805, gain=gain)
         out["unet__weight_probe"] = np.concatenate([probe[k].ravel()[:3] for k in list(probe)[::5]])   # the recipe must reproduce these bits
-        vox = g.integers(-3, 4, size=(3, 1, 5, 64, 64)).astype(np.float32)
+        vox = g.integers(-3, 4, size=(3, 2, 5, 64, 64)).astype(np.float32)      # [T, B = 2, bins, H, W]
         vox[g.random(vox.shape) < 0.6] = 0.0                    # sparse, like event counts
         imgs = [net(torch.from_numpy(vox[t]))["image"].numpy() for t in range(3)]
         sd = net.state_dict()

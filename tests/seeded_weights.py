@@ -21,6 +21,11 @@ def seeded_state(shapes, seed, gain=1.0):
     return out
 
 
+def seeded_input(seed, *shape):
+    """float32 N(0,1) tensor values for a test input: same recipe in the generator and in the tests."""
+    return np.random.Generator(np.random.PCG64(int(seed))).standard_normal(tuple(int(s) for s in shape)).astype(np.float32)
+
+
 def load_seeded(module, seed, gain=1.0):
     """Fill `module` (any torch.nn.Module) with seeded_state values for its own state_dict keys and shapes; returns the dict."""
     import torch

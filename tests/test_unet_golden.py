@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from seeded_weights import load_seeded, seeded_state
+from seeded_weights import load_seeded, seeded_input, seeded_state
 
 gpu = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -70,7 +70,7 @@ def test_stock_restatement_of_the_network_equals_the_reference_on_cpu(g18):
     sd = reference_to_stock_keys({k: torch.from_numpy(v) for k, v in vals.items()})
     assert set(stock_to_reference_keys(sd)) == set(vals)
     net.load_state_dict(sd, strict=True)
-    vox = torch.from_numpy(g18["unet__vox"].astype(np.float32)).permute(1, 0, 2, 3, 4)          # [B=1, T=3, 5, 64, 64]
+    vox = torch.from_numpy(g18["unet__vox"].astype(np.float32)).permute(1, 0, 2, 3, 4)          # [B=2, T=3, 5, 64, 64]
     with torch.no_grad():
         imgs = forward_sequence(net, vox)
     for t in range(3):
@@ -86,8 +86,9 @@ def test_convlstm_two_steps_vs_reference(g18):
     m = ConvLSTM(64, 64, 3).cuda().eval()
     load_seeded(m, int(g18["convlstm__seed"]))
     with torch.no_grad():
-        h1, c1 = m(torch.from_numpy(g18["convlstm__x0"]).cuda(), None)
-        h2, c2 = m(torch.from_numpy(g18["convlstm__x1"]).cuda(), (h1, c1))
+        x0, x1 = (torch.from_numpy(seeded_input(sd, *g18["convlstm__x_shape"])).cuda() for sd in g18["convlstm__x_seeds"])
+        h1, c1 = m(x0, None)
+        h2, c2 = m(x1, (h1, c1))
     for name, got in (("h1", h1), ("c1", c1), ("h2", h2), ("c2", c2)):
         mx, rms = _err(got.float().cpu().numpy(), g18["convlstm__" + name])
         assert mx <= 1e-2 and rms <= 2e-3, (name, mx, rms)
@@ -104,7 +105,7 @@ def test_single_layers_vs_reference(g18, layout):
     for name, mod in cases:
         mod = mod.cuda().eval()
         load_seeded(mod, int(g18[name + "__seed"]))
-        x = torch.from_numpy(g18[name + "__x"]).cuda()
+        x = torch.from_numpy(seeded_input(g18[name + "__x_seed"], *g18[name + "__x_shape"])).cuda()
         if layout == "channels_last_bf16":
             x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         with torch.no_grad():
@@ -130,7 +131,7 @@ def test_unet_recurrent_three_steps_vs_reference(g18):
     with torch.no_grad():
         for t in range(3):
             img = net(vox[t])["image"]
-            assert img.dtype == torch.float32 and tuple(img.shape) == (1, 1, 64, 64)
+            assert img.dtype == torch.float32 and tuple(img.shape) == (2, 1, 64, 64)
             mx, rms = _err(img.cpu().numpy(), g18["unet__images"][t])
             assert mx <= 4e-2 and rms <= 8e-3, (t, mx, rms)
     st = net.states                                                   # model/model.py:205-207: a copy, (hidden, cell) per encoder

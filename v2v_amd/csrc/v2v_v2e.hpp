@@ -522,6 +522,9 @@ __device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, 
             inv_n[j] = (float)((1.0 / nt[j]) * 0x1.fffff8p-1);
         }
     };
+    // float -> uint32 with the hardware's saturation (negative and NaN -> 0, >= 2^32 -> 0xFFFFFFFF): v_cvt_u32_f32 IS the
+    // clip(x, 0, inf) + floor of compute_event_map for the quotient estimate; a C cast of a negative float is undefined
+    auto cvt_u32_sat = [](float t) -> uint32_t { uint32_t q; asm("v_cvt_u32_f32 %0, %1" : "=v"(q) : "v"(t)); return q; };
     derive_thres();
 
     float leak_cur[VEC];                                   // float32 product leak_rate_hz * noise_rate_array (:204); widening it once
@@ -614,9 +617,12 @@ __device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, 
             }
         }
 
-        // ---- low pass, leak, event map: floor_divide(clip(+-diff, 0), thres) as floor(x * low-biased reciprocal) with
-        // the exact fma residual; the correction (quotient one short, or a non-finite operand) is a rare wave-level path
-        double fpos[VEC], fneg[VEC];
+        // ---- low pass, leak, event map.  floor_divide(clip(+-diff, 0), thres): the quotient is ESTIMATED in float32 --
+        // trunc(float(diff) * reciprocal), reciprocal biased low by 2^-22 so that the two float32 roundings (2^-24 each) can
+        // never lift the estimate above the true quotient; v_cvt_u32_f32 clips the negative side to 0 -- and VERIFIED in float64
+        // with the exact fma residual 0 <= diff - q*thres < thres (sign-exact).  An estimate one short, a quotient beyond
+        // float32's integers or a non-finite operand fail the check and send the wave down the exact float64 path below.
+        uint32_t qp[VEC], qn[VEC];
         unsigned long long fix = 0;                       // wave-level masks (SGPR pairs): no per-lane bool materialised
         auto cur_diff = [&](int j) -> double {            // lp - base in NumPy's dtypes (recomputed by the rare fix-up path)
             if (lp32 && base32) { const float d = lp_f[j] - base_f[j]; return (double)d; }
@@ -651,27 +657,18 @@ __device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, 
             const double diff = cur_diff(j);
             // compute_event_map (:42-62).  The residuals are taken against +-diff itself: for the side that is clipped
             // to zero they are negative (check passes), for a NaN difference they are NaN (check fails -> exact path)
-            fpos[j] = floor(__builtin_fmax(diff, 0.0) * (double)inv_p[j]);
-            fneg[j] = floor(__builtin_fmax(-diff, 0.0) * (double)inv_n[j]);
-            const double rp = __builtin_fma(-fpos[j], pt[j], diff), rn = __builtin_fma(-fneg[j], nt[j], -diff);
+            const float d32 = (float)diff;
+            qp[j] = cvt_u32_sat(d32 * inv_p[j]);
+            qn[j] = cvt_u32_sat(-d32 * inv_n[j]);
+            const double fq = (double)qp[j], fn = (double)qn[j];
+            const double rp = __builtin_fma(-fq, pt[j], diff), rn = __builtin_fma(-fn, nt[j], -diff);
             fix |= __ballot(!(rp < pt[j]));
             fix |= __ballot(!(rn < nt[j]));
         }
-        if (__builtin_expect(fix != 0, 0)) {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                double diff = cur_diff(j);
-                asm volatile("" : "+v"(diff));             // opaque: recomputed here, not kept alive from the common path
-                const double nd = -diff;
-                const double pos_frame = diff > 0 ? diff : (diff == diff ? 0.0 : diff);
-                const double neg_frame = nd > 0 ? nd : (nd == nd ? 0.0 : nd);
-                fpos[j] = floor(pos_frame * (double)inv_p[j]);
-                fneg[j] = floor(neg_frame * (double)inv_n[j]);
-                { const double r = __builtin_fma(-fpos[j], pt[j], pos_frame); if (r >= pt[j]) fpos[j] += 1.0; else if (!(r < pt[j])) fpos[j] = pos_frame / pt[j]; }
-                { const double r = __builtin_fma(-fneg[j], nt[j], neg_frame); if (r >= nt[j]) fneg[j] += 1.0; else if (!(r < nt[j])) fneg[j] = neg_frame / nt[j]; }
-            }
-        }
 
+        int cnt_p[VEC], cnt_n[VEC];                       // native shot-noise counts (0 without shot noise / in replay mode)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { cnt_p[j] = 0; cnt_n[j] = 0; }
         if (shot) {                                                                     // generate_shot_noise (:65-105)
             if constexpr (RNG == kRngPhilox) {
                 // mean = (intensity factor / threshold) x (nominal threshold x rate/2 dt / frame mean) in float32; inversion
@@ -688,7 +685,6 @@ __device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, 
                     }
                     return pz;
                 };
-                int cnt_p[VEC], cnt_n[VEC];
                 unsigned long long more = 0;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
@@ -718,9 +714,33 @@ __device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, 
                         if (u_sn[j] > s2.y) cnt_n[j] = (int)poisson_tail_f32(lam.y, u_sn[j], pz.y * (hl.y * lam.y), s2.y);
                     }
                 }
+            }
+        }
+
+        // ---- totals.  Common case: signal quotient + shot count as INTEGERS, one convert each.  A failed residual check takes the
+        // exact float64 evaluation (quotient one short; NaN / infinite operands keep NumPy's results: np.floor_divide's own terms)
+        double fpos[VEC], fneg[VEC];
+        if (__builtin_expect(fix == 0, 1)) {
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) { fpos[j] = fpos[j] + (double)cnt_p[j]; fneg[j] = fneg[j] + (double)cnt_n[j]; }
-            } else {
+            for (int j = 0; j < VEC; ++j) { fpos[j] = (double)(qp[j] + (uint32_t)cnt_p[j]); fneg[j] = (double)(qn[j] + (uint32_t)cnt_n[j]); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                double diff = cur_diff(j);
+                asm volatile("" : "+v"(diff));             // opaque: recomputed here, not kept alive from the common path
+                const double nd = -diff;
+                const double pos_frame = diff > 0 ? diff : (diff == diff ? 0.0 : diff);
+                const double neg_frame = nd > 0 ? nd : (nd == nd ? 0.0 : nd);
+                fpos[j] = floor(pos_frame * (double)inv_p[j]);
+                fneg[j] = floor(neg_frame * (double)inv_n[j]);
+                { const double r = __builtin_fma(-fpos[j], pt[j], pos_frame); if (r >= pt[j]) fpos[j] += 1.0; else if (!(r < pt[j])) fpos[j] = pos_frame / pt[j]; }
+                { const double r = __builtin_fma(-fneg[j], nt[j], neg_frame); if (r >= nt[j]) fneg[j] += 1.0; else if (!(r < nt[j])) fneg[j] = neg_frame / nt[j]; }
+                fpos[j] = fpos[j] + (double)cnt_p[j];
+                fneg[j] = fneg[j] + (double)cnt_n[j];
+            }
+        }
+        if constexpr (RNG != kRngPhilox) {
+            if (shot) {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     const int64_t o = ((int64_t)clip * a.K + k) * a.HW + p0 + j;
