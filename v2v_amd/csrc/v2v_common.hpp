@@ -21,6 +21,9 @@ namespace v2v {
 #ifndef V2V_V2E_MIN_WAVES
 #define V2V_V2E_MIN_WAVES 3  // __launch_bounds__ occupancy target of the v2e kernel (waves per SIMD): 2 -> 3 waves is worth 12 % (2.27 -> 2.06 ms, config 3) despite ~25 spilled dwords; 4 spills the loop (3.3 ms)
 #endif
+#ifndef V2V_ESIM_ASYM4
+#define V2V_ESIM_ASYM4 1   // general device-noise ESIM instances: by-polarity loop only, 2-frame ring, 4 waves per SIMD
+#endif
 #ifndef V2V_MIN_WAVES
 #define V2V_MIN_WAVES 1
 #endif

@@ -110,13 +110,21 @@ __device__ __forceinline__ void pix_logs(const Raw<IN, VEC> &r, const typename L
 // EXT    : put_noise_external (v2v_core_esim.py:46-49 vs :60-65): the noise goes into the voxel, not into the potential.
 //          Compile-time: as a run-time flag the compiler turned both uses into selects over speculated float64 adds and
 //          converts (~28 of 213 VALU instructions per 4-pixel step of the noise-on launch, SQ_INSTS_VALU).
+// The GENERAL device-noise instances (4 pixels per work-item, float32 grid, thresholds unknown to the host -- per-clip device
+// parameters as the dataset draws them, data/v2v_datasets.py:368-386) carry ONE time loop, the by-polarity one: it is exact for
+// C+ == C- too, and without the second (symmetric) loop and with a 2-frame ring the kernel fits 128 VGPRs = 4 waves per SIMD.
+template <int VEC, int RNG, bool NOISE, bool OUT64, bool EXT, bool SYMONLY>
+constexpr bool esim_asym4() { return V2V_ESIM_ASYM4 && NOISE && RNG == kRngPhilox && VEC == 4 && !OUT64 && !EXT && !SYMONLY; }
+
 template <int IN, int VEC, int BIN, int RNG, bool NOISE, bool OUT64, bool EXT = false, bool SYMONLY = false>
-__global__ void __launch_bounds__(kBlock, SYMONLY ? 4 : V2V_MIN_WAVES) esim_voxel_kernel(const EsimArgs a)
+__global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE, OUT64, EXT, SYMONLY>()) ? 4 : V2V_MIN_WAVES) esim_voxel_kernel(const EsimArgs a)
 {
+    constexpr bool ASYM4 = esim_asym4<VEC, RNG, NOISE, OUT64, EXT, SYMONLY>();
     // SYMONLY (V2V_FLAG_SYMMETRIC: the caller guarantees C+ == C- for every clip): compiled without the asymmetric loop and with a
     // 2-frame ring, which fits 128 VGPRs = 4 waves per SIMD (-4.6 % on the headline, same box); a clip that breaks the
     // guarantee gets NaN planes (loud, never a wrong count)
-    constexpr int kRing = SYMONLY ? 2 : kDepth;
+    // (uint8 frames are 4 bytes per lane and frame: their ring stays kDepth deep -- with 2 in flight config 4's shape lost 20 %)
+    constexpr int kRing = (SYMONLY || (ASYM4 && IN == kInF32)) ? 2 : kDepth;
     static_assert(NOISE || !EXT, "external noise needs the noise path");
     using lut_t = typename LutT<IN>::type;
     using acc_t = typename std::conditional<OUT64, double, float>::type;
@@ -447,6 +455,8 @@ __global__ void __launch_bounds__(kBlock, SYMONLY ? 4 : V2V_MIN_WAVES) esim_voxe
             return;
         }
         run(std::true_type{});
+    } else if constexpr (ASYM4) {
+        run(std::false_type{});
     } else {
         if (pp[0] == pp[1]) run(std::true_type{});                     // wave-uniform (per clip)
         else run(std::false_type{});
