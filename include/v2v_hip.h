@@ -76,9 +76,10 @@ typedef enum v2v_bin_mode {
                                      /* results; a clip that breaks the guarantee comes out as NaN.  A hint: ignored */
                                      /* where no such instance exists (float64 output, replay, external noise ...)   */
 #define V2V_FLAG_MAP_4PX 0x8u        /* work-item mapping: by default 4 pixels per work-item when the layout allows  */
-#define V2V_FLAG_MAP_1PX 0x10u       /* it AND the batch gives more than one such wave per SIMD, else 1 pixel; these */
-                                     /* two pin the choice (4PX still needs the aligned layout).  Results do not     */
-                                     /* depend on the mapping; tests use them to cover both families of instances    */
+#define V2V_FLAG_MAP_1PX 0x10u       /* it AND the batch gives more than one such wave per SIMD, else 2 pixels, and 1 */
+#define V2V_FLAG_MAP_2PX 0x20u       /* pixel below half a wave per SIMD; these three pin the choice (4PX / 2PX still */
+                                     /* need the aligned layout).  Results do not depend on the mapping; tests use   */
+                                     /* them to cover all three families of instances                                */
 
 /* Replay fields, all float64 device arrays, one set per clip (clip-major). */
 typedef struct v2v_esim_replay {

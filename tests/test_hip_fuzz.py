@@ -48,7 +48,7 @@ def test_random_esim_case(oracle_c, luts, case):
                                        num_bins=nb, frames_per_bin=fpb)
     # small shapes would all take the 1-pixel mapping: pin one at random so that both families of instances are swept
     kw = dict(bin_mode="bilinear" if bilinear else "sum", num_bins=nb, frames_per_bin=fpb, seed=seed, clip_id0=cid0,
-              put_noise_external=ext, mapping=["4px", "1px", "auto"][int(g.integers(0, 3))])
+              put_noise_external=ext, mapping=["4px", "2px", "1px", "auto"][int(g.integers(0, 4))])
     counts = torch.zeros((b, 2), dtype=torch.int64, device="cuda")
     got = E.esim_voxel_batch(torch.from_numpy(video).cuda(), params, out_dtype=torch.float64, counts=counts, **kw)
     assert np.array_equal(got.cpu().numpy(), want), (b, n, h, w, dt, kw)

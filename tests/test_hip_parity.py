@@ -10,7 +10,7 @@ from oracle import v2v_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["4px", "1px"])
+@pytest.fixture(autouse=True, params=["4px", "2px", "1px"])
 def _both_mappings(request, monkeypatch):
     """Every parity case runs through both families of instances (4 pixels / 1 pixel per work-item): left alone, shapes this
     small would all take the 1-pixel mapping the launcher picks for small batches."""

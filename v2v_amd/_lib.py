@@ -16,7 +16,7 @@ BIN_SUM, BIN_BILINEAR = 0, 1
 FLAG_NOISE_EXTERNAL = 0x1
 FLAG_NO_NOISE = 0x2
 FLAG_SYMMETRIC = 0x4
-FLAG_MAP_4PX, FLAG_MAP_1PX = 0x8, 0x10
+FLAG_MAP_4PX, FLAG_MAP_1PX, FLAG_MAP_2PX = 0x8, 0x10, 0x20
 OK, ERR_NULL, ERR_SHAPE, ERR_BINS, ERR_DTYPE, ERR_MODE, ERR_ALIGN, ERR_HIP, ERR_PARAM = 0, -1, -2, -3, -4, -5, -6, -7, -8
 ABI_VERSION = 2
 

@@ -56,8 +56,8 @@ struct V2eArgs {
 };
 
 // defined in v2v_esim_{u8,f32}_tu.hip / v2v_v2e_tu.hip
-hipError_t launch_esim_u8(bool vec4, int bin, int rng, bool noise, bool out64, const EsimArgs &a, dim3 grid, size_t lds, hipStream_t s);
-hipError_t launch_esim_f32(bool vec4, int bin, int rng, bool noise, bool out64, const EsimArgs &a, dim3 grid, size_t lds, hipStream_t s);
+hipError_t launch_esim_u8(int vec, int bin, int rng, bool noise, bool out64, const EsimArgs &a, dim3 grid, size_t lds, hipStream_t s);
+hipError_t launch_esim_f32(int vec, int bin, int rng, bool noise, bool out64, const EsimArgs &a, dim3 grid, size_t lds, hipStream_t s);
 hipError_t launch_v2e(bool in_u8, bool vec4, int bin, int rng, bool out64, bool presum, const V2eArgs &a, dim3 grid, size_t lds,
                       hipStream_t s);
 // specialised v2e instances (v2v_v2e_spec_{u8,f32}_tu.hip): 4 pixels per work-item, float32 grid, device RNG, static

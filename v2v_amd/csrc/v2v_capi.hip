@@ -162,20 +162,30 @@ int v2v_esim_voxel_padded_hip(const void *frames, int in_dtype, int64_t B, int64
         return fail(V2V_ERR_ALIGN, "buffer not aligned to its element size");
     if (B == 0) return V2V_OK;
 
-    // 4 pixels per work-item when every row segment a lane touches is 16-byte (fp32) / 4-byte (u8) aligned
-    bool vec4 = (HW % 4 == 0) && (frame_stride % 4 == 0) && (B == 1 || clip_stride % 4 == 0) &&
-                aligned(frames, 4 * in_sz) && aligned(out_voxel, 16) &&
-                (out_row_pitch == W ? out_plane_size % 4 == 0 : (W % 4 == 0 && out_row_pitch % 4 == 0 && out_plane_size % 4 == 0));
-    // Small batches (the reference's training shape, 12 clips of 128x128 = 768 waves for 1024 SIMDs) leave SIMDs idle and run
-    // one wave per SIMD: at up to one 4-pixel wave per SIMD the 1-pixel-per-work-item instances (4x the waves; the Philox block
-    // is recomputed per pixel, affordable since the Gaussians became table reads) are faster -- 0.084 vs 0.097 ms at 12 clips,
-    // but 0.149 vs 0.138 ms at 24 (same box), hence the threshold.  Results do not depend on the mapping.
-    if (flags & V2V_FLAG_MAP_1PX) vec4 = false;
-    else if (!(flags & V2V_FLAG_MAP_4PX) && vec4 && B * ((HW + 1023) / 1024) * 4 <= (int64_t)simd_count()) vec4 = false;
+    // 4 (or 2) pixels per work-item when every row segment a lane touches is 16-byte (8-byte) fp32 / 4-byte (2-byte) u8 aligned
+    auto layout_ok = [&](int64_t v) {
+        return (HW % v == 0) && (frame_stride % v == 0) && (B == 1 || clip_stride % v == 0) && aligned(frames, (size_t)v * in_sz) &&
+               aligned(out_voxel, (size_t)v * 4) &&
+               (out_row_pitch == W ? out_plane_size % v == 0 : (W % v == 0 && out_row_pitch % v == 0 && out_plane_size % v == 0));
+    };
+    const bool ok4 = layout_ok(4), ok2 = layout_ok(2) && (out_dtype == V2V_F32 || aligned(out_voxel, 16));
+    // Small batches leave SIMDs idle at 4 pixels per work-item (the reference's training shape: 12 clips of 128x128 = 768 such
+    // waves for 1024 SIMDs).  Fewer pixels per work-item = more waves, at the price of a Philox block per work-item and step
+    // whatever it covers.  Same box, 201x128x128 uint8 -> 40x5 SUM bins, ms (4 / 2 / 1 pixels): 12 clips 0.095 / 0.093 / 0.075;
+    // 24 clips 0.136 / 0.128 / 0.128; 48 clips 0.177 / 0.237 / 0.234; float32 input 24 clips 0.189 / 0.130 / 0.172
+    // (tools/train_shape_time.py, profiles/r03/train_shape_time.json).  Hence: up to one 4-pixel wave per SIMD -> 1 pixel,
+    // up to two -> 2 pixels, above -> 4.  Results do not depend on the mapping.
+    int vec = ok4 ? 4 : ok2 ? 2 : 1;
+    const int64_t waves4 = B * ((HW + 1023) / 1024) * 4, simds = (int64_t)simd_count();
+    if (flags & V2V_FLAG_MAP_1PX) vec = 1;
+    else if (flags & V2V_FLAG_MAP_2PX) vec = ok2 ? 2 : 1;
+    else if (!(flags & V2V_FLAG_MAP_4PX)) {
+        if (waves4 <= simds) vec = 1;
+        else if (waves4 <= 2 * simds && ok2) vec = 2;
+    }
 #ifdef V2V_FORCE_SCALAR_PATH       // kernel-tuning builds only: no environment lookups on the product's launch path
-    vec4 = false;
+    vec = 1;
 #endif
-    const int vec = vec4 ? 4 : 1;
 
     v2v::EsimArgs a{};
     a.frames = frames;
@@ -214,8 +224,8 @@ int v2v_esim_voxel_padded_hip(const void *frames, int in_dtype, int64_t B, int64
     hipStream_t s = static_cast<hipStream_t>(stream);
 
     hipError_t e;
-    e = in_dtype == V2V_U8 ? v2v::launch_esim_u8(vec4, bin_mode, rng_mode, noise, out64, a, grid, lds, s)
-                           : v2v::launch_esim_f32(vec4, bin_mode, rng_mode, noise, out64, a, grid, lds, s);
+    e = in_dtype == V2V_U8 ? v2v::launch_esim_u8(vec, bin_mode, rng_mode, noise, out64, a, grid, lds, s)
+                           : v2v::launch_esim_f32(vec, bin_mode, rng_mode, noise, out64, a, grid, lds, s);
     return e == hipSuccess ? V2V_OK : hip_fail(e, "esim_voxel_kernel launch");
 }
 

@@ -43,8 +43,10 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, U...>, F &
 // raw input vectors
 template <int IN, int VEC> struct Raw;
 template <> struct Raw<kInF32, 4> { float4 v; };
+template <> struct Raw<kInF32, 2> { float2 v; };
 template <> struct Raw<kInF32, 1> { float v; };
 template <> struct Raw<kInU8, 4> { uint32_t v; };
+template <> struct Raw<kInU8, 2> { uint16_t v; };
 template <> struct Raw<kInU8, 1> { uint8_t v; };
 
 template <int IN, int VEC, bool NT = (V2V_NT_LOADS != 0)>
@@ -57,8 +59,17 @@ __device__ __forceinline__ Raw<IN, VEC> load_raw(const void *base, int64_t elem_
         f32x4 t;
         if constexpr (NT) t = __builtin_nontemporal_load(ptr); else t = *ptr;
         r.v = make_float4(t.x, t.y, t.z, t.w);
+    } else if constexpr (IN == kInF32 && VEC == 2) {
+        typedef float f32x2v __attribute__((ext_vector_type(2)));
+        const f32x2v *ptr = reinterpret_cast<const f32x2v *>(static_cast<const float *>(base) + elem_off);
+        f32x2v t;
+        if constexpr (NT) t = __builtin_nontemporal_load(ptr); else t = *ptr;
+        r.v = make_float2(t.x, t.y);
     } else if constexpr (IN == kInF32) r.v = static_cast<const float *>(base)[elem_off];
-    else if constexpr (VEC == 4) {
+    else if constexpr (VEC == 2) {
+        const uint16_t *ptr = reinterpret_cast<const uint16_t *>(static_cast<const uint8_t *>(base) + elem_off);
+        if constexpr (NT) r.v = __builtin_nontemporal_load(ptr); else r.v = *ptr;
+    } else if constexpr (VEC == 4) {
         const uint32_t *ptr = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(base) + elem_off);
         if constexpr (NT) r.v = __builtin_nontemporal_load(ptr); else r.v = *ptr;
     } else r.v = static_cast<const uint8_t *>(base)[elem_off];
@@ -72,6 +83,7 @@ template <int VEC>
 __device__ __forceinline__ float raw_f32(const Raw<kInF32, VEC> &r, int j)
 {
     if constexpr (VEC == 4) return (j == 0) ? r.v.x : (j == 1) ? r.v.y : (j == 2) ? r.v.z : r.v.w;
+    else if constexpr (VEC == 2) return (j == 0) ? r.v.x : r.v.y;
     else return r.v;
 }
 
@@ -87,6 +99,12 @@ __device__ __forceinline__ void store_vec(void *out, int64_t off, const T (&v)[V
     } else if constexpr (VEC == 4) {
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4 *>(o));
+    } else if constexpr (VEC == 2 && sizeof(T) == 8) {
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(f64x2{v[0], v[1]}, reinterpret_cast<f64x2 *>(o));
+    } else if constexpr (VEC == 2) {
+        typedef float f32x2v __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(f32x2v{v[0], v[1]}, reinterpret_cast<f32x2v *>(o));
     } else {
         __builtin_nontemporal_store(v[0], o);
     }
@@ -96,6 +114,10 @@ __device__ __forceinline__ void store_vec(void *out, int64_t off, const T (&v)[V
         reinterpret_cast<double2 *>(o)[1] = make_double2(v[2], v[3]);
     } else if constexpr (VEC == 4) {
         *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (VEC == 2 && sizeof(T) == 8) {
+        *reinterpret_cast<double2 *>(o) = make_double2(v[0], v[1]);
+    } else if constexpr (VEC == 2) {
+        *reinterpret_cast<float2 *>(o) = make_float2(v[0], v[1]);
     } else {
         o[0] = v[0];
     }

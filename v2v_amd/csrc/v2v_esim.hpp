@@ -76,6 +76,10 @@ __device__ __forceinline__ void pix_logs(const Raw<IN, VEC> &r, const typename L
             out[1] = at((r.v >> (8u - kSh)) & kMask);
             out[2] = at((r.v >> (16u - kSh)) & kMask);
             out[3] = at((r.v >> (24u - kSh)) & kMask);
+        } else if constexpr (VEC == 2) {
+            const uint32_t v = r.v;
+            out[0] = at((v << kSh) & kMask);
+            out[1] = at((v >> (8u - kSh)) & kMask);
         } else {
             out[0] = lut[r.v];
         }

@@ -131,6 +131,11 @@ __device__ __forceinline__ void field_gauss_pairs(uint64_t seed, uint32_t clip, 
         const u32x4 w = philox4x32<ROUNDS>(p0 >> 2, field, clip, stream, k0, k1);
         const uint32_t j = p0 & 3u;
         icdf_pair(j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w, tab, ga[0], gb[0]);
+    } else if constexpr (VEC == 2) {                       // p0 even: the lower or the upper word pair of the block
+        const u32x4 w = philox4x32<ROUNDS>(p0 >> 2, field, clip, stream, k0, k1);
+        const bool up = (p0 & 2u) != 0;
+        icdf_pair(up ? w.z : w.x, tab, ga[0], gb[0]);
+        icdf_pair(up ? w.w : w.y, tab, ga[1], gb[1]);
     } else {
 #pragma unroll
         for (int j = 0; j < VEC; j += 4) {

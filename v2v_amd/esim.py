@@ -61,7 +61,7 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
     symmetric True asserts pos_thres == neg_thres for every clip (EventEmulator's own defaults): instances compiled without
             the asymmetric loop, 4 waves per SIMD (identical results; a clip that breaks the promise comes out as NaN).
             Default: detected from host `params`, False for a device tensor.
-    mapping   "auto" (4 pixels per work-item for aligned layouts unless the batch is small, then 1), "4px" or "1px" to pin it;
+    mapping   "auto" (4 pixels per work-item for aligned layouts unless the batch is small, then 2 or 1), "4px", "2px" or "1px" to pin it;
             results do not depend on it.  None = the module default DEFAULT_MAPPING ("auto"; the test-suite sweeps it).
     """
     _lib.require_gpu()
@@ -132,7 +132,7 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
             C.c_void_p(frames.data_ptr()), _TORCH_IN[frames.dtype], b, n, h, w,
             frames.stride(0) if b > 1 else n * frames.stride(1), frames.stride(1),
             C.c_void_p(p.data_ptr()), pstride,
-            (_lib.FLAG_NOISE_EXTERNAL if put_noise_external else 0) | (_lib.FLAG_NO_NOISE if no_noise else 0) | (_lib.FLAG_SYMMETRIC if symmetric else 0) | {"auto": 0, "4px": _lib.FLAG_MAP_4PX, "1px": _lib.FLAG_MAP_1PX}[mapping or DEFAULT_MAPPING],
+            (_lib.FLAG_NOISE_EXTERNAL if put_noise_external else 0) | (_lib.FLAG_NO_NOISE if no_noise else 0) | (_lib.FLAG_SYMMETRIC if symmetric else 0) | {"auto": 0, "4px": _lib.FLAG_MAP_4PX, "2px": _lib.FLAG_MAP_2PX, "1px": _lib.FLAG_MAP_1PX}[mapping or DEFAULT_MAPPING],
             RNG_MODES[rng_mode], C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_uint64(clip_id0),
             C.c_void_p(clip_keys.data_ptr()) if clip_keys is not None else None,
             C.byref(rp) if rp is not None else None, BIN_MODES[bin_mode], num_bins, frames_per_bin,
