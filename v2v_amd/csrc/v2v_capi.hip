@@ -170,18 +170,18 @@ int v2v_esim_voxel_padded_hip(const void *frames, int in_dtype, int64_t B, int64
     };
     const bool ok4 = layout_ok(4), ok2 = layout_ok(2) && (out_dtype == V2V_F32 || aligned(out_voxel, 16));
     // Small batches leave SIMDs idle at 4 pixels per work-item (the reference's training shape: 12 clips of 128x128 = 768 such
-    // waves for 1024 SIMDs).  Fewer pixels per work-item = more waves, at the price of a Philox block per work-item and step
-    // whatever it covers.  Same box, 201x128x128 uint8 -> 40x5 SUM bins, ms (4 / 2 / 1 pixels): 12 clips 0.095 / 0.093 / 0.075;
-    // 24 clips 0.136 / 0.128 / 0.128; 48 clips 0.177 / 0.237 / 0.234; float32 input 24 clips 0.189 / 0.130 / 0.172
-    // (tools/train_shape_time.py, profiles/r03/train_shape_time.json).  Hence: up to one 4-pixel wave per SIMD -> 1 pixel,
-    // up to two -> 2 pixels, above -> 4.  Results do not depend on the mapping.
+    // waves for 1024 SIMDs).  Fewer pixels per work-item = more waves; the 1-pixel instances share one Philox block between the
+    // four lanes of a pixel quad (v2v_esim.hpp), so they pay no extra generator work for it.  Same box, 201x128x128 uint8 ->
+    // 40x5 SUM bins, ms (4 / 2 / 1 pixels): 12 clips 0.095 / 0.093 / 0.064; 24 clips 0.136 / 0.128 / 0.113; 48 clips
+    // 0.177 / 0.238 / 0.201 (tools/train_shape_time.py, profiles/r03/train_shape_time.json).  Hence: up to two 4-pixel waves per
+    // SIMD -> 1 pixel (float32 frames: up to one; then 2 pixels up to two), above -> 4; 2 pixels also serve layouts whose rows are only 2-pixel aligned.  Results do not depend on the mapping.
     int vec = ok4 ? 4 : ok2 ? 2 : 1;
     const int64_t waves4 = B * ((HW + 1023) / 1024) * 4, simds = (int64_t)simd_count();
     if (flags & V2V_FLAG_MAP_1PX) vec = 1;
     else if (flags & V2V_FLAG_MAP_2PX) vec = ok2 ? 2 : 1;
     else if (!(flags & V2V_FLAG_MAP_4PX)) {
-        if (waves4 <= simds) vec = 1;
-        else if (waves4 <= 2 * simds && ok2) vec = 2;
+        if (waves4 <= simds || (in_dtype == V2V_U8 && waves4 <= 2 * simds)) vec = 1;
+        else if (waves4 <= 2 * simds && ok2) vec = 2;             // float32 frames, 24 clips: 0.188 / 0.132 / 0.174 ms
     }
 #ifdef V2V_FORCE_SCALAR_PATH       // kernel-tuning builds only: no environment lookups on the product's launch path
     vec = 1;

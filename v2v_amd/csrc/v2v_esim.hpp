@@ -278,6 +278,12 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
     float g_pend[NOISE ? VEC : 1];
 #pragma unroll
     for (int j = 0; j < (NOISE ? VEC : 1); ++j) g_pend[j] = 0.0f;
+    // 1 pixel per work-item (small batches): the four lanes of a pixel quad need the SAME Philox block every other step and use
+    // one word of it each.  Instead of four identical blocks per couple of steps, lane j of the quad computes the block of couple
+    // c0 + j once per 8 steps and a 4x4 transpose inside the quad (two DPP quad_perm exchanges) hands every lane its own word of
+    // all four blocks: a quarter of the Philox work, bit-identical fields.  Needs whole quads (H*W % 4 == 0; else the plain path).
+    uint32_t gw0 = 0, gw1 = 0, gw2 = 0, gw3 = 0;
+    const bool share_quads = VEC == 1 && (a.HW & 3) == 0;
 
     // SYM (compile-time tag): C+ == C- for this clip (wave-uniform), so no per-lane threshold selection.
     // PAR (compile-time tag): k & 1 -- the time loop is unrolled by an even factor from an even k.
@@ -299,6 +305,26 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
                 if (has_base) {                                        // uniform (scalar); 0*g adds nothing
                     float g[VEC];
                     if constexpr (PAR == 0) {
+                        if (VEC == 1 && share_quads) {
+                            if ((k & 7) == 0) {                                // wave-uniform: a new period of four couples
+                                const uint32_t lq = p0 & 3u;
+                                const u32x4 w = philox4x32<kNoiseRounds>(p0 >> 2, kFieldBase0 + (uint32_t)(k >> 1) + lq, clip_id, kStreamEsim,
+                                                                        (uint32_t)seed_, (uint32_t)(seed_ >> 32));
+                                uint32_t w0 = w.x, w1 = w.y, w2 = w.z, w3 = w.w;   // lane r of the quad: words of couple c0 + r
+                                const bool odd = (lq & 1u) != 0, upper = (lq & 2u) != 0;
+                                auto xchg = [](uint32_t v, auto ctrl_tag) {
+                                    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl_tag)::value, 0xF, 0xF, true);
+                                };
+                                // 2x2 blocks between lanes l and l ^ 1 (quad_perm [1,0,3,2] = 0xB1), then between l and l ^ 2 ([2,3,0,1] = 0x4E)
+                                { const uint32_t y = xchg(odd ? w0 : w1, std::integral_constant<int, 0xB1>{}); if (odd) w0 = y; else w1 = y; }
+                                { const uint32_t y = xchg(odd ? w2 : w3, std::integral_constant<int, 0xB1>{}); if (odd) w2 = y; else w3 = y; }
+                                { const uint32_t y = xchg(upper ? w0 : w2, std::integral_constant<int, 0x4E>{}); if (upper) w0 = y; else w2 = y; }
+                                { const uint32_t y = xchg(upper ? w1 : w3, std::integral_constant<int, 0x4E>{}); if (upper) w1 = y; else w3 = y; }
+                                gw0 = w0; gw1 = w1; gw2 = w2; gw3 = w3;            // this pixel's word for couples c0 .. c0 + 3
+                            }
+                            const int sel = (k >> 1) & 3;                          // wave-uniform
+                            icdf_pair(sel == 0 ? gw0 : sel == 1 ? gw1 : sel == 2 ? gw2 : gw3, s_icdf, g[0], g_pend[0]);
+                        } else
                         field_gauss_pairs<VEC, kNoiseRounds>(seed_, clip_id, kFieldBase0 + (uint32_t)(k >> 1), kStreamEsim, p0, s_icdf, g, g_pend);
                     } else {
 #pragma unroll
