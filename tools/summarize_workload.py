@@ -26,6 +26,23 @@ def short(name):
     return None
 
 
+# register / spill figures from the code objects' own metadata (tools/kernel_resources.py), keyed by the demangled kernel name
+RES = {}
+for cand in ("profiles/r03/kernel_resources.json", "profiles/kernel_resources.json"):
+    rp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), cand)
+    if os.path.exists(rp):
+        RES = {v["demangled"]: v for v in json.load(open(rp)).values()}
+        break
+
+
+def code_object_resources(kernel_name):
+    r = RES.get(kernel_name) or RES.get(kernel_name.replace(" [clone .kd]", ""))
+    if r is None:
+        return {}
+    return {"instance": kernel_name, "vgpr_code_object": r.get("vgpr"), "vgpr_spill_code_object": r.get("vgpr_spill"), "sgpr_code_object": r.get("sgpr"),
+            "waves_per_simd_by_registers": r.get("waves_per_simd_by_registers"), "lds_static_bytes_code_object": r.get("lds_static_bytes")}
+
+
 summary = {"workload": workload}
 bench = None
 p = os.path.join(out_dir, "bench_under_stats.json")
@@ -45,8 +62,8 @@ for r in rows("stats/**/*kernel_trace.csv"):
     if k:
         durs.setdefault(k, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         vg = r.get("VGPR_Count") or r.get("Arch_VGPR_Count")
-        # rocprofv3 (ROCm 7.2) reports this field in units of 2 registers on gfx950: 84 here is the code object's 167/168
-        meta[k] = {"vgpr_field_of_rocprofv3": vg, "vgpr_allocated_estimate": int(vg) * 2 if vg and str(vg).isdigit() else None, "sgpr": r.get("SGPR_Count"), "lds_bytes": r.get("LDS_Block_Size"),
+        # the register figures come from the code object's metadata; rocprofv3's own field (in units of 2 on gfx950) is kept beside it
+        meta[k] = {**code_object_resources(r.get("Kernel_Name", "")), "vgpr_field_of_rocprofv3": vg, "sgpr": r.get("SGPR_Count"), "lds_bytes": r.get("LDS_Block_Size"),
                    "grid": r.get("Grid_Size_X") or r.get("Grid_Size"), "workgroup": r.get("Workgroup_Size_X") or r.get("Workgroup_Size")}
 n_steps = (bench["steps"] + bench["warmup"]) if isinstance(bench, dict) else None
 summary["kernels"] = {}

@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
     // 2-frame ring, which fits 128 VGPRs = 4 waves per SIMD (-4.6 % on the headline, same box); a clip that breaks the
     // guarantee gets NaN planes (loud, never a wrong count)
     // (uint8 frames are 4 bytes per lane and frame: their ring stays kDepth deep -- with 2 in flight config 4's shape lost 20 %)
-    constexpr int kRing = (SYMONLY || (ASYM4 && IN == kInF32)) ? 2 : kDepth;
+    constexpr int kRing = ((SYMONLY || ASYM4) && IN == kInF32) ? 2 : kDepth;
     static_assert(NOISE || !EXT, "external noise needs the noise path");
     using lut_t = typename LutT<IN>::type;
     using acc_t = typename std::conditional<OUT64, double, float>::type;
