@@ -169,24 +169,40 @@ def test_symmetric_hint_is_exact_and_loud(oracle_c, luts):
     breaks the promise comes out as NaN (never as a wrong count), the other clips of the batch are unaffected."""
     from oracle import v2v_oracle as O
     from v2v_amd import esim
-    b, n, h, w = 5, 11, 256, 256                    # enough waves for the 4-pixel mapping (the hint has no 1-pixel instances)
+    b, n, h, w = 5, 11, 256, 256
+    kw4 = dict(mapping="4px")                       # the hint has 4-pixel instances only (a batch this small would map 1 or 2 pixels)
     sym = [[0.2, 0.2, 0.1, 1e-3, 0.1], [0.35, 0.35, 0.05, 0.0, 0.0], [0.2, 0.2, 0.0, 2e-3, 0.3], [0.11, 0.11, 0.07, 1e-3, 0.2], [0.5, 0.5, 0.2, 0.0, 0.0]]
     for dt in (np.uint8, np.float32):
         video = np.stack([O.synth_clip_s1(n, h, w, seed=70 + i, dtype=dt) for i in range(b)])
         frames = torch.from_numpy(video).cuda()
         ptensor = torch.tensor(sym, dtype=torch.float64, device="cuda")
         for mode, kw in (("bilinear", dict(num_bins=5)), ("sum", dict(num_bins=5, frames_per_bin=2))):
-            general = esim.esim_voxel_batch(frames, ptensor, bin_mode=mode, seed=3, symmetric=False, **kw)     # device params: no auto-detection
-            hinted = esim.esim_voxel_batch(frames, ptensor, bin_mode=mode, seed=3, symmetric=True, **kw)
-            auto = esim.esim_voxel_batch(frames, sym, bin_mode=mode, seed=3, **kw)                              # host params: detected
+            general = esim.esim_voxel_batch(frames, ptensor, bin_mode=mode, seed=3, symmetric=False, **kw, **kw4)     # device params: no auto-detection
+            hinted = esim.esim_voxel_batch(frames, ptensor, bin_mode=mode, seed=3, symmetric=True, **kw, **kw4)
+            auto = esim.esim_voxel_batch(frames, sym, bin_mode=mode, seed=3, **kw, **kw4)                              # host params: detected
+            assert torch.equal(general, esim.esim_voxel_batch(frames, sym, bin_mode=mode, seed=3, **kw))                 # and the mapping the launcher picks
             assert torch.equal(general, hinted) and torch.equal(general, auto)
             bm = oracle_c.BIN_BILINEAR if mode == "bilinear" else oracle_c.BIN_SUM
             want, _ = oracle_c.esim_voxel(video, np.asarray(sym), luts, seed=3, bin_mode=bm, **kw)
             np.testing.assert_allclose(hinted.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
             broken = [list(r) for r in sym]
             broken[2][1] = 0.25                                                                               # clip 2 is asymmetric now
-            out = esim.esim_voxel_batch(frames, torch.tensor(broken, dtype=torch.float64, device="cuda"), bin_mode=mode, seed=3, symmetric=True, **kw)
+            out = esim.esim_voxel_batch(frames, torch.tensor(broken, dtype=torch.float64, device="cuda"), bin_mode=mode, seed=3, symmetric=True, **kw, **kw4)
             assert bool(torch.isnan(out[2]).all()) and torch.equal(out[[0, 1, 3, 4]], general[[0, 1, 3, 4]])
+
+
+@pytest.mark.parametrize("workload,batch", [("cfg4_pipeline_720p_to_256_41f_sum5", 2), ("cfg5_fused_convlstm_channels_last", 2)])
+def test_bench_pipeline_workloads_run_with_two_ranks(workload, batch):
+    """The configs BASELINE names for 8 GPUs (config 4: 720p -> front-end -> simulator; config 5: + the recurrent UNet) through the
+    N > 1 path: two ranks on this box's one GPU (gloo), each with its own clips (global clip ids by rank), one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", str(batch),
+                          "--workload", workload, "--share-gpu", "--backend", "gloo", "--hip-graph", "off"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["dist_world_size"] == 2 and d["config"]["workload"] == workload and d["config"]["clips_per_gpu"] == batch
+    assert d["parity_check"] == "ok" and d["value"] > 0
 
 
 def test_bench_gpus_n_without_a_launcher_starts_the_ranks_itself():
