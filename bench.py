@@ -342,6 +342,27 @@ def convlstm_roofline(torch, dev):
     return out
 
 
+def load_valu(name, kernel_ms):
+    """VALU-issue view of a launch, next to the HBM one (the noise-on kernels are issue-bound, not bandwidth-bound): the kernel's
+    dynamic vector-instruction count per launch (SQ_INSTS_VALU of the rocprofv3 --pmc pass in profiles/r03/<workload>/summary.json --
+    static per binary, like `traffic`) over this run's kernel time, against what 4 SIMDs x 256 CUs can issue at the 2.4 GHz peak
+    clock: one wave-instruction per 2 cycles for the cheap class (add/sub/mul/logic/shift/mov) and per 4 cycles for everything else
+    (all float64, fma, convert, compare, select, packed: profiles/valu_rates_ubench.txt).  The true ceiling of a kernel lies between
+    the two by its instruction mix and is lowered further by the clock the chip holds under load (~1.7-1.9 GHz here)."""
+    path = os.path.join(ROOT, "profiles", "r03", name, "summary.json")
+    try:
+        d = json.load(open(path))
+        insts = d["sq_counters_per_step"]["SQ_INSTS_VALU"]
+    except Exception:  # noqa: BLE001
+        return None
+    simds, clock = 1024, 2.4e9
+    rate = insts / (kernel_ms * 1e-3)
+    return {"bound": "valu-issue", "wave_instructions_per_launch": insts, "achieved_Ginstr_per_s": rate / 1e9,
+            "peak_Ginstr_per_s_2cycle_class": simds * clock / 2 / 1e9, "peak_Ginstr_per_s_4cycle_class": simds * clock / 4 / 1e9,
+            "frac_of_2cycle_peak": rate / (simds * clock / 2), "frac_of_4cycle_peak": rate / (simds * clock / 4),
+            "source": f"static: profiles/r03/{name}/summary.json (SQ_INSTS_VALU, rocprofv3 --pmc pass) over this run's kernel time"}
+
+
 def load_traffic(name):
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # rocprofv3 --pmc passes, see profiles/README.md
     try:
@@ -496,7 +517,7 @@ def main():
                 ach = S.alg_bytes / (avg * 1e-3) / 1e9
                 also[name] = {"kernel": S.kernel_name, "kernel_ms_avg": avg, "kernel_ms_p50": ms[len(ms) // 2], "grids_per_s": S.grids_per_step / (avg * 1e-3),
                               "algorithmic_bytes_per_launch": S.alg_bytes, "achieved_GBps": ach, "frac_of_hbm_peak": ach / HBM_PEAK_GBPS,
-                              "traffic_bytes_per_launch": load_traffic(name), "sim_params": S.wl["params"], "input_dtype": S.wl["dtype"],
+                              "traffic_bytes_per_launch": load_traffic(name), "valu_issue": load_valu(name, avg), "sim_params": S.wl["params"], "input_dtype": S.wl["dtype"],
                               "bin_mode": S.wl["bin"], "launch": "hipGraph replay" if s_graph else "eager", "parity_check": S.parity()}
                 S.free()
                 del S, s_step
@@ -534,7 +555,9 @@ def main():
                          "measured_ceilings_GBps": MEASURED_CEILINGS_GBPS,
                          "kernel_ms_avg": kern_avg_ms, "kernel_ms_p10": kern_ms[len(kern_ms) // 10],
                          "kernel_ms_p50": kern_ms[len(kern_ms) // 2], "kernel_ms_p90": kern_ms[(len(kern_ms) * 9) // 10],
-                         "note": "noise-on launches are VALU-issue-bound, not HBM-bound (DESIGN.md §4.1); `frac` is still quoted against the HBM peak"},
+                         "valu_issue": load_valu(args.workload, kern_avg_ms),
+                         "note": "noise-on launches are VALU-issue-bound, not HBM-bound (DESIGN.md §4.1); `frac` is still quoted against the HBM peak; "
+                                 "`valu_issue` gives the same launch against the vector-issue ceilings"},
             "cpu_baseline": cpu,
             "cpu_baseline_numpy_pool": cpu_pool,
             "cpu_baseline_c_omp": cpu_c,
