@@ -287,8 +287,9 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
 
     // SYM (compile-time tag): C+ == C- for this clip (wave-uniform), so no per-lane threshold selection.
     // PAR (compile-time tag): k & 1 -- the time loop is unrolled by an even factor from an even k.
-    auto step = [&](auto sym_tag, auto par_tag, int k, const Raw<IN, VEC> &raw) __attribute__((always_inline)) {
+    auto step = [&](auto sym_tag, auto hot_tag, auto par_tag, int k, const Raw<IN, VEC> &raw) __attribute__((always_inline)) {
         constexpr bool SYM = decltype(sym_tag)::value;
+        constexpr bool HOT = decltype(hot_tag)::value;     // false: no work-item of this WAVE owns a hot pixel -> no hot-pixel add
         constexpr int PAR = decltype(par_tag)::value;
         if constexpr (BIN == kBinBilinear) {
             while (k >= next_k) {                                      // scalar compare; rarely taken
@@ -360,7 +361,7 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
             // :48-49.  (Skipping the hot-pixel add for waves without a hot pixel is exact -- x + (+0.0) is x unless x is -0.0,
             // which a round-to-nearest sum with the never-negative-zero log difference cannot be -- but the scalar branch
             // costs more than the four adds: +2.5 % on the same box, round 2.)
-            if constexpr (NOISE && !EXT) { p = p + base[j]; p = p + hot[j]; }
+            if constexpr (NOISE && !EXT) { p = p + base[j]; if constexpr (HOT) p = p + hot[j]; }
             sgn[j] = (uint32_t)__double2hiint(p) & 0x80000000u;
             mag[j] = fabs(p);
             double inv;
@@ -449,14 +450,14 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
     //      kDepth-1 loads (x 1 KiB per wave for fp32 input) stay in flight behind the arithmetic.  Loads are
     //      UNCONDITIONAL (frame index clamped to the last frame) so the compiler can count them and wait with
     //      vmcnt(kDepth-1) instead of vmcnt(0); the kDepth clamped re-reads at the end of a clip hit in cache.
-    auto tail = [&](auto sym_tag, int k0, const Raw<IN, VEC> (&ring)[kRing]) {
+    auto tail = [&](auto sym_tag, auto hot_tag, int k0, const Raw<IN, VEC> (&ring)[kRing]) {
         // up to kRing-1 remaining steps, with compile-time slot index (and parity)
         static_for(std::make_integer_sequence<int, kRing - 1>{}, [&](auto u_tag) {
             constexpr int u = decltype(u_tag)::value;
-            if (k0 + u < a.K) step(sym_tag, std::integral_constant<int, (u & 1)>{}, k0 + u, ring[u]);
+            if (k0 + u < a.K) step(sym_tag, hot_tag, std::integral_constant<int, (u & 1)>{}, k0 + u, ring[u]);
         });
     };
-    auto run = [&](auto sym_tag) {
+    auto run_hot = [&](auto sym_tag, auto hot_tag) {
         static_assert(kRing % 2 == 0, "the time loop must be unrolled by an even factor (noise pairs)");
         Raw<IN, VEC> ring[kRing];
 #pragma unroll
@@ -469,12 +470,31 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
             static_for(std::make_integer_sequence<int, kRing>{}, [&](auto u_tag) {
                 constexpr int u = decltype(u_tag)::value;
                 const int k = k0 + u;
-                step(sym_tag, std::integral_constant<int, (u & 1)>{}, k, ring[u]);
+                step(sym_tag, hot_tag, std::integral_constant<int, (u & 1)>{}, k, ring[u]);
                 const int fn = k + 1 + kRing;
                 ring[u] = load_raw<IN, VEC>(a.frames, in_base + (int64_t)(fn <= a.K ? fn : a.K) * a.frame_stride);
             });
         }
-        tail(sym_tag, k0, ring);
+        tail(sym_tag, hot_tag, k0, ring);
+    };
+    // Hot pixels are 0.1 % of the pixels (hot_pixel_fraction <= 1e-3 in the reference's defaults and in the dataset's draws):
+    // 3 of 4 waves own none, and for them `p + hot` adds +0.0 to a sum that is never -0.0 (a round-to-nearest sum with the
+    // never-negative-zero log difference), i.e. nothing.  The choice is made ONCE per wave and clip -- two copies of the time loop
+    // in the device-noise instances -- not per step (round 2 measured a per-step scalar branch: +2.5 %, worse than the adds).
+    bool wave_has_hot = true;
+    if constexpr (NOISE && !EXT && RNG == kRngPhilox && !OUT64) {
+        bool mine = false;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) mine = mine || (hot[j] != 0.0);
+        wave_has_hot = __builtin_amdgcn_ballot_w64(mine) != 0;
+    }
+    auto run = [&](auto sym_tag) {
+        if constexpr (NOISE && !EXT && RNG == kRngPhilox && !OUT64) {
+            if (wave_has_hot) run_hot(sym_tag, std::true_type{});
+            else run_hot(sym_tag, std::false_type{});
+        } else {
+            run_hot(sym_tag, std::true_type{});
+        }
     };
     if constexpr (SYMONLY) {
         if (pp[0] != pp[1]) {                                          // guarantee broken: poison this clip's planes
