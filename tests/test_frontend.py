@@ -69,6 +69,29 @@ def test_hip_frontend_equals_oracle(color_mode, flip, crop_before, shake):
     imgs, gray = frontend.prepare_clip(torch.from_numpy(raw).cuda(), crop_before, 11, 23, flip, crop, idxes, di, dj, color_mode)
     assert np.array_equal(gray.cpu().numpy(), want_gray)
     assert np.array_equal(imgs.cpu().numpy(), want_imgs)
+    if color_mode == "gray":                # gray output only: the LDS-tiled kernel (with the per-frame shake offsets since round 3)
+        _, gray_t = frontend.prepare_clip(torch.from_numpy(raw).cuda(), crop_before, 11, 23, flip, crop, idxes, di, dj, color_mode, want_imgs=False)
+        assert np.array_equal(gray_t.cpu().numpy(), want_gray)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flip", [False, True])
+def test_hip_frontend_tiled_with_shake_at_training_size(flip):
+    """color_mode 'gray' + shake_frames > 0 (data/v2v_datasets.py:145-161, 217-224) on the LDS-tiled kernel at the training geometry:
+    resize to 128 + the largest offset in each direction (need_h != need_w), flip, per-frame cut-out; partial tiles, up- and
+    down-scaling, the exact-2x area shortcut (crop_before = 2 * need in both directions only without shake)."""
+    import torch
+    from v2v_amd import frontend
+    g = np.random.default_rng(17 + flip)
+    t, hs, ws, crop = 9, 300, 420, 128
+    raw = g.integers(0, 256, size=(t, hs, ws, 3), dtype=np.uint8)
+    raw_d = torch.from_numpy(raw).cuda()
+    idxes = [0, 1, 2, 2, 3, 4, 5, 6, 7, 8, 8]
+    for cb in (97, 128, 200, 256, 277):
+        di, dj = g.integers(-4, 5, size=t), g.integers(-6, 3, size=t)
+        _, want = F.frontend(raw, cb, 13, 31, flip, crop, idxes, di, dj, "gray")
+        _, got = frontend.prepare_clip(raw_d, cb, 13, 31, flip, crop, idxes, di, dj, "gray", want_imgs=False)
+        assert np.array_equal(got.cpu().numpy(), want), cb
 
 
 @pytest.mark.gpu

@@ -380,7 +380,7 @@ static hipError_t launch_frontend(const v2v::FrontendArgs &a, int64_t B, int64_t
 #else
     const bool force_gather = false;
 #endif
-    const bool tiled = !force_gather && a.gray_first && a.Cs == 3 && !a.out_imgs && !a.di && a.need_h == a.crop && a.need_w == a.crop &&
+    const bool tiled = !force_gather && a.gray_first && a.Cs == 3 && !a.out_imgs && (a.di != nullptr || (a.need_h == a.crop && a.need_w == a.crop)) &&
                        a.Hs <= 32767 && a.Ws <= 32767;                        // 16-bit source coordinates in the LDS coefficient tables
     if (tiled) {
         const int64_t frame_min = a.Hs < a.Ws ? a.Hs : a.Ws;

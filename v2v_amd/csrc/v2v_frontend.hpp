@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256) frontend_kernel(const FrontendArgs a_in)
     }
 }
 
-// ---- LDS-tiled variant for the training configuration (BGR source, color_mode 'gray', no shake, gray output only) ---
+// ---- LDS-tiled variant for the training configuration (BGR source, color_mode 'gray', gray output only; shake offsets per frame) ---
 // The gather kernel above spends ~350 VALU instructions (float64 coordinate maths, four gray conversions) and eight
 // unaligned 8-byte loads per four output pixels.  Here a workgroup owns a tile of (4 x rows_per_wave) x (64 x CPL) output
 // pixels of one frame:
@@ -265,14 +265,19 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
     const int t = a.frame_idx[(int64_t)clip * a.N + n];
     const uint8_t *frame = a.src + (((int64_t)clip * a.T + t) * a.Hs * a.Ws + (int64_t)min_i * a.Ws + min_j) * 3;
     uint8_t *out = a.out_gray + ((int64_t)clip * a.N + n) * a.crop * a.crop;
-    const bool area2 = cb == 2 * a.crop;
-    const double scale = 1.0 / ((double)a.crop / (double)cb);
+    // shake (data/v2v_datasets.py:217-224): the clip is resized to need_h x need_w = crop + the largest offset, flipped, and frame t
+    // is cut out at (di[t], dj[t]); without shake need == crop and both offsets are 0.  The batch form has no shake.
+    const int di = a.di ? a.di[(int64_t)clip * a.T + t] : 0, dj = a.dj ? a.dj[(int64_t)clip * a.T + t] : 0;
+    const int need_w = a.need_w, need_h = a.need_h;
+    const bool area2 = cb == 2 * need_w && cb == 2 * need_h;
+    const double scale = 1.0 / ((double)need_w / (double)cb), scale_y = 1.0 / ((double)need_h / (double)cb);
     const int tid = threadIdx.x;
+    auto col_of = [&](int x) { const int X = x + dj; return flip ? need_w - 1 - X : X; };       // column in the resized image
 
     // (1) extent of the source rectangle
-    const int Xa = flip ? a.crop - 1 - (x0 + ncol - 1) : x0, Xb = flip ? a.crop - 1 - x0 : x0 + ncol - 1;
-    const int sx_lo = resize_src_lo(Xa, cb, scale), sy_lo = resize_src_lo(y0, cb, scale);
-    const int sx_hi = min(resize_src_lo(Xb, cb, scale) + 1, cb - 1), sy_hi = min(resize_src_lo(y0 + nrow - 1, cb, scale) + 1, cb - 1);
+    const int Xa = flip ? col_of(x0 + ncol - 1) : col_of(x0), Xb = flip ? col_of(x0) : col_of(x0 + ncol - 1);
+    const int sx_lo = resize_src_lo(Xa, cb, scale), sy_lo = resize_src_lo(y0 + di, cb, scale_y);
+    const int sx_hi = min(resize_src_lo(Xb, cb, scale) + 1, cb - 1), sy_hi = min(resize_src_lo(y0 + di + nrow - 1, cb, scale_y) + 1, cb - 1);
     const int rows = sy_hi - sy_lo + 1;
     const int span = (sx_hi - sx_lo + 1) * 3;
     const int nch = (span + 12 + 15) >> 4;               // 16-byte chunks per row: misalignment (<= 3) + span + the 12-byte tap reads
@@ -295,16 +300,14 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
         }
     }
     if (tid < ncol) {
-        int X = x0 + tid;
-        if (flip) X = a.crop - 1 - X;
-        const Coef c = resize_coef(X, cb, scale);
+        const Coef c = resize_coef(col_of(x0 + tid), cb, scale);
         // right tap clamped onto the left one (last source column): g*a0 + g*a1 == g*(a0+a1) + anything*0, so the
         // blend needs no special case
         const bool single = c.s1 == c.s0;
         s_col[tid] = ColC{(uint16_t)c.s0, (uint16_t)single, (int16_t)(single ? c.a0 + c.a1 : c.a0), (int16_t)(single ? 0 : c.a1)};
     }
     if (tid < nrow) {
-        const Coef c = resize_coef(y0 + tid, cb, scale);
+        const Coef c = resize_coef(y0 + di + tid, cb, scale_y);
         s_row[tid] = RowC{(int16_t)c.s0, (int16_t)c.s1, (int16_t)c.a0, (int16_t)c.a1};
     }
     __syncthreads();
@@ -371,11 +374,10 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
             uint32_t packed = 0;
             for (int j = 0; j < CPL; ++j) {
                 if (cg + j >= ncol) break;
-                int X = x0 + cg + j;
-                if (flip) X = a.crop - 1 - X;
+                const int X = col_of(x0 + cg + j);
                 int v;
                 if (area2) {
-                    const uint8_t *p0 = frame + ((int64_t)(2 * (y0 + y)) * a.Ws + 2 * X) * 3, *p1 = p0 + (int64_t)a.Ws * 3;
+                    const uint8_t *p0 = frame + ((int64_t)(2 * (y0 + di + y)) * a.Ws + 2 * X) * 3, *p1 = p0 + (int64_t)a.Ws * 3;
                     v = (bgr2gray_cv(p0, gk) + bgr2gray_cv(p0 + 3, gk) + bgr2gray_cv(p1, gk) + bgr2gray_cv(p1 + 3, gk) + 2) >> 2;
                 } else {
                     const ColC c1 = s_col[cg + j];
