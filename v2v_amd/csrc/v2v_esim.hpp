@@ -481,15 +481,18 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
     // 3 of 4 waves own none, and for them `p + hot` adds +0.0 to a sum that is never -0.0 (a round-to-nearest sum with the
     // never-negative-zero log difference), i.e. nothing.  The choice is made ONCE per wave and clip -- two copies of the time loop
     // in the device-noise instances -- not per step (round 2 measured a per-step scalar branch: +2.5 %, worse than the adds).
+    // (not in the general float32 bilinear instance: the second loop copy costs it 2 spilled registers at its 128-VGPR budget and
+    // measured no gain there)
+    constexpr bool HOT_SPLIT = NOISE && !EXT && RNG == kRngPhilox && !OUT64 && !(ASYM4 && IN == kInF32 && BIN == kBinBilinear);
     bool wave_has_hot = true;
-    if constexpr (NOISE && !EXT && RNG == kRngPhilox && !OUT64) {
+    if constexpr (HOT_SPLIT) {
         bool mine = false;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) mine = mine || (hot[j] != 0.0);
         wave_has_hot = __builtin_amdgcn_ballot_w64(mine) != 0;
     }
     auto run = [&](auto sym_tag) {
-        if constexpr (NOISE && !EXT && RNG == kRngPhilox && !OUT64) {
+        if constexpr (HOT_SPLIT) {
             if (wave_has_hot) run_hot(sym_tag, std::true_type{});
             else run_hot(sym_tag, std::false_type{});
         } else {
