@@ -15,6 +15,9 @@ namespace v2v {
 #ifndef V2V_DEPTH
 #define V2V_DEPTH 4
 #endif
+#ifndef V2V_V2E_LP_TABLE
+#define V2V_V2E_LP_TABLE 1   // v2e, float32 input: tabulated low-pass factors in the feature-specialised instances
+#endif
 #ifndef V2V_V2E_DEPTH
 #define V2V_V2E_DEPTH 2     // frames in flight per work-item of the v2e kernel (even)
 #endif

@@ -434,13 +434,32 @@ __device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, 
     const bool shot = FEAT < 0 ? P.shot_noise_rate_hz > 0 : (FEAT & kV2eShot) != 0;
     const bool refractory = P.refractory_period_s > 0;   // always a run-time (wave-uniform) switch
     const bool temporal = FEAT < 0 ? P.threshold_model == kV2eSpatialTemporalIndependent : (FEAT & kV2eTemporal) != 0;
+    // float32 input, low-pass on, feature-specialised instance: the IIR step's two intensity-dependent factors are TABULATED.
+    // eps = min(inten01 * float32(dt / tau), 1) depends on the 8-bit intensity and on dt / tau only, and float32(dt / tau) is the
+    // same bit pattern for every frame of a clip (dt = i/fps - (i-1)/fps wobbles in the last float64 ulp, which the float32 cast
+    // absorbs: checked on the host, launch_v2e routes anything else to the run-time-feature kernel) -- so (1 - eps) and
+    // eps * log_new, with the reference's own roundings, sit in the intensity record in place of log value and inten01:
+    // lp = E1 * lp + E2, two instructions instead of six.
+    constexpr bool LP_TAB = V2V_V2E_LP_TABLE && FEAT >= 0 && (FEAT & kV2eLowpass) != 0 && IN == kInF32;
     {   // ---- workgroup prologue: the two LDS tables
         double i64, fac; float i32;
         v2e_inten_direct<IN>((float)threadIdx.x, P.uint8_wrap, i64, i32, fac);
         inten_t e;
         e.logv = a.lut[threadIdx.x];
         e.fac = (float)fac;
-        if constexpr (IN == kInU8) e.i01 = i64; else { e.i01 = i32; e.pad = 0.0f; }
+        if constexpr (IN == kInU8) e.i01 = i64;
+        else {
+            e.i01 = i32; e.pad = 0.0f;
+            if constexpr (LP_TAB) {
+                const double dt1 = 1.0 / P.fps - 0.0 / P.fps;                                    // frame 1's time step; every frame's float32(dt / tau) equals it
+                const float dtt = (float)(dt1 / (1 / (3.141592653589793 * 2 * P.cutoff_hz)));
+                float eps = i32 * dtt;
+                eps = __builtin_fminf(eps, 1.0f);
+                const float lg = e.logv;
+                e.logv = 1.0f - eps;                                                             // E1
+                e.i01 = eps * lg;                                                                // E2
+            }
+        }
         s_int[threadIdx.x] = e;
     }
     const double tau = lowpass ? 1 / (3.141592653589793 * 2 * P.cutoff_hz) : 0.0;
@@ -612,6 +631,13 @@ __device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, 
                         log_new[j] = v2e_linlog(x[j], a.lut);
                         v2e_inten_direct<IN>(x[j], P.uint8_wrap, i01_64[j], i01_32[j], fac);
                         fac32[j] = (float)fac;
+                        if constexpr (LP_TAB) {                                                  // (E1, E2) of a pixel outside the table
+                            float eps = i01_32[j] * dt_tau32;
+                            eps = __builtin_fminf(eps, 1.0f);
+                            const float lg = log_new[j];
+                            log_new[j] = 1.0f - eps;
+                            i01_32[j] = eps * lg;
+                        }
                     }
                 }
             }
@@ -631,7 +657,10 @@ __device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, 
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             if (lowpass) {                                                              // low_pass_filter (:139-182)
-                if constexpr (IN == kInF32) {
+                if constexpr (LP_TAB) {
+                    const float ta = log_new[j] * lp_f[j];                          // log_new = E1 = 1 - eps, i01_32 = E2 = eps * log value
+                    lp_f[j] = ta + i01_32[j];
+                } else if constexpr (IN == kInF32) {
                     float eps = i01_32[j] * dt_tau32;
                     eps = __builtin_fminf(eps, 1.0f);                               // np.minimum (:173); eps is never NaN here: one v_min_f32
                     const float ta = (1.0f - eps) * lp_f[j], tb2 = eps * log_new[j];

@@ -52,7 +52,14 @@ hipError_t launch_v2e(bool in_u8, bool vec4, int bin, int rng, bool out64, bool 
     if (e != hipSuccess) return e;
     a.lut = static_cast<const float *>(lut);
     const V2eParams &P = a.P;
-    const bool spec = vec4 && !out64 && rng == V2V_RNG_PHILOX && P.threshold_model != kV2eSpatialTemporalIndependent;
+    bool spec = vec4 && !out64 && rng == V2V_RNG_PHILOX && P.threshold_model != kV2eSpatialTemporalIndependent;
+    if (spec && !in_u8 && P.cutoff_hz > 0) {
+        // the specialised float32 instances tabulate the low-pass factors for ONE float32(dt / tau): true for every frame rate and
+        // cut-off tried (the float64 wobble of i/fps - (i-1)/fps disappears in the cast), but checked, not assumed
+        const double tau = 1 / (3.141592653589793 * 2 * P.cutoff_hz);
+        const float first = (float)((1.0 / P.fps - 0.0 / P.fps) / tau);
+        for (int i = 2; i <= a.K && spec; ++i) spec = (float)(((double)i / P.fps - (double)(i - 1) / P.fps) / tau) == first;
+    }
     if (spec) {
         const int feat = (P.cutoff_hz > 0 ? kV2eLowpass : 0) | (P.leak_rate_hz > 0 ? kV2eLeak : 0) | (P.shot_noise_rate_hz > 0 ? kV2eShot : 0);
         if (presum) {
