@@ -262,3 +262,24 @@ def test_hip_v2e_errors():
         v2e.v2e_voxel_batch(f, p, num_bins=5)
     with pytest.raises(ValueError):
         v2e.v2e_voxel_batch(f, p, num_bins=7, rng_mode="replay")
+
+
+@gpu
+def test_hip_lowpass_table_falls_back_when_dt_over_tau_is_not_one_float32(oracle_c, luts):
+    """The specialised float32 instances tabulate the low-pass factors for ONE float32(dt / tau) (true for every ordinary frame
+    rate / cut-off: the float64 wobble of i/fps - (i-1)/fps vanishes in the cast).  This cut-off is CONSTRUCTED so that dt / tau
+    straddles a float32 rounding boundary (two distinct values over 31 frames at 24 fps): the launcher must notice and take the
+    run-time-feature kernel -- same results as the oracle either way, and as the ordinary cut-off right beside it."""
+    import torch
+    from v2v_amd import esim, v2e
+    fps, cutoff = 24.0, 26.738033171514086
+    i = np.arange(1, 32, dtype=np.float64)
+    tau = 1 / (np.pi * 2 * cutoff)
+    assert len(set(((i / fps - (i - 1) / fps) / tau).astype(np.float32).tolist())) == 2          # the premise of this test
+    frames = esim.synth_clips(3, 32, 64, 64, dtype=torch.float32, seed=31, clip_id0=0)
+    for co in (cutoff, 30.0):
+        args = [fps, "pn_related", 0.5, 0.1, 0.0, 0.1, co, 0.1, 0, 5.0, 0.1, 0.1]
+        got = v2e.v2e_voxel_batch(frames, v2e.make_params(*args), bin_mode="sum", num_bins=31, seed=9, clip_id0=0)
+        want, _ = oracle_c.v2e_voxel(frames.cpu().numpy(), oracle_c.v2e_params(*args), luts, seed=9, clip_id0=0,
+                                     bin_mode=oracle_c.BIN_SUM, num_bins=31)
+        assert np.array_equal(got.cpu().numpy().astype(np.float64), want), co
