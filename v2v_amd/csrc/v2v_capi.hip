@@ -380,7 +380,9 @@ static hipError_t launch_frontend(const v2v::FrontendArgs &a, int64_t B, int64_t
 #else
     const bool force_gather = false;
 #endif
-    const bool tiled = !force_gather && a.gray_first && a.Cs == 3 && !a.out_imgs && (a.di != nullptr || (a.need_h == a.crop && a.need_w == a.crop)) &&
+    // LDS-tiled kernel: BGR source, either color_mode 'gray' with gray output only, or 'gray_in_bgr_out' (resized BGR frames optional)
+    const bool bgr_mode = !a.gray_first && a.Cs == 3;
+    const bool tiled = !force_gather && a.Cs == 3 && (bgr_mode || !a.out_imgs) && (a.di != nullptr || (a.need_h == a.crop && a.need_w == a.crop)) &&
                        a.Hs <= 32767 && a.Ws <= 32767;                        // 16-bit source coordinates in the LDS coefficient tables
     if (tiled) {
         const int64_t frame_min = a.Hs < a.Ws ? a.Hs : a.Ws;
@@ -407,7 +409,10 @@ static hipError_t launch_frontend(const v2v::FrontendArgs &a, int64_t B, int64_t
                 const int64_t nblocks = (int64_t)ta.tiles_x * ta.tiles_y * a.N;
                 if (nblocks > 0x7FFFFFFF) break;
                 const size_t lds = (size_t)(v2v::tile_hdr_bytes(cpl) + max_rows * pitch);
-                if (cpl == 4) hipLaunchKernelGGL(v2v::frontend_tile_kernel<4>, dim3((unsigned)nblocks, (unsigned)B), dim3(256), lds, s, ta);
+                if (bgr_mode) {
+                    if (cpl == 4) hipLaunchKernelGGL((v2v::frontend_tile_kernel<4, true>), dim3((unsigned)nblocks, (unsigned)B), dim3(256), lds, s, ta);
+                    else hipLaunchKernelGGL((v2v::frontend_tile_kernel<2, true>), dim3((unsigned)nblocks, (unsigned)B), dim3(256), lds, s, ta);
+                } else if (cpl == 4) hipLaunchKernelGGL(v2v::frontend_tile_kernel<4>, dim3((unsigned)nblocks, (unsigned)B), dim3(256), lds, s, ta);
                 else hipLaunchKernelGGL(v2v::frontend_tile_kernel<2>, dim3((unsigned)nblocks, (unsigned)B), dim3(256), lds, s, ta);
                 return hipGetLastError();
             }

@@ -242,9 +242,14 @@ __device__ __forceinline__ void lds_gray_pair(const unsigned char *row, uint32_t
     g1 = bgr2gray_dot4(__builtin_amdgcn_alignbyte(hi, lo, 3), k);        // bytes o+3 .. o+6
 }
 
-template <int CPL>
+// BGR = false: color_mode 'gray' (cvtColor at the taps, gray clip out).  BGR = true: color_mode 'gray_in_bgr_out' (round 3): the three
+// channels are resized as they are -- per source row one horizontal pass per channel (the two taps' bytes picked out of the
+// aligned LDS dwords with v_perm, one v_dot2 with the 11-bit weights), one vertical blend per channel --, the resized BGR frame
+// goes to out_imgs (when asked for) and its bgr_to_gray (data/v2v_datasets.py:19-22: float64 fma chain, golden G15) to out_gray.
+template <int CPL, bool BGR = false>
 __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileArgs ta)
 {
+    constexpr int NC = BGR ? 3 : 1;                       // channels carried through the two passes
     constexpr int kCols = 64 * CPL;
     extern __shared__ __align__(16) unsigned char s_mem[];
     ColC *s_col = reinterpret_cast<ColC *>(s_mem);
@@ -265,6 +270,7 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
     const int t = a.frame_idx[(int64_t)clip * a.N + n];
     const uint8_t *frame = a.src + (((int64_t)clip * a.T + t) * a.Hs * a.Ws + (int64_t)min_i * a.Ws + min_j) * 3;
     uint8_t *out = a.out_gray + ((int64_t)clip * a.N + n) * a.crop * a.crop;
+    uint8_t *out3 = (BGR && a.out_imgs) ? a.out_imgs + ((int64_t)clip * a.N + n) * a.crop * a.crop * 3 : nullptr;
     // shake (data/v2v_datasets.py:217-224): the clip is resized to need_h x need_w = crop + the largest offset, flipped, and frame t
     // is cut out at (di[t], dj[t]); without shake need == crop and both offsets are 0.  The batch form has no shake.
     const int di = a.di ? a.di[(int64_t)clip * a.T + t] : 0, dj = a.dj ? a.dj[(int64_t)clip * a.T + t] : 0;
@@ -325,6 +331,28 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
             for (int j = 0; j < CPL && cg + j < ncol; ++j) o[j] = (uint8_t)(packed >> (8 * j));
         }
     };
+    // BGR: the CPL resized pixels of one output row -> out_imgs (3 bytes each) and their bgr_to_gray -> out_gray
+    auto store_row_bgr = [&](int y, const int (&v)[CPL][3]) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const double sgr = __builtin_fma((double)v[j][1], 0.1140, (double)v[j][0] * 0.5870);     // the gather kernel's expression (G15)
+            packed |= (uint32_t)(uint8_t)__builtin_fma((double)v[j][2], 0.2989, sgr) << (8 * j);
+        }
+        store_row(y, packed);
+        if (out3) {
+            uint8_t *o = out3 + ((int64_t)(y0 + y) * a.crop + x0 + cg) * 3;
+            if (CPL == 4 && cg + CPL <= ncol && (reinterpret_cast<uintptr_t>(o) & 3u) == 0) {
+                uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
+                o32[0] = (uint32_t)v[0][0] | ((uint32_t)v[0][1] << 8) | ((uint32_t)v[0][2] << 16) | ((uint32_t)v[1][0] << 24);
+                o32[1] = (uint32_t)v[1][1] | ((uint32_t)v[1][2] << 8) | ((uint32_t)v[2][0] << 16) | ((uint32_t)v[2][1] << 24);
+                o32[2] = (uint32_t)v[2][2] | ((uint32_t)v[3][0] << 8) | ((uint32_t)v[3][1] << 16) | ((uint32_t)v[3][2] << 24);
+            } else {
+                for (int j = 0; j < CPL && cg + j < ncol; ++j)
+                    for (int c = 0; c < 3; ++c) o[3 * j + c] = (uint8_t)v[j][c];
+            }
+        }
+    };
     if (staged) {
         ColC cc[CPL];
         uint32_t off[CPL];
@@ -337,9 +365,12 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
         int y = yw0;
         const int sr_first = __builtin_amdgcn_readfirstlane((int)s_row[yw0].s0);
         const int sr_last = __builtin_amdgcn_readfirstlane((int)s_row[yw1].s1);
-        int h_prev[CPL], h_cur[CPL];
+        int h_prev[CPL][NC], h_cur[CPL][NC];
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) h_prev[j] = 0;
+        for (int j = 0; j < CPL; ++j)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) h_prev[j][c] = 0;
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
         for (int sr = sr_first; sr <= sr_last && y <= yw1; ++sr) {
             // rows between two output rows' taps (down-scaling by more than 2) are not needed by anyone
             if (__builtin_amdgcn_readfirstlane((int)s_row[y].s0) > sr) continue;
@@ -348,9 +379,24 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
             const uint32_t mis = (frame_lo + (uint32_t)((sr * a.Ws + sx_lo) * 3)) & 3u;          // low address bits: wrap-safe
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
-                int g0, g1;
-                lds_gray_pair(lrow, off[j] + mis, gk, g0, g1);
-                h_cur[j] = (g0 * cc[j].a0 + g1 * cc[j].a1) >> 4;
+                if constexpr (BGR) {
+                    // bytes o .. o+5 = B0 G0 R0 B1 G1 R1 of the two taps: lo = bytes o..o+3, hi = bytes o+4..o+7
+                    const uint32_t o = off[j] + mis;
+                    const uint32_t *w = reinterpret_cast<const uint32_t *>(lrow + (o & ~3u));
+                    const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], sh = o & 3u;
+                    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                    const u16x2 wa = u16x2{(unsigned short)cc[j].a0, (unsigned short)cc[j].a1};
+                    // v_perm_b32(hi, lo, sel): selector bytes 0-3 address lo, 4-7 address hi, 0x0c = zero -> {tap0 | tap1 << 16} per channel
+                    const uint32_t pb = __builtin_amdgcn_perm(hi, lo, 0x0c030c00u), pg = __builtin_amdgcn_perm(hi, lo, 0x0c040c01u),
+                                   pr = __builtin_amdgcn_perm(hi, lo, 0x0c050c02u);
+                    h_cur[j][0] = (int)(__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pb), wa, 0u, false) >> 4);
+                    h_cur[j][NC > 1 ? 1 : 0] = (int)(__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pg), wa, 0u, false) >> 4);
+                    h_cur[j][NC > 2 ? 2 : 0] = (int)(__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pr), wa, 0u, false) >> 4);
+                } else {
+                    int g0, g1;
+                    lds_gray_pair(lrow, off[j] + mis, gk, g0, g1);
+                    h_cur[j][0] = (g0 * cc[j].a0 + g1 * cc[j].a1) >> 4;
+                }
             }
             // vertical pass of every output row whose lower tap is sr
             while (y <= yw1) {
@@ -358,19 +404,53 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
                 const int rs0 = __builtin_amdgcn_readfirstlane((int)rc.s0), rs1 = __builtin_amdgcn_readfirstlane((int)rc.s1);
                 if (rs1 != sr) break;
                 const int ya0 = __builtin_amdgcn_readfirstlane((int)rc.a0), ya1 = __builtin_amdgcn_readfirstlane((int)rc.a1);
-                uint32_t packed = 0;
+                if constexpr (BGR) {
+                    int v[CPL][3];
 #pragma unroll
-                for (int j = 0; j < CPL; ++j)
-                    packed |= (uint32_t)vblend_cv(rs0 == sr ? h_cur[j] : h_prev[j], h_cur[j], ya0, ya1) << (8 * j);
-                store_row(y, packed);
+                    for (int j = 0; j < CPL; ++j)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) v[j][c] = vblend_cv(rs0 == sr ? h_cur[j][c % NC] : h_prev[j][c % NC], h_cur[j][c % NC], ya0, ya1);
+                    store_row_bgr(y, v);
+                } else {
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j)
+                        packed |= (uint32_t)vblend_cv(rs0 == sr ? h_cur[j][0] : h_prev[j][0], h_cur[j][0], ya0, ya1) << (8 * j);
+                    store_row(y, packed);
+                }
                 ++y;
             }
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) h_prev[j] = h_cur[j];
+            for (int j = 0; j < CPL; ++j)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) h_prev[j][c] = h_cur[j][c];
         }
     } else {
         for (int y = yw0; y <= yw1; ++y) {
             const RowC rc = s_row[y];
+            if constexpr (BGR) {                                        // per-pixel global reads, one channel at a time
+                int v3[CPL][3];
+                for (int j = 0; j < CPL; ++j) {
+                    for (int c = 0; c < 3; ++c) v3[j][c] = 0;
+                    if (cg + j >= ncol) continue;
+                    const int X = col_of(x0 + cg + j);
+                    for (int c = 0; c < 3; ++c) {
+                        if (area2) {
+                            const uint8_t *p0 = frame + ((int64_t)(2 * (y0 + di + y)) * a.Ws + 2 * X) * 3 + c, *p1 = p0 + (int64_t)a.Ws * 3;
+                            v3[j][c] = ((int)p0[0] + (int)p0[3] + (int)p1[0] + (int)p1[3] + 2) >> 2;
+                        } else {
+                            const ColC c1 = s_col[cg + j];
+                            const int s1 = c1.single ? c1.s0 : c1.s0 + 1;
+                            const uint8_t *p0 = frame + (int64_t)rc.s0 * a.Ws * 3 + c, *p1 = frame + (int64_t)rc.s1 * a.Ws * 3 + c;
+                            const int h0 = ((int)p0[c1.s0 * 3] * c1.a0 + (int)p0[s1 * 3] * c1.a1) >> 4;
+                            const int h1 = ((int)p1[c1.s0 * 3] * c1.a0 + (int)p1[s1 * 3] * c1.a1) >> 4;
+                            v3[j][c] = vblend_cv(h0, h1, rc.a0, rc.a1);
+                        }
+                    }
+                }
+                store_row_bgr(y, v3);
+                continue;
+            }
             uint32_t packed = 0;
             for (int j = 0; j < CPL; ++j) {
                 if (cg + j >= ncol) break;
