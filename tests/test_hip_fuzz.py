@@ -1,5 +1,6 @@
 """Randomised parity sweep: HIP (through the C ABI) vs the scalar C oracle over random shapes, dtypes, parameters,
-binning modes and batch splits.  Float64 output must be bit-exact, float32 output within 1e-5, totals exact."""
+binning modes and batch splits.  Float64 output must be bit-exact, float32 output within 1e-5 (relative, and absolute in
+units of the grid's largest magnitude), totals exact."""
 import os
 
 import numpy as np
@@ -54,7 +55,9 @@ def test_random_esim_case(oracle_c, luts, case):
     assert np.array_equal(got.cpu().numpy(), want), (b, n, h, w, dt, kw)
     assert np.array_equal(counts.cpu().numpy(), totals)
     got32 = E.esim_voxel_batch(torch.from_numpy(video).cuda(), params, **kw)
-    np.testing.assert_allclose(got32.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    # float32 grid = the same terms accumulated in float32: a bin whose +/- contributions cancel keeps the rounding of its
+    # largest partial sum, so the absolute bound scales with the grid's magnitude (soak case 5798: 1.4e-5 on 0.26 beside 12.0)
+    np.testing.assert_allclose(got32.cpu().numpy(), want, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(want).max())))
     if b > 1:                                                  # any split of the batch gives the same clips
         cut = int(g.integers(1, b))
         tail = E.esim_voxel_batch(torch.from_numpy(video[cut:]).cuda(), params[cut:], out_dtype=torch.float64,
@@ -97,7 +100,7 @@ def test_random_v2e_case(oracle_c, luts, case):
                                 out_dtype=torch.float32, counts=counts.zero_()).cpu().numpy()
     assert np.array_equal(counts.cpu().numpy(), totals)
     if bilinear:
-        np.testing.assert_allclose(got32, want, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(got32, want, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(want).max())))
     else:
         assert np.array_equal(got32, want.astype(np.float32)), (args, dt, h, w)      # integer counts: exact
 
