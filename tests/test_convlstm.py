@@ -418,6 +418,14 @@ def test_upsample2x_matches_interpolate(shape, with_skip):
     want = F.interpolate(src.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
     err = ((out.float() - want).abs() / (want.abs() + 2.0 ** -6)).max()
     assert float(err) < 2.0 ** -8
+    # rows per work-item (the launcher's choice depends on the size) never changes a bit, ragged last segment included
+    import os
+    try:
+        for rs in ("1", "3", "4", "64"):
+            os.environ["V2V_UP_RS"] = rs
+            assert torch.equal(CL.upsample2x_nhwc(x, s), out), rs
+    finally:
+        os.environ.pop("V2V_UP_RS", None)
     with pytest.raises(ValueError):
         CL.upsample2x_nhwc(x.float())
     with pytest.raises(ValueError):

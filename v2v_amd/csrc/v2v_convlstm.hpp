@@ -432,32 +432,35 @@ __device__ __forceinline__ void cl_unpack8(const uint4 v, float (&f)[8])
     for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u); }
 }
 
-__global__ void __launch_bounds__(256) upsample2x_nhwc_bf16_kernel(const uint16_t *x, const uint16_t *skip, uint16_t *out, int B, int H, int W, int C)
+// One work-item walks `rs` consecutive input rows of one (image, column, 8-channel group): it keeps the horizontally filtered
+// rows iy - 1, iy, iy + 1 (left / right output column) in registers and loads only row iy + 1 per step -- 3 (+3 skip) 16-byte
+// loads per input pixel instead of 9 (+9) when every pixel gathers its own 3 x 3 neighbourhood.  Same expressions in the
+// same order as before (horizontal 0.25 / 0.75 first, then vertical), so the output is bit-identical for any rs.
+__global__ void __launch_bounds__(256) upsample2x_nhwc_bf16_kernel(const uint16_t *x, const uint16_t *skip, uint16_t *out, int B, int H, int W, int C, int rs)
 {
-    const int c8n = C >> 3;
-    const int64_t n = (int64_t)B * H * W * c8n;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t c8n = (uint32_t)C >> 3, segs = (uint32_t)(H + rs - 1) / (uint32_t)rs;
+    const uint32_t n = (uint32_t)B * segs * (uint32_t)W * c8n;   // < 2^31: checked by the launcher (32-bit divisions below)
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    const int c8 = (int)(i % c8n);
-    int64_t r = i / c8n;
-    const int ix = (int)(r % W); r /= W;
-    const int iy = (int)(r % H);
-    const int b = (int)(r / H);
-    const int ys[3] = {iy > 0 ? iy - 1 : 0, iy, iy < H - 1 ? iy + 1 : iy}, xs[3] = {ix > 0 ? ix - 1 : 0, ix, ix < W - 1 ? ix + 1 : ix};
-    float L[3][8], R[3][8];                                       // per input row: the left (2 ix) and right (2 ix + 1) output column
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    uint32_t r = i / c8n;
+    const int c8 = (int)(i - r * c8n);
+    const uint32_t r2 = r / (uint32_t)W;
+    const int ix = (int)(r - r2 * (uint32_t)W);
+    const int b = (int)(r2 / segs), seg = (int)(r2 - (uint32_t)b * segs);
+    const int xs[3] = {ix > 0 ? ix - 1 : 0, ix, ix < W - 1 ? ix + 1 : ix};
+    float L[3][8], R[3][8];                                       // rows iy - 1, iy, iy + 1: the left (2 ix) and right (2 ix + 1) output column
+    auto hrow = [&](int y, float (&l)[8], float (&rr)[8]) __attribute__((always_inline)) {
         float v[3][8];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const int64_t o = (((int64_t)b * H + ys[j]) * W + xs[k]) * C + c8 * 8;
+            const int64_t o = (((int64_t)b * H + y) * W + xs[k]) * C + c8 * 8;
             cl_unpack8(*reinterpret_cast<const uint4 *>(x + o), v[k]);
             if (skip) {
-                float s[8];
-                cl_unpack8(*reinterpret_cast<const uint4 *>(skip + o), s);
+                float sk[8];
+                cl_unpack8(*reinterpret_cast<const uint4 *>(skip + o), sk);
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
-                    const uint32_t pk = cl_pack_bf16(v[k][e] + s[e], v[k][e + 1] + s[e + 1]);
+                    const uint32_t pk = cl_pack_bf16(v[k][e] + sk[e], v[k][e + 1] + sk[e + 1]);
                     v[k][e] = __uint_as_float(pk << 16);
                     v[k][e + 1] = __uint_as_float(pk & 0xFFFF0000u);
                 }
@@ -466,20 +469,32 @@ __global__ void __launch_bounds__(256) upsample2x_nhwc_bf16_kernel(const uint16_
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float mid = 0.75f * v[1][e];
-            L[j][e] = 0.25f * v[0][e] + mid;
-            R[j][e] = mid + 0.25f * v[2][e];
+            l[e] = 0.25f * v[0][e] + mid;
+            rr[e] = mid + 0.25f * v[2][e];
         }
-    }
+    };
     auto put = [&](int oy, int ox, const float (&top)[8], float wt, const float (&bot)[8], float wb) __attribute__((always_inline)) {
         uint32_t w[4];
 #pragma unroll
         for (int e = 0; e < 8; e += 2) w[e >> 1] = cl_pack_bf16(wt * top[e] + wb * bot[e], wt * top[e + 1] + wb * bot[e + 1]);
         *reinterpret_cast<uint4 *>(out + ((((int64_t)b * 2 * H + oy) * 2 * W + ox) * C + c8 * 8)) = make_uint4(w[0], w[1], w[2], w[3]);
     };
-    put(2 * iy, 2 * ix, L[0], 0.25f, L[1], 0.75f);
-    put(2 * iy, 2 * ix + 1, R[0], 0.25f, R[1], 0.75f);
-    put(2 * iy + 1, 2 * ix, L[1], 0.75f, L[2], 0.25f);
-    put(2 * iy + 1, 2 * ix + 1, R[1], 0.75f, R[2], 0.25f);
+    const int y0 = seg * rs, y1 = min(y0 + rs, H);
+    hrow(y0 > 0 ? y0 - 1 : 0, L[0], R[0]);
+    hrow(y0, L[1], R[1]);
+    for (int iy = y0; iy < y1; ++iy) {
+        if (iy < H - 1) hrow(iy + 1, L[2], R[2]);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { L[2][e] = L[1][e]; R[2][e] = R[1][e]; }
+        }
+        put(2 * iy, 2 * ix, L[0], 0.25f, L[1], 0.75f);
+        put(2 * iy, 2 * ix + 1, R[0], 0.25f, R[1], 0.75f);
+        put(2 * iy + 1, 2 * ix, L[1], 0.75f, L[2], 0.25f);
+        put(2 * iy + 1, 2 * ix + 1, R[1], 0.75f, R[2], 0.25f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { L[0][e] = L[1][e]; R[0][e] = R[1][e]; L[1][e] = L[2][e]; R[1][e] = R[2][e]; }
+    }
 }
 
 // ---- stride-1 convolutions with few output channels (the decoders: 5x5, 32 / 64 / 128 columns): HALO tiles ------------------

@@ -196,8 +196,16 @@ hipError_t launch_conv1x1_nhwc(const uint16_t *x, const uint16_t *skip, const fl
 
 hipError_t launch_upsample2x_nhwc(const uint16_t *x, const uint16_t *skip, uint16_t *out, int B, int H, int W, int C, hipStream_t s)
 {
-    const int64_t n = (int64_t)B * H * W * (C / 8);                  // one work-item per input pixel and 8 channels
-    hipLaunchKernelGGL(upsample2x_nhwc_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, skip, out, B, H, W, C);
+    // one work-item per (image, segment of rs rows, column, 8 channels).  8 clips, same box, us per launch (events) for
+    // rs = 1 / 2 / 4 / 8: 256 ch @32^2 17.1 / 18.0 / 17.9 / 23.8, 128 ch @64^2 23.0 / 20.7 / 20.0 / 22.6, 64 ch @128^2
+    // 38.1 / 30.0 / 25.6 / 30.8 -> 4 rows where that leaves >= 2048 waves, else 1 (tools/upsample_time.py)
+    const int64_t cols = (int64_t)B * W * (C / 8);
+    int rs = 4;
+    if (const char *e = getenv("V2V_UP_RS")) rs = atoi(e) > 0 ? atoi(e) : rs;    // EXPERIMENT knob (tools/upsample_time.py)
+    else if (cols * ((H + rs - 1) / rs) < 2048 * 64) rs = 1;
+    const int64_t n = cols * ((H + rs - 1) / rs);
+    if (n >= (int64_t)1 << 31) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(upsample2x_nhwc_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, skip, out, B, H, W, C, rs);
     return hipGetLastError();
 }
 
