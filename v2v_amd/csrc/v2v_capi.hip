@@ -391,13 +391,19 @@ static hipError_t launch_frontend(const v2v::FrontendArgs &a, int64_t B, int64_t
         // tile = (4 waves x rows_per_wave) rows x (64 lanes x cpl) columns; shrink until the worst-case source rectangle fits
         for (int cpl = a.crop > 128 ? 4 : 2; cpl >= 2; cpl -= 2) {
             const int64_t span_px = (int64_t)(64 * cpl * s_max) + 3;
-            const int64_t pitch = ((span_px * 3 + 12 + 15) / 16) * 16 + 16;
+            // BGR rows as they are (misalignment + span + tap reads); gray rows: one byte per source pixel in granules of 4 + the window reads
+            const int64_t pitch = bgr_mode ? ((span_px * 3 + 12 + 15) / 16) * 16 + 16 : (((span_px + 3) / 4) * 4 + 12 + 15) / 16 * 16;
 #ifndef V2V_FRONTEND_LDS_KB
 #define V2V_FRONTEND_LDS_KB 48
 #endif
             const int64_t budget = V2V_FRONTEND_LDS_KB * 1024 - v2v::tile_hdr_bytes(cpl);
             int rpw_cap = (int)((a.crop + 3) / 4);                        // no point in more rows per wave than the image has
-            if (rpw_cap > 4) rpw_cap = 4;
+            // rows per wave: gray rows are a third of the bytes, so twice the rows still leave >= 4 blocks per CU -- fewer source
+            // rows are passed twice (tile borders) and the set-up is shared by more pixels (same box, config 4: 0.107 -> 0.092 ms)
+#ifndef V2V_FRONTEND_RPW_CAP
+#define V2V_FRONTEND_RPW_CAP (bgr_mode ? 4 : 8)
+#endif
+            if (rpw_cap > V2V_FRONTEND_RPW_CAP) rpw_cap = V2V_FRONTEND_RPW_CAP;
             for (int rpw = rpw_cap; rpw >= 1; rpw >>= 1) {
                 const int64_t max_rows = (int64_t)(4 * rpw * s_max) + 3;
                 if (max_rows * pitch > budget) continue;
@@ -406,7 +412,15 @@ static hipError_t launch_frontend(const v2v::FrontendArgs &a, int64_t B, int64_t
                 ta.pitch = (int32_t)pitch; ta.max_rows = (int32_t)max_rows; ta.rows_per_wave = rpw;
                 ta.tiles_x = (a.crop + 64 * cpl - 1) / (64 * cpl);
                 ta.tiles_y = (a.crop + 4 * rpw - 1) / (4 * rpw);
-                const int64_t nblocks = (int64_t)ta.tiles_x * ta.tiles_y * a.N;
+                // frames per block: the per-block set-up (extents, coefficient tables) is shared by the frames of a clip unless
+                // the frames are shaken; as many as still leave 4 blocks for every CU slot (4 per CU)
+#ifndef V2V_FRONTEND_FPB
+#define V2V_FRONTEND_FPB 4
+#endif
+                int fpb = a.di ? 1 : V2V_FRONTEND_FPB;
+                while (fpb > 1 && (int64_t)ta.tiles_x * ta.tiles_y * ((a.N + fpb - 1) / fpb) * B < 4096) fpb >>= 1;
+                ta.frames_per_block = fpb;
+                const int64_t nblocks = (int64_t)ta.tiles_x * ta.tiles_y * ((a.N + fpb - 1) / fpb);
                 if (nblocks > 0x7FFFFFFF) break;
                 const size_t lds = (size_t)(v2v::tile_hdr_bytes(cpl) + max_rows * pitch);
                 if (bgr_mode) {

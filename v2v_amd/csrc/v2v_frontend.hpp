@@ -200,6 +200,7 @@ struct FrontendTileArgs {
     int32_t pitch, max_rows;      // LDS row pitch (bytes, multiple of 16) and row capacity
     int32_t rows_per_wave;        // output rows per wave (tile = 4 x rows_per_wave rows)
     int32_t tiles_x, tiles_y;
+    int32_t frames_per_block;     // consecutive output frames walked by one block (1 with shake)
 };
 
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
@@ -216,8 +217,18 @@ __device__ __noinline__ u32x4v load16_clipped(const uint8_t *g, const uint8_t *e
 
 __device__ __forceinline__ int vblend_cv(int h0, int h1, int ya0, int ya1)
 {
-    const int v = (((ya0 * h0) >> 16) + ((ya1 * h1) >> 16) + 2) >> 2;
+    // operands: h < 2^15 (255 * 2048 >> 4), 0 <= ya <= 2048 -> 24-bit multiplies (v_mul_i32_i24; a 32-bit v_mul_lo is quarter rate)
+    const int v = ((__mul24(ya0, h0) >> 16) + (__mul24(ya1, h1) >> 16) + 2) >> 2;
     return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+// the same blend on h16 = 16 * (h >> 4)'s operand form: h16 = (horizontal sum) & ~15 < 2^24 and yb = ya << 12 <= 2^23 are unsigned
+// 24-bit operands whose 48-bit product is (ya * h) << 16, so v_mul_hi_u32_u24 IS (ya * h) >> 16 -- no shifts around the multiplies
+__device__ __forceinline__ int vblend16_cv(int h16_0, int h16_1, uint32_t yb0, uint32_t yb1)
+{
+    auto mulhi24 = [](uint32_t x, uint32_t y) { return (uint32_t)(((uint64_t)(x & 0xFFFFFFu) * (uint64_t)(y & 0xFFFFFFu)) >> 32); };
+    const int v = (int)(mulhi24((uint32_t)h16_0, yb0) + mulhi24((uint32_t)h16_1, yb1) + 2u) >> 2;
+    return v > 255 ? 255 : v;
 }
 
 // cv2's BGR2GRAY of the pixel in the three low bytes of p (byte 3 is ignored): (B*wb + G*wg + R*wr + half) >> shift with
@@ -259,14 +270,22 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
     const GrayCoef gk = gray_coef(a.gray_first);
     const int clip = blockIdx.y;
     const int tiles = ta.tiles_x * ta.tiles_y;
-    const int n = blockIdx.x / tiles;
-    const int tile = blockIdx.x - n * tiles;
+    // a block walks ta.frames_per_block consecutive output frames of its tile: without shake the extents and the coefficient
+    // tables (a third of the kernel's vector instructions: float64 divisions, floors and conversions per work-item) are the
+    // same for every frame of a clip and are computed once
+    const int ngrp = blockIdx.x / tiles;
+    const int tile = blockIdx.x - ngrp * tiles;
+    const int n_first = ngrp * ta.frames_per_block, n_last = min(n_first + ta.frames_per_block, (int)a.N) - 1;
     const int ty = tile / ta.tiles_x, tx = tile - ty * ta.tiles_x;
     const int tile_rows = 4 * ta.rows_per_wave;
     const int y0 = ty * tile_rows, x0 = tx * kCols;
     const int ncol = min(kCols, a.crop - x0), nrow = min(tile_rows, a.crop - y0);
     int min_i = a.min_i, min_j = a.min_j, cb = a.crop_before, flip = a.flip;
     if (a.clip_table) { const int32_t *t4 = a.clip_table + (int64_t)clip * 4; min_i = t4[0]; min_j = t4[1]; cb = t4[2]; flip = t4[3]; }
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform: steers scalar loops
+    for (int n = n_first; n <= n_last; ++n) {
+    if (n > n_first) __syncthreads();                    // everyone is done with the previous frame's rows (and tables, with shake)
     const int t = a.frame_idx[(int64_t)clip * a.N + n];
     const uint8_t *frame = a.src + (((int64_t)clip * a.T + t) * a.Hs * a.Ws + (int64_t)min_i * a.Ws + min_j) * 3;
     uint8_t *out = a.out_gray + ((int64_t)clip * a.N + n) * a.crop * a.crop;
@@ -277,7 +296,6 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
     const int need_w = a.need_w, need_h = a.need_h;
     const bool area2 = cb == 2 * need_w && cb == 2 * need_h;
     const double scale = 1.0 / ((double)need_w / (double)cb), scale_y = 1.0 / ((double)need_h / (double)cb);
-    const int tid = threadIdx.x;
     auto col_of = [&](int x) { const int X = x + dj; return flip ? need_w - 1 - X : X; };       // column in the resized image
 
     // (1) extent of the source rectangle
@@ -285,34 +303,77 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
     const int sx_lo = resize_src_lo(Xa, cb, scale), sy_lo = resize_src_lo(y0 + di, cb, scale_y);
     const int sx_hi = min(resize_src_lo(Xb, cb, scale) + 1, cb - 1), sy_hi = min(resize_src_lo(y0 + di + nrow - 1, cb, scale_y) + 1, cb - 1);
     const int rows = sy_hi - sy_lo + 1;
-    const int span = (sx_hi - sx_lo + 1) * 3;
-    const int nch = (span + 12 + 15) >> 4;               // 16-byte chunks per row: misalignment (<= 3) + span + the 12-byte tap reads
-    const bool staged = !area2 && rows <= ta.max_rows && nch * 16 <= ta.pitch && cb <= 32767;
+    const int span_px = sx_hi - sx_lo + 1;
+    const int span = span_px * 3;
+    // BGR instance: rows are staged as they are, nch 16-byte chunks each (misalignment <= 3 + span + the 12-byte tap reads).
+    // Gray instance: rows are staged AS GRAY, a granule of 4 source pixels (12 bytes) -> one dword; the horizontal pass reads a
+    // 12-byte window at the lane's first tap (+ 8 bytes of slack in the pitch)
+    const int nch = BGR ? (span + 12 + 15) >> 4 : (span_px + 3) >> 2;
+    const bool staged = !area2 && rows <= ta.max_rows && (BGR ? nch * 16 : nch * 4 + 12) <= ta.pitch && cb <= 32767;
 
-    // (2) source rectangle -> LDS (row r at s_rows + r*pitch, starting at the 4-byte-aligned address below its first byte)
-    const int lane = tid & 63, wave = tid >> 6;
+    // (2) source rectangle -> LDS.  One wave per source row (wave-uniform row address), rows wave, wave + 4, ...  The loads of
+    // kStageRows rows x 2 chunks per lane are ALL issued before the first LDS write: written as load -> write per chunk the
+    // compiler waits for every load in turn (s_waitcnt vmcnt(0) in front of each ds_write), 7-14 serial round trips per wave.
     if (staged) {
-        for (int r = wave; r < rows; r += 4) {                           // one wave per source row: wave-uniform row address
-            const uint8_t *grow = frame + ((int64_t)(sy_lo + r) * a.Ws + sx_lo) * 3;
-            grow -= reinterpret_cast<uintptr_t>(grow) & 3u;
-            unsigned char *lrow = s_rows + (size_t)r * ta.pitch;
-            for (int c = lane; c < nch; c += 64) {
-                const uint8_t *g = grow + c * 16;
-                u32x4v v;
-                if (__builtin_expect(g + 16 <= a.src_end, 1)) __builtin_memcpy(&v, g, 16);
-                else v = load16_clipped(g, a.src_end);                   // last bytes of the whole source buffer
-                *reinterpret_cast<u32x4v *>(lrow + c * 16) = v;
+        constexpr int kStageRows = 4;
+        for (int c0 = 0; c0 < nch; c0 += 128) {
+            for (int r0 = wave; r0 < rows; r0 += 4 * kStageRows) {
+                u32x4v v[kStageRows][2];
+                uint32_t mis[kStageRows];
+#pragma unroll
+                for (int q = 0; q < kStageRows; ++q) {
+                    const int r = r0 + 4 * q;
+                    mis[q] = 0;
+                    if (r >= rows) break;
+                    const uint8_t *grow = frame + ((int64_t)(sy_lo + r) * a.Ws + sx_lo) * 3;
+                    mis[q] = (uint32_t)(reinterpret_cast<uintptr_t>(grow) & 3u);
+                    grow -= mis[q];                                          // the 4-byte-aligned address below the row's first byte
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int c = c0 + lane + 64 * k;
+                        if (c < nch) {
+                            const uint8_t *g = grow + c * (BGR ? 16 : 12);   // gray: 12 bytes of the granule + misalignment <= 3 are inside 16
+                            if (__builtin_expect(g + 16 <= a.src_end, 1)) __builtin_memcpy(&v[q][k], g, 16);
+                            else v[q][k] = load16_clipped(g, a.src_end);     // last bytes of the whole source buffer
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < kStageRows; ++q) {
+                    const int r = r0 + 4 * q;
+                    if (r >= rows) break;
+                    unsigned char *lrow = s_rows + (size_t)r * ta.pitch;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int c = c0 + lane + 64 * k;
+                        if (c < nch) {
+                            if constexpr (BGR) {
+                                *reinterpret_cast<u32x4v *>(lrow + c * 16) = v[q][k];
+                            } else {
+                                // every source pixel is converted ONCE (cv2 converts the frame before it resizes): the granule's 12
+                                // bytes B G R B | G R B G | R B G R -> four gray bytes
+                                const u32x4v w = v[q][k];
+                                const uint32_t d0 = __builtin_amdgcn_alignbyte(w.y, w.x, mis[q]), d1 = __builtin_amdgcn_alignbyte(w.z, w.y, mis[q]),
+                                               d2 = __builtin_amdgcn_alignbyte(w.w, w.z, mis[q]);
+                                const uint32_t g0 = (uint32_t)bgr2gray_dot4(d0, gk), g1 = (uint32_t)bgr2gray_dot4(__builtin_amdgcn_alignbyte(d1, d0, 3), gk),
+                                               g2 = (uint32_t)bgr2gray_dot4(__builtin_amdgcn_alignbyte(d2, d1, 2), gk), g3 = (uint32_t)bgr2gray_dot4(d2 >> 8, gk);
+                                *reinterpret_cast<uint32_t *>(lrow + c * 4) = (g0 | (g1 << 8)) | ((g2 << 16) | (g3 << 24));
+                            }
+                        }
+                    }
+                }
             }
         }
     }
-    if (tid < ncol) {
+    const bool tables = n == n_first || a.di != nullptr;              // the tables depend on the frame only through the shake offsets
+    if (tables && tid < ncol) {
         const Coef c = resize_coef(col_of(x0 + tid), cb, scale);
         // right tap clamped onto the left one (last source column): g*a0 + g*a1 == g*(a0+a1) + anything*0, so the
         // blend needs no special case
         const bool single = c.s1 == c.s0;
         s_col[tid] = ColC{(uint16_t)c.s0, (uint16_t)single, (int16_t)(single ? c.a0 + c.a1 : c.a0), (int16_t)(single ? 0 : c.a1)};
     }
-    if (tid < nrow) {
+    if (tables && tid < nrow) {
         const Coef c = resize_coef(y0 + di + tid, cb, scale_y);
         s_row[tid] = RowC{(int16_t)c.s0, (int16_t)c.s1, (int16_t)c.a0, (int16_t)c.a1};
     }
@@ -321,7 +382,7 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
     // (3) a wave: rows_per_wave adjacent output rows; a lane: CPL adjacent columns
     const int yw0 = wave * ta.rows_per_wave, yw1 = min(yw0 + ta.rows_per_wave, nrow) - 1;      // tile-relative, inclusive
     const int cg = lane * CPL;
-    if (yw0 > yw1 || cg >= ncol) return;
+    if (yw0 > yw1 || cg >= ncol) continue;
     auto store_row = [&](int y, uint32_t packed) {
         uint8_t *o = out + (int64_t)(y0 + y) * a.crop + x0 + cg;
         if (cg + CPL <= ncol && (reinterpret_cast<uintptr_t>(o) & (CPL - 1)) == 0) {
@@ -359,24 +420,25 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
             cc[j] = s_col[min(cg + j, ncol - 1)];
-            off[j] = (uint32_t)(cc[j].s0 - sx_lo) * 3u;
+            off[j] = (uint32_t)(cc[j].s0 - sx_lo) * (BGR ? 3u : 1u);     // byte of the left tap in a staged row
+        }
+        // gray rows: the lane's CPL left taps lie within 7 bytes of the lowest one when the scale is <= 2 (taps of neighbouring
+        // columns are <= 2 apart): one 8-byte window per source row, each column picks its two taps out of it with v_perm
+        // (selector bytes 0-7 address the window, 0x0c = zero) as {tap0 | tap1 << 16} for one v_dot2 with the 11-bit weights
+        const uint32_t win = BGR ? 0u : min(off[0], off[CPL - 1]);
+        const bool wide = !BGR && cb > 2 * need_w;                       // taps further apart: byte reads
+        uint32_t sel[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const uint32_t rel = (off[j] - win) & 7u;
+            sel[j] = rel | 0x0c000c00u | (((rel + 1u) & 7u) << 16);
         }
         const uint32_t frame_lo = (uint32_t)reinterpret_cast<uintptr_t>(frame);
-        int y = yw0;
-        const int sr_first = __builtin_amdgcn_readfirstlane((int)s_row[yw0].s0);
-        const int sr_last = __builtin_amdgcn_readfirstlane((int)s_row[yw1].s1);
-        int h_prev[CPL][NC], h_cur[CPL][NC];
-#pragma unroll
-        for (int j = 0; j < CPL; ++j)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) h_prev[j][c] = 0;
         typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-        for (int sr = sr_first; sr <= sr_last && y <= yw1; ++sr) {
-            // rows between two output rows' taps (down-scaling by more than 2) are not needed by anyone
-            if (__builtin_amdgcn_readfirstlane((int)s_row[y].s0) > sr) continue;
-            // horizontal pass of source row sr
+        // horizontal pass of source row sr -> h (the value cv2 keeps between its two passes: (g0*a0 + g1*a1) >> 4)
+        auto hpass = [&](int sr, int (&h)[CPL][NC]) __attribute__((always_inline)) {
             const unsigned char *lrow = s_rows + (size_t)(sr - sy_lo) * ta.pitch;
-            const uint32_t mis = (frame_lo + (uint32_t)((sr * a.Ws + sx_lo) * 3)) & 3u;          // low address bits: wrap-safe
+            [[maybe_unused]] const uint32_t mis = (frame_lo + (uint32_t)((sr * a.Ws + sx_lo) * 3)) & 3u;   // low address bits: wrap-safe
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
                 if constexpr (BGR) {
@@ -389,41 +451,73 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
                     // v_perm_b32(hi, lo, sel): selector bytes 0-3 address lo, 4-7 address hi, 0x0c = zero -> {tap0 | tap1 << 16} per channel
                     const uint32_t pb = __builtin_amdgcn_perm(hi, lo, 0x0c030c00u), pg = __builtin_amdgcn_perm(hi, lo, 0x0c040c01u),
                                    pr = __builtin_amdgcn_perm(hi, lo, 0x0c050c02u);
-                    h_cur[j][0] = (int)(__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pb), wa, 0u, false) >> 4);
-                    h_cur[j][NC > 1 ? 1 : 0] = (int)(__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pg), wa, 0u, false) >> 4);
-                    h_cur[j][NC > 2 ? 2 : 0] = (int)(__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pr), wa, 0u, false) >> 4);
-                } else {
-                    int g0, g1;
-                    lds_gray_pair(lrow, off[j] + mis, gk, g0, g1);
-                    h_cur[j][0] = (g0 * cc[j].a0 + g1 * cc[j].a1) >> 4;
+                    h[j][0] = (int)(__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pb), wa, 0u, false) & ~15u);
+                    h[j][NC > 1 ? 1 : 0] = (int)(__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pg), wa, 0u, false) & ~15u);
+                    h[j][NC > 2 ? 2 : 0] = (int)(__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pr), wa, 0u, false) & ~15u);
                 }
             }
-            // vertical pass of every output row whose lower tap is sr
-            while (y <= yw1) {
-                const RowC rc = s_row[y];
-                const int rs0 = __builtin_amdgcn_readfirstlane((int)rc.s0), rs1 = __builtin_amdgcn_readfirstlane((int)rc.s1);
-                if (rs1 != sr) break;
-                const int ya0 = __builtin_amdgcn_readfirstlane((int)rc.a0), ya1 = __builtin_amdgcn_readfirstlane((int)rc.a1);
+            if constexpr (!BGR) {
+                if (wide) {
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) h[j][0] = ((int)lrow[off[j]] * cc[j].a0 + (int)lrow[off[j] + 1] * cc[j].a1) & ~15;
+                } else {
+                    const uint32_t *w = reinterpret_cast<const uint32_t *>(lrow + (win & ~3u));
+                    const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], sh = win & 3u;
+                    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        const u16x2 wa = u16x2{(unsigned short)cc[j].a0, (unsigned short)cc[j].a1};
+                        h[j][0] = (int)(__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi, lo, sel[j])), wa, 0u, false) & ~15u);
+                    }
+                }
+            }
+        };
+        // the two most recent source rows' passes (ids idA < idB): an output row's taps are rs0 and rs1 in {rs0, rs0 + 1}, rows
+        // only move down, so a tap is either cached or newer than both; rows between two output rows' taps (down-scaling by more
+        // than 2) are never touched.  Everything that steers this loop is wave-uniform and lives in scalar registers.
+        int idA = -1, idB = -1;
+        int hA[CPL][NC], hB[CPL][NC];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) hA[j][c] = hB[j][c] = 0;
+        auto need = [&](int sr) __attribute__((always_inline)) {
+            if (sr != idA && sr != idB) {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) hA[j][c] = hB[j][c];
+                idA = idB;
+                hpass(sr, hB);
+                idB = sr;
+            }
+        };
+        for (int y = yw0; y <= yw1; ++y) {
+            const RowC rc = s_row[y];
+            const int rs0 = __builtin_amdgcn_readfirstlane((int)rc.s0), rs1 = __builtin_amdgcn_readfirstlane((int)rc.s1);
+            const int ya0 = __builtin_amdgcn_readfirstlane((int)rc.a0), ya1 = __builtin_amdgcn_readfirstlane((int)rc.a1);
+            need(rs0);
+            need(rs1);
+            const uint32_t yb0 = (uint32_t)ya0 << 12, yb1 = (uint32_t)ya1 << 12;
+            // (scalar) branch on which cached pass is which tap: the usual case is top = older, bottom = newer
+            auto emit = [&](const int (&top)[CPL][NC], const int (&bot)[CPL][NC]) __attribute__((always_inline)) {
                 if constexpr (BGR) {
                     int v[CPL][3];
 #pragma unroll
                     for (int j = 0; j < CPL; ++j)
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) v[j][c] = vblend_cv(rs0 == sr ? h_cur[j][c % NC] : h_prev[j][c % NC], h_cur[j][c % NC], ya0, ya1);
+                        for (int c = 0; c < 3; ++c) v[j][c] = vblend16_cv(top[j][c % NC], bot[j][c % NC], yb0, yb1);
                     store_row_bgr(y, v);
                 } else {
                     uint32_t packed = 0;
 #pragma unroll
-                    for (int j = 0; j < CPL; ++j)
-                        packed |= (uint32_t)vblend_cv(rs0 == sr ? h_cur[j][0] : h_prev[j][0], h_cur[j][0], ya0, ya1) << (8 * j);
+                    for (int j = 0; j < CPL; ++j) packed |= (uint32_t)vblend16_cv(top[j][0], bot[j][0], yb0, yb1) << (8 * j);
                     store_row(y, packed);
                 }
-                ++y;
-            }
-#pragma unroll
-            for (int j = 0; j < CPL; ++j)
-#pragma unroll
-                for (int c = 0; c < NC; ++c) h_prev[j][c] = h_cur[j][c];
+            };
+            if (rs0 != idB) emit(hA, hB);                               // rs0 = idA, rs1 = idB
+            else if (rs1 == idB) emit(hB, hB);                          // both taps on the newest row (clamped at the border)
+            else emit(hB, hA);                                           // cannot happen for rows that only move down; kept for completeness
         }
     } else {
         for (int y = yw0; y <= yw1; ++y) {
@@ -472,6 +566,7 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
             store_row(y, packed);
         }
     }
+    }   // frames of this block
 }
 
 }  // namespace v2v
