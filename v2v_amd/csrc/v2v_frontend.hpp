@@ -65,6 +65,7 @@ __device__ __forceinline__ int resize_src_lo(int d, int ssize, double scale)
 struct GrayCoef {
     int cb, cg, cr, half, shift;
     uint32_t lo, hi;              // the weights split into bytes for v_dot4_u32_u8: w = hi * 256 + lo per channel
+    uint32_t lo16, hi16, half16;  // the same sum scaled by 2^(16 - shift): gray = byte 2 of it (every scaled weight still splits into two bytes)
 };
 __device__ __forceinline__ GrayCoef gray_coef(int mode)
 {
@@ -74,6 +75,10 @@ __device__ __forceinline__ GrayCoef gray_coef(int mode)
     k.shift = v4 ? 15 : 14; k.half = 1 << (k.shift - 1);
     k.lo = (uint32_t)(k.cb & 255) | ((uint32_t)(k.cg & 255) << 8) | ((uint32_t)(k.cr & 255) << 16);
     k.hi = (uint32_t)(k.cb >> 8) | ((uint32_t)(k.cg >> 8) << 8) | ((uint32_t)(k.cr >> 8) << 16);
+    const int up = 16 - k.shift, b16 = k.cb << up, g16 = k.cg << up, r16 = k.cr << up;          // 7470 / 38470 / 19596 (cv4), x4 for cv3
+    k.lo16 = (uint32_t)(b16 & 255) | ((uint32_t)(g16 & 255) << 8) | ((uint32_t)(r16 & 255) << 16);
+    k.hi16 = (uint32_t)(b16 >> 8) | ((uint32_t)(g16 >> 8) << 8) | ((uint32_t)(r16 >> 8) << 16);
+    k.half16 = (uint32_t)k.half << up;
     return k;
 }
 __device__ __forceinline__ int bgr2gray_cv(const uint8_t *p, const GrayCoef &k)
@@ -355,9 +360,13 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
                                 const u32x4v w = v[q][k];
                                 const uint32_t d0 = __builtin_amdgcn_alignbyte(w.y, w.x, mis[q]), d1 = __builtin_amdgcn_alignbyte(w.z, w.y, mis[q]),
                                                d2 = __builtin_amdgcn_alignbyte(w.w, w.z, mis[q]);
-                                const uint32_t g0 = (uint32_t)bgr2gray_dot4(d0, gk), g1 = (uint32_t)bgr2gray_dot4(__builtin_amdgcn_alignbyte(d1, d0, 3), gk),
-                                               g2 = (uint32_t)bgr2gray_dot4(__builtin_amdgcn_alignbyte(d2, d1, 2), gk), g3 = (uint32_t)bgr2gray_dot4(d2 >> 8, gk);
-                                *reinterpret_cast<uint32_t *>(lrow + c * 4) = (g0 | (g1 << 8)) | ((g2 << 16) | (g3 << 24));
+                                // with the weights scaled to a shift of 16 the gray value is byte 2 of the sum: v_perm_b32(hi, lo, sel)
+                                // packs the four of them (selector 2 = byte 2 of lo, 6 = byte 2 of hi, 0x0c = zero)
+                                auto sum16 = [&](uint32_t px) { return __builtin_amdgcn_udot4(px, gk.lo16, gk.half16, false) + (__builtin_amdgcn_udot4(px, gk.hi16, 0u, false) << 8); };
+                                const uint32_t s0 = sum16(d0), s1 = sum16(__builtin_amdgcn_alignbyte(d1, d0, 3)),
+                                               s2 = sum16(__builtin_amdgcn_alignbyte(d2, d1, 2)), s3 = sum16(d2 >> 8);
+                                const uint32_t g01 = __builtin_amdgcn_perm(s1, s0, 0x0c0c0602u), g23 = __builtin_amdgcn_perm(s3, s2, 0x06020c0cu);
+                                *reinterpret_cast<uint32_t *>(lrow + c * 4) = g01 | g23;
                             }
                         }
                     }
