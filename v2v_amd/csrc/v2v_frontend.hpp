@@ -222,7 +222,7 @@ __device__ __noinline__ u32x4v load16_clipped(const uint8_t *g, const uint8_t *e
 
 __device__ __forceinline__ int vblend_cv(int h0, int h1, int ya0, int ya1)
 {
-    // operands: h < 2^15 (255 * 2048 >> 4), 0 <= ya <= 2048 -> 24-bit multiplies (v_mul_i32_i24; a 32-bit v_mul_lo is quarter rate)
+    // operands: h < 2^15 (255 * 2048 >> 4), 0 <= ya <= 2048 -> 24-bit multiplies (v_mul_i32_i24)
     const int v = ((__mul24(ya0, h0) >> 16) + (__mul24(ya1, h1) >> 16) + 2) >> 2;
     return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
