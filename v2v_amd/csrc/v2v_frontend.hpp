@@ -316,58 +316,54 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
     const int nch = BGR ? (span + 12 + 15) >> 4 : (span_px + 3) >> 2;
     const bool staged = !area2 && rows <= ta.max_rows && (BGR ? nch * 16 : nch * 4 + 12) <= ta.pitch && cb <= 32767;
 
-    // (2) source rectangle -> LDS.  One wave per source row (wave-uniform row address), rows wave, wave + 4, ...  The loads of
-    // kStageRows rows x 2 chunks per lane are ALL issued before the first LDS write: written as load -> write per chunk the
-    // compiler waits for every load in turn (s_waitcnt vmcnt(0) in front of each ds_write), 7-14 serial round trips per wave.
+    // (2) source rectangle -> LDS.  A wave takes FOUR source rows at a time, 16 lanes each (lane >> 4 = row, lane & 15 = chunk
+    // column, chunks 16 apart): a row of 70-100 chunks fills 16-lane groups to ~90 % where 64-lane groups of one row were 57 %
+    // full -- and the conversion below runs for every lane of a wave whether it holds a chunk or not.  The kStageK loads of a
+    // lane are ALL issued before the first LDS write (as load -> write per chunk the compiler waits for every load in turn).
     if (staged) {
-        constexpr int kStageRows = 4;
-        for (int c0 = 0; c0 < nch; c0 += 128) {
-            for (int r0 = wave; r0 < rows; r0 += 4 * kStageRows) {
-                u32x4v v[kStageRows][2];
-                uint32_t mis[kStageRows];
+        constexpr int kStageK = 4;
+        constexpr uint32_t kChunk = BGR ? 16u : 12u;         // gray: the granule's 12 bytes + misalignment <= 3 are inside the 16 loaded
+        constexpr uint32_t kOut = BGR ? 16u : 4u;
+        const int sub = lane >> 4, cl = lane & 15;
+        // (scalar) the tile's last row ends inside the source buffer: no per-load end test (only the last rows of the last frame fail)
+        const bool inside = frame + ((int64_t)sy_hi * a.Ws + sx_lo) * 3 + (size_t)nch * kChunk + 16 <= a.src_end;
+        for (int rg = wave * 4; rg < rows; rg += 16) {
+            const int r = rg + sub;
+            const bool rok = r < rows;
+            const uint8_t *grow = frame + ((int64_t)(sy_lo + (rok ? r : rows - 1)) * a.Ws + sx_lo) * 3;
+            const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(grow) & 3u);
+            grow -= mis;                                                     // the 4-byte-aligned address below the row's first byte
+            unsigned char *lrow = s_rows + (size_t)r * ta.pitch;
+            for (int c0 = 0; c0 < nch; c0 += 16 * kStageK) {
+                u32x4v v[kStageK];
 #pragma unroll
-                for (int q = 0; q < kStageRows; ++q) {
-                    const int r = r0 + 4 * q;
-                    mis[q] = 0;
-                    if (r >= rows) break;
-                    const uint8_t *grow = frame + ((int64_t)(sy_lo + r) * a.Ws + sx_lo) * 3;
-                    mis[q] = (uint32_t)(reinterpret_cast<uintptr_t>(grow) & 3u);
-                    grow -= mis[q];                                          // the 4-byte-aligned address below the row's first byte
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int c = c0 + lane + 64 * k;
-                        if (c < nch) {
-                            const uint8_t *g = grow + c * (BGR ? 16 : 12);   // gray: 12 bytes of the granule + misalignment <= 3 are inside 16
-                            if (__builtin_expect(g + 16 <= a.src_end, 1)) __builtin_memcpy(&v[q][k], g, 16);
-                            else v[q][k] = load16_clipped(g, a.src_end);     // last bytes of the whole source buffer
-                        }
+                for (int k = 0; k < kStageK; ++k) {
+                    const int c = c0 + cl + 16 * k;
+                    if (rok && c < nch) {
+                        const uint8_t *g = grow + (uint32_t)c * kChunk;
+                        if (__builtin_expect(inside, 1)) __builtin_memcpy(&v[k], g, 16);
+                        else v[k] = load16_clipped(g, a.src_end);             // last bytes of the whole source buffer
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < kStageRows; ++q) {
-                    const int r = r0 + 4 * q;
-                    if (r >= rows) break;
-                    unsigned char *lrow = s_rows + (size_t)r * ta.pitch;
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int c = c0 + lane + 64 * k;
-                        if (c < nch) {
-                            if constexpr (BGR) {
-                                *reinterpret_cast<u32x4v *>(lrow + c * 16) = v[q][k];
-                            } else {
-                                // every source pixel is converted ONCE (cv2 converts the frame before it resizes): the granule's 12
-                                // bytes B G R B | G R B G | R B G R -> four gray bytes
-                                const u32x4v w = v[q][k];
-                                const uint32_t d0 = __builtin_amdgcn_alignbyte(w.y, w.x, mis[q]), d1 = __builtin_amdgcn_alignbyte(w.z, w.y, mis[q]),
-                                               d2 = __builtin_amdgcn_alignbyte(w.w, w.z, mis[q]);
-                                // with the weights scaled to a shift of 16 the gray value is byte 2 of the sum: v_perm_b32(hi, lo, sel)
-                                // packs the four of them (selector 2 = byte 2 of lo, 6 = byte 2 of hi, 0x0c = zero)
-                                auto sum16 = [&](uint32_t px) { return __builtin_amdgcn_udot4(px, gk.lo16, gk.half16, false) + (__builtin_amdgcn_udot4(px, gk.hi16, 0u, false) << 8); };
-                                const uint32_t s0 = sum16(d0), s1 = sum16(__builtin_amdgcn_alignbyte(d1, d0, 3)),
-                                               s2 = sum16(__builtin_amdgcn_alignbyte(d2, d1, 2)), s3 = sum16(d2 >> 8);
-                                const uint32_t g01 = __builtin_amdgcn_perm(s1, s0, 0x0c0c0602u), g23 = __builtin_amdgcn_perm(s3, s2, 0x06020c0cu);
-                                *reinterpret_cast<uint32_t *>(lrow + c * 4) = g01 | g23;
-                            }
+                for (int k = 0; k < kStageK; ++k) {
+                    const int c = c0 + cl + 16 * k;
+                    if (rok && c < nch) {
+                        if constexpr (BGR) {
+                            *reinterpret_cast<u32x4v *>(lrow + (uint32_t)c * kOut) = v[k];
+                        } else {
+                            // every source pixel is converted ONCE (cv2 converts the frame before it resizes): the granule's 12
+                            // bytes B G R B | G R B G | R B G R -> four gray bytes.  With the weights scaled to a shift of 16 the
+                            // gray value is byte 2 of the sum: v_perm_b32(hi, lo, sel) packs the four of them (selector 2 = byte 2
+                            // of lo, 6 = byte 2 of hi, 0x0c = zero)
+                            const u32x4v w = v[k];
+                            const uint32_t d0 = __builtin_amdgcn_alignbyte(w.y, w.x, mis), d1 = __builtin_amdgcn_alignbyte(w.z, w.y, mis),
+                                           d2 = __builtin_amdgcn_alignbyte(w.w, w.z, mis);
+                            auto sum16 = [&](uint32_t px) { return __builtin_amdgcn_udot4(px, gk.lo16, gk.half16, false) + (__builtin_amdgcn_udot4(px, gk.hi16, 0u, false) << 8); };
+                            const uint32_t s0 = sum16(d0), s1 = sum16(__builtin_amdgcn_alignbyte(d1, d0, 3)),
+                                           s2 = sum16(__builtin_amdgcn_alignbyte(d2, d1, 2)), s3 = sum16(d2 >> 8);
+                            const uint32_t g01 = __builtin_amdgcn_perm(s1, s0, 0x0c0c0602u), g23 = __builtin_amdgcn_perm(s3, s2, 0x06020c0cu);
+                            *reinterpret_cast<uint32_t *>(lrow + (uint32_t)c * kOut) = g01 | g23;
                         }
                     }
                 }
