@@ -21,15 +21,15 @@ def time_ms(fn, reps=30):
     return t[len(t) // 2]
 
 
-P = [0.2, 0.2, 0.1, 1e-3, 0.1]
 full = esim.synth_clips(256, 33, 256, 256, dtype=torch.float32, seed=1, clip_id0=0)
-pt = torch.tensor(P, dtype=torch.float64, device="cuda")
 o = torch.empty((256, 5, 256, 256), dtype=torch.float32, device="cuda")
-xs, ys = [], []
-for n in (3, 5, 9, 17, 33):
-    frames = full[:, :n].contiguous()
-    ms = time_ms(lambda: esim.esim_voxel_batch(frames, pt, bin_mode="bilinear", num_bins=5, seed=1, out=o, validate=False))
-    xs.append(n - 1); ys.append(ms)
-    print(n, round(ms, 4), flush=True)
-a, b = np.polyfit(xs, ys, 1)
-print(f"slope {a:.5f} ms per frame pair, intercept {b:.4f} ms; output stores alone: {o.numel() * 4 / 5.5e9:.4f} ms at 5.5 TB/s")
+for name, P in (("reference defaults", [0.2, 0.2, 0.1, 1e-3, 0.1]), ("base noise only", [0.2, 0.2, 0.1, 0.0, 0.0]), ("noise-free", [0.2, 0.2, 0.0, 0.0, 0.0])):
+    pt = torch.tensor(P, dtype=torch.float64, device="cuda")
+    xs, ys = [], []
+    for n in (3, 5, 9, 17, 33):
+        frames = full[:, :n].contiguous()
+        ms = time_ms(lambda: esim.esim_voxel_batch(frames, pt, bin_mode="bilinear", num_bins=5, seed=1, out=o, validate=False))
+        xs.append(n - 1); ys.append(ms)
+    a, b = np.polyfit(xs, ys, 1)
+    print(f"{name:20s} ms {[round(y, 4) for y in ys]}  slope {a:.5f} ms per frame pair, intercept {b:.4f} ms", flush=True)
+print(f"output stores alone: {o.numel() * 4 / 5.5e9:.4f} ms at 5.5 TB/s")
