@@ -144,3 +144,33 @@ def test_random_frontend_tiles(case):
     assert np.array_equal(gray.cpu().numpy(), want), (hs, ws, crop, cb, mi, mj, flip)
     _, gather = frontend.prepare_clip(raw_d, cb, mi, mj, flip, crop, idxes, want_imgs=True)
     assert torch.equal(gray, gather)
+
+
+@pytest.mark.parametrize("case", range(12 * _SCALE))
+def test_random_frontend_modes(case):
+    """The tiled front-end's other instances against the restatement on random frames: colour mode gray_in_bgr_out (three channels
+    through both passes, resized frames + the reference's float64 bgr_to_gray), per-frame shake offsets (resize to crop + the
+    largest offset, cut per frame), both cvtColor weight sets."""
+    from oracle import frontend_oracle as F
+    from v2v_amd import frontend
+    g = np.random.default_rng(11000 + case)
+    hs, ws = int(g.integers(8, 220)), int(g.integers(8, 260))
+    crop = int(g.integers(1, 150)) if case % 3 else int(g.integers(129, 200))
+    t = 3
+    shake = case % 2 == 1
+    di = g.integers(-3, 4, size=t) if shake else None
+    dj = g.integers(-3, 4, size=t) if shake else None
+    cb = int(g.integers(1, min(hs, ws) + 1))
+    mi, mj = int(g.integers(0, hs - cb + 1)), int(g.integers(0, ws - cb + 1))
+    flip = bool(g.integers(0, 2))
+    mode = "gray_in_bgr_out" if case % 4 < 2 else "gray"
+    ver = "cv3" if case % 5 == 0 else "cv4"
+    raw = g.integers(0, 256, size=(t, hs, ws, 3), dtype=np.uint8)
+    idxes = [2, 0, 1, 1]
+    want_imgs, want_gray = F.frontend(raw, cb, mi, mj, flip, crop, idxes, di, dj, mode, ver)
+    raw_d = torch.from_numpy(raw).cuda()
+    imgs, gray = frontend.prepare_clip(raw_d, cb, mi, mj, flip, crop, idxes, all_di=di, all_dj=dj, color_mode=mode, want_imgs=True, cv_version=ver)
+    assert np.array_equal(gray.cpu().numpy(), want_gray), (hs, ws, crop, cb, mi, mj, flip, mode, ver, shake)
+    assert np.array_equal(imgs.cpu().numpy(), want_imgs)
+    _, gray2 = frontend.prepare_clip(raw_d, cb, mi, mj, flip, crop, idxes, all_di=di, all_dj=dj, color_mode=mode, want_imgs=False, cv_version=ver)
+    assert torch.equal(gray2, gray)                                   # the tiled kernel (gray clip only) and the one that also returns frames
