@@ -19,4 +19,5 @@ for (b,c,h,w) in ((8,64,128,128),(8,128,64,64),(8,256,32,32),(8,64,64,64),(8,128
             row[tr] = f"{ms:.4f}ms/{flops/ms/1e9:.0f}TF"
         except Exception as e:
             row[tr] = "n/a"
-    print((b,c,h,w), row, flush=True)
+    ms0 = t(lambda: CL.convlstm_step(xn, None, None, packed, bias, nchw_dtype=None, tile_rows=256)) if (b*h*w) % 256 == 0 else None
+    print((b,c,h,w), row, "zero state (half the chunks), 256-px tile:", None if ms0 is None else round(ms0, 4), flush=True)

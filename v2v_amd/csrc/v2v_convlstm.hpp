@@ -167,6 +167,9 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
     // the same box with two buffers AND with three (every piece issued between MFMAs stalls the wave's instruction stream for
     // its turn in the address unit)
     auto stage = [&](int ck, int buf, int part, int nparts) __attribute__((always_inline)) {
+#ifdef V2V_CL_ABLATE_STAGE                                         // timing ablation (results invalid): no LDS-DMA after the first chunk
+        if (ck > 1) return;
+#endif
         if constexpr (TPC == 2) {
             const int t0 = 2 * ck, t1 = 2 * ck + 1;
             const int dy0 = t0 / ks - pad, dx0 = t0 % ks - pad, dy1 = t1 / ks - pad, dx1 = t1 % ks - pad;
@@ -237,6 +240,9 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
         // fragments of k-step s+1 are read before the MFMAs of k-step s are issued (two register sets: +1..3 %)
         cl_bf16x8 af[2][MF], bf[2][NF];
         auto load = [&](int s, int slot) __attribute__((always_inline)) {
+#ifdef V2V_CL_ABLATE_READS                                         // timing ablation (results invalid): fragments read once per chunk
+            if (s > 0) { for (int i = 0; i < MF; ++i) af[slot][i] = af[0][i]; for (int g = 0; g < NF; ++g) bf[slot][g] = bf[0][g]; return; }
+#endif
 #pragma unroll
             for (int i = 0; i < MF; ++i) af[slot][i] = *reinterpret_cast<const cl_bf16x8 *>(base + a_row + i * (32 * 128) + koff[s]);
 #pragma unroll
@@ -250,7 +256,11 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
 #pragma unroll
             for (int i = 0; i < MF; ++i)
 #pragma unroll
+#ifdef V2V_CL_ABLATE_MFMA                                          // timing ablation (results invalid): the fragments stay live, no matrix work
+                for (int g = 0; g < NF; ++g) asm volatile("" :: "v"(af[s & 1][i]), "v"(bf[s & 1][g]));
+#else
                 for (int g = 0; g < NF; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], bf[s & 1][g], acc[i][g], 0, 0, 0);
+#endif
         }
     };
     // 64- and 128-pixel tiles (MF = 1): the previous cell state of this lane's outputs is fetched while the LAST chunk's MFMAs
@@ -280,7 +290,9 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
             CL_STAMP(t_rest)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             CL_STAMP(t_wait)
+#ifndef V2V_CL_ABLATE_BARRIER                                      // timing ablation (results invalid): no barrier per chunk
             __syncthreads();                                     // chunk ck has landed; everyone is done with the other buffer
+#endif
             CL_STAMP(t_bar)
             const bool more = ck + KS < n_chunks;
             if (it + 1 == n_it) prefetch_c();
