@@ -63,8 +63,12 @@ __device__ __forceinline__ uint32_t cl_pack_bf16(float lo, float hi)
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(cl_f32x2{lo, hi}, cl_hwbf16x2));
 }
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) { return (uint16_t)cl_pack_bf16(f, f); }
-__device__ __forceinline__ float cl_sigmoid(float v) { return __frcp_rn(1.0f + __expf(-v)); }
-__device__ __forceinline__ float cl_tanh(float v) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * v)) - 1.0f; }
+// gate activations on the hardware transcendentals: ONE v_exp_f32 (2^x, the log2(e) folded into the multiply) and ONE v_rcp_f32 (1 ulp)
+// per activation.  Round 2 wrote __frcp_rn(1 + __expf(-v)): the IEEE-rounded reciprocal expands to a 10-instruction division
+// (v_div_scale x 2, v_rcp, 4 fma, v_div_fmas, v_div_fixup) and __expf adds a denormal-range rescue -- 80 divisions per wave made the
+// gate epilogue ~9 us of a 49 us tile.  Saturation is exact: exp2(+inf) = inf -> rcp = 0, exp2(-inf) = 0 -> rcp(1) = 1.
+__device__ __forceinline__ float cl_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
+__device__ __forceinline__ float cl_tanh(float v) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -2.8853900817779268f)) - 1.0f; }
 
 __device__ __forceinline__ void cl_glds16(const void *src, unsigned char *lds_wave_base)
 {
