@@ -33,3 +33,14 @@ for name, P in (("reference defaults", [0.2, 0.2, 0.1, 1e-3, 0.1]), ("base noise
     a, b = np.polyfit(xs, ys, 1)
     print(f"{name:20s} ms {[round(y, 4) for y in ys]}  slope {a:.5f} ms per frame pair, intercept {b:.4f} ms", flush=True)
 print(f"output stores alone: {o.numel() * 4 / 5.5e9:.4f} ms at 5.5 TB/s")
+
+# the same question for the v2e launch (config 3's parameters): pre-pass + simulation per call
+from v2v_amd import v2e  # noqa: E402
+vp = v2e.make_params(24, "pn_related", 0.5, 0.1, 0.0, 0.1, 30, 0.1, 0, 5.0, 0.1, 0.1)          # bench.py's V2E_NOISY
+xs, ys = [], []
+for n in (3, 5, 9, 17, 33):
+    frames = full[:, :n].contiguous()
+    ms = time_ms(lambda: v2e.v2e_voxel_batch(frames, vp, bin_mode="bilinear", num_bins=5, seed=1, out=o))
+    xs.append(n - 1); ys.append(ms)
+a, b = np.polyfit(xs, ys, 1)
+print(f"{'v2e (config 3)':20s} ms {[round(y, 4) for y in ys]}  slope {a:.5f} ms per frame pair, intercept {b:.4f} ms", flush=True)

@@ -80,21 +80,23 @@ __device__ __forceinline__ void cl_glds16(const void *src, unsigned char *lds_wa
 template <int MF, int NF>
 __device__ __forceinline__ void cl_epilogue_conv(const ConvLstmArgs &a, cl_f32x16 (&acc)[MF][NF], int64_t mw0, int col0, int fh)
 {
-    const int N = a.n_cols;
+    // one 64-bit element index per lane; every element adds a wave-uniform 32-bit offset (pixel row x column count) to it
+    const uint32_t N = (uint32_t)a.n_cols;
+    const int64_t lane0 = (mw0 + 4 * fh) * (int64_t)N + col0;
+    uint16_t *const obase = a.out_nhwc + lane0;
+    const uint16_t *const rbase = a.residual ? a.residual + lane0 : nullptr;
 #pragma unroll
     for (int g = 0; g < NF; ++g) {
-        const int oc = col0 + g * 32;
-        const float bias = a.bias[oc];
+        const float bias = a.bias[col0 + g * 32];
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t m = mw0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                const int64_t idx = m * N + oc;
+                const uint32_t eo = (uint32_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * N + (uint32_t)(g * 32);
                 float v = acc[i][g][r] + bias;
-                if (a.residual) v += __uint_as_float((uint32_t)a.residual[idx] << 16);
+                if (rbase) v += __uint_as_float((uint32_t)rbase[eo] << 16);
                 if (a.relu) v = v > 0.0f ? v : (v != v ? v : 0.0f);
-                a.out_nhwc[idx] = f32_to_bf16_rne(v);
+                obase[eo] = f32_to_bf16_rne(v);
             }
         }
     }
@@ -645,22 +647,26 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const ConvLstmArgs a,
     }
 
     // ---- epilogue: bias (+ residual) (+ ReLU) -> bf16 NHWC ---------------------------------------------------------------------
-    const int N = a.n_cols;
+    // element (i, r) of lane (fr, fh): patch row (wave * 2 + i) * 2 + (r >> 3), patch column (r & 3) + 8 ((r >> 2) & 1) + 4 fh.
+    // One 64-bit element index per lane; every element adds a scalar (rows) and a compile-time (columns) 32-bit offset to it
+    // (written as one 64-bit index expression per element this was ~23 vector instructions per element, a third of a tile's matrix time)
+    constexpr int N = kBN;                                               // the halo tile IS the layer's column count
+    const int64_t lane0 = ((((int64_t)bimg * H + ty * 16 + wave * 4) * W) + tx * 16 + 4 * fh) * N + fr;
+    const uint32_t row_pitch = (uint32_t)W * (uint32_t)N;
+    uint16_t *const obase = a.out_nhwc + lane0;
+    const uint16_t *const rbase = a.residual ? a.residual + lane0 : nullptr;
 #pragma unroll
     for (int q = 0; q < NF; ++q) {
-        const int oc = q * 32 + fr;
-        const float bias = a.bias[oc];
+        const float bias = a.bias[q * 32 + fr];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;                   // pixel inside the 32-pixel fragment row
-                const int py = (wave * 2 + i) * 2 + (row >> 4), px = row & 15;
-                const int64_t idx = ((((int64_t)bimg * H + ty * 16 + py) * W) + tx * 16 + px) * N + oc;
+                const uint32_t eo = (uint32_t)(i * 2 + (r >> 3)) * row_pitch + (uint32_t)(((r & 3) + 8 * ((r >> 2) & 1)) * N + q * 32);
                 float v = acc[i][q][r] + bias;
-                if (a.residual) v += __uint_as_float((uint32_t)a.residual[idx] << 16);
+                if (rbase) v += __uint_as_float((uint32_t)rbase[eo] << 16);
                 if (a.relu) v = v > 0.0f ? v : (v != v ? v : 0.0f);
-                a.out_nhwc[idx] = f32_to_bf16_rne(v);
+                obase[eo] = f32_to_bf16_rne(v);
             }
         }
     }
