@@ -137,7 +137,11 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
     const int64_t m0 = (int64_t)(blockIdx.x / n_ct) * kClBM;      // first pixel of the tile (flattened b,y,x)
     const int cc_x = TPC == 2 ? 1 : C / kClBK, cc_all = EPI == 0 ? 2 * cc_x : cc_x;
     const int cc_eff = (EPI == 0 && a.h_prev) ? cc_all : cc_x;    // zero state: skip h's chunks
+#ifdef V2V_CL_ABLATE_LOOP                                          // timing ablation (results invalid): prologue + ONE chunk + epilogue
+    const int n_chunks = 1;
+#else
     const int n_chunks = TPC == 2 ? (n_taps + 1) / 2 : n_taps * cc_eff;
+#endif
 
     // ---- staging plan: wave w issues A pieces NA*w.. (8 rows each) and B pieces NB*w.. per chunk ----------------------
     const int srow = lane >> 3, sslot = lane & 7;                 // this lane's (row in piece, LDS slot)
@@ -538,7 +542,11 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const ConvLstmArgs a,
     unsigned char *const a_lds = cl_lds, *const b_lds = cl_lds + a_bytes;    // ONE patch buffer (two workgroups per CU), two weight-group buffers
     const int tiles_x = W >> 4, tiles_y = H >> 4;
     const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, bimg = blockIdx.x / (tiles_x * tiles_y);
+#ifdef V2V_CL_ABLATE_LOOP
+    const int cc_x = C / kClBK, n_groups = (n_taps + tps - 1) / tps, n_chunks = 1;
+#else
     const int cc_x = C / kClBK, n_groups = (n_taps + tps - 1) / tps, n_chunks = cc_x * n_groups;
+#endif
     const int srow = lane >> 3, sslot = lane & 7;
 
     // ---- A staging plan: wave w stages patch pieces w, w + 4, ... (8 patch pixels each) ----------------------------------
@@ -568,6 +576,9 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const ConvLstmArgs a,
     };
     // weights of chunk (cc, tap group g) -> buffer `buf`: pieces of 8 columns, tap-major
     auto stage_b = [&](int ck, int buf) __attribute__((always_inline)) {
+#ifdef V2V_CL_ABLATE_STAGE                                         // timing ablation (results invalid): weights staged once
+        if (ck > 0) return;
+#endif
         const int cc = ck / n_groups, g = ck - cc * n_groups;
         const int tap0 = g * tps, nt = min(tps, n_taps - tap0), n_pb = nt * (kBN / 8);
         unsigned char *dst = b_lds + buf * b_bytes;
@@ -605,6 +616,9 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const ConvLstmArgs a,
         // 32 columns: fragments of tap t + 1 are read before the MFMAs of tap t are issued (two register sets)
         cl_bf16x8 af0[2][4], bf0[NF][4], af1[2][4], bf1[NF][4];
         auto load = [&](int tig, cl_bf16x8 (&af)[2][4], cl_bf16x8 (&bf)[NF][4]) __attribute__((always_inline)) {
+#ifdef V2V_CL_ABLATE_READS                                         // timing ablation (results invalid): one tap's fragments per group
+            if (tig > 0) return;
+#endif
             const int tap = tap0 + tig, dy = tap / ks, dx = tap - dy * ks;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -625,7 +639,11 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const ConvLstmArgs a,
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
+#ifdef V2V_CL_ABLATE_MFMA                                          // timing ablation (results invalid)
+                    for (int q = 0; q < NF; ++q) asm volatile("" :: "v"(af[i][s]), "v"(bf[q][s]));
+#else
                     for (int q = 0; q < NF; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][s], bf[q][s], acc[i][q], 0, 0, 0);
+#endif
         };
         if constexpr (NF == 1) {                                          // wider column tiles run one tap per group: nothing to prefetch
             load(0, af0, bf0);
