@@ -528,10 +528,14 @@ int v2v_normalize_pad_ex_hip(const float *voxel, int64_t B, int64_t planes, int6
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(hist)");
         hipLaunchKernelGGL(v2v::select_init_kernel, dim3((unsigned)((B * 2 + 255) / 256)), dim3(256), 0, s, st, B * 2,
                            (uint64_t)(min_k - 1), (uint64_t)(max_k - 1));
-        const unsigned gx = (unsigned)std::min<int64_t>((per_sample + 256 * 8 - 1) / (256 * 8), 512);
+        const int64_t want = (2048 + B - 1) / B, most = (per_sample + 256 * 8 - 1) / (256 * 8);      // few, fat workgroups (see the counting path)
+        const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, most));
         const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
         for (int p = 0; p < 3; ++p) {
-            hipLaunchKernelGGL(v2v::select_hist_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, voxel, per_sample, st, hist, shifts[p], bits[p]);
+            if (per_sample % 4 == 0 && (reinterpret_cast<uintptr_t>(voxel) & 15u) == 0)
+                hipLaunchKernelGGL(v2v::select_hist4_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, voxel, per_sample, st, hist, shifts[p], bits[p]);
+            else
+                hipLaunchKernelGGL(v2v::select_hist_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, voxel, per_sample, st, hist, shifts[p], bits[p]);
             hipLaunchKernelGGL(v2v::select_pick_kernel, dim3((unsigned)(B * 2)), dim3(256), 0, s, st, hist, shifts[p], bits[p]);
         }
     } else if (method == V2V_NORM_COUNT) {
@@ -542,14 +546,31 @@ int v2v_normalize_pad_ex_hip(const float *voxel, int64_t B, int64_t planes, int6
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(hist)");
         const int64_t per_in = planes * H_in * W_in;
         const unsigned gx = (unsigned)std::min<int64_t>((per_in + 256 * 8 - 1) / (256 * 8), 512);
-        hipLaunchKernelGGL(v2v::count_hist_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, voxel, per_in, hist, bad);
-        hipLaunchKernelGGL(v2v::count_pick_kernel, dim3((unsigned)((B * 2 + 255) / 256)), dim3(256), 0, s, st, hist, bad, B * 2,
+        // 16-byte loads + wave-aggregated histogram updates when a sample is whole float4s (every layout the simulator writes)
+        if (per_in % 4 == 0 && (reinterpret_cast<uintptr_t>(voxel) & 15u) == 0) {
+            // few, fat workgroups: every workgroup ends with one global atomic per non-empty bin of ITS sample, and hundreds of them
+            // on the same few words serialise at the L2 (9,600 workgroups: 78 us for 157 MB; ~2,048: see tools/postops_time.py)
+            const int64_t want = (2048 + B - 1) / B, most = (per_in / 4 + 511) / 512;
+            const unsigned gx4 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, most));
+            hipLaunchKernelGGL(v2v::count_hist4_kernel, dim3(gx4, (unsigned)B), dim3(256), 0, s, voxel, per_in, hist, bad);
+        } else {
+            hipLaunchKernelGGL(v2v::count_hist_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, voxel, per_in, hist, bad);
+        }
+        hipLaunchKernelGGL(v2v::count_pick_kernel, dim3((unsigned)(B * 2)), dim3(64), 0, s, st, hist, bad, B * 2,
                            (uint64_t)(per_in - per_sample), (uint64_t)(min_k - 1), (uint64_t)(max_k - 1));
     }
     const int64_t per_out = planes * Hp * Wp;
-    const unsigned gx2 = (unsigned)std::min<int64_t>((per_out + 256 * 4 - 1) / (256 * 4), 2048);
-    hipLaunchKernelGGL(v2v::normalize_pad_kernel, dim3(gx2, (unsigned)B), dim3(256), 0, s, voxel, out, st, normalize ? 1 : 0, planes,
-                       (int)H, (int)W, Hp, Wp, (int)H_in, (int)W_in);
+    const bool rows4 = W % 4 == 0 && Wp % 4 == 0 && W_in % 4 == 0 && planes * Hp < ((int64_t)1 << 31) &&
+                       ((reinterpret_cast<uintptr_t>(voxel) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
+    if (rows4) {                                                 // a wave per output row, 16 bytes per lane
+        const unsigned gr = (unsigned)std::min<int64_t>((planes * Hp + 3) / 4, 4096);
+        hipLaunchKernelGGL(v2v::normalize_pad_rows_kernel, dim3(gr, (unsigned)B), dim3(256), 0, s, voxel, out, st, normalize ? 1 : 0, (int)planes,
+                           (int)H, (int)W, Hp, Wp, (int)H_in, (int)W_in);
+    } else {
+        const unsigned gx2 = (unsigned)std::min<int64_t>((per_out + 256 * 4 - 1) / (256 * 4), 2048);
+        hipLaunchKernelGGL(v2v::normalize_pad_kernel, dim3(gx2, (unsigned)B), dim3(256), 0, s, voxel, out, st, normalize ? 1 : 0, planes,
+                           (int)H, (int)W, Hp, Wp, (int)H_in, (int)W_in);
+    }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? V2V_OK : hip_fail(e, "normalize_pad launch");
 }

@@ -65,6 +65,49 @@ __global__ void __launch_bounds__(256) select_hist_kernel(const float *x, int64_
         if (lh[i]) atomicAdd(&gh[i], lh[i]);
 }
 
+// The same pass with 16-byte loads and the wave's LEADING digit peeled by ballot before the LDS adds: a voxel grid is mostly one
+// value (zero), i.e. one digit per pass for most of a wave's 64 lanes -- 64 same-address LDS atomics serialise, one add of the
+// population count by one lane does not; lanes with another digit add as before.  per_sample % 4 == 0, 16-byte aligned samples.
+__global__ void __launch_bounds__(256) select_hist4_kernel(const float *x, int64_t per_sample, const SelectState *st,
+                                                           unsigned int *hist, int shift, int bits)
+{
+    __shared__ unsigned int lh[2 * kSelBins];
+    const int sample = blockIdx.y;
+    for (int i = threadIdx.x; i < 2 * kSelBins; i += 256) lh[i] = 0;
+    __syncthreads();
+    const SelectState s0 = st[sample * 2], s1 = st[sample * 2 + 1];
+    const uint32_t dmask = (1u << bits) - 1u;
+    const float4 *xs = reinterpret_cast<const float4 *>(x + (int64_t)sample * per_sample);
+    const int64_t n4 = per_sample >> 2;
+    const int lane = threadIdx.x & 63;
+    auto add = [&](bool match, uint32_t d, unsigned int *h) __attribute__((always_inline)) {
+        const unsigned long long m = __ballot(match);
+        if (m == 0) return;                                                   // wave-uniform
+        const int src = __builtin_ctzll(m);
+        const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)d, src);
+        const unsigned long long same = __ballot(match && d == lead);
+        if (lane == src) atomicAdd(&h[lead], (unsigned int)__popcll(same));
+        if (match && d != lead) atomicAdd(&h[d], 1u);
+    };
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n4; i0 += (int64_t)gridDim.x * 256) {
+        const int64_t i = i0 + threadIdx.x;
+        const bool in = i < n4;
+        const float4 v4 = in ? xs[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t k = float_key(vv[e]);
+            const uint32_t d = (k >> shift) & dmask;
+            add(in && (k & s0.prefix_mask) == s0.prefix, d, lh);
+            add(in && (k & s1.prefix_mask) == s1.prefix, d, lh + kSelBins);
+        }
+    }
+    __syncthreads();
+    unsigned int *gh = hist + (int64_t)sample * 2 * kSelBins;
+    for (int i = threadIdx.x; i < 2 * kSelBins; i += 256)
+        if (lh[i]) atomicAdd(&gh[i], lh[i]);
+}
+
 // one workgroup per (sample, which): find the bin holding the remaining rank, extend the prefix, clear the histogram
 __global__ void __launch_bounds__(256) select_pick_kernel(SelectState *st, unsigned int *hist, int shift, int bits)
 {
@@ -124,6 +167,45 @@ __global__ void __launch_bounds__(256) normalize_pad_kernel(const float *x, floa
     }
 }
 
+// The same pass for rows that are whole float4s on both sides (W, Wp, Win multiples of 4, 16-byte aligned tensors: every layout
+// the simulator writes): a wave walks output rows, a lane moves 16 bytes.  No 64-bit division per element (the kernel above pays
+// two), one 32-bit division per row; the float32 division of the reference's voxel / pos_max stays an IEEE division.
+// Round 3: 157 MB at the training shape 0.082 -> ... ms (tools/postops_time.py).
+__global__ void __launch_bounds__(256) normalize_pad_rows_kernel(const float *x, float *out, const SelectState *st, int normalize,
+                                                                int planes, int H, int W, int Hp, int Wp, int Hin, int Win)
+{
+    const int sample = blockIdx.y;
+    float pos_max = 1.0f, neg_max = 1.0f;
+    if (normalize) {
+        const float hi = key_float(st[sample * 2 + 1].prefix), lo = -key_float(st[sample * 2].prefix);
+        pos_max = hi < 1.0f ? 1.0f : hi;                                      // torch.clamp(kth(0.99), min=1): a NaN stays a NaN
+        neg_max = lo < 1.0f ? 1.0f : lo;                                      // torch.clamp(-kth(0.01), min=1)
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t rows = (uint32_t)planes * (uint32_t)Hp;                    // < 2^31: checked by the launcher
+    const float *xs = x + (int64_t)sample * planes * Hin * Win;
+    float *os = out + (int64_t)sample * rows * Wp;
+    for (uint32_t r = blockIdx.x * 4u + (uint32_t)wave; r < rows; r += gridDim.x * 4u) {
+        const uint32_t p = r / (uint32_t)Hp, yh = r - p * (uint32_t)Hp;
+        const float *xrow = xs + ((int64_t)p * Hin + yh) * Win;
+        float *orow = os + (int64_t)r * Wp;
+        const bool live = yh < (uint32_t)H;
+        for (int x4 = lane * 4; x4 < Wp; x4 += 256) {
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (live && x4 < W) {                                              // W % 4 == 0: a float4 is inside or outside
+                v = *reinterpret_cast<const float4 *>(xrow + x4);
+                if (normalize) {
+                    v.x = v.x > 0.0f ? v.x / pos_max : v.x / neg_max;           // torch.where(voxel > 0, ...)
+                    v.y = v.y > 0.0f ? v.y / pos_max : v.y / neg_max;
+                    v.z = v.z > 0.0f ? v.z / pos_max : v.z / neg_max;
+                    v.w = v.w > 0.0f ? v.w / pos_max : v.w / neg_max;
+                }
+            }
+            *reinterpret_cast<float4 *>(orow + x4) = v;
+        }
+    }
+}
+
 // ---- counting path (integer-valued voxels, |v| <= kCntMax) ------------------------------------------------------------
 constexpr int kCntMax = 255, kCntBins = 2 * kCntMax + 1;
 
@@ -160,20 +242,88 @@ __global__ void __launch_bounds__(256) count_hist_kernel(const float *x, int64_t
 
 // one thread per (sample, which): walk the cumulative counts to the bin holding 0-based rank k; pad zeros (n_pad per sample,
 // counted with the data) are removed from bin 0 first.  A sample with a bad value gets NaN k-th values (its output is NaN).
-__global__ void count_pick_kernel(SelectState *st, const unsigned int *hist, const unsigned int *bad, int64_t n_sw, uint64_t n_pad,
-                                  uint64_t rank_lo, uint64_t rank_hi)
+// The same histogram with 16-byte loads; the three values that fill a voxel grid (0 and +-1) are counted per wave with one ballot each
+// (64 lanes adding to the same LDS word serialise), everything else goes to the LDS word of its value.  Measured and not kept:
+// peeling EVERY distinct value of the wave by ballot -- exact and atomic-free, but 13 distinct values (a uniform test pattern)
+// cost 13 rounds per element: 236 us against 124 for the scalar kernel above.  per_sample % 4 == 0.
+__global__ void __launch_bounds__(256) count_hist4_kernel(const float *x, int64_t per_sample, unsigned int *hist, unsigned int *bad)
 {
-    const int64_t sw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ unsigned int lh[kCntBins + 1];
+    const int sample = blockIdx.y;
+    for (int i = threadIdx.x; i <= kCntBins; i += 256) lh[i] = 0;
+    __syncthreads();
+    const float4 *xs = reinterpret_cast<const float4 *>(x + (int64_t)sample * per_sample);
+    const int64_t n4 = per_sample >> 2;
+    unsigned int n0 = 0, np = 0, nm = 0;                          // wave totals of 0 / +1 / -1, kept by every lane (wave-uniform adds)
+    bool any_bad = false;
+    for (int64_t i0 = (int64_t)blockIdx.x * 512; i0 < n4; i0 += (int64_t)gridDim.x * 512) {          // two 16-byte loads in flight per lane
+        const int64_t ia = i0 + threadIdx.x, ib = ia + 256;
+        const bool ina = ia < n4, inb = ib < n4;
+        const float4 va = ina ? xs[ia] : make_float4(0.0f, 0.0f, 0.0f, 0.0f), vb = inb ? xs[ib] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float vv[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool in = e < 4 ? ina : inb;
+            const float v = vv[e];
+            const int iv = (int)v;
+            const bool ok = (float)iv == v && iv >= -kCntMax && iv <= kCntMax;
+            any_bad |= in && !ok;
+            n0 += (unsigned int)__popcll(__ballot(in && v == 0.0f));
+            np += (unsigned int)__popcll(__ballot(in && v == 1.0f));
+            nm += (unsigned int)__popcll(__ballot(in && v == -1.0f));
+            if (in && ok && (iv > 1 || iv < -1)) atomicAdd(&lh[iv + kCntMax], 1u);
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (n0) atomicAdd(&lh[kCntMax], n0);
+        if (np) atomicAdd(&lh[kCntMax + 1], np);
+        if (nm) atomicAdd(&lh[kCntMax - 1], nm);
+    }
+    if (any_bad) lh[kCntBins] = 1u;                             // benign race: every writer stores 1
+    __syncthreads();
+    unsigned int *gh = hist + (int64_t)sample * kCntBins;
+    for (int i = threadIdx.x; i < kCntBins; i += 256)
+        if (lh[i]) atomicAdd(&gh[i], lh[i]);
+    if (threadIdx.x == 0 && lh[kCntBins]) atomicExch(&bad[sample], 1u);
+}
+
+// One 64-lane workgroup per (sample, side): a lane sums 8 bins, the wave's inclusive prefix finds the lane that holds the rank, that
+// lane walks its 8 bins (round 2 walked the 511 bins of every (sample, side) in ONE work-item: 511 dependent global loads, 44-210 us)
+__global__ void __launch_bounds__(64) count_pick_kernel(SelectState *st, const unsigned int *hist, const unsigned int *bad, int64_t n_sw, uint64_t n_pad,
+                                                      uint64_t rank_lo, uint64_t rank_hi)
+{
+    const int64_t sw = blockIdx.x;
     if (sw >= n_sw) return;
     const int64_t sample = sw >> 1;
     const unsigned int *h = hist + sample * kCntBins;
-    uint64_t r = (sw & 1) ? rank_hi : rank_lo;
-    int b = 0;
-    for (; b < kCntBins - 1; ++b) {
-        const uint64_t c = (b == kCntMax) ? (uint64_t)h[b] - n_pad : (uint64_t)h[b];
-        if (r < c) break;
-        r -= c;
+    const uint64_t rank = (sw & 1) ? rank_hi : rank_lo;
+    const int lane = threadIdx.x;
+    uint64_t c[8], mine = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int b = lane * 8 + j;
+        c[j] = b < kCntBins ? ((b == kCntMax) ? (uint64_t)h[b] - n_pad : (uint64_t)h[b]) : 0;
+        mine += c[j];
     }
+    uint64_t incl = mine;                                       // inclusive prefix sum over the lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    // first lane whose inclusive count exceeds the rank; a rank beyond the total (cannot happen: rank < elements) ends in the last bin
+    const unsigned long long over = __ballot(rank < incl);
+    const int owner = over ? __builtin_ctzll(over) : 63;
+    if (lane != owner) return;
+    uint64_t r = rank - (incl - mine);
+    int b = lane * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (b >= kCntBins - 1 || r < c[j]) break;
+        r -= c[j];
+        ++b;
+    }
+    if (b > kCntBins - 1) b = kCntBins - 1;
     SelectState s;
     s.prefix = bad[sample] ? float_key(__uint_as_float(0x7FC00000u)) : float_key((float)(b - kCntMax));
     s.prefix_mask = 0xFFFFFFFFu;
