@@ -111,20 +111,31 @@ __global__ void __launch_bounds__(256) select_hist4_kernel(const float *x, int64
 // one workgroup per (sample, which): find the bin holding the remaining rank, extend the prefix, clear the histogram
 __global__ void __launch_bounds__(256) select_pick_kernel(SelectState *st, unsigned int *hist, int shift, int bits)
 {
-    __shared__ unsigned int part[256];
+    // a work-item sums its `per` bins, the workgroup scans the 256 sums (wave prefix by shuffles + the four wave totals), and the
+    // ONE work-item whose range holds the rank walks its own bins (round 2: work-item 0 walked the 256 partial sums alone, 17 us)
+    __shared__ uint64_t wtot[4];
     const int sw = blockIdx.x;                                  // sample*2 + which
     unsigned int *h = hist + (int64_t)sw * kSelBins;
     const int nb = 1 << bits, per = (nb + 255) / 256;
-    unsigned int local = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t local = 0;
     for (int j = 0; j < per; ++j) { const int b = threadIdx.x * per + j; if (b < nb) local += h[b]; }
-    part[threadIdx.x] = local;
+    uint64_t incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) wtot[wave] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        SelectState s = st[sw];
-        uint64_t r = s.rank;
-        int t = 0;
-        while (t < 255 && r >= part[t]) { r -= part[t]; ++t; }
-        int b = t * per;
+    for (int w = 0; w < wave; ++w) incl += wtot[w];
+    const uint64_t excl = incl - local;
+    SelectState s = st[sw];
+    // the owner: rank inside [excl, incl); a rank beyond the total (cannot happen: rank < matching elements) falls to the last work-item
+    const bool own = s.rank >= excl && (s.rank < incl || threadIdx.x == 255);
+    if (own) {
+        uint64_t r = s.rank - excl;
+        int b = threadIdx.x * per;
         while (b < nb - 1 && r >= h[b]) { r -= h[b]; ++b; }
         s.prefix |= (uint32_t)b << shift;
         s.prefix_mask |= ((1u << bits) - 1u) << shift;
