@@ -28,7 +28,10 @@ extern "C" {
 /* 2: every device-native (V2V_RNG_PHILOX) random stream differs from ABI 1 for the same (seed, clip id): Gaussians by
  *    table inversion (was Box-Muller), Philox4x32-7 for per-step fields, two time steps per Gaussian field id; the v2e
  *    shot-noise sampler and its fields changed again in round 3; v2v_v2e_workspace_bytes and v2v_postops_workspace_bytes
- *    grew; v2v_lut_set acts on the current device only.  A client must re-query workspace sizes and cannot replay ABI-1
+ *    grew; v2v_lut_set acts on the current device only (a single-process multi-GPU host calls it once per device).  The
+ *    front-end's `gray_first` was RE-MAPPED: 1 now selects OpenCV 4.x's 15-bit BGR2GRAY weights (3735 / 19235 / 9798, >> 15);
+ *    the 14-bit OpenCV 2.x/3.x form that ABI 1 ran for gray_first = 1 moved to gray_first = 2 -- an ABI-1 caller passing 1 gets
+ *    different gray values on some colours, with no error.  A client must re-query workspace sizes and cannot replay ABI-1
  *    native noise.  Replay-mode (V2V_RNG_REPLAY) results are unchanged. */
 #define V2V_ABI_VERSION 2
 

@@ -84,7 +84,7 @@ def noise_rounds():
 
 
 def philox_gauss_field(seed, clip_id, field, n_pix, stream=0, comp=0, rounds=10):
-    """Normal `comp` (0: first, 1: second) of every pixel's Box-Muller pair in Philox block `field`."""
+    """Normal `comp` (0: first, 1: second) of every pixel's table-inversion deviate pair (the two halves of one word) in Philox block `field`."""
     out = np.empty(n_pix, dtype=np.float32)
     lib().oracle_philox_gauss_field(C.c_uint64(seed), C.c_uint32(clip_id & 0xFFFFFFFF), C.c_uint32(field),
                                     C.c_uint32(stream), C.c_int64(n_pix), C.c_int(comp), C.c_int(rounds), _p(out))

@@ -122,7 +122,7 @@ static double px_uniform53(uint64_t seed, uint32_t clip, uint32_t field, uint32_
     return (p & 1u) ? uniform53(c[2], c[3]) : uniform53(c[0], c[1]);
 }
 
-/* normal `comp` (0/1) of pixel p's Box-Muller pair in block `field`: word p&3 of Philox block (p>>2, field, clip, stream) */
+/* normal `comp` (0/1) of pixel p's table-inversion deviate pair in block `field`: word p&3 of Philox block (p>>2, field, clip, stream) */
 static float px_gauss_r(uint64_t seed, uint32_t clip, uint32_t field, uint32_t stream, uint32_t p, int comp, int rounds)
 {
     uint32_t c[4] = {p >> 2, field, clip, stream};

@@ -169,9 +169,9 @@ def philox_uniform53(seed: int, clip_id: int, field: int, n_pix: int, stream: in
 
 
 def philox_gauss32(seed: int, clip_id: int, field: int, n_pix: int, stream: int = STREAM_ESIM, comp: int = 0, rounds: int = 10):
-    """float32 standard normals from Philox words through the 16+16-bit fp32 Box-Muller of oracle/v2v_oracle.c
-    (bit-identical op sequence to the device's; needs the built C oracle because NumPy has no fma).
-    Pixel p: word p&3 of block (p>>2, field, clip_id, stream) -> one Box-Muller pair; comp picks its member."""
+    """float32 standard normals from Philox words by direct table inversion (oracle/v2v_oracle.c: each 16-bit half of a word
+    indexes the 8192-entry inverse-CDF table oracle/gauss_icdf.inc, sign from the top bit -- the same data the device holds).
+    Pixel p: word p&3 of block (p>>2, field, clip_id, stream) -> one deviate pair (low half, high half); comp picks its member."""
     from oracle import clib  # local import: the C twin is optional for everything else
     return clib.philox_gauss_field(seed, clip_id, field, n_pix, stream, comp, rounds)
 
@@ -192,7 +192,7 @@ class PhiloxFieldRNG:
 
     def randn(self, h, w):
         # draw 0: hot-pixel normals (first member of block 2); draw 1+k: base noise of frame pair k = member k&1 of
-        # block 3 + (k>>1) -- one Philox block and one Box-Muller pair per pixel serve two consecutive pairs
+        # block 3 + (k>>1) -- one Philox block and one deviate pair (one word) per pixel serve two consecutive pairs
         from oracle import clib
         if self._n_randn == 0:
             field, comp, rounds = FIELD_HOT_GAUSS, 0, 10

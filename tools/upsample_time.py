@@ -1,5 +1,5 @@
 """Time v2v_upsample2x_nhwc_hip at the decoder levels of the E2VID-shaped network (8 clips, 256x256 input), per rows-per-work-item
-setting (V2V_UP_RS experiment knob; unset = the launcher's choice) and check every setting against rs = 1 bit for bit."""
+setting (V2V_UP_RS knob of a tuning build: make -C v2v_amd/csrc EXTRA=-DV2V_TUNING_KNOBS; unset = the launcher's choice) and check every setting against rs = 1 bit for bit."""
 import os
 import sys
 

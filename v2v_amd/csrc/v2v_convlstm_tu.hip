@@ -201,8 +201,11 @@ hipError_t launch_upsample2x_nhwc(const uint16_t *x, const uint16_t *skip, uint1
     // 38.1 / 30.0 / 25.6 / 30.8 -> 4 rows where that leaves >= 2048 waves, else 1 (tools/upsample_time.py)
     const int64_t cols = (int64_t)B * W * (C / 8);
     int rs = 4;
-    if (const char *e = getenv("V2V_UP_RS")) rs = atoi(e) > 0 ? atoi(e) : rs;    // EXPERIMENT knob (tools/upsample_time.py)
-    else if (cols * ((H + rs - 1) / rs) < 2048 * 64) rs = 1;
+#ifdef V2V_TUNING_KNOBS                                                           // tuning builds only (tools/upsample_time.py): never in the product launch path
+    if (const char *e = getenv("V2V_UP_RS")) rs = atoi(e) > 0 ? atoi(e) : rs;
+    else
+#endif
+    if (cols * ((H + rs - 1) / rs) < 2048 * 64) rs = 1;
     const int64_t n = cols * ((H + rs - 1) / rs);
     if (n >= (int64_t)1 << 31) return hipErrorInvalidValue;
     hipLaunchKernelGGL(upsample2x_nhwc_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, skip, out, B, H, W, C, rs);

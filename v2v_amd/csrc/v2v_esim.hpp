@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
 
     const bool has_base = __builtin_amdgcn_readfirstlane((int)(base_std != 0.0)) != 0;   // per clip: a scalar branch
     // base-noise normals of the odd pair of each (even, odd) couple of time steps: one Philox block and four
-    // Box-Muller pairs feed 4 pixels x 2 steps (v2v_rng.hpp); drawn at the even step, consumed at the odd one
+    // table-inversion deviate pairs (the two 16-bit halves of a word, v2v_rng.hpp) feed 4 pixels x 2 steps; drawn at the even step, consumed at the odd one
     float g_pend[NOISE ? VEC : 1];
 #pragma unroll
     for (int j = 0; j < (NOISE ? VEC : 1); ++j) g_pend[j] = 0.0f;

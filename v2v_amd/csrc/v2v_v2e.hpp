@@ -563,7 +563,7 @@ __device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, 
 #pragma unroll
     for (int j = 0; j < VEC; ++j) gleak_pend[j] = 0.0f;
 
-    // PAR (compile-time): k & 1 -- the leak-jitter normals come as Box-Muller pairs shared by two consecutive frame pairs
+    // PAR (compile-time): k & 1 -- the leak-jitter normals come as deviate pairs (the two 16-bit halves of one Philox word, table inversion) shared by two consecutive frame pairs
     auto step = [&](auto par_tag, int k, const Raw<IN, VEC> &raw) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_tag)::value;
         const int i = k + 1;
@@ -594,7 +594,7 @@ __device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, 
         float gleak[VEC];
         float u_sp[VEC], u_sn[VEC];
         if constexpr (RNG == kRngPhilox) {
-            if (leak) {                     // one Box-Muller pair per pixel and couple of frame pairs (2m, 2m+1): block of couple m
+            if (leak) {                     // one deviate pair (one Philox word) per pixel and couple of frame pairs (2m, 2m+1): block of couple m
                 if constexpr (PAR == 0) field_gauss_pairs<VEC, kNoiseRounds>(a.seed, clip_id, kV2eFFrame0 + kV2eFStride * (uint32_t)(k >> 1) + 2u, kStreamV2e, p0, s_icdf, gleak, gleak_pend);
                 else {
 #pragma unroll
@@ -644,10 +644,13 @@ __device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, 
         }
 
         // ---- low pass, leak, event map.  floor_divide(clip(+-diff, 0), thres): the quotient is ESTIMATED in float32 --
-        // trunc(float(diff) * reciprocal), reciprocal biased low by 2^-22 so that the two float32 roundings (2^-24 each) can
-        // never lift the estimate above the true quotient; v_cvt_u32_f32 clips the negative side to 0 -- and VERIFIED in float64
-        // with the exact fma residual 0 <= diff - q*thres < thres (sign-exact).  An estimate one short, a quotient beyond
-        // float32's integers or a non-finite operand fail the check and send the wave down the exact float64 path below.
+        // trunc(float(diff) * reciprocal); v_cvt_u32_f32 clips the negative side to 0.  The estimate can never EXCEED the true
+        // quotient: reciprocal = fl32(fl64(1/thres) * (1 - 2^-22)), and the three float32 roundings on the way (the reciprocal's,
+        // float(diff)'s, the product's: <= 2^-24 each, plus 2^-53 of the float64 division) leave the real value of the product at
+        // most diff/thres * (1 - 2^-22)(1 + 2^-24)^3(1 + 2^-53) < diff/thres * (1 - 2^-24), and truncation only lowers it.  So only
+        // the UPPER bound needs a run-time test: the exact (sign-exact fma) float64 residual diff - q*thres < thres.  An estimate
+        // one short, a quotient beyond float32's integers or a non-finite operand fail it and send the wave down the exact
+        // float64 path below (the lower bound 0 <= residual holds by the inequality above and is not tested).
         uint32_t qp[VEC], qn[VEC];
         unsigned long long fix = 0;                       // wave-level masks (SGPR pairs): no per-lane bool materialised
         auto cur_diff = [&](int j) -> double {            // lp - base in NumPy's dtypes (recomputed by the rare fix-up path)
