@@ -525,6 +525,15 @@ def main():
             except Exception as exc:  # noqa: BLE001 - a secondary figure must not take the headline down
                 also[name] = {"error": f"{type(exc).__name__}: {exc}"}
         try:
+            # what train.py would receive through the drop-in loader at the reference's training shape (B = 12, 201 x 128 x 128 ->
+            # [12,40,5,128,128]): samples/s, host us per batch by stage, GPU-busy fraction, next to the round-2/3 loader and to the
+            # reference's deployment (NumPy port inside 9 DataLoader workers) on the same clips -- tools/loader_bench.py
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import loader_bench
+            also["train_loader_b12_201x128x128"] = loader_bench.measure(batches=200, workers=9, batch=12, dev=dev, simulating_batches=40)
+        except Exception as exc:  # noqa: BLE001
+            also["train_loader_b12_201x128x128"] = {"error": f"{type(exc).__name__}: {exc}"}
+        try:
             also["convlstm_step_mfma"] = convlstm_roofline(torch, dev)
         except Exception as exc:  # noqa: BLE001
             also["convlstm_step_mfma"] = {"error": f"{type(exc).__name__}: {exc}"}

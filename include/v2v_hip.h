@@ -342,6 +342,13 @@ int v2v_conv1x1_nhwc_hip(const void *x, const void *skip, const float *weight, c
  * model/submodules.py:267-271 RecurrentConvLayer = ConvLayer(relu) -> ConvLSTM).  C % 64 == 0 and (H*W) % 64 == 0. */
 int v2v_nchw_to_nhwc_bf16_hip(const void *src, int src_dtype, int64_t B, int64_t C, int64_t H, int64_t W, int relu, void *dst, void *stream);
 
+/* The `frame` tensor of a batch from the uint8 clips already in HBM (WebvidDatasetV2.__getitem__, data/v2v_datasets.py:329-338, 352:
+ * frame[l] = float(all_imgs[idx_l]).permute(2,0,1) / 255): out[b,l,c,y,x] = float(src[b, pick[l], y, x, c]) / 255.0f (IEEE division:
+ * torch's CPU values bit for bit).  src uint8 [B, *, H, W, C] with element strides clip_stride / frame_stride; pick = L device int32
+ * frame indices (NULL: frames 0..L-1); out float32 [B,L,C,H,W] contiguous.  C >= 1. */
+int v2v_clip_frames_f32_hip(const void *src, int64_t clip_stride, int64_t frame_stride, const int32_t *pick, int64_t B, int64_t L, int64_t H,
+                            int64_t W, int64_t C, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -108,3 +108,35 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert res.returncode != 0 and "WORLD_SIZE=1" in (res.stderr + res.stdout)
+
+
+def test_pause_chain_draws_equal_the_scalar_loop(tmp_path):
+    """_draw_geometry draws the pause chain's uniforms in ONE np.random.rand(n) call.  The reference's loop
+    (data/v2v_datasets.py:292-300) calls np.random.rand() once per step (the other test of the if / elif short-circuits before its
+    draw): restated here literally with scalar draws -- same frame indices, same stream state afterwards, for running-heavy,
+    pause-heavy and extreme probabilities."""
+    from v2v_amd.datasets import WebvidDatasetV2
+    lst = _mk_list(tmp_path, [["a.mp4", 450, 0.2, 0.3]])
+    for p_run, p_paused, extra in ((0.0102, 0.9791, {}), (0.3, 0.5, {"output_additional_evs": True}), (0.0, 0.98, {}), (1.0, 0.0, {}), (0.5, 1.0, {})):
+        ds = WebvidDatasetV2(str(tmp_path), dict({"video_list_file": lst, "crop_size": 32, "video_size": (640, 360), "frame_source": lambda *a: [],
+                                                  "proba_pause_when_running": p_run, "proba_pause_when_paused": p_paused, "fixed_crop": True,
+                                                  "random_flip": False, "min_resize_scale": 1, "max_resize_scale": 1}, **extra))
+        for seed in range(5):
+            np.random.seed(seed)
+            np.random.uniform(1, 1)                                                   # the resize-scale draw in front of the chain (:272)
+            img_idxes, idx, is_pause = [], 0, False
+            additional = ds.frames_per_img if ds.output_additional_evs else 0
+            for _ in range(ds.L * ds.frames_per_img + 1 + additional):
+                img_idxes.append(idx)
+                if is_pause and np.random.rand() > ds.proba_pause_when_paused:
+                    is_pause = False
+                elif not is_pause and np.random.rand() < ds.proba_pause_when_running:
+                    is_pause = True
+                if not is_pause:
+                    idx += 1
+            want_state = np.random.get_state()
+            np.random.seed(seed)
+            _, start, end, _, _, _, _, got, _ = ds._draw_geometry(0)
+            st = np.random.get_state()
+            assert got == img_idxes and end - start == idx + 1
+            assert np.array_equal(st[1], want_state[1]) and st[2:] == want_state[2:]

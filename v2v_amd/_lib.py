@@ -26,7 +26,7 @@ EXPORTS = ("v2v_version", "v2v_last_error", "v2v_device_count", "v2v_lut_get", "
            "v2v_normalize_pad_hip", "v2v_postops_workspace_bytes",
            "v2v_convlstm_packed_bytes", "v2v_convlstm_pack_weights_hip", "v2v_convlstm_step_hip", "v2v_nchw_to_nhwc_bf16_hip",
            "v2v_conv3x3_pack_weights_hip", "v2v_conv3x3_nhwc_hip", "v2v_conv_pack_weights_hip", "v2v_conv_nhwc_hip", "v2v_upsample2x_nhwc_hip", "v2v_conv1x1_nhwc_hip", "v2v_conv_packed_elems", "v2v_conv_head_packed_elems", "v2v_conv_head_pack_weights_hip",
-           "v2v_to_nhwc8_bf16_hip", "v2v_conv_head_nhwc_hip")
+           "v2v_to_nhwc8_bf16_hip", "v2v_conv_head_nhwc_hip", "v2v_clip_frames_f32_hip")
 EV_MAKE_VOXEL_DISCRETE, EV_MAKE_VOXEL_INTERP, EV_BILINEAR = 0, 1, 2
 NORM_NONE, NORM_RADIX, NORM_COUNT = 0, 1, 2
 
@@ -154,6 +154,9 @@ def lib():
     L.v2v_upsample2x_nhwc_hip.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     L.v2v_nchw_to_nhwc_bf16_hip.restype = C.c_int
     L.v2v_nchw_to_nhwc_bf16_hip.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    L.v2v_clip_frames_f32_hip.restype = C.c_int
+    L.v2v_clip_frames_f32_hip.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                          C.c_void_p, C.c_void_p]
     L.v2v_v2e_workspace_bytes.restype = C.c_int64
     L.v2v_v2e_workspace_bytes.argtypes = [C.c_int64, C.c_int64]
     L.v2v_v2e_voxel_hip.restype = C.c_int

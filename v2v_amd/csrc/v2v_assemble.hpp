@@ -1,0 +1,50 @@
+// v2v_assemble.hpp -- the `frame` tensor of a batch, built on the device from the uint8 clips the simulator reads (gfx950).
+//
+// Replaces the per-sample assembly of WebvidDatasetV2.__getitem__ (data/v2v_datasets.py:329-338, 352):
+//     frame[l] = torch.tensor(all_imgs[idx_l]).float().permute(2, 0, 1) / 255          idx_l = (l+1)*frames_per_img (or l*..)
+// for the whole batch: out[b, l, c, y, x] = float(src[b, pick[l], y, x, c]) / 255.0f.  The division is IEEE float32 division
+// (the library is built without fast-math; v_div_scale / v_div_fmas / v_div_fixup), i.e. torch's CPU result bit for bit --
+// tests/test_loader.py checks all 256 values.  HBM-bound: L*H*W*C bytes read, 4x that written, per clip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace v2v {
+
+// C == 1, HW % 4 == 0, 4-byte aligned rows: a work-item converts 4 pixels (one dword in, 16 bytes out)
+__global__ void __launch_bounds__(256) clip_frames4_kernel(const uint8_t *src, int64_t clip_stride, int64_t frame_stride, const int32_t *pick,
+                                                           int L, int HW4, float *out)
+{
+    const int bl = blockIdx.y;                                   // b * L + l
+    const int b = bl / L, l = bl - b * L;
+    const int f = pick ? pick[l] : l;
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(src + (int64_t)b * clip_stride + (int64_t)f * frame_stride);
+    float4 *o = reinterpret_cast<float4 *>(out + (int64_t)bl * HW4 * 4);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW4; i += gridDim.x * 256) {
+        const uint32_t v = __builtin_nontemporal_load(s + i);
+        float4 r;
+        r.x = (float)(v & 255u) / 255.0f;
+        r.y = (float)((v >> 8) & 255u) / 255.0f;
+        r.z = (float)((v >> 16) & 255u) / 255.0f;
+        r.w = (float)(v >> 24) / 255.0f;
+        o[i] = r;
+    }
+}
+
+// any C (interleaved HWC source -> planar CHW output), any alignment: a work-item per (pixel, channel)
+__global__ void __launch_bounds__(256) clip_frames_kernel(const uint8_t *src, int64_t clip_stride, int64_t frame_stride, const int32_t *pick,
+                                                          int L, int HW, int C, float *out)
+{
+    const int bl = blockIdx.y;
+    const int b = bl / L, l = bl - b * L;
+    const int f = pick ? pick[l] : l;
+    const uint8_t *s = src + (int64_t)b * clip_stride + (int64_t)f * frame_stride;
+    float *o = out + (int64_t)bl * HW * C;
+    const int n = HW * C;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int c = i / HW, p = i - c * HW;                   // output order: channel-major planes
+        o[i] = (float)s[(int64_t)p * C + c] / 255.0f;
+    }
+}
+
+}  // namespace v2v

@@ -17,6 +17,7 @@
 #include "v2v_frontend.hpp"
 #include "v2v_postops.hpp"
 #include "v2v_synth.hpp"
+#include "v2v_assemble.hpp"
 
 namespace {
 
@@ -227,6 +228,32 @@ int v2v_esim_voxel_padded_hip(const void *frames, int in_dtype, int64_t B, int64
     e = in_dtype == V2V_U8 ? v2v::launch_esim_u8(vec, bin_mode, rng_mode, noise, out64, a, grid, lds, s)
                            : v2v::launch_esim_f32(vec, bin_mode, rng_mode, noise, out64, a, grid, lds, s);
     return e == hipSuccess ? V2V_OK : hip_fail(e, "esim_voxel_kernel launch");
+}
+
+int v2v_clip_frames_f32_hip(const void *src, int64_t clip_stride, int64_t frame_stride, const int32_t *pick, int64_t B, int64_t L, int64_t H,
+                            int64_t W, int64_t C, float *out, void *stream)
+{
+    if (!src || !out) return fail(V2V_ERR_NULL, "v2v_clip_frames_f32_hip: src/out is NULL");
+    if (B < 0 || L < 1 || H < 1 || W < 1 || C < 1 || C > 4) return fail(V2V_ERR_SHAPE, "need B>=0, L,H,W>=1, 1<=C<=4");
+    const int64_t HW = H * W;
+    if (HW * C >= (int64_t)1 << 30 || B * L > 0x7FFFFFFF) return fail(V2V_ERR_SHAPE, "frame or batch too large");
+    if (frame_stride < HW * C || (B > 1 && clip_stride < frame_stride)) return fail(V2V_ERR_SHAPE, "strides smaller than the extent");
+    if (!aligned(out, 4)) return fail(V2V_ERR_ALIGN, "out must be 4-byte aligned");
+    if (B == 0) return V2V_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint8_t *sp = static_cast<const uint8_t *>(src);
+    const bool v4 = C == 1 && HW % 4 == 0 && frame_stride % 4 == 0 && (B == 1 || clip_stride % 4 == 0) && aligned(src, 4) && aligned(out, 16);
+    if (v4) {
+        const int hw4 = (int)(HW / 4);
+        const unsigned gx = (unsigned)std::min<int64_t>((hw4 + 255) / 256, 64);
+        hipLaunchKernelGGL(v2v::clip_frames4_kernel, dim3(gx, (unsigned)(B * L)), dim3(256), 0, s, sp, clip_stride, frame_stride, pick, (int)L, hw4, out);
+    } else {
+        const int64_t n = HW * C;
+        const unsigned gx = (unsigned)std::min<int64_t>((n + 255) / 256, 256);
+        hipLaunchKernelGGL(v2v::clip_frames_kernel, dim3(gx, (unsigned)(B * L)), dim3(256), 0, s, sp, clip_stride, frame_stride, pick, (int)L, (int)HW, (int)C, out);
+    }
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "clip_frames kernel launch");
 }
 
 int v2v_synth_clips_hip(void *frames, int dtype, int64_t B, int64_t N, int64_t H, int64_t W, uint64_t seed,
@@ -557,7 +584,7 @@ int v2v_normalize_pad_ex_hip(const float *voxel, int64_t B, int64_t planes, int6
             hipLaunchKernelGGL(v2v::count_hist_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, voxel, per_in, hist, bad);
         }
         hipLaunchKernelGGL(v2v::count_pick_kernel, dim3((unsigned)(B * 2)), dim3(64), 0, s, st, hist, bad, B * 2,
-                           (uint64_t)(per_in - per_sample), (uint64_t)(min_k - 1), (uint64_t)(max_k - 1));
+                           (uint64_t)(per_in - per_sample), (uint64_t)(min_k - 1), (uint64_t)(max_k - 1), 0, (uint64_t)per_sample, (float *)nullptr);
     }
     const int64_t per_out = planes * Hp * Wp;
     const bool rows4 = W % 4 == 0 && Wp % 4 == 0 && W_in % 4 == 0 && planes * Hp < ((int64_t)1 << 31) &&

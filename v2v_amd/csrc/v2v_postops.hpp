@@ -219,11 +219,16 @@ __global__ void __launch_bounds__(256) normalize_pad_rows_kernel(const float *x,
     }
 }
 
-// ---- counting path (integer-valued voxels, |v| <= kCntMax) ------------------------------------------------------------
-constexpr int kCntMax = 255, kCntBins = 2 * kCntMax + 1;
+// ---- counting path (integer-valued voxels) ----------------------------------------------------------------------------
+// Bins for the integers -255..255 plus one OVERFLOW bin per side (everything below -255 / above 255): hot pixels (<= 0.1 % of the
+// pixels, hot_pixel_std up to 10 in the training configuration = hundreds of events per frame) land there, far outside the 1 % the
+// k-th values cut off on each side.  A rank that does fall into an overflow bin has no exact answer here: that sample's k-th value
+// is NaN (loud), as for a sample holding a non-integer.
+constexpr int kCntMax = 255, kCntZero = kCntMax + 1, kCntBins = 2 * kCntMax + 3;
+__device__ __forceinline__ int cnt_bin(int iv) { return (iv < -kCntMax - 1 ? -kCntMax - 1 : iv > kCntMax + 1 ? kCntMax + 1 : iv) + kCntZero; }
 
-// hist[sample][v + kCntMax] += 1 over the sample's (possibly padded) planes; bad[sample] != 0 if a value is not an integer
-// in range.  Zeros (the bulk of a voxel grid) are counted per wave with one ballot instead of 64 same-address LDS atomics.
+// hist[sample][bin(v)] += 1 over the sample's (possibly padded) planes; bad[sample] != 0 if a value is not an integer.
+// Zeros (the bulk of a voxel grid) are counted per wave with one ballot instead of 64 same-address LDS atomics.
 __global__ void __launch_bounds__(256) count_hist_kernel(const float *x, int64_t per_sample, unsigned int *hist, unsigned int *bad)
 {
     __shared__ unsigned int lh[kCntBins + 1];
@@ -238,13 +243,13 @@ __global__ void __launch_bounds__(256) count_hist_kernel(const float *x, int64_t
         const bool in = i < per_sample;
         const float v = in ? xs[i] : 0.0f;
         const int iv = (int)v;
-        const bool ok = (float)iv == v && iv >= -kCntMax && iv <= kCntMax;
+        const bool ok = (float)iv == v;
         any_bad |= in && !ok;
         const unsigned long long zmask = __ballot(in && v == 0.0f);
         if ((threadIdx.x & 63) == 0) zeros += (unsigned int)__popcll(zmask);
-        if (in && ok && iv != 0) atomicAdd(&lh[iv + kCntMax], 1u);
+        if (in && ok && iv != 0) atomicAdd(&lh[cnt_bin(iv)], 1u);
     }
-    if ((threadIdx.x & 63) == 0 && zeros) atomicAdd(&lh[kCntMax], zeros);
+    if ((threadIdx.x & 63) == 0 && zeros) atomicAdd(&lh[kCntZero], zeros);
     if (any_bad) lh[kCntBins] = 1u;                             // benign race: every writer stores 1
     __syncthreads();
     unsigned int *gh = hist + (int64_t)sample * kCntBins;
@@ -253,8 +258,6 @@ __global__ void __launch_bounds__(256) count_hist_kernel(const float *x, int64_t
     if (threadIdx.x == 0 && lh[kCntBins]) atomicExch(&bad[sample], 1u);
 }
 
-// one thread per (sample, which): walk the cumulative counts to the bin holding 0-based rank k; pad zeros (n_pad per sample,
-// counted with the data) are removed from bin 0 first.  A sample with a bad value gets NaN k-th values (its output is NaN).
 // The same histogram with 16-byte loads; the three values that fill a voxel grid (0 and +-1) are counted per wave with one ballot each
 // (64 lanes adding to the same LDS word serialise), everything else goes to the LDS word of its value.  Measured and not kept:
 // peeling EVERY distinct value of the wave by ballot -- exact and atomic-free, but 13 distinct values (a uniform test pattern)
@@ -279,18 +282,18 @@ __global__ void __launch_bounds__(256) count_hist4_kernel(const float *x, int64_
             const bool in = e < 4 ? ina : inb;
             const float v = vv[e];
             const int iv = (int)v;
-            const bool ok = (float)iv == v && iv >= -kCntMax && iv <= kCntMax;
+            const bool ok = (float)iv == v;
             any_bad |= in && !ok;
             n0 += (unsigned int)__popcll(__ballot(in && v == 0.0f));
             np += (unsigned int)__popcll(__ballot(in && v == 1.0f));
             nm += (unsigned int)__popcll(__ballot(in && v == -1.0f));
-            if (in && ok && (iv > 1 || iv < -1)) atomicAdd(&lh[iv + kCntMax], 1u);
+            if (in && ok && (iv > 1 || iv < -1)) atomicAdd(&lh[cnt_bin(iv)], 1u);
         }
     }
     if ((threadIdx.x & 63) == 0) {
-        if (n0) atomicAdd(&lh[kCntMax], n0);
-        if (np) atomicAdd(&lh[kCntMax + 1], np);
-        if (nm) atomicAdd(&lh[kCntMax - 1], nm);
+        if (n0) atomicAdd(&lh[kCntZero], n0);
+        if (np) atomicAdd(&lh[kCntZero + 1], np);
+        if (nm) atomicAdd(&lh[kCntZero - 1], nm);
     }
     if (any_bad) lh[kCntBins] = 1u;                             // benign race: every writer stores 1
     __syncthreads();
@@ -300,10 +303,13 @@ __global__ void __launch_bounds__(256) count_hist4_kernel(const float *x, int64_
     if (threadIdx.x == 0 && lh[kCntBins]) atomicExch(&bad[sample], 1u);
 }
 
-// One 64-lane workgroup per (sample, side): a lane sums 8 bins, the wave's inclusive prefix finds the lane that holds the rank, that
-// lane walks its 8 bins (round 2 walked the 511 bins of every (sample, side) in ONE work-item: 511 dependent global loads, 44-210 us)
+// One 64-lane workgroup per (sample, side): a lane sums 9 bins, the wave's inclusive prefix finds the lane that holds the rank, that
+// lane walks its bins (round 2 walked the bins of every (sample, side) in ONE work-item: 511 dependent global loads, 44-210 us).
+// The zero bin either holds the counted zeros incl. the n_pad padding zeros (count_hist*: removed here) or -- derive_zero, the
+// histogram the SIMULATOR's writer accumulates (it counts non-zero values only) -- is whatever the other bins leave of n_elems.
+constexpr int kCntPerLane = (kCntBins + 63) / 64;
 __global__ void __launch_bounds__(64) count_pick_kernel(SelectState *st, const unsigned int *hist, const unsigned int *bad, int64_t n_sw, uint64_t n_pad,
-                                                      uint64_t rank_lo, uint64_t rank_hi)
+                                                      uint64_t rank_lo, uint64_t rank_hi, int derive_zero, uint64_t n_elems, float *scales)
 {
     const int64_t sw = blockIdx.x;
     if (sw >= n_sw) return;
@@ -311,12 +317,22 @@ __global__ void __launch_bounds__(64) count_pick_kernel(SelectState *st, const u
     const unsigned int *h = hist + sample * kCntBins;
     const uint64_t rank = (sw & 1) ? rank_hi : rank_lo;
     const int lane = threadIdx.x;
-    uint64_t c[8], mine = 0;
+    uint64_t c[kCntPerLane], mine = 0, nonzero = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int b = lane * 8 + j;
-        c[j] = b < kCntBins ? ((b == kCntMax) ? (uint64_t)h[b] - n_pad : (uint64_t)h[b]) : 0;
+    for (int j = 0; j < kCntPerLane; ++j) {
+        const int b = lane * kCntPerLane + j;
+        c[j] = b < kCntBins ? ((b == kCntZero) ? (derive_zero ? 0 : (uint64_t)h[b] - n_pad) : (uint64_t)h[b]) : 0;
         mine += c[j];
+    }
+    if (derive_zero) {                                          // wave total of the non-zero bins -> the zero bin's count
+        nonzero = mine;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) nonzero += __shfl_xor(nonzero, d);
+        if (lane == kCntZero / kCntPerLane) {
+            const uint64_t z = n_elems > nonzero ? n_elems - nonzero : 0;
+            c[kCntZero % kCntPerLane] = z;
+            mine += z;
+        }
     }
     uint64_t incl = mine;                                       // inclusive prefix sum over the lanes
 #pragma unroll
@@ -329,19 +345,25 @@ __global__ void __launch_bounds__(64) count_pick_kernel(SelectState *st, const u
     const int owner = over ? __builtin_ctzll(over) : 63;
     if (lane != owner) return;
     uint64_t r = rank - (incl - mine);
-    int b = lane * 8;
+    int b = lane * kCntPerLane;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < kCntPerLane; ++j) {
         if (b >= kCntBins - 1 || r < c[j]) break;
         r -= c[j];
         ++b;
     }
     if (b > kCntBins - 1) b = kCntBins - 1;
+    const bool exact = !bad[sample] && b > 0 && b < kCntBins - 1;              // an overflow bin has no single value
+    const float kth = exact ? (float)(b - kCntZero) : __uint_as_float(0x7FC00000u);
     SelectState s;
-    s.prefix = bad[sample] ? float_key(__uint_as_float(0x7FC00000u)) : float_key((float)(b - kCntMax));
+    s.prefix = float_key(kth);
     s.prefix_mask = 0xFFFFFFFFu;
     s.rank = 0;
     st[sw] = s;
+    if (scales) {                                               // (neg_max, pos_max) = clamp(-kth(1 %), min=1), clamp(kth(99 %), min=1)
+        const float m = (sw & 1) ? kth : -kth;
+        scales[sw] = m < 1.0f ? 1.0f : m;                       // a NaN stays a NaN (m < 1 is false)
+    }
 }
 
 }  // namespace v2v

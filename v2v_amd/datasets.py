@@ -369,12 +369,9 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
         return params, (vox.cpu().numpy() if is_np else vox)
 
     # ------------------------------------------------------------------ sample assembly
-    def __getitem__(self, sample_idx):
-        old_state = None
-        if self.fixed_seed is not None:
-            # the reference reads an unbound `idx` here (UnboundLocalError); the intended key is the sample index
-            old_state = np.random.get_state()
-            np.random.seed(self.fixed_seed + int(sample_idx))
+    def _draw_geometry(self, sample_idx):
+        """The per-sample draws in front of the decode, in the reference's order (:260-301): resize scale, crop origin, flip, pause
+        chain.  Returns (video_path, start_frame, end_frame, crop_before, min_i, min_j, flip, img_idxes, img_cnt)."""
         video_name = self.sample_video_name[sample_idx]
         start_frame = int(self.sample_begin_idx[sample_idx])
         img_cnt = int(self.sample_L[sample_idx])
@@ -396,16 +393,79 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
 
         # pause schedule: a two-state Markov chain deciding which decoded frame each simulator frame shows (:286-301)
         extra = self.frames_per_img if self.output_additional_evs else 0
+        # Every step consumes exactly ONE uniform (a paused chain tests `rand() > proba_pause_when_paused`, a running one
+        # `rand() < proba_pause_when_running`; the other test short-circuits before its draw), and legacy np.random.rand(n) IS the
+        # next n scalar draws -- so the chain's uniforms are drawn in one call (tests/test_host_logic.py checks chain and stream state)
+        n_steps = img_cnt * self.frames_per_img + 1 + extra
         img_idxes, idx, paused = [], 0, False
-        for _ in range(img_cnt * self.frames_per_img + 1 + extra):
+        p_stay, p_pause = self.proba_pause_when_paused, self.proba_pause_when_running
+        for u in np.random.rand(n_steps).tolist():
             img_idxes.append(idx)
-            if paused and np.random.rand() > self.proba_pause_when_paused:
-                paused = False
-            elif not paused and np.random.rand() < self.proba_pause_when_running:
+            if paused:
+                if u > p_stay:
+                    paused = False
+            elif u < p_pause:
                 paused = True
             if not paused:
                 idx += 1
-        end_frame = start_frame + idx + 1
+        return video_path, start_frame, start_frame + idx + 1, crop_before, min_i, min_j, flip, img_idxes, img_cnt
+
+    def frame_pick(self, img_cnt=None):
+        """Indices (into the simulator's N frames) of the frames a sample hands out as `frame` (:325-338)."""
+        img_cnt = self.L if img_cnt is None else img_cnt
+        off = self.frames_per_img if self.output_additional_evs else 0                                  # :325-326
+        if not self.output_additional_frame:
+            return [off + (i + 1) * self.frames_per_img for i in range(img_cnt)]                       # :329-333
+        return [off + i * self.frames_per_img for i in range(img_cnt + 1)]                              # :334-338
+
+    def host_sample_into(self, sample_idx, clip_out, params_out, key_out, frames_out=None):
+        """The HOST half of a sample written straight into caller-owned arrays (v2v_amd.loader.RingLoader: slots of page-locked
+        shared memory): same np.random draw order as __getitem__ with `defer_sim: true`, no intermediate stack, no float frames.
+            clip_out   uint8 [N,H,W]    the simulator's frames (pause-index gather applied; gray)
+            params_out float64 [5]      pos_thres, neg_thres, base_noise_std, hot_pixel_fraction, hot_pixel_std
+            key_out    int64 [2]        {seed drawn from np.random, sample index}: the device RNG key of this sample
+            frames_out uint8 [Lf,H,W,3] only for color_mode 'gray_in_bgr_out': the colour frames handed out as `frame`
+        Returns the v2e_params dict."""
+        if self.gpu_frontend:
+            raise NotImplementedError("host_sample_into serves host-decoded clips; gpu_frontend samples are assembled on the device")
+        old_state = None
+        if self.fixed_seed is not None:
+            old_state = np.random.get_state()
+            np.random.seed(self.fixed_seed + int(sample_idx))
+        video_path, start_frame, end_frame, crop_before, min_i, min_j, flip, img_idxes, img_cnt = self._draw_geometry(sample_idx)
+        raw_imgs = self.read_video(video_path, start_frame, end_frame, crop_before, min_i, min_j, flip, sample_idx)
+        if self.video_degrade is not None and np.random.rand() < self.degrade_ratio:                    # :307-308
+            raw_imgs = self.degrade_video(raw_imgs)
+        n = len(img_idxes)
+        assert (n - 1) % (self.num_bins * self.frames_per_bin) == 0                                      # :365
+        if tuple(clip_out.shape) != (n,) + tuple(raw_imgs[0].shape[:2]):
+            raise ValueError(f"clip_out is {tuple(clip_out.shape)}, the clip is {(n,) + tuple(raw_imgs[0].shape[:2])}")
+        if self.color_mode == "gray":
+            for j, i in enumerate(img_idxes):
+                clip_out[j] = raw_imgs[i][..., 0]
+        else:
+            all_imgs = np.stack([raw_imgs[i] for i in img_idxes])
+            clip_out[:] = bgr_to_gray(all_imgs)
+            frames_out[:] = all_imgs[self.frame_pick(img_cnt)]
+        pos = self.sample_pos_thres[sample_idx] if self.use_fixed_thresholds else None
+        neg = self.sample_neg_thres[sample_idx] if self.use_fixed_thresholds else None
+        v2e_params = sample_sim_params(self.threshold_range, self.max_thres_pos_neg_gap, self.base_noise_std_range,
+                                       self.hot_pixel_fraction_range, self.hot_pixel_std_range, self.use_fixed_thresholds,
+                                       pos, neg, self.scale_noise_strength, self.put_noise_external)
+        params_out[:] = [v2e_params[k] for k in ("pos_thres", "neg_thres", "base_noise_std", "hot_pixel_fraction", "hot_pixel_std")]
+        key_out[0] = draw_sim_seed()                                  # same draw order as imgs_to_voxels(sim_rng='philox')
+        key_out[1] = int(sample_idx)
+        if old_state is not None:
+            np.random.set_state(old_state)
+        return v2e_params
+
+    def __getitem__(self, sample_idx):
+        old_state = None
+        if self.fixed_seed is not None:
+            # the reference reads an unbound `idx` here (UnboundLocalError, SURVEY §4); the intended key is the sample index
+            old_state = np.random.get_state()
+            np.random.seed(self.fixed_seed + int(sample_idx))
+        video_path, start_frame, end_frame, crop_before, min_i, min_j, flip, img_idxes, img_cnt = self._draw_geometry(sample_idx)
         if self.gpu_frontend:
             imgs_d, gray = self.read_video_gpu(video_path, start_frame, end_frame, crop_before, min_i, min_j, flip, img_idxes,
                                                sample_idx)
@@ -440,10 +500,9 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
         else:
             pick = [i * self.frames_per_img for i in range(img_cnt + 1)]                                # :334-338
         if isinstance(all_imgs, torch.Tensor):
-            # device frames: v/255 through a table computed on the host, so the float32 values are the reference's
-            # (CPU division) bit for bit whatever division the device's elementwise kernels use
-            table = (torch.arange(256, dtype=torch.float32) / 255).to(all_imgs.device)
-            frames = table[all_imgs[pick].long()].permute(0, 3, 1, 2)                                   # [L,C,H,W] in [0,1]
+            # device frames: v / 255 in the library's own kernel (IEEE float32 division = the reference's CPU values bit for bit)
+            from .loader import clip_frames_f32
+            frames = clip_frames_f32(all_imgs.unsqueeze(0), pick)[0]                                    # [L,C,H,W] in [0,1]
         else:
             frames = torch.from_numpy(all_imgs[pick]).to(torch.float32).permute(0, 3, 1, 2) / 255
         n_ev = img_cnt + 1 if self.output_additional_evs else img_cnt
@@ -493,6 +552,7 @@ class SimulatingCollator:
         # integer SUM-mode grids; radix select when the noise is external).  Then run the model with normalize_voxels: false.
         self.pad_to, self.normalize = int(pad_to), bool(normalize)
         self._stager = stager                     # a shared v2v_amd.staging.HostStager; one is created on first use otherwise
+        self.timers = None                        # optional dict: host seconds per stage (tools/loader_bench.py)
 
     @property
     def stager(self):
@@ -516,8 +576,17 @@ class SimulatingCollator:
         from torch.utils.data import default_collate
         return self.simulate(default_collate(samples))
 
+    def _t(self, key, t0):
+        if self.timers is not None:
+            import time
+            self.timers[key] = self.timers.get(key, 0.0) + (time.perf_counter() - t0)
+        import time as _time
+        return _time.perf_counter()
+
     def simulate(self, batch):
         """batch = default-collated deferred samples (sim_frames [B,N,H,W] uint8, sim_params [B,5], sim_key [B,2])."""
+        import time
+        t0 = time.perf_counter()
         batch = dict(batch)
         clips, params, keys = batch.pop("sim_frames"), batch.pop("sim_params"), batch.pop("sim_key")
         staged = batch.pop("_staged_clips", None)     # SimulatingLoader started this batch's H2D copy one batch ahead
@@ -527,24 +596,25 @@ class SimulatingCollator:
             clips = self.stager.ready(self.stager.stage(clips))   # page-locked double buffers + copy stream (v2v_amd/staging.py)
         pa = params.cpu().numpy()
         no_noise = bool((pa[:, 2] == 0).all() and (pa[:, 3] <= 0).all())
+        t0 = self._t("stage_ready", t0)
         vox = esim.esim_voxel_batch(clips, params.to(self.device), bin_mode="sum", num_bins=self.num_bins,
                                     frames_per_bin=self.frames_per_bin, rng_mode=self.rng_mode, clip_keys=keys,
                                     put_noise_external=self.put_noise_external, no_noise=no_noise, pad_to=self.pad_to)   # [B,L(+1),Tb,Hp,Wp]
+        t0 = self._t("sim", t0)
         if self.normalize:
             from . import postops
             h, w = clips.shape[-2:]
-            # The counting select is exact for integer grids with |v| <= 255 and turns any other sample into NaN.  A SUM bin holds
-            # at most frames_per_bin * (log-intensity range 6.91 + noise excursion) / C events: when the batch's own parameters
-            # cannot rule out |v| > 255 (several frames per bin, very small thresholds), take the radix select instead of
-            # handing NaN samples to training (advisor finding, round 2).
-            noise_span = 8.1 * float(pa[:, 2].max() + pa[:, 4].max())       # table Gaussians end at 4.009 sigma, both signs
-            count_bound = self.frames_per_bin * (6.91 + noise_span) / max(float(pa[:, :2].min()), 1e-12) + 1
-            if self.put_noise_external or count_bound > 255:  # non-integer or possibly large voxels: exact radix select on the unpadded interior
+            # exact counting select (integers -255..255 + overflow bins for the rare hot pixels) when the batch's own parameters bound
+            # the normal pixels' counts, else the radix select on the unpadded interior (v2v_amd/loader.py:choose_normalize_method)
+            from .loader import choose_normalize_method
+            if choose_normalize_method(pa, self.frames_per_bin, self.put_noise_external) == "radix":
                 vox = postops.normalize_and_pad(vox[..., :h, :w], True, self.pad_to, method="radix")
             else:
                 vox = postops.normalize_and_pad(vox, True, self.pad_to, method="count", valid_hw=(h, w), inplace=True)
+        t0 = self._t("postops", t0)
         batch["events"] = vox.to(self.output_device)
         batch["frame"] = batch["frame"].to(self.output_device)
+        self._t("to_output_device", t0)
         return batch
 
 
@@ -566,8 +636,14 @@ class SimulatingLoader:
         # one batch of look-ahead: batch k+1's clips cross PCIe (page-locked double buffers, copy stream) while batch k is
         # simulated; the simulator's stream only waits on the copy's event
         it = iter(self.loader)
-        stage = (lambda raw: dict(raw, _staged_clips=self.collator.stager.stage(raw["sim_frames"]))) \
-            if self.collator.device.type == "cuda" else (lambda raw: raw)
+        def stage(raw):
+            if self.collator.device.type != "cuda":
+                return raw
+            import time
+            t0 = time.perf_counter()
+            out = dict(raw, _staged_clips=self.collator.stager.stage(raw["sim_frames"]))
+            self.collator._t("stage_copy", t0)
+            return out
         try:
             nxt = stage(next(it))
         except StopIteration:

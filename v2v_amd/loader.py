@@ -1,0 +1,343 @@
+"""RingLoader -- the batch loader of the drop-in path: what `train.py:52-65` builds (DataLoader over the dataset, default collate,
+`.to(device)` per tensor, train.py:76-82) re-laid for one-process-per-GPU on MI355X.
+
+    loader = RingLoader(dataset, batch_size=12, sampler=sampler, num_workers=9, drop_last=True, pad_to=16, normalize=True)
+    for batch in loader: ...   # the reference's batch dict: frame [B,L,C,H,W] f32, events [B,L,Tb,Hp,Wp] f32 (both on the GPU),
+                               # data_source_idx [B] int64, v2e_params {5 x [B] float64}
+
+Why not DataLoader + default_collate + SimulatingCollator (the round-2/3 path, kept in v2v_amd/datasets.py): per batch of 12
+training samples that path moves 39.5 MB of uint8 clips and 31 MB of float frames through (worker) np.stack -> torch tensor ->
+default_collate copy -> shared-memory copy -> (main) page-locked copy -> H2D, builds the float frames on the host, and crosses
+PCIe with both.  Here:
+  * fork()ed DataLoader workers (they never touch HIP) write each sample's uint8 clip, its five simulator parameters and its
+    RNG key STRAIGHT into a slot of a ring of shared memory that the GPU process has page-locked (hipHostRegister): no stack,
+    no collate copy, no queue payload (a worker returns the slot number), no staging copy in the GPU process;
+  * the GPU process issues ONE asynchronous H2D copy per batch (the whole slot: clips + parameters + keys) on a copy stream,
+    one batch ahead of the compute stream;
+  * the `frame` tensor is produced on the device from the clip that is already there (v2v_clip_frames_f32_hip), so float frames
+    never exist on the host or on PCIe (colour frames of 'gray_in_bgr_out' travel as uint8);
+  * simulator (+ x16 padding in place, + normalize_batch_voxel) = the fused launches of v2v_amd.esim / v2v_amd.postops on the
+    compute stream.
+Every sample gets exactly what WebvidDatasetV2.__getitem__ / SimulatingCollator give for the same np.random draws
+(tests/test_loader.py).  Samplers, shuffling, worker seeding, drop_last and persistent workers are torch's own DataLoader's.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import mmap
+import time
+
+import numpy as np
+import torch
+from torch.utils.data import BatchSampler, ConcatDataset, DataLoader, RandomSampler, SequentialSampler
+
+from . import _lib, esim
+
+_PARAM_KEYS = ("pos_thres", "neg_thres", "base_noise_std", "hot_pixel_fraction", "hot_pixel_std")
+
+
+def clip_frames_f32(src: torch.Tensor, pick=None, frames: int | None = None) -> torch.Tensor:
+    """uint8 CUDA [B,T,H,W] (gray) or [B,T,H,W,C] -> float32 [B,L,C,H,W] = src[:, pick] / 255 (data/v2v_datasets.py:329-338,352),
+    IEEE division on the device = torch's CPU values bit for bit.  pick: int32 CUDA tensor / list of frame indices (None: the first
+    `frames` frames, default all)."""
+    _lib.require_gpu()
+    if not src.is_cuda or src.dtype != torch.uint8 or src.ndim not in (4, 5):
+        raise ValueError("src must be a uint8 CUDA tensor [B,T,H,W] or [B,T,H,W,C]")
+    if src.ndim == 4:
+        src = src.unsqueeze(-1)
+    b, t, h, w, c = src.shape
+    if src.stride(4) != 1 or src.stride(3) != c or src.stride(2) != w * c:
+        src = src.contiguous()
+    if pick is not None and not isinstance(pick, torch.Tensor):
+        if len(pick) and (min(pick) < 0 or max(pick) >= t):
+            raise IndexError("pick outside the clip")
+        pick = torch.tensor(list(pick), dtype=torch.int32, device=src.device)
+    n_l = int(pick.numel()) if pick is not None else (t if frames is None else int(frames))
+    out = torch.empty((b, n_l, c, h, w), dtype=torch.float32, device=src.device)
+    if b == 0 or n_l == 0:
+        return out
+    with torch.cuda.device(src.device):
+        rc = _lib.lib().v2v_clip_frames_f32_hip(C.c_void_p(src.data_ptr()), src.stride(0) if b > 1 else t * src.stride(1), src.stride(1),
+                                                C.c_void_p(pick.data_ptr()) if pick is not None else None, b, n_l, h, w, c,
+                                                C.c_void_p(out.data_ptr()), _lib.stream_ptr())
+    _lib.check(rc)
+    return out
+
+
+def choose_normalize_method(params: np.ndarray, frames_per_bin: int, put_noise_external: bool) -> str:
+    """'count' (exact counting select over the integers -255..255 with overflow bins) when the batch's own parameters bound every
+    NON-hot pixel's |count| by 255 and hot pixels stay far below the 1 % the quantiles cut off; else 'radix' (any float32 content).
+    A SUM bin of a normal pixel holds at most frames_per_bin * (log-intensity range 6.91 + base-noise excursion) / C events (the
+    table Gaussians end at 4.009 sigma, both signs); a hot pixel adds hot_pixel_std * |g| / C per frame and can exceed 255 -- those
+    land in the overflow bins, which the k-th values never reach while hot pixels are < 0.5 % (hot_pixel_fraction_range ends at
+    0.001 in every shipped config; a sample whose rank does reach an overflow bin comes out NaN, never mis-scaled)."""
+    if put_noise_external:
+        return "radix"
+    c_min = max(float(params[:, :2].min()), 1e-12)
+    bound = frames_per_bin * (6.91 + 8.1 * float(params[:, 2].max())) / c_min + 1
+    return "count" if bound <= 255 and float(params[:, 3].max()) < 0.005 else "radix"
+
+
+# --------------------------------------------------------------------------------------------------------------------- ring
+class _SlotLayout:
+    """Byte layout of one slot: [clips u8 B*N*H*W][colour frames u8 B*Lf*H*W*3 (gray_in_bgr_out only)][params f64 B*5][keys i64 B*2]."""
+
+    def __init__(self, batch, n, h, w, lf, colour):
+        self.batch, self.n, self.h, self.w, self.lf, self.colour = batch, n, h, w, lf, colour
+        al = lambda v: (v + 255) // 256 * 256                           # noqa: E731
+        self.off_clips = 0
+        self.off_frames = al(batch * n * h * w)
+        self.off_params = self.off_frames + (al(batch * lf * h * w * 3) if colour else 0)
+        self.off_keys = self.off_params + al(batch * 5 * 8)
+        self.nbytes = self.off_keys + al(batch * 2 * 8)
+
+    def views(self, buf: np.ndarray):
+        """NumPy views of one slot (a uint8 array of nbytes)."""
+        b, n, h, w = self.batch, self.n, self.h, self.w
+        clips = buf[self.off_clips:self.off_clips + b * n * h * w].reshape(b, n, h, w)
+        frames = buf[self.off_frames:self.off_frames + b * self.lf * h * w * 3].reshape(b, self.lf, h, w, 3) if self.colour else None
+        params = buf[self.off_params:self.off_params + b * 40].view(np.float64).reshape(b, 5)
+        keys = buf[self.off_keys:self.off_keys + b * 16].view(np.int64).reshape(b, 2)
+        return clips, frames, params, keys
+
+    def device_views(self, dbuf: torch.Tensor):
+        b, n, h, w = self.batch, self.n, self.h, self.w
+        clips = dbuf[self.off_clips:self.off_clips + b * n * h * w].view(b, n, h, w)
+        frames = dbuf[self.off_frames:self.off_frames + b * self.lf * h * w * 3].view(b, self.lf, h, w, 3) if self.colour else None
+        params = dbuf[self.off_params:self.off_params + b * 40].view(torch.float64).view(b, 5)
+        keys = dbuf[self.off_keys:self.off_keys + b * 16].view(torch.int64).view(b, 2)
+        return clips, frames, params, keys
+
+
+def _leaf(dataset, idx):
+    """(leaf dataset, local index) through the ConcatDataset nesting of data/data_interface.py:19-27."""
+    while isinstance(dataset, ConcatDataset):
+        if idx < 0:
+            idx += len(dataset)
+        import bisect
+        di = bisect.bisect_right(dataset.cumulative_sizes, idx)
+        idx = idx if di == 0 else idx - dataset.cumulative_sizes[di - 1]
+        dataset = dataset.datasets[di]
+    return dataset, idx
+
+
+def _leaves(dataset):
+    if isinstance(dataset, ConcatDataset):
+        for d in dataset.datasets:
+            yield from _leaves(d)
+    else:
+        yield dataset
+
+
+class _RingDataset(torch.utils.data.Dataset):
+    """What the workers index: item = (sample index, slot, position in the batch).  The sample's host half is written into the
+    slot; only the slot number travels back through the worker queue."""
+
+    def __init__(self, base, ring: np.ndarray, layout: _SlotLayout):
+        self.base, self.ring, self.layout = base, ring, layout
+
+    def __len__(self):
+        return len(self.base)
+
+    def __getitem__(self, item):
+        idx, slot, pos = item
+        leaf, li = _leaf(self.base, idx)
+        clips, frames, params, keys = self.layout.views(self.ring[slot])
+        leaf.host_sample_into(li, clips[pos], params[pos], keys[pos], frames[pos] if frames is not None else None)
+        return slot, leaf.data_source_idx
+
+
+class _SlotBatchSampler:
+    """Wraps a batch sampler: batch number c of the loader's lifetime goes to ring slot c % slots."""
+
+    def __init__(self, batch_sampler, slots, counter):
+        self.batch_sampler, self.slots, self.counter = batch_sampler, slots, counter
+
+    def __len__(self):
+        return len(self.batch_sampler)
+
+    def __iter__(self):
+        for batch in self.batch_sampler:
+            slot = self.counter[0] % self.slots
+            self.counter[0] += 1
+            yield [(int(i), slot, pos) for pos, i in enumerate(batch)]
+
+
+def _ring_collate(items):
+    return items[0][0], [it[1] for it in items]
+
+
+class RingLoader:
+    """See the module docstring.  Arguments as torch's DataLoader where they share a name; the dataset is a
+    v2v_amd.datasets.WebvidDatasetV2 (any `defer_sim` setting; not `gpu_frontend`) or ConcatDatasets of them with one clip shape.
+
+    pad_to / normalize   the consumer-side post-ops done where the voxels are produced (model/train_utils.py:147-166, 322-326): events
+                         are written into the x`pad_to`-padded layout and, with normalize=True, normalize_batch_voxel is applied in
+                         place -- then run the model with normalize_voxels: false.
+    depth                device-side slots (batches in flight on the GPU): 2 = copy of batch k+1 under the compute of batch k.
+    timers               optional dict: accumulates host seconds per stage (wait_batch, h2d_enqueue, sim, postops, frames, assemble)."""
+
+    def __init__(self, dataset, batch_size=1, shuffle=False, sampler=None, num_workers=0, drop_last=True, prefetch_factor=2,
+                 persistent_workers=False, worker_init_fn=None, generator=None, pad_to=1, normalize=False, device="cuda", depth=2,
+                 timers=None):
+        _lib.require_gpu()
+        self.dataset, self.batch_size = dataset, int(batch_size)
+        self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.pad_to, self.normalize = int(pad_to), normalize
+        self.timers = timers
+        leaves = list(_leaves(dataset))
+        if not leaves:
+            raise ValueError("empty dataset")
+        lf0 = leaves[0]
+        shape = lambda d: (d.frames_per_seq + 1, d.crop_size, d.color_mode, len(d.frame_pick()), d.num_bins, d.frames_per_bin,   # noqa: E731
+                           d.put_noise_external, d.output_additional_evs)
+        for d in leaves:
+            if not hasattr(d, "host_sample_into"):
+                raise TypeError("RingLoader needs v2v_amd.datasets.WebvidDatasetV2 leaves")
+            if shape(d) != shape(lf0):
+                raise ValueError("all datasets of a RingLoader must share clip length, crop size, colour mode and binning")
+            if d.shake_frames or d.gpu_frontend:
+                pass                                                       # shake crops back to crop_size on the host; gpu_frontend raises in host_sample_into
+        self.leaf = lf0
+        n, hw = lf0.frames_per_seq + 1, lf0.crop_size
+        self.pick = lf0.frame_pick()
+        self.layout = _SlotLayout(self.batch_size, n, hw, hw, len(self.pick), lf0.color_mode != "gray")
+        if sampler is None:
+            sampler = RandomSampler(dataset, generator=generator) if shuffle else SequentialSampler(dataset)
+        self.num_workers = int(num_workers)
+        self.depth = max(2, int(depth))
+        in_flight = max(1, self.num_workers) * (prefetch_factor if self.num_workers else 1)
+        self.slots = in_flight + self.depth + 1
+        # anonymous shared mapping: inherited by fork()ed workers, not limited by the size of /dev/shm; page-locked below
+        self._map = mmap.mmap(-1, self.slots * self.layout.nbytes)
+        self.ring = np.frombuffer(self._map, dtype=np.uint8).reshape(self.slots, self.layout.nbytes)
+        self._registered = False
+        self._register()
+        self._counter = [0]
+        bs = _SlotBatchSampler(BatchSampler(sampler, self.batch_size, drop_last), self.slots, self._counter)
+        kw = dict(num_workers=self.num_workers, collate_fn=_ring_collate, worker_init_fn=worker_init_fn)
+        if self.num_workers:
+            kw.update(prefetch_factor=prefetch_factor, persistent_workers=persistent_workers, multiprocessing_context="fork")
+        self.loader = DataLoader(_RingDataset(dataset, self.ring, self.layout), batch_sampler=bs, **kw)
+        self._it = None
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self._dev = [torch.empty(self.layout.nbytes, dtype=torch.uint8, device=self.device) for _ in range(self.depth)]
+        self._dev_free = [torch.cuda.Event() for _ in range(self.depth)]          # the slot's last consumer is done
+        self._pick_d = torch.tensor(self.pick, dtype=torch.int32, device=self.device)
+        self._ring_t = torch.from_numpy(self.ring)
+
+    # ---- page-locking
+    def _register(self):
+        with torch.cuda.device(self.device):
+            rc = torch.cuda.cudart().cudaHostRegister(self.ring.ctypes.data, self.ring.nbytes, 0)
+        if int(rc) != 0:
+            raise RuntimeError(f"hipHostRegister of the {self.ring.nbytes >> 20} MiB clip ring failed ({rc}): raise RLIMIT_MEMLOCK or lower num_workers / prefetch_factor")
+        self._registered = True
+
+    def close(self):
+        if self._registered:
+            torch.cuda.synchronize(self.device)
+            torch.cuda.cudart().cudaHostUnregister(self.ring.ctypes.data)
+            self._registered = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def __len__(self):
+        return len(self.loader)
+
+    # ---- one batch
+    def _t(self, key, t0):
+        if self.timers is not None:
+            self.timers[key] = self.timers.get(key, 0.0) + (time.perf_counter() - t0)
+
+    def _stage(self, item, k):
+        """Enqueue the H2D copy of ring slot `slot` into device slot k % depth; returns what _finish needs."""
+        slot, src_idx = item
+        t0 = time.perf_counter()
+        d = k % self.depth
+        cur = torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(self._dev_free[d])            # the launches that read this device slot `depth` batches ago
+            self._dev[d].copy_(self._ring_t[slot], non_blocking=True)
+            ev.record(self.copy_stream)
+        del cur
+        # host-side values of the batch, read before the ring slot can be recycled
+        _, _, params, _ = self.layout.views(self.ring[slot])
+        params = params.copy()
+        self._t("h2d_enqueue", t0)
+        return d, ev, params, src_idx
+
+    def _finish(self, staged):
+        d, ev, params, src_idx = staged
+        lay, leaf = self.layout, self.leaf
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
+        clips, cframes, params_d, keys_d = lay.device_views(self._dev[d])
+        t0 = time.perf_counter()
+        no_noise = bool((params[:, 2] == 0).all() and (params[:, 3] <= 0).all())
+        vox = esim.esim_voxel_batch(clips, params_d, bin_mode="sum", num_bins=leaf.num_bins, frames_per_bin=leaf.frames_per_bin,
+                                    rng_mode="philox", clip_keys=keys_d, put_noise_external=leaf.put_noise_external, no_noise=no_noise,
+                                    pad_to=self.pad_to, validate=False)
+        self._t("sim", t0)
+        t0 = time.perf_counter()
+        batch = {}
+        if self.normalize:
+            from . import postops
+            method = choose_normalize_method(params, leaf.frames_per_bin, leaf.put_noise_external)
+            h, w = lay.h, lay.w
+            if method == "radix":
+                vox = postops.normalize_and_pad(vox[..., :h, :w], True, self.pad_to, method="radix")
+            else:
+                vox = postops.normalize_and_pad(vox, True, self.pad_to, method="count", valid_hw=(h, w), inplace=True)
+        self._t("postops", t0)
+        t0 = time.perf_counter()
+        if cframes is None:
+            frame = clip_frames_f32(clips, self._pick_d)
+        else:
+            frame = clip_frames_f32(cframes)
+        self._dev_free[d].record(cur)                                     # everything that reads the device slot is enqueued
+        self._t("frames", t0)
+        t0 = time.perf_counter()
+        batch["frame"] = frame
+        batch["events"] = vox
+        batch["data_source_idx"] = torch.tensor(src_idx, dtype=torch.int64)
+        batch["v2e_params"] = {k: torch.from_numpy(params[:, i].copy()) for i, k in enumerate(_PARAM_KEYS)}
+        self._t("assemble", t0)
+        return batch
+
+    def __iter__(self):
+        # an abandoned epoch's workers may still be writing into ring slots: end them (non-persistent workers are joined when their
+        # iterator goes; persistent ones drain their queue when the DataLoader restarts them) before slots are handed out again
+        self._it = None
+        it = self._it = iter(self.loader)
+        k = 0
+        copies = []                                                       # H2D events of the batches whose ring slot may still be read
+
+        def fetch():
+            nonlocal k
+            # a ring slot is rewritten `slots` batches later, and a worker may start on it once the batch `in_flight` before it
+            # has been handed out: make sure the H2D copy of the batch `depth + 1` back has left the ring before asking for more
+            while len(copies) > self.depth:
+                copies.pop(0).synchronize()
+            t0 = time.perf_counter()
+            try:
+                item = next(it)
+            except StopIteration:
+                return None
+            self._t("wait_batch", t0)
+            st = self._stage(item, k)
+            copies.append(st[1])
+            k += 1
+            return st
+
+        nxt = fetch()
+        while nxt is not None:
+            cur, nxt = nxt, fetch()                                       # one batch of look-ahead: copy of k+1 under the compute of k
+            yield self._finish(cur)
