@@ -328,6 +328,10 @@ int64_t v2v_conv_head_packed_elems(int ks);
 int v2v_conv_head_pack_weights_hip(const float *weight, int64_t Cin, int ks, void *packed, void *stream);
 int v2v_to_nhwc8_bf16_hip(const float *src, int64_t stride_b, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t B, int64_t C,
                           int64_t H, int64_t W, void *dst, void *stream);
+/* the same conversion with normalize_batch_voxel's scaling folded into the read (model/train_utils.py:162-166): scales float32 [B,2] =
+ * {neg_max, pos_max} (v2v_voxel_scales_hip), x -> where(x > 0, x / pos_max, x / neg_max) before the bf16 rounding; NULL = no scaling */
+int v2v_to_nhwc8_bf16_scaled_hip(const float *src, int64_t stride_b, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t B, int64_t C,
+                                 int64_t H, int64_t W, const float *scales, void *dst, void *stream);
 int v2v_conv_head_nhwc_hip(const void *x8, const void *packed, const float *bias, int relu, int64_t B, int64_t H, int64_t W, int ks, void *out, void *stream);
 
 /* The prediction layer: ConvLayer(base_num_channels, out, kernel_size=1, activation=None) (model/unet.py:58-64) applied to
@@ -341,6 +345,32 @@ int v2v_conv1x1_nhwc_hip(const void *x, const void *skip, const float *weight, c
 /* fp32 or bf16 [B,C,H,W] (src_dtype V2V_F32 / V2V_BF16) -> bf16 [B,H,W,C] (relu != 0: through max(x,0), the activation in front of the recurrent block,
  * model/submodules.py:267-271 RecurrentConvLayer = ConvLayer(relu) -> ConvLSTM).  C % 64 == 0 and (H*W) % 64 == 0. */
 int v2v_nchw_to_nhwc_bf16_hip(const void *src, int src_dtype, int64_t B, int64_t C, int64_t H, int64_t W, int relu, void *dst, void *stream);
+
+/* normalize_batch_voxel's per-sample k-th values gathered BY THE SIMULATOR'S WRITER (model/train_utils.py:147-166):
+ * v2v_esim_voxel_stats_hip = v2v_esim_voxel_padded_hip + `stats`, uint32 [B][V2V_VOXEL_STATS_WORDS] (zeroed here, then accumulated by
+ * the launch): word 256 + v counts the voxels of clip b equal to the integer v in -255..255 except v = 0 (left 0: the reader derives
+ * it from the element count), words 0 / 512 the voxels below -255 / above 255 (hot pixels), word 513 != 0 flags a clip whose planes
+ * are not counts.  SUM mode, float32 grid, no V2V_FLAG_NOISE_EXTERNAL (anything else: V2V_ERR_MODE).
+ * v2v_voxel_scales_hip: scales[b] = {neg_max, pos_max} = {clamp(-kthvalue(1 %), min=1), clamp(kthvalue(99 %), min=1)} (:153-160; ranks
+ * int(0.01*M), int(0.99*M), 1-based, M = elems_per_sample = the sample's voxel count WITHOUT padding) from those statistics, exact;
+ * NaN when a rank falls into an overflow word or the clip is flagged.
+ * v2v_voxel_apply_scales_hip: out = where(voxel > 0, voxel / pos_max, voxel / neg_max) (:162-166; IEEE division) [+ zero padding of H, W to
+ * multiples of pad_to]; voxel [B,planes,H_in,W_in] (interior H x W valid), out [B,planes,Hp,Wp]; out == voxel allowed when the layouts
+ * agree; scales NULL = copy / pad only.  A consumer that scales while it reads (v2v_to_nhwc8_bf16_scaled_hip) needs no such pass. */
+#define V2V_VOXEL_STATS_WORDS 516
+int v2v_esim_voxel_stats_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W,
+                             int64_t clip_stride, int64_t frame_stride, const double *params, int64_t params_stride,
+                             uint32_t flags, int rng_mode, uint64_t seed, uint64_t clip_id0, const uint64_t *clip_keys,
+                             const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
+                             void *out_voxel, int out_dtype, int64_t out_row_pitch, int64_t out_plane_size, int64_t *out_counts, uint32_t *stats,
+                             void *stream);
+int v2v_voxel_scales_hip(const uint32_t *stats, int64_t B, int64_t elems_per_sample, float *scales, void *stream);
+int v2v_voxel_apply_scales_hip(const float *voxel, int64_t B, int64_t planes, int64_t H, int64_t W, int64_t H_in, int64_t W_in, int pad_to,
+                               const float *scales, float *out, void *stream);
+/* The same scales by selection over a FINISHED tensor (what v2v_normalize_pad_ex_hip does before it scales): method V2V_NORM_RADIX (any
+ * float32 content, unpadded input) or V2V_NORM_COUNT (integer-valued, padded input allowed); workspace of v2v_postops_workspace_bytes(B). */
+int v2v_voxel_scales_select_hip(const float *voxel, int64_t B, int64_t planes, int64_t H, int64_t W, int64_t H_in, int64_t W_in, int method,
+                                float *scales, void *workspace, void *stream);
 
 /* The `frame` tensor of a batch from the uint8 clips already in HBM (WebvidDatasetV2.__getitem__, data/v2v_datasets.py:329-338, 352:
  * frame[l] = float(all_imgs[idx_l]).permute(2,0,1) / 255): out[b,l,c,y,x] = float(src[b, pick[l], y, x, c]) / 255.0f (IEEE division:

@@ -144,3 +144,27 @@ def test_ring_loader_equals_simulating_collator(tmp_path, extra, workers):
             n += 1
         assert n == 2
     loader.close()
+
+
+@pytest.mark.gpu
+def test_ring_loader_scales_mode_and_hot_pixels(tmp_path):
+    """normalize='scales': raw events + (neg_max, pos_max) per sample; scaling them afterwards equals normalize=True, which equals the
+    reference's normalize_batch_voxel on the raw events (NumPy restatement pinned by G13) -- with the training configuration's hot pixels
+    (hundreds of events per frame on a few pixels, config/train_v2v_e2vid_10k.yaml:75 draws hot_pixel_std up to 10; more here) in the batch."""
+    from v2v_amd import postops
+    from v2v_amd.loader import RingLoader
+    cfg = dict(defer_sim=True, fixed_seed=11, hot_pixel_std_range=[60, 80], hot_pixel_fraction_range=[0.003, 0.004], threshold_range=[0.1, 0.3])
+    ds = _make_ds(tmp_path, **cfg)
+    raw = next(iter(RingLoader(ds, batch_size=4, num_workers=0, pad_to=16, normalize="scales")))
+    done = next(iter(RingLoader(ds, batch_size=4, num_workers=0, pad_to=16, normalize=True)))
+    plain = next(iter(RingLoader(ds, batch_size=4, num_workers=0, pad_to=16, normalize=False)))
+    assert torch.equal(raw["events"], plain["events"]) and "event_scales" not in done and raw["event_scales"].shape == (4, 2)
+    assert float(raw["events"].abs().max()) > 255                                                  # hot pixels beyond the counting range
+    assert torch.equal(postops.apply_scales(raw["events"], raw["event_scales"], 16), done["events"])
+    v = plain["events"].cpu().numpy()
+    flat = np.sort(v.reshape(4, -1), axis=1)
+    m = flat.shape[1]
+    pos = np.maximum(flat[:, int(0.99 * m) - 1], 1).reshape(4, 1, 1, 1, 1)
+    neg = np.maximum(-flat[:, int(0.01 * m) - 1], 1).reshape(4, 1, 1, 1, 1)
+    assert np.array_equal(done["events"].cpu().numpy(), np.where(v > 0, v / pos, v / neg).astype(np.float32))
+    assert np.array_equal(raw["event_scales"].cpu().numpy(), np.concatenate([neg.reshape(4, 1), pos.reshape(4, 1)], 1).astype(np.float32))

@@ -21,15 +21,22 @@ FIELDS = {".vgpr_count": "vgpr", ".vgpr_spill_count": "vgpr_spill", ".sgpr_count
 
 
 def parse(path):
+    """One dict per kernel entry of `amdhsa.kernels` (an entry starts at the list item `  - .agpr_count: ...`; its fields come in
+    alphabetical order, i.e. .agpr_count / .group_segment_fixed_size BEFORE .name -- attach them to the entry, not to the last name seen)."""
     out, cur = {}, None
     for line in open(path):
-        m = re.match(r"\s+-?\s*(\.[a-z_]+):\s+(\S+)", line)
+        item = re.match(r"  - (\.[a-z_]+):\s+(\S+)", line)              # kernel-level list item (argument items are indented deeper)
+        m = item or re.match(r"    (\.[a-z_]+):\s+(\S+)", line)
         if not m:
             continue
+        if item:
+            cur = {}
         key, val = m.group(1), m.group(2)
+        if cur is None:
+            continue
         if key == ".name" and val.startswith("_Z"):
-            cur = out.setdefault(val, {})
-        elif cur is not None and key in FIELDS:
+            out[val] = cur
+        elif key in FIELDS:
             cur[FIELDS[key]] = int(val)
     return out
 

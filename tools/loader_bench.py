@@ -146,16 +146,23 @@ def run_loader(make_iterable, n_batches, batch, dev, timers=None, gpu_ms_per_bat
 
 
 def gpu_ms_of_batch(batch, dev, pad_to=16):
-    """Kernel time of one batch's device work (simulator + normalise/pad [+ frame gather]) at this shape: HIP events around a
-    hipGraph replay of exactly the launches the loader issues, device-resident inputs."""
+    """Kernel time of one batch's device work (simulator with the writer's statistics, scales, the scaling pass, the frame tensor) at
+    this shape: HIP events around a hipGraph replay of exactly the launches the loader issues, device-resident inputs."""
     from v2v_amd import esim, postops
     clips = esim.synth_clips(batch, 201, 128, 128, dtype=torch.uint8, device=dev)
     params = torch.tensor([[0.3, 0.4, 0.02, 5e-4, 0.5]] * batch, dtype=torch.float64, device=dev)
     keys = torch.stack([torch.arange(batch) + 99, torch.arange(batch)], 1).to(dev)
 
+    from v2v_amd import _lib
+    from v2v_amd.loader import clip_frames_f32
+    stats = torch.empty((batch, _lib.VOXEL_STATS_WORDS), dtype=torch.int32, device=dev)
+    pick = torch.arange(5, 201, 5, dtype=torch.int32, device=dev)
+
     def step():
-        vox = esim.esim_voxel_batch(clips, params, bin_mode="sum", num_bins=5, clip_keys=keys, no_noise=False, pad_to=pad_to)
-        postops.normalize_and_pad(vox, True, pad_to, method="count", valid_hw=(128, 128), inplace=True)
+        vox = esim.esim_voxel_batch(clips, params, bin_mode="sum", num_bins=5, clip_keys=keys, no_noise=False, pad_to=pad_to, stats=stats)
+        sc = postops.scales_from_stats(stats, 40 * 5 * 128 * 128)
+        postops.apply_scales(vox, sc, pad_to, valid_hw=(128, 128), inplace=True)
+        clip_frames_f32(clips, pick)
     for _ in range(3):
         step()
     torch.cuda.synchronize(dev)
@@ -174,7 +181,8 @@ def gpu_ms_of_batch(batch, dev, pad_to=16):
     return sum(ms) / len(ms)
 
 
-def measure(batches=200, workers=9, batch=12, modes=("ring", "simulating"), cpu_port=True, dev=None, cpu_port_budget_s=60.0, simulating_batches=None):
+def measure(batches=200, workers=9, batch=12, modes=("ring", "simulating"), cpu_port=True, dev=None, cpu_port_budget_s=60.0, simulating_batches=None, ring_kw=None):
+    ring_kw = ring_kw or {}
     from torch.utils.data import DataLoader
     from v2v_amd.datasets import SimulatingCollator, SimulatingLoader
     dev = dev or torch.device("cuda", torch.cuda.current_device())
@@ -208,7 +216,8 @@ def measure(batches=200, workers=9, batch=12, modes=("ring", "simulating"), cpu_
         if "ring" in modes:
             from v2v_amd.loader import RingLoader
             timers = {}
-            mk = lambda: RingLoader(ds, batch_size=batch, num_workers=workers, drop_last=True, pad_to=16, normalize=True, timers=timers)   # noqa: E731
+            mk = lambda: RingLoader(ds, batch_size=batch, num_workers=workers, drop_last=True, pad_to=16, timers=timers,   # noqa: E731
+                                    **dict(dict(normalize=True), **ring_kw))
             res["ring_loader"] = run_loader(mk, batches, batch, dev, timers, gpu_ms)
             res["ring_loader"]["fraction_of_pcie_floor"] = res["pcie"]["floor_ms_per_batch"] / res["ring_loader"]["ms_per_batch"]
         if cpu_port:
@@ -226,6 +235,9 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--mode", default="both", choices=["ring", "simulating", "both"])
     ap.add_argument("--no-cpu-port", action="store_true")
+    ap.add_argument("--depth", type=int, default=2)
+    ap.add_argument("--normalize", default="True")
     a = ap.parse_args()
     modes = ("ring", "simulating") if a.mode == "both" else (a.mode,)
-    print(json.dumps(measure(a.batches, a.workers, a.batch, modes, not a.no_cpu_port), indent=1))
+    kw = dict(depth=a.depth, normalize={"True": True, "False": False}.get(a.normalize, a.normalize))
+    print(json.dumps(measure(a.batches, a.workers, a.batch, modes, not a.no_cpu_port, ring_kw=kw), indent=1))

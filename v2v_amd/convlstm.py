@@ -305,15 +305,19 @@ def conv1x1_nhwc(x, weight, bias, skip=None, out_dtype=torch.bfloat16):
     return out
 
 
-def to_nhwc8_bf16(x):
-    """float32 [B, C <= 8, H, W] of any strides -> bfloat16 [B, H, W, 8] with the channels zero-padded to 8: the head's input layout."""
+def to_nhwc8_bf16(x, scales=None):
+    """float32 [B, C <= 8, H, W] of any strides -> bfloat16 [B, H, W, 8] with the channels zero-padded to 8: the head's input layout.
+    scales: optional float32 [B,2] = (neg_max, pos_max) per sample (v2v_amd.postops.scales_from_stats): normalize_batch_voxel's
+    where(x > 0, x / pos_max, x / neg_max) (model/train_utils.py:162-166) applied while the voxels are read."""
     _lib.require_gpu()
     if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] > 8:
         raise ValueError("x must be a float32 CUDA tensor [B, C <= 8, H, W]")
     b, c, h, w = x.shape
+    if scales is not None and (scales.dtype != torch.float32 or tuple(scales.shape) != (b, 2) or not scales.is_contiguous() or scales.device != x.device):
+        raise ValueError(f"scales must be a contiguous float32 [{b},2] tensor on x's device")
     out = torch.empty((b, h, w, 8), dtype=torch.bfloat16, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().v2v_to_nhwc8_bf16_hip(_ptr(x), *x.stride(), b, c, h, w, _ptr(out), _lib.stream_ptr()))
+        _lib.check(_lib.lib().v2v_to_nhwc8_bf16_scaled_hip(_ptr(x), *x.stride(), b, c, h, w, _ptr(scales), _ptr(out), _lib.stream_ptr()))
     return out
 
 
@@ -378,7 +382,7 @@ class ConvLayer(nn.Module):
             self._packed = (key, (pack_head_weights if self.head else pack_conv_weights)(w.detach()))
         return self._packed[1]
 
-    def forward(self, x, skip=None):
+    def forward(self, x, skip=None, scales=None):
         """skip (upsample=True only): the sum skip connection model/unet.py:304 adds in front of the decoder, folded into the
         upsampling kernel -- layer(x, skip) == layer(x + skip)."""
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
@@ -402,7 +406,7 @@ class ConvLayer(nn.Module):
             # channels-last out when the input or (as torch's own convolution decides) the weight is channels-last
             w = self.conv2d.weight
             cl = self.force_channels_last or any(v.is_contiguous(memory_format=torch.channels_last) and not v.is_contiguous() for v in (x, w))
-            out = conv_head_nhwc(to_nhwc8_bf16(x.float()), self._weights(), self.conv2d.bias, self.conv2d.kernel_size[0], relu=self.relu).permute(0, 3, 1, 2)
+            out = conv_head_nhwc(to_nhwc8_bf16(x.float(), scales), self._weights(), self.conv2d.bias, self.conv2d.kernel_size[0], relu=self.relu).permute(0, 3, 1, 2)
             out = out if cl else out.contiguous()
             return out if low else out.to(x.dtype)
 

@@ -27,7 +27,14 @@ struct EsimArgs {
     uint32_t sym_only;                     // V2V_FLAG_SYMMETRIC: every clip has C+ == C- (instances without the asymmetric loop)
     int32_t W;                             // row length (for the padded output layout)
     int64_t out_pitch, out_plane;          // output row pitch / plane size in elements (W, H*W when unpadded)
+    unsigned int *stats;                   // optional [B, kStatWords] per-clip value histogram of the voxels written (SUM mode, float32 grid)
 };
+
+// Per-clip statistics the simulator's writer accumulates for the consumer's normalize_batch_voxel (model/train_utils.py:147-166):
+// word kStatZero + v counts the voxels equal to the integer v in -255..255 -- EXCEPT v = 0, which is left at 0 (the reader derives
+// it from the element count) --, words 0 and kStatBins - 1 the voxels below -255 / above 255, word kStatBad != 0 flags a clip
+// whose planes are not counts (NaN-poisoned).  Same bin layout as the counting select of v2v_postops.hpp.
+constexpr int kStatMax = 255, kStatZero = kStatMax + 1, kStatBins = 2 * kStatMax + 3, kStatBad = kStatBins, kStatWords = 516;
 
 struct V2eParams {            // mirrors v2v_v2e_params (include/v2v_hip.h)
     double fps;
@@ -95,7 +102,7 @@ hipError_t launch_conv_nhwc(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
 int conv_tile_cols(int Cout);             // columns per tile of the instance launch_conv_nhwc takes for Cout (0: unsupported)
 hipError_t launch_conv_head(const uint16_t *x8, const uint16_t *wp, const float *bias, uint16_t *out, int B, int H, int W, int ks, int relu, hipStream_t s);
 hipError_t launch_conv_head_pack(const float *w, uint16_t *wp, int Cin, int ks, hipStream_t s);
-hipError_t launch_to_nhwc8_bf16(const float *src, int64_t sb, int64_t sc, int64_t sh, int64_t sw, uint16_t *dst, int B, int C, int H, int W, hipStream_t s);
+hipError_t launch_to_nhwc8_bf16(const float *src, int64_t sb, int64_t sc, int64_t sh, int64_t sw, uint16_t *dst, int B, int C, int H, int W, const float *scales, hipStream_t s);
 hipError_t launch_conv1x1_nhwc(const uint16_t *x, const uint16_t *skip, const float *w, const float *bias, void *out, int out_bf16, int64_t M,
                                int C, int Cout, hipStream_t s);
 hipError_t launch_upsample2x_nhwc(const uint16_t *x, const uint16_t *skip, uint16_t *out, int B, int H, int W, int C, hipStream_t s);

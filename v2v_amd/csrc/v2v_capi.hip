@@ -130,11 +130,90 @@ int v2v_esim_voxel_keyed_hip(const void *frames, int in_dtype, int64_t B, int64_
                                      out_counts, stream);
 }
 
+static int esim_launch_impl(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W,
+                            int64_t clip_stride, int64_t frame_stride, const double *params, int64_t params_stride,
+                            uint32_t flags, int rng_mode, uint64_t seed, uint64_t clip_id0, const uint64_t *clip_keys,
+                            const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
+                            void *out_voxel, int out_dtype, int64_t out_row_pitch, int64_t out_plane_size, int64_t *out_counts, uint32_t *stats,
+                            void *stream);
+
 int v2v_esim_voxel_padded_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W,
                               int64_t clip_stride, int64_t frame_stride, const double *params, int64_t params_stride,
                               uint32_t flags, int rng_mode, uint64_t seed, uint64_t clip_id0, const uint64_t *clip_keys,
                               const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
                               void *out_voxel, int out_dtype, int64_t out_row_pitch, int64_t out_plane_size, int64_t *out_counts, void *stream)
+{
+    return esim_launch_impl(frames, in_dtype, B, N, H, W, clip_stride, frame_stride, params, params_stride, flags, rng_mode, seed, clip_id0, clip_keys,
+                            replay, bin_mode, num_bins, frames_per_bin, out_voxel, out_dtype, out_row_pitch, out_plane_size, out_counts, nullptr, stream);
+}
+
+int v2v_esim_voxel_stats_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W,
+                             int64_t clip_stride, int64_t frame_stride, const double *params, int64_t params_stride,
+                             uint32_t flags, int rng_mode, uint64_t seed, uint64_t clip_id0, const uint64_t *clip_keys,
+                             const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
+                             void *out_voxel, int out_dtype, int64_t out_row_pitch, int64_t out_plane_size, int64_t *out_counts, uint32_t *stats,
+                             void *stream)
+{
+    if (!stats) return fail(V2V_ERR_NULL, "v2v_esim_voxel_stats_hip: stats is NULL");
+    if (bin_mode != V2V_BIN_SUM || out_dtype != V2V_F32 || (flags & V2V_FLAG_NOISE_EXTERNAL))
+        return fail(V2V_ERR_MODE, "voxel statistics are kept for SUM-mode float32 grids without external noise (integer counts)");
+    if (!aligned(stats, 4)) return fail(V2V_ERR_ALIGN, "stats must be 4-byte aligned");
+    if (B > 0) {
+        const hipError_t e = hipMemsetAsync(stats, 0, sizeof(uint32_t) * (size_t)B * V2V_VOXEL_STATS_WORDS, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(stats)");
+    }
+    return esim_launch_impl(frames, in_dtype, B, N, H, W, clip_stride, frame_stride, params, params_stride, flags, rng_mode, seed, clip_id0, clip_keys,
+                            replay, bin_mode, num_bins, frames_per_bin, out_voxel, out_dtype, out_row_pitch, out_plane_size, out_counts, stats, stream);
+}
+
+int v2v_voxel_scales_hip(const uint32_t *stats, int64_t B, int64_t elems_per_sample, float *scales, void *stream)
+{
+    if (!stats || !scales) return fail(V2V_ERR_NULL, "v2v_voxel_scales_hip: stats/scales is NULL");
+    if (B < 0 || elems_per_sample < 1) return fail(V2V_ERR_SHAPE, "need B>=0, elems_per_sample>=1");
+    // torch.kthvalue is 1-based: max_k = int(0.99*M), min_k = int(0.01*M) (model/train_utils.py:153-154)
+    const int64_t max_k = (int64_t)(0.99 * (double)elems_per_sample), min_k = (int64_t)(0.01 * (double)elems_per_sample);
+    if (min_k < 1 || max_k < 1) return fail(V2V_ERR_SHAPE, "k-th value undefined: fewer than 100 elements per sample (torch.kthvalue would raise)");
+    if (B == 0) return V2V_OK;
+    static_assert(v2v::kStatBins == v2v::kCntBins && v2v::kStatZero == v2v::kCntZero && V2V_VOXEL_STATS_WORDS == v2v::kStatWords, "one bin layout");
+    hipLaunchKernelGGL(v2v::count_pick_kernel, dim3((unsigned)(B * 2)), dim3(64), 0, static_cast<hipStream_t>(stream), stats, (int64_t)v2v::kStatWords,
+                       stats + v2v::kStatBad, (int64_t)v2v::kStatWords, B * 2, (uint64_t)0, (uint64_t)(min_k - 1), (uint64_t)(max_k - 1), 1,
+                       (uint64_t)elems_per_sample, scales);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "count_pick_kernel launch");
+}
+
+int v2v_voxel_apply_scales_hip(const float *voxel, int64_t B, int64_t planes, int64_t H, int64_t W, int64_t H_in, int64_t W_in, int pad_to,
+                               const float *scales, float *out, void *stream)
+{
+    if (!voxel || !out) return fail(V2V_ERR_NULL, "v2v_voxel_apply_scales_hip: voxel/out is NULL");
+    if (B < 0 || planes < 1 || H < 1 || W < 1 || pad_to < 1 || H_in < H || W_in < W) return fail(V2V_ERR_SHAPE, "need B>=0, planes,H,W,pad_to>=1, H_in>=H, W_in>=W");
+    if (!aligned(voxel, 4) || !aligned(out, 4) || (scales && !aligned(scales, 4))) return fail(V2V_ERR_ALIGN, "buffers misaligned");
+    if (B == 0) return V2V_OK;
+    const int Hp = (int)((H + pad_to - 1) / pad_to * pad_to), Wp = (int)((W + pad_to - 1) / pad_to * pad_to);
+    if (out == voxel && (Hp != H_in || Wp != W_in)) return fail(V2V_ERR_SHAPE, "in-place scaling needs identical input and output layouts");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t per_out = planes * Hp * Wp;
+    const bool rows4 = W % 4 == 0 && Wp % 4 == 0 && W_in % 4 == 0 && planes * Hp < ((int64_t)1 << 31) &&
+                       ((reinterpret_cast<uintptr_t>(voxel) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
+    if (rows4) {
+        const unsigned gr = (unsigned)std::min<int64_t>((planes * Hp + 3) / 4, 4096);
+        hipLaunchKernelGGL(v2v::normalize_pad_rows_kernel, dim3(gr, (unsigned)B), dim3(256), 0, s, voxel, out, scales, (int)planes, (int)H, (int)W, Hp, Wp,
+                           (int)H_in, (int)W_in);
+    } else {
+        const unsigned gx2 = (unsigned)std::min<int64_t>((per_out + 256 * 4 - 1) / (256 * 4), 2048);
+        hipLaunchKernelGGL(v2v::normalize_pad_kernel, dim3(gx2, (unsigned)B), dim3(256), 0, s, voxel, out, scales, planes, (int)H, (int)W, Hp, Wp, (int)H_in,
+                           (int)W_in);
+    }
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "normalize_pad launch");
+}
+
+static int esim_launch_impl(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W,
+                            int64_t clip_stride, int64_t frame_stride, const double *params, int64_t params_stride,
+                            uint32_t flags, int rng_mode, uint64_t seed, uint64_t clip_id0, const uint64_t *clip_keys,
+                            const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
+                            void *out_voxel, int out_dtype, int64_t out_row_pitch, int64_t out_plane_size, int64_t *out_counts, uint32_t *stats,
+                            void *stream)
 {
     if (out_row_pitch < W || out_plane_size < out_row_pitch * (H - 1) + W) return fail(V2V_ERR_SHAPE, "out_row_pitch / out_plane_size smaller than the frame");
     if (!frames || !params || !out_voxel) return fail(V2V_ERR_NULL, "v2v_esim_voxel_hip: frames/params/out_voxel is NULL");
@@ -209,6 +288,7 @@ int v2v_esim_voxel_padded_hip(const void *frames, int in_dtype, int64_t B, int64
     a.W = (int32_t)W;
     a.out_pitch = out_row_pitch;
     a.out_plane = out_plane_size;
+    a.stats = stats;
     const int64_t nblocks = B * a.blocks_per_clip;
     if (nblocks > 0x7FFFFFFF) return fail(V2V_ERR_SHAPE, "grid too large");
     const dim3 grid((unsigned)nblocks);
@@ -530,24 +610,14 @@ int v2v_normalize_pad_hip(const float *voxel, int64_t B, int64_t planes, int64_t
     return v2v_normalize_pad_ex_hip(voxel, B, planes, H, W, H, W, normalize ? V2V_NORM_RADIX : V2V_NORM_NONE, pad_to, out, workspace, stream);
 }
 
-int v2v_normalize_pad_ex_hip(const float *voxel, int64_t B, int64_t planes, int64_t H, int64_t W, int64_t H_in, int64_t W_in, int method,
-                             int pad_to, float *out, void *workspace, void *stream)
+// the k-th value selection of normalize_batch_voxel -> scales_out[b] = {neg_max, pos_max}; workspace as v2v_postops_workspace_bytes(B)
+static int select_scales(const float *voxel, int64_t B, int64_t planes, int64_t H, int64_t W, int64_t H_in, int64_t W_in, int method, void *workspace,
+                         float *scales_out, hipStream_t s)
 {
-    if (!voxel || !out) return fail(V2V_ERR_NULL, "v2v_normalize_pad_hip: voxel/out is NULL");
-    if (B < 0 || planes < 1 || H < 1 || W < 1 || pad_to < 1 || H_in < H || W_in < W) return fail(V2V_ERR_SHAPE, "need B>=0, planes,H,W,pad_to>=1, H_in>=H, W_in>=W");
-    if (method < V2V_NORM_NONE || method > V2V_NORM_COUNT) return fail(V2V_ERR_MODE, "unknown normalisation method %d", method);
-    const bool normalize = method != V2V_NORM_NONE;
-    if (normalize && !workspace) return fail(V2V_ERR_NULL, "normalisation needs a workspace of v2v_postops_workspace_bytes(B)");
-    if (method == V2V_NORM_RADIX && (H_in != H || W_in != W)) return fail(V2V_ERR_MODE, "the radix select reads unpadded input; use V2V_NORM_COUNT for padded input");
-    if (!aligned(voxel, 4) || !aligned(out, 4) || (workspace && !aligned(workspace, 16))) return fail(V2V_ERR_ALIGN, "buffers misaligned");
-    if (B == 0) return V2V_OK;
     const int64_t per_sample = planes * H * W;
     // torch.kthvalue is 1-based: max_k = int(0.99*M), min_k = int(0.01*M) (model/train_utils.py:153-154)
     const int64_t max_k = (int64_t)(0.99 * (double)per_sample), min_k = (int64_t)(0.01 * (double)per_sample);
-    if (normalize && (min_k < 1 || max_k < 1)) return fail(V2V_ERR_SHAPE, "k-th value undefined: fewer than 100 elements per sample (torch.kthvalue would raise)");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int Hp = (int)((H + pad_to - 1) / pad_to * pad_to), Wp = (int)((W + pad_to - 1) / pad_to * pad_to);
-    if (out == voxel && (Hp != H_in || Wp != W_in)) return fail(V2V_ERR_SHAPE, "in-place normalisation needs identical input and output layouts");
+    if (min_k < 1 || max_k < 1) return fail(V2V_ERR_SHAPE, "k-th value undefined: fewer than 100 elements per sample (torch.kthvalue would raise)");
     v2v::SelectState *st = static_cast<v2v::SelectState *>(workspace);
     if (method == V2V_NORM_RADIX) {
         unsigned int *hist = reinterpret_cast<unsigned int *>(st + B * 2);
@@ -565,7 +635,8 @@ int v2v_normalize_pad_ex_hip(const float *voxel, int64_t B, int64_t planes, int6
                 hipLaunchKernelGGL(v2v::select_hist_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, voxel, per_sample, st, hist, shifts[p], bits[p]);
             hipLaunchKernelGGL(v2v::select_pick_kernel, dim3((unsigned)(B * 2)), dim3(256), 0, s, st, hist, shifts[p], bits[p]);
         }
-    } else if (method == V2V_NORM_COUNT) {
+        hipLaunchKernelGGL(v2v::state_scales_kernel, dim3((unsigned)((B * 2 + 255) / 256)), dim3(256), 0, s, st, scales_out, B * 2);
+    } else {
         static_assert(v2v::kCntBins <= 2 * v2v::kSelBins, "the counting histogram reuses the radix workspace");
         unsigned int *hist = reinterpret_cast<unsigned int *>(st + B * 2);
         unsigned int *bad = hist + (size_t)B * 2 * v2v::kSelBins;
@@ -583,23 +654,46 @@ int v2v_normalize_pad_ex_hip(const float *voxel, int64_t B, int64_t planes, int6
         } else {
             hipLaunchKernelGGL(v2v::count_hist_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, voxel, per_in, hist, bad);
         }
-        hipLaunchKernelGGL(v2v::count_pick_kernel, dim3((unsigned)(B * 2)), dim3(64), 0, s, st, hist, bad, B * 2,
-                           (uint64_t)(per_in - per_sample), (uint64_t)(min_k - 1), (uint64_t)(max_k - 1), 0, (uint64_t)per_sample, (float *)nullptr);
-    }
-    const int64_t per_out = planes * Hp * Wp;
-    const bool rows4 = W % 4 == 0 && Wp % 4 == 0 && W_in % 4 == 0 && planes * Hp < ((int64_t)1 << 31) &&
-                       ((reinterpret_cast<uintptr_t>(voxel) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
-    if (rows4) {                                                 // a wave per output row, 16 bytes per lane
-        const unsigned gr = (unsigned)std::min<int64_t>((planes * Hp + 3) / 4, 4096);
-        hipLaunchKernelGGL(v2v::normalize_pad_rows_kernel, dim3(gr, (unsigned)B), dim3(256), 0, s, voxel, out, st, normalize ? 1 : 0, (int)planes,
-                           (int)H, (int)W, Hp, Wp, (int)H_in, (int)W_in);
-    } else {
-        const unsigned gx2 = (unsigned)std::min<int64_t>((per_out + 256 * 4 - 1) / (256 * 4), 2048);
-        hipLaunchKernelGGL(v2v::normalize_pad_kernel, dim3(gx2, (unsigned)B), dim3(256), 0, s, voxel, out, st, normalize ? 1 : 0, planes,
-                           (int)H, (int)W, Hp, Wp, (int)H_in, (int)W_in);
+        hipLaunchKernelGGL(v2v::count_pick_kernel, dim3((unsigned)(B * 2)), dim3(64), 0, s, hist, (int64_t)v2v::kCntBins, bad, (int64_t)1, B * 2,
+                           (uint64_t)(per_in - per_sample), (uint64_t)(min_k - 1), (uint64_t)(max_k - 1), 0, (uint64_t)per_sample, scales_out);
     }
     const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? V2V_OK : hip_fail(e, "normalize_pad launch");
+    return e == hipSuccess ? V2V_OK : hip_fail(e, "k-th value selection launch");
+}
+
+int v2v_voxel_scales_select_hip(const float *voxel, int64_t B, int64_t planes, int64_t H, int64_t W, int64_t H_in, int64_t W_in, int method,
+                                float *scales, void *workspace, void *stream)
+{
+    if (!voxel || !scales || !workspace) return fail(V2V_ERR_NULL, "v2v_voxel_scales_select_hip: voxel/scales/workspace is NULL");
+    if (B < 0 || planes < 1 || H < 1 || W < 1 || H_in < H || W_in < W) return fail(V2V_ERR_SHAPE, "need B>=0, planes,H,W>=1, H_in>=H, W_in>=W");
+    if (method != V2V_NORM_RADIX && method != V2V_NORM_COUNT) return fail(V2V_ERR_MODE, "method must be V2V_NORM_RADIX or V2V_NORM_COUNT");
+    if (method == V2V_NORM_RADIX && (H_in != H || W_in != W)) return fail(V2V_ERR_MODE, "the radix select reads unpadded input; use V2V_NORM_COUNT for padded input");
+    if (!aligned(voxel, 4) || !aligned(scales, 4) || !aligned(workspace, 16)) return fail(V2V_ERR_ALIGN, "buffers misaligned");
+    if (B == 0) return V2V_OK;
+    return select_scales(voxel, B, planes, H, W, H_in, W_in, method, workspace, scales, static_cast<hipStream_t>(stream));
+}
+
+int v2v_normalize_pad_ex_hip(const float *voxel, int64_t B, int64_t planes, int64_t H, int64_t W, int64_t H_in, int64_t W_in, int method,
+                             int pad_to, float *out, void *workspace, void *stream)
+{
+    if (!voxel || !out) return fail(V2V_ERR_NULL, "v2v_normalize_pad_hip: voxel/out is NULL");
+    if (B < 0 || planes < 1 || H < 1 || W < 1 || pad_to < 1 || H_in < H || W_in < W) return fail(V2V_ERR_SHAPE, "need B>=0, planes,H,W,pad_to>=1, H_in>=H, W_in>=W");
+    if (method < V2V_NORM_NONE || method > V2V_NORM_COUNT) return fail(V2V_ERR_MODE, "unknown normalisation method %d", method);
+    const bool normalize = method != V2V_NORM_NONE;
+    if (normalize && !workspace) return fail(V2V_ERR_NULL, "normalisation needs a workspace of v2v_postops_workspace_bytes(B)");
+    if (method == V2V_NORM_RADIX && (H_in != H || W_in != W)) return fail(V2V_ERR_MODE, "the radix select reads unpadded input; use V2V_NORM_COUNT for padded input");
+    if (!aligned(voxel, 4) || !aligned(out, 4) || (workspace && !aligned(workspace, 16))) return fail(V2V_ERR_ALIGN, "buffers misaligned");
+    if (B == 0) return V2V_OK;
+    const int Hp = (int)((H + pad_to - 1) / pad_to * pad_to), Wp = (int)((W + pad_to - 1) / pad_to * pad_to);
+    if (out == voxel && (Hp != H_in || Wp != W_in)) return fail(V2V_ERR_SHAPE, "in-place normalisation needs identical input and output layouts");
+    // workspace: [SelectState x 2B][histograms 2B x 2048 words][bad flags B words][scales 2B floats]
+    float *scales = nullptr;
+    if (normalize) {
+        scales = reinterpret_cast<float *>(reinterpret_cast<unsigned int *>(static_cast<v2v::SelectState *>(workspace) + B * 2) + (size_t)B * 2 * v2v::kSelBins + (size_t)B);
+        const int rc = select_scales(voxel, B, planes, H, W, H_in, W_in, method, workspace, scales, static_cast<hipStream_t>(stream));
+        if (rc != V2V_OK) return rc;
+    }
+    return v2v_voxel_apply_scales_hip(voxel, B, planes, H, W, H_in, W_in, pad_to, scales, out, stream);
 }
 
 static int events_f32_launch(const float *ts, const double *ts64, const int64_t *xs, const int64_t *ys, const float *ps, int64_t n,
@@ -747,11 +841,17 @@ int v2v_conv_head_pack_weights_hip(const float *weight, int64_t Cin, int ks, voi
 int v2v_to_nhwc8_bf16_hip(const float *src, int64_t stride_b, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t B, int64_t C,
                           int64_t H, int64_t W, void *dst, void *stream)
 {
+    return v2v_to_nhwc8_bf16_scaled_hip(src, stride_b, stride_c, stride_h, stride_w, B, C, H, W, nullptr, dst, stream);
+}
+
+int v2v_to_nhwc8_bf16_scaled_hip(const float *src, int64_t stride_b, int64_t stride_c, int64_t stride_h, int64_t stride_w, int64_t B, int64_t C,
+                                 int64_t H, int64_t W, const float *scales, void *dst, void *stream)
+{
     if (!src || !dst) return fail(V2V_ERR_NULL, "v2v_to_nhwc8_bf16_hip: src/dst is NULL");
     if (B < 1 || C < 1 || C > 8 || H < 1 || W < 1 || B * H * W > 0x7FFFFFFFLL) return fail(V2V_ERR_SHAPE, "need B,H,W >= 1, 1 <= C <= 8, B*H*W < 2^31");
-    if (!aligned(dst, 16) || !aligned(src, 4)) return fail(V2V_ERR_ALIGN, "dst needs 16-byte alignment");
+    if (!aligned(dst, 16) || !aligned(src, 4) || (scales && !aligned(scales, 4))) return fail(V2V_ERR_ALIGN, "dst needs 16-byte alignment");
     const hipError_t e = v2v::launch_to_nhwc8_bf16(src, stride_b, stride_c, stride_h, stride_w, static_cast<uint16_t *>(dst), (int)B, (int)C, (int)H, (int)W,
-                                                   static_cast<hipStream_t>(stream));
+                                                   scales, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? V2V_OK : hip_fail(e, "to_nhwc8_bf16_kernel launch");
 }
 

@@ -819,7 +819,11 @@ __global__ void __launch_bounds__(256) conv_head_pack_kernel(const float *w, uin
 }
 
 // float32 [B, C <= 8, H, W] with arbitrary element strides -> bf16 [B, H, W, 8], channels C..7 zero (the head's input layout)
-__global__ void __launch_bounds__(256) to_nhwc8_bf16_kernel(const float *src, int64_t sb, int64_t sc, int64_t sh, int64_t sw, uint16_t *dst, int B, int C, int H, int W)
+// scales (optional, [B,2] = {neg_max, pos_max} of normalize_batch_voxel, model/train_utils.py:157-166): the voxels are normalised WHILE
+// they are read -- where(v > 0, v / pos_max, v / neg_max) in IEEE float32 division, then rounded to bf16 -- so a normalised copy of the
+// event tensor never exists
+__global__ void __launch_bounds__(256) to_nhwc8_bf16_kernel(const float *src, int64_t sb, int64_t sc, int64_t sh, int64_t sw, uint16_t *dst, int B, int C, int H, int W,
+                                                            const float *scales)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)B * H * W) return;
@@ -827,6 +831,11 @@ __global__ void __launch_bounds__(256) to_nhwc8_bf16_kernel(const float *src, in
     float v[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) v[c] = c < C ? src[b * sb + c * sc + y * sh + x * sw] : 0.0f;
+    if (scales) {
+        const float neg_max = scales[2 * b], pos_max = scales[2 * b + 1];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = v[c] > 0.0f ? v[c] / pos_max : v[c] / neg_max;
+    }
     *reinterpret_cast<uint4 *>(dst + i * 8) = make_uint4(cl_pack_bf16(v[0], v[1]), cl_pack_bf16(v[2], v[3]), cl_pack_bf16(v[4], v[5]), cl_pack_bf16(v[6], v[7]));
 }
 

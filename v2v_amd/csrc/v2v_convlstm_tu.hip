@@ -173,10 +173,10 @@ hipError_t launch_conv_head_pack(const float *w, uint16_t *wp, int Cin, int ks, 
     return hipGetLastError();
 }
 
-hipError_t launch_to_nhwc8_bf16(const float *src, int64_t sb, int64_t sc, int64_t sh, int64_t sw, uint16_t *dst, int B, int C, int H, int W, hipStream_t s)
+hipError_t launch_to_nhwc8_bf16(const float *src, int64_t sb, int64_t sc, int64_t sh, int64_t sw, uint16_t *dst, int B, int C, int H, int W, const float *scales, hipStream_t s)
 {
     const int64_t n = (int64_t)B * H * W;
-    hipLaunchKernelGGL(to_nhwc8_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, sb, sc, sh, sw, dst, B, C, H, W);
+    hipLaunchKernelGGL(to_nhwc8_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, sb, sc, sh, sw, dst, B, C, H, W, scales);
     return hipGetLastError();
 }
 

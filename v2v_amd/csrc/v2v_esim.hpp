@@ -147,6 +147,13 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
     // each) are static too; only the K- and Tb-sized bilinear tables live in the dynamic region
     __shared__ __align__(16) ent_t s_lut[256];
     __shared__ __align__(16) double s_thr[4];
+    // The writer's value histogram (a.stats: the consumer's normalize_batch_voxel needs the 1 % / 99 % k-th values of every sample;
+    // SUM-mode integer grids only): +-1 are counted per wave with one ballot each into scalar registers, |v| >= 2 by LDS atomics under
+    // a wave-level branch, zeros not at all (derived from the element count) -- 3 compares per stored voxel instead of a 157 MB pass.
+    constexpr bool STATS = BIN == kBinSum && !OUT64 && !EXT;
+    __shared__ unsigned int s_hist[STATS ? kStatBins : 1];
+    const bool want_stats = STATS && a.stats != nullptr;                    // wave-uniform (kernel argument)
+    uint32_t st_p1 = 0, st_m1 = 0;                                          // wave totals of +1 / -1 (scalar registers)
     acc_t *s_wlo = reinterpret_cast<acc_t *>(s_raw);
     acc_t *s_whi = s_wlo + a.K;
     int *s_kb = reinterpret_cast<int *>(s_whi + a.K);      // [Tb] first pair index of each bin segment
@@ -160,6 +167,9 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
     }
     if constexpr (IN == kInU8) s_lut[threadIdx.x] = g_lut_esim64[threadIdx.x];
     else s_lut[threadIdx.x] = make_float2(g_lut_esim32[threadIdx.x], (float)threadIdx.x);
+    if constexpr (STATS) {
+        if (want_stats) for (int i = threadIdx.x; i < kStatBins; i += kBlock) s_hist[i] = 0;
+    }
     if constexpr (BIN == kBinBilinear) {
         // Pair k contributes to bins seg(k) and seg(k)+1 with the float64 weights of event_utils.py:715-719:
         // t_norm = (k - 0)/((K-1) - 0)*(Tb-1), w_b = max(0, 1 - |t_norm - b|); every other bin's weight is exactly 0.
@@ -438,6 +448,20 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
         if constexpr (BIN == kBinSum) {
             if (++sub == a.fpb) {                                      // wave-uniform
                 store_vec<VEC, acc_t>(a.out, out_base + (int64_t)plane * a.out_plane, acc_lo);
+                if constexpr (STATS) {
+                    if (want_stats) {                                  // wave-uniform
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) {
+                            const float v = (float)acc_lo[j];
+                            st_p1 += (uint32_t)__popcll(__ballot(v == 1.0f));
+                            st_m1 += (uint32_t)__popcll(__ballot(v == -1.0f));
+                            if (__builtin_fabsf(v) >= 2.0f) {              // exec-masked region; skipped by the wave when no lane is in
+                                const int iv = (int)v;                     // saturating convert; the clamp keeps hot pixels in the overflow bins
+                                atomicAdd(&s_hist[(iv < -kStatMax - 1 ? -kStatMax - 1 : iv > kStatMax + 1 ? kStatMax + 1 : iv) + kStatZero], 1u);
+                            }
+                        }
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) acc_lo[j] = 0;
                 sub = 0;
@@ -505,6 +529,9 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
 #pragma unroll
             for (int j = 0; j < VEC; ++j) bad[j] = (acc_t)__builtin_nanf("");
             for (int64_t pl = 0; pl < planes_per_clip; ++pl) store_vec<VEC, acc_t>(a.out, (int64_t)clip * planes_per_clip * a.out_plane + pl * a.out_plane + pix_off, bad);
+            if constexpr (STATS) {
+                if (want_stats && p0 == 0) atomicExch(&a.stats[(int64_t)clip * kStatWords + kStatBad], 1u);
+            }
             return;
         }
         run(std::true_type{});
@@ -520,6 +547,21 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
         flush_lower(cur_seg);
         if (cur_seg + 1 < a.Tb) flush_lower(cur_seg + 1);
         for (int b = cur_seg + 2; b < a.Tb; ++b) flush_lower(b);       // zeros by now
+    }
+    if constexpr (STATS) {
+        if (want_stats) {
+            // lanes past the end of the clip left above; a wave that is still here has its lane 0.  Finished waves do not hold the barrier.
+            if ((threadIdx.x & 63) == 0) {
+                if (st_p1) atomicAdd(&s_hist[kStatZero + 1], st_p1);
+                if (st_m1) atomicAdd(&s_hist[kStatZero - 1], st_m1);
+            }
+            __syncthreads();
+            // only the work-items that own pixels are still here (the last workgroup of a clip may be partly empty): stride by their number
+            const int left = (a.HW - blk * kBlock * VEC + VEC - 1) / VEC, n_act = left < kBlock ? left : kBlock;
+            unsigned int *gs = a.stats + (int64_t)clip * kStatWords;
+            for (int i = threadIdx.x; i < kStatBins; i += n_act)
+                if (s_hist[i]) atomicAdd(&gs[i], s_hist[i]);
+        }
     }
     const uint32_t n_on = n_all - n_off;
     if (want_counts) {

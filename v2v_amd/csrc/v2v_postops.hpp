@@ -155,16 +155,22 @@ __global__ void select_init_kernel(SelectState *st, int64_t n_sw, uint64_t rank_
 }
 
 // out[b, p, 0:H, 0:W] = normalised voxel, zero elsewhere (padded to Hp x Wp)
-__global__ void __launch_bounds__(256) normalize_pad_kernel(const float *x, float *out, const SelectState *st, int normalize,
+// scales[sample] = {neg_max, pos_max} = {clamp(-kth(1 %), min=1), clamp(kth(99 %), min=1)} (model/train_utils.py:157-160); nullptr: no scaling
+__global__ void state_scales_kernel(const SelectState *st, float *scales, int64_t n_sw)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sw) return;
+    const float k = key_float(st[i].prefix), m = (i & 1) ? k : -k;
+    scales[i] = m < 1.0f ? 1.0f : m;                                          // torch.clamp(..., min=1): a NaN stays a NaN
+}
+
+__global__ void __launch_bounds__(256) normalize_pad_kernel(const float *x, float *out, const float *scales,
                                                            int64_t planes, int H, int W, int Hp, int Wp, int Hin, int Win)
 {
     const int sample = blockIdx.y;
+    const bool normalize = scales != nullptr;
     float pos_max = 1.0f, neg_max = 1.0f;
-    if (normalize) {
-        const float hi = key_float(st[sample * 2 + 1].prefix), lo = -key_float(st[sample * 2].prefix);
-        pos_max = hi < 1.0f ? 1.0f : hi;                                      // torch.clamp(kth(0.99), min=1): a NaN stays a NaN
-        neg_max = lo < 1.0f ? 1.0f : lo;                                      // torch.clamp(-kth(0.01), min=1)
-    }
+    if (normalize) { neg_max = scales[sample * 2]; pos_max = scales[sample * 2 + 1]; }
     const int64_t per_out = planes * Hp * Wp;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_out; i += (int64_t)gridDim.x * 256) {
         const int xw = (int)(i % Wp);
@@ -184,16 +190,13 @@ __global__ void __launch_bounds__(256) normalize_pad_kernel(const float *x, floa
 // the simulator writes): a wave walks output rows, a lane moves 16 bytes.  No 64-bit division per element (the kernel above pays
 // two), one 32-bit division per row; the float32 division of the reference's voxel / pos_max stays an IEEE division.
 // Round 3: 143 -> 76 us average over the three shapes of tools/postops_time.py (5.9 TB/s).
-__global__ void __launch_bounds__(256) normalize_pad_rows_kernel(const float *x, float *out, const SelectState *st, int normalize,
+__global__ void __launch_bounds__(256) normalize_pad_rows_kernel(const float *x, float *out, const float *scales,
                                                                 int planes, int H, int W, int Hp, int Wp, int Hin, int Win)
 {
     const int sample = blockIdx.y;
+    const bool normalize = scales != nullptr;
     float pos_max = 1.0f, neg_max = 1.0f;
-    if (normalize) {
-        const float hi = key_float(st[sample * 2 + 1].prefix), lo = -key_float(st[sample * 2].prefix);
-        pos_max = hi < 1.0f ? 1.0f : hi;                                      // torch.clamp(kth(0.99), min=1): a NaN stays a NaN
-        neg_max = lo < 1.0f ? 1.0f : lo;                                      // torch.clamp(-kth(0.01), min=1)
-    }
+    if (normalize) { neg_max = scales[sample * 2]; pos_max = scales[sample * 2 + 1]; }
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t rows = (uint32_t)planes * (uint32_t)Hp;                    // < 2^31: checked by the launcher
     const float *xs = x + (int64_t)sample * planes * Hin * Win;
@@ -308,13 +311,14 @@ __global__ void __launch_bounds__(256) count_hist4_kernel(const float *x, int64_
 // The zero bin either holds the counted zeros incl. the n_pad padding zeros (count_hist*: removed here) or -- derive_zero, the
 // histogram the SIMULATOR's writer accumulates (it counts non-zero values only) -- is whatever the other bins leave of n_elems.
 constexpr int kCntPerLane = (kCntBins + 63) / 64;
-__global__ void __launch_bounds__(64) count_pick_kernel(SelectState *st, const unsigned int *hist, const unsigned int *bad, int64_t n_sw, uint64_t n_pad,
-                                                      uint64_t rank_lo, uint64_t rank_hi, int derive_zero, uint64_t n_elems, float *scales)
+__global__ void __launch_bounds__(64) count_pick_kernel(const unsigned int *hist, int64_t hist_stride, const unsigned int *bad, int64_t bad_stride,
+                                                      int64_t n_sw, uint64_t n_pad, uint64_t rank_lo, uint64_t rank_hi, int derive_zero,
+                                                      uint64_t n_elems, float *scales)
 {
     const int64_t sw = blockIdx.x;
     if (sw >= n_sw) return;
     const int64_t sample = sw >> 1;
-    const unsigned int *h = hist + sample * kCntBins;
+    const unsigned int *h = hist + sample * hist_stride;
     const uint64_t rank = (sw & 1) ? rank_hi : rank_lo;
     const int lane = threadIdx.x;
     uint64_t c[kCntPerLane], mine = 0, nonzero = 0;
@@ -346,24 +350,16 @@ __global__ void __launch_bounds__(64) count_pick_kernel(SelectState *st, const u
     if (lane != owner) return;
     uint64_t r = rank - (incl - mine);
     int b = lane * kCntPerLane;
-#pragma unroll
     for (int j = 0; j < kCntPerLane; ++j) {
         if (b >= kCntBins - 1 || r < c[j]) break;
         r -= c[j];
         ++b;
     }
     if (b > kCntBins - 1) b = kCntBins - 1;
-    const bool exact = !bad[sample] && b > 0 && b < kCntBins - 1;              // an overflow bin has no single value
+    const bool exact = !bad[sample * bad_stride] && b > 0 && b < kCntBins - 1;  // an overflow bin has no single value
     const float kth = exact ? (float)(b - kCntZero) : __uint_as_float(0x7FC00000u);
-    SelectState s;
-    s.prefix = float_key(kth);
-    s.prefix_mask = 0xFFFFFFFFu;
-    s.rank = 0;
-    st[sw] = s;
-    if (scales) {                                               // (neg_max, pos_max) = clamp(-kth(1 %), min=1), clamp(kth(99 %), min=1)
-        const float m = (sw & 1) ? kth : -kth;
-        scales[sw] = m < 1.0f ? 1.0f : m;                       // a NaN stays a NaN (m < 1 is false)
-    }
+    const float m = (sw & 1) ? kth : -kth;                      // (neg_max, pos_max) = clamp(-kth(1 %), min=1), clamp(kth(99 %), min=1)
+    scales[sw] = m < 1.0f ? 1.0f : m;                           // a NaN stays a NaN (m < 1 is false)
 }
 
 }  // namespace v2v

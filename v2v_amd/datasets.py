@@ -597,20 +597,25 @@ class SimulatingCollator:
         pa = params.cpu().numpy()
         no_noise = bool((pa[:, 2] == 0).all() and (pa[:, 3] <= 0).all())
         t0 = self._t("stage_ready", t0)
+        # normalize: the k-th values come from statistics the simulator's writer keeps (exact counting over the integers -255..255 +
+        # overflow words for the rare hot pixels) when the batch's own parameters bound the normal pixels' counts, else from a radix
+        # select over the finished tensor (v2v_amd/loader.py:choose_normalize_method); then ONE scaling pass in place
+        from . import _lib
+        from .loader import choose_normalize_method
+        method = choose_normalize_method(pa, self.frames_per_bin, self.put_noise_external) if self.normalize else None
+        stats = torch.empty((clips.shape[0], _lib.VOXEL_STATS_WORDS), dtype=torch.int32, device=self.device) if method == "count" and self.rng_mode != "replay" else None
         vox = esim.esim_voxel_batch(clips, params.to(self.device), bin_mode="sum", num_bins=self.num_bins,
                                     frames_per_bin=self.frames_per_bin, rng_mode=self.rng_mode, clip_keys=keys,
-                                    put_noise_external=self.put_noise_external, no_noise=no_noise, pad_to=self.pad_to)   # [B,L(+1),Tb,Hp,Wp]
+                                    put_noise_external=self.put_noise_external, no_noise=no_noise, pad_to=self.pad_to, stats=stats)   # [B,L(+1),Tb,Hp,Wp]
         t0 = self._t("sim", t0)
         if self.normalize:
             from . import postops
             h, w = clips.shape[-2:]
-            # exact counting select (integers -255..255 + overflow bins for the rare hot pixels) when the batch's own parameters bound
-            # the normal pixels' counts, else the radix select on the unpadded interior (v2v_amd/loader.py:choose_normalize_method)
-            from .loader import choose_normalize_method
-            if choose_normalize_method(pa, self.frames_per_bin, self.put_noise_external) == "radix":
-                vox = postops.normalize_and_pad(vox[..., :h, :w], True, self.pad_to, method="radix")
+            if stats is not None:
+                scales = postops.scales_from_stats(stats, vox.shape[1] * vox.shape[2] * h * w)
             else:
-                vox = postops.normalize_and_pad(vox, True, self.pad_to, method="count", valid_hw=(h, w), inplace=True)
+                scales = postops.voxel_scales_radix(vox[..., :h, :w])
+            vox = postops.apply_scales(vox, scales, self.pad_to, valid_hw=(h, w), inplace=True)
         t0 = self._t("postops", t0)
         batch["events"] = vox.to(self.output_device)
         batch["frame"] = batch["frame"].to(self.output_device)

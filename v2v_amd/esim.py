@@ -43,7 +43,7 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
                      out: Optional[torch.Tensor] = None, counts: Optional[torch.Tensor] = None,
                      replay: Optional[Sequence[torch.Tensor]] = None, validate: bool = True,
                      no_noise: Optional[bool] = None, clip_keys: Optional[torch.Tensor] = None, pad_to: int = 1,
-                     symmetric: Optional[bool] = None, mapping: Optional[str] = None) -> torch.Tensor:
+                     symmetric: Optional[bool] = None, mapping: Optional[str] = None, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Simulate a batch of clips and bin the events, in one kernel launch on the current stream.
 
     frames  [B,N,H,W] uint8 or float32 CUDA tensor (grayscale; dims 2,3 contiguous).
@@ -61,6 +61,9 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
     symmetric True asserts pos_thres == neg_thres for every clip (EventEmulator's own defaults): instances compiled without
             the asymmetric loop, 4 waves per SIMD (identical results; a clip that breaks the promise comes out as NaN).
             Default: detected from host `params`, False for a device tensor.
+    stats     optional int32 [B, VOXEL_STATS_WORDS] CUDA tensor: the writer's per-clip value histogram for normalize_batch_voxel
+            (v2v_esim_voxel_stats_hip; zeroed and filled by the launch; SUM mode, float32 grid, no external noise) -> feed it to
+            v2v_amd.postops.scales_from_stats.
     mapping   "auto" (4 pixels per work-item for aligned layouts unless the batch is small, then 2 or 1), "4px", "2px" or "1px" to pin it;
             results do not depend on it.  None = the module default DEFAULT_MAPPING ("auto"; the test-suite sweeps it).
     """
@@ -127,8 +130,13 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
         clip_keys = torch.as_tensor(clip_keys).to(device=frames.device, dtype=torch.int64).contiguous()
         if tuple(clip_keys.shape) != (b, 2):
             raise ValueError("clip_keys must be [B,2] (seed, clip id)")
+    if stats is not None:
+        if stats.dtype != torch.int32 or tuple(stats.shape) != (b, _lib.VOXEL_STATS_WORDS) or not stats.is_contiguous() or stats.device != frames.device:
+            raise ValueError(f"stats must be a contiguous int32 [{b},{_lib.VOXEL_STATS_WORDS}] tensor on the frames' device")
+    fn = _lib.lib().v2v_esim_voxel_padded_hip if stats is None else _lib.lib().v2v_esim_voxel_stats_hip
+    extra = () if stats is None else (C.c_void_p(stats.data_ptr()),)
     with torch.cuda.device(frames.device):
-        rc = _lib.lib().v2v_esim_voxel_padded_hip(
+        rc = fn(
             C.c_void_p(frames.data_ptr()), _TORCH_IN[frames.dtype], b, n, h, w,
             frames.stride(0) if b > 1 else n * frames.stride(1), frames.stride(1),
             C.c_void_p(p.data_ptr()), pstride,
@@ -137,7 +145,7 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
             C.c_void_p(clip_keys.data_ptr()) if clip_keys is not None else None,
             C.byref(rp) if rp is not None else None, BIN_MODES[bin_mode], num_bins, frames_per_bin,
             C.c_void_p(out.data_ptr()), _OUT[out.dtype], wp, hp * wp,
-            C.c_void_p(counts.data_ptr()) if counts is not None else None, _lib.stream_ptr())
+            C.c_void_p(counts.data_ptr()) if counts is not None else None, *extra, _lib.stream_ptr())
     _lib.check(rc)
     # The launch is asynchronous: PyTorch's caching allocator keeps freed blocks stream-ordered, so dropping
     # p / keep here is safe for work queued on the same stream.

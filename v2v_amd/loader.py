@@ -173,7 +173,10 @@ class RingLoader:
 
     pad_to / normalize   the consumer-side post-ops done where the voxels are produced (model/train_utils.py:147-166, 322-326): events
                          are written into the x`pad_to`-padded layout and, with normalize=True, normalize_batch_voxel is applied in
-                         place -- then run the model with normalize_voxels: false.
+                         place -- then run the model with normalize_voxels: false.  The k-th values come from statistics the
+                         simulator's writer keeps (no histogram pass over the tensor).  normalize='scales' leaves the events raw and
+                         adds batch['event_scales'] float32 [B,2] = (neg_max, pos_max) for a consumer that scales while it reads them
+                         (v2v_amd.unet's head): no pass over the tensor at all.
     depth                device-side slots (batches in flight on the GPU): 2 = copy of batch k+1 under the compute of batch k.
     timers               optional dict: accumulates host seconds per stage (wait_batch, h2d_enqueue, sim, postops, frames, assemble)."""
 
@@ -264,7 +267,8 @@ class RingLoader:
         cur = torch.cuda.current_stream(self.device)
         ev = torch.cuda.Event()
         with torch.cuda.stream(self.copy_stream):
-            self.copy_stream.wait_event(self._dev_free[d])            # the launches that read this device slot `depth` batches ago
+            # the launches that read this device slot `depth` batches ago (a host-side wait instead was measured: no faster)
+            self.copy_stream.wait_event(self._dev_free[d])
             self._dev[d].copy_(self._ring_t[slot], non_blocking=True)
             ev.record(self.copy_stream)
         del cur
@@ -282,20 +286,25 @@ class RingLoader:
         clips, cframes, params_d, keys_d = lay.device_views(self._dev[d])
         t0 = time.perf_counter()
         no_noise = bool((params[:, 2] == 0).all() and (params[:, 3] <= 0).all())
+        method = choose_normalize_method(params, leaf.frames_per_bin, leaf.put_noise_external) if self.normalize else None
+        stats = torch.empty((lay.batch, _lib.VOXEL_STATS_WORDS), dtype=torch.int32, device=self.device) if method == "count" else None
         vox = esim.esim_voxel_batch(clips, params_d, bin_mode="sum", num_bins=leaf.num_bins, frames_per_bin=leaf.frames_per_bin,
                                     rng_mode="philox", clip_keys=keys_d, put_noise_external=leaf.put_noise_external, no_noise=no_noise,
-                                    pad_to=self.pad_to, validate=False)
+                                    pad_to=self.pad_to, validate=False, stats=stats)
         self._t("sim", t0)
         t0 = time.perf_counter()
         batch = {}
         if self.normalize:
             from . import postops
-            method = choose_normalize_method(params, leaf.frames_per_bin, leaf.put_noise_external)
             h, w = lay.h, lay.w
-            if method == "radix":
-                vox = postops.normalize_and_pad(vox[..., :h, :w], True, self.pad_to, method="radix")
+            if method == "count":                                         # the writer's statistics -> exact scales, no pass over the tensor
+                scales = postops.scales_from_stats(stats, vox.shape[1] * vox.shape[2] * h * w)
+            else:                                                         # counts beyond the counting range / external noise: radix select
+                scales = postops.voxel_scales_radix(vox[..., :h, :w])
+            if self.normalize == "scales":
+                batch["event_scales"] = scales
             else:
-                vox = postops.normalize_and_pad(vox, True, self.pad_to, method="count", valid_hw=(h, w), inplace=True)
+                vox = postops.apply_scales(vox, scales, self.pad_to, valid_hw=(h, w), inplace=True)
         self._t("postops", t0)
         t0 = time.perf_counter()
         if cframes is None:

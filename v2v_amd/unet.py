@@ -91,11 +91,14 @@ class UNetRecurrent(nn.Module):
         self.pred = ConvLayer(self.base_num_channels, self.num_output_channels, 1, activation=None, norm=self.norm)
         self.states = [None] * self.num_encoders
 
-    def forward(self, x):
-        """x: [N, num_bins, H, W] float voxel grid (any layout), H and W multiples of 2^num_encoders -> {'image': [N,1,H,W]}."""
+    def forward(self, x, event_scales=None):
+        """x: [N, num_bins, H, W] float voxel grid (any layout), H and W multiples of 2^num_encoders -> {'image': [N,1,H,W]}.
+        event_scales (this implementation only): float32 [N,2] = (neg_max, pos_max) per sample, e.g. RingLoader(normalize='scales')'s
+        batch['event_scales'] -- normalize_batch_voxel (model/train_utils.py:147-166) is then applied by the head while it reads the
+        RAW voxel grid; None = x is used as it is."""
         out_dtype = torch.bfloat16 if (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()) else x.dtype
         with torch.autocast("cuda", dtype=torch.bfloat16):      # the head hands out bfloat16; every later layer keeps it
-            x = self.head(x)                                    # reads any strides (its own layout kernel), bfloat16 NHWC out
+            x = self.head(x, scales=event_scales)               # reads any strides (its own layout kernel), bfloat16 NHWC out
         head = x
         blocks = []
         for i, encoder in enumerate(self.encoders):
@@ -139,5 +142,5 @@ class E2VIDRecurrent(nn.Module):
     def reset_states(self):
         self.unetrecurrent.states = [None] * self.unetrecurrent.num_encoders
 
-    def forward(self, event_tensor):
-        return self.unetrecurrent.forward(event_tensor)
+    def forward(self, event_tensor, event_scales=None):
+        return self.unetrecurrent.forward(event_tensor, event_scales)
