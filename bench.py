@@ -48,6 +48,10 @@ WORKLOADS = {
     # 256x256, flip) -> fused sim + sum binning.  41 frames so that (N-1) % 5 == 0 as the reference asserts.
     "cfg4_pipeline_720p_to_256_41f_sum5": dict(model="pipeline", b=24, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1,
                                                params=DATASET_STYLE, src_hw=(720, 1280)),
+    # BASELINE config 4 as BASELINE.json words it: 40-frame clips (39 pairs, not divisible by 5 -> the reference's SUM binning would
+    # assert) into 5 temporal-bilinear bins
+    "cfg4_pipeline_720p_to_256_40f_bilinear5": dict(model="pipeline", b=24, n=40, h=256, w=256, dtype="uint8", bin="bilinear", tb=5, fpb=1,
+                                                    params=DATASET_STYLE, src_hw=(720, 1280)),
     # BASELINE config 5 (per GPU): config 4's pipeline feeding a random-init E2VID-shaped recurrent UNet (bf16 autocast,
     # tools/e2vid_consumer.py) -- end-to-end "dataloader -> model forward" throughput.
     "cfg5_pipeline_plus_e2vid_bf16": dict(model="pipeline", b=8, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1,
@@ -67,7 +71,8 @@ WORKLOADS = {
 }
 DEFAULT_WORKLOAD = "cfg2_esim_f32_256x32x256x256_bilinear5"
 ALSO_MEASURED = ["cfg2_noise_free", "cfg2_dataset_style", "cfg2_u8", "cfg3_v2e_f32_256x32x256x256_bilinear5", "cfg3_v2e_u8",
-                 "cfg4_u8_256x41x256x256_sum5", "cfg4_pipeline_720p_to_256_41f_sum5", "train_u8_12x201x128x128_sum5",
+                 "cfg4_u8_256x41x256x256_sum5", "cfg4_pipeline_720p_to_256_41f_sum5", "cfg4_pipeline_720p_to_256_40f_bilinear5",
+                 "train_u8_12x201x128x128_sum5",
                  "cfg5_pipeline_plus_e2vid_bf16", "cfg5_fused_convlstm", "cfg5_channels_last", "cfg5_fused_convlstm_channels_last"]
 
 
@@ -165,9 +170,10 @@ class Workload:
             import numpy as np
             from v2v_amd import frontend
             sh, sw = wl["src_hw"]
-            gray_video = esim.synth_clips(b, n, sh, sw, dtype=torch.uint8, seed=20240001, clip_id0=clip_id0, device=dev)
-            self.raw = raw = gray_video.unsqueeze(-1).expand(b, n, sh, sw, 3).contiguous()              # decoded BGR frames [B,T,720,1280,3]
-            del gray_video
+            # decoded BGR frames [B,T,720,1280,3] with three DIFFERENT channels (round 3 fed B = G = R, which cannot catch a swapped weight)
+            self.raw = raw = torch.empty((b, n, sh, sw, 3), dtype=torch.uint8, device=dev)
+            for ch in range(3):
+                raw[..., ch] = esim.synth_clips(b, n, sh, sw, dtype=torch.uint8, seed=20240001 + 7919 * ch, clip_id0=clip_id0, device=dev)
             g = np.random.default_rng(20240001 + rank)
             keep_h = int(sh * 0.54)                                                          # keep_top_percentile (v2v_datasets.py:73)
             min_scale = max(0, h / keep_h, h / sw)
@@ -278,7 +284,7 @@ def time_launches(step, steps, torch):
         step()
         e.record()
     torch.cuda.synchronize()
-    return sorted(s.elapsed_time(e) for s, e in ev)
+    return [s.elapsed_time(e) for s, e in ev]                      # in launch order (callers sort their own copy for percentiles)
 
 
 def maybe_graph(step, torch, dev, want):
@@ -327,7 +333,7 @@ def convlstm_roofline(torch, dev):
         step = lambda: CL.convlstm_step(xn, hn, cn, packed, bias, nchw_dtype=torch.float32)   # noqa: E731
         for _ in range(3):
             got = step()
-        ms = time_launches(step, 20, torch)
+        ms = sorted(time_launches(step, 20, torch))
         r16 = lambda v: v.to(torch.bfloat16).float()   # noqa: E731
         gates = torch.nn.functional.conv2d(torch.cat([r16(x), r16(hp)], 1), r16(wgt), bias, padding=1)
         gi, gr, go, gg = gates.chunk(4, 1)
@@ -430,7 +436,8 @@ def main():
     step, use_graph = maybe_graph(step, torch, dev, args.hip_graph == "on" or (args.hip_graph == "auto" and wl["model"] == "pipeline"))
     sharding.barrier(dist, local_rank)
     t0 = time.perf_counter()
-    kern_ms = time_launches(step, args.steps, torch)
+    kern_trace = time_launches(step, args.steps, torch)
+    kern_ms = sorted(kern_trace)
     sharding.barrier(dist, local_rank)
     my_elapsed = time.perf_counter() - t0
     elapsed = sharding.max_over_ranks(dist, my_elapsed, dev)
@@ -512,7 +519,7 @@ def main():
                 for _ in range(3):
                     S.step()
                 s_step, s_graph = maybe_graph(S.step, torch, dev, S.wl["model"] == "pipeline")
-                ms = time_launches(s_step, 12, torch)
+                ms = sorted(time_launches(s_step, 12, torch))
                 avg = sum(ms) / len(ms)
                 ach = S.alg_bytes / (avg * 1e-3) / 1e9
                 also[name] = {"kernel": S.kernel_name, "kernel_ms_avg": avg, "kernel_ms_p50": ms[len(ms) // 2], "grids_per_s": S.grids_per_step / (avg * 1e-3),
@@ -564,6 +571,8 @@ def main():
                          "measured_ceilings_GBps": MEASURED_CEILINGS_GBPS,
                          "kernel_ms_avg": kern_avg_ms, "kernel_ms_p10": kern_ms[len(kern_ms) // 10],
                          "kernel_ms_p50": kern_ms[len(kern_ms) // 2], "kernel_ms_p90": kern_ms[(len(kern_ms) * 9) // 10],
+                         # every timed launch in order: a monotone ramp after the warm-up launches = clocks settling, scatter = neighbours
+                         "kernel_ms_trace": [round(v, 4) for v in kern_trace],
                          "valu_issue": load_valu(args.workload, kern_avg_ms),
                          "note": "noise-on launches are VALU-issue-bound, not HBM-bound (DESIGN.md §4.1); `frac` is still quoted against the HBM peak; "
                                  "`valu_issue` gives the same launch against the vector-issue ceilings"},

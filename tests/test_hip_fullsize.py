@@ -125,16 +125,17 @@ def test_cfg3_v2e_full_batch_256x32x256x256(oracle_c, luts, dt_name):
 
 
 @gpu
-@pytest.mark.parametrize("n,bin_mode", [(41, "sum"), (40, "bilinear")])
-def test_cfg4_720p_to_256_pipeline(oracle_c, luts, n, bin_mode):
+@pytest.mark.parametrize("n,bin_mode,b", [(41, "sum", 6), (40, "bilinear", 6), (41, "sum", 24), (40, "bilinear", 24)])
+def test_cfg4_720p_to_256_pipeline(oracle_c, luts, n, bin_mode, b):
     """BASELINE config 4 at its real geometry: decoded 1280x720x3 frames, keep_top_percentile 0.54, crop -> 256x256, flip,
     N = 41 frames (SUM, the reference's assert holds) and N = 40 (temporal-bilinear): GPU front-end against the OpenCV-algorithm
     restatement (oracle/frontend_oracle.py; parity with cv2 itself is unpinned -- OpenCV is not in the image), then the
-    simulator on the front-end's output against the C oracle, on sampled clips."""
+    simulator on the front-end's output against the C oracle, on sampled clips.  b = 24 is the batch bench.py times per GPU (the
+    tiled front-end's batch table with four frames per block)."""
     import torch
     from oracle import frontend_oracle as FO
     from v2v_amd import esim, frontend
-    b, sh, sw, crop, tb = 6, 720, 1280, 256, 5
+    sh, sw, crop, tb = 720, 1280, 256, 5
     g = np.random.default_rng(404 + n)
     # decoded BGR frames with real colour content (three different channels), resident in HBM
     base = esim.synth_clips(b, n, sh, sw, dtype=torch.uint8, seed=SEED + 7, clip_id0=0)
