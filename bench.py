@@ -43,6 +43,8 @@ WORKLOADS = {
     "cfg2_u8_noise_free": dict(_CFG2, dtype="uint8", params=NOISE_FREE),
     "cfg3_v2e_f32_256x32x256x256_bilinear5": dict(_CFG2, model="v2e", params=V2E_NOISY),
     "cfg3_v2e_u8": dict(_CFG2, model="v2e", dtype="uint8", params=V2E_NOISY),
+    # the run-time-feature instance of the v2e kernel (per-frame thresholds: no specialised instance): what the rare configurations run
+    "cfg3_v2e_f32_per_frame_thresholds": dict(_CFG2, model="v2e", params=[V2E_NOISY[0], "spatial_temporal_independent"] + V2E_NOISY[2:]),
     "cfg4_u8_256x41x256x256_sum5": dict(model="esim", b=256, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1, params=DATASET_STYLE),
     # BASELINE config 4 (per GPU): decoded 720p BGR frames resident in HBM -> GPU front-end (cvtColor, crop, resize to
     # 256x256, flip) -> fused sim + sum binning.  41 frames so that (N-1) % 5 == 0 as the reference asserts.
@@ -71,6 +73,7 @@ WORKLOADS = {
 }
 DEFAULT_WORKLOAD = "cfg2_esim_f32_256x32x256x256_bilinear5"
 ALSO_MEASURED = ["cfg2_noise_free", "cfg2_dataset_style", "cfg2_u8", "cfg3_v2e_f32_256x32x256x256_bilinear5", "cfg3_v2e_u8",
+                 "cfg3_v2e_f32_per_frame_thresholds",
                  "cfg4_u8_256x41x256x256_sum5", "cfg4_pipeline_720p_to_256_41f_sum5", "cfg4_pipeline_720p_to_256_40f_bilinear5",
                  "train_u8_12x201x128x128_sum5",
                  "cfg5_pipeline_plus_e2vid_bf16", "cfg5_fused_convlstm", "cfg5_channels_last", "cfg5_fused_convlstm_channels_last"]

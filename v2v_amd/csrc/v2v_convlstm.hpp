@@ -118,7 +118,7 @@ template <int MF, int WM, int STAGES = 2, int EPI = 0, int WN = 2, int NF = 4, i
 __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 1 : (STAGES == 2 && MF == 1) || WM * WN == 8 || NF < 4 ? 2 : 1) convlstm_step_kernel(const ConvLstmArgs a)
 {
     static_assert(KS == 1 || KS == 2, "one or two K groups");
-    static_assert(EPI == 1 || (WN == 2 && NF == 4), "the gate epilogue needs the four gates of a channel in one wave");
+    static_assert(EPI == 1 || NF == 4, "the gate epilogue needs the four gates of a channel in one wave");
     static_assert(TPC == 1 || (TPC == 2 && EPI == 1), "two taps per chunk: plain convolution of 32 input channels");
     constexpr int kBN = WN * NF * 32, kBBytes = kBN * kClBK * 2;
     constexpr int kClBM = 32 * MF * WM, kClABytes = kClBM * kClBK * 2, kClStage = kClABytes + kBBytes;
@@ -132,7 +132,8 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
     const int C = a.C, HW = a.H * a.W;
     const int ks = EPI == 0 ? 3 : a.ks, pad = ks >> 1, n_taps = ks * ks, stride = EPI == 0 ? 1 : a.stride;
     const int Hin = EPI == 0 ? a.H : a.Hin, Win = EPI == 0 ? a.W : a.Win;
-    const int n_ct = EPI == 0 ? C / kClCh : a.n_cols / kBN;       // column tiles
+    constexpr int kStepCh = WN * 32;                              // hidden channels per column tile of the step (64, or 32 with one wave column)
+    const int n_ct = EPI == 0 ? C / kStepCh : a.n_cols / kBN;     // column tiles
     const int ct = blockIdx.x % n_ct;
     const int64_t m0 = (int64_t)(blockIdx.x / n_ct) * kClBM;      // first pixel of the tile (flattened b,y,x)
     const int cc_x = TPC == 2 ? 1 : C / kClBK, cc_all = EPI == 0 ? 2 * cc_x : cc_x;
@@ -169,7 +170,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
         boff[j] = (uint32_t)(row * kClBK + (sslot ^ ((row >> 1) & 7)) * 8);
     }
     // a column tile narrower than the packed one (EPI = 1, 128-column instances on 256-column packing): sub-tile `ct % per`
-    const int pcols = (EPI == 1 && a.pack_cols) ? a.pack_cols : kBN, per = pcols / kBN;
+    const int pcols = EPI == 0 ? kClBN : a.pack_cols ? a.pack_cols : kBN, per = pcols / kBN;   // the step's weights are packed per 64 channels
     const uint16_t *wtile = a.wp + (int64_t)(ct / per) * (TPC == 2 ? n_chunks : n_taps * cc_all) * (pcols * kClBK) + (ct % per) * (kBN * kClBK);
 
     // LDS-DMA of chunk ck into buffer buf (part / nparts: a subset of the pieces, j % nparts == part).  The main loop issues
@@ -280,7 +281,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
     float cpre[kCpre ? MF : 1][16];
     auto prefetch_c = [&]() __attribute__((always_inline)) {
         if constexpr (kCpre) {
-            const int ch = ct * kClCh + wn * 32 + fr;
+            const int ch = ct * kStepCh + wn * 32 + fr;
 #pragma unroll
             for (int i = 0; i < MF; ++i)
 #pragma unroll
@@ -373,7 +374,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
     if constexpr (EPI == 0) {
     // ---- epilogue: gates -> cell / hidden, straight from the accumulators ---------------------------------------------------
     // accumulator element r of lane l: column (channel) l & 31, row (pixel) (r & 3) + 8 (r >> 2) + 4 (l >> 5)
-    const int ch = ct * kClCh + wn * 32 + fr;
+    const int ch = ct * kStepCh + wn * 32 + fr;
     const float b_i = a.bias[ch], b_r = a.bias[C + ch], b_o = a.bias[2 * C + ch], b_g = a.bias[3 * C + ch];
 #pragma unroll
     for (int i = 0; i < MF; ++i) {

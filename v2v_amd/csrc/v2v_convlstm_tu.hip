@@ -21,7 +21,7 @@ hipError_t launch_step_t(const ConvLstmArgs &a, hipStream_t s)
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) raised[dev].store(true, std::memory_order_release);
     }
-    const int64_t tiles = (int64_t)a.B * a.H * a.W / (32 * MF * WM) * (EPI == 0 ? a.C / kClCh : a.n_cols / (WN * NF * 32));
+    const int64_t tiles = (int64_t)a.B * a.H * a.W / (32 * MF * WM) * (EPI == 0 ? a.C / (WN * 32) : a.n_cols / (WN * NF * 32));
     hipLaunchKernelGGL((convlstm_step_kernel<MF, WM, STAGES, EPI, WN, NF, TPC, KS>), dim3((unsigned)tiles), dim3(64 * WM * WN * KS), lds, s, a);
     return hipGetLastError();
 }
@@ -42,6 +42,10 @@ hipError_t launch_convlstm_step(const ConvLstmArgs &a, int tile_rows, hipStream_
         // 128 ch @32^2 0.039 -> 0.033 ms, 256 ch @16^2 0.067 -> 0.053 ms; slower where more tiles exist: 0.115 -> 0.144 ms)
         if (tile_rows == 64 && m / 64 * ct <= cus) tile_rows = 65;
     }
+    // EXPERIMENT codes: one wave column (32 hidden channels x 4 gates = 128 columns per tile)
+    if (tile_rows == 129) return launch_step_t<1, 4, 2, 0, 1, 4>(a, s);        // 128 px x 32 ch, 4 waves, 64 KB: two workgroups per CU
+    if (tile_rows == 130) return launch_step_t<1, 4, 3, 0, 1, 4>(a, s);        // the same on three stages (96 KB: one workgroup)
+    if (tile_rows == 257) return launch_step_t<2, 4, 2, 0, 1, 4>(a, s);        // 256 px x 32 ch, 4 waves of 64 px, 96 KB
     if (tile_rows == 65) return launch_step_t<1, 2, 2, 0, 2, 4, 1, 2>(a, s);   // 64 px as two K groups of 4 waves (160 KB, internal code)
     // 256 px as 16 waves of 32 px x 128 columns (4 per SIMD, 114 VGPRs) instead of 8 of 64 x 128: bit-identical, -2...-4 % same box
     if (tile_rows == 256) return launch_step_t<1, 8, 2>(a, s);

@@ -895,8 +895,11 @@ __device__ __forceinline__ void v2e_main_body(const V2eArgs &a, const int clip, 
     }
 }
 
+// The run-time-feature instances (FEAT < 0: float64 grids, replayed fields, 1 pixel per work-item, the per-frame threshold model,
+// a cut-off whose float32(dt / tau) takes two values -- parity modes and rare configurations; launch_v2e routes everything a
+// dataset draws to the specialised ones) are compiled for 2 waves per SIMD: the float32 / 4-pixel ones kept 2-12 spilled VGPRs at 3.
 template <int IN, int VEC, int BIN, int RNG, bool OUT64, int FEAT = -1>
-__global__ void __launch_bounds__(kBlock, V2V_V2E_MIN_WAVES) v2e_voxel_kernel(const V2eArgs a)
+__global__ void __launch_bounds__(kBlock, (FEAT < 0 && IN == kInF32 && VEC == 4) ? 2 : V2V_V2E_MIN_WAVES) v2e_voxel_kernel(const V2eArgs a)
 {
     extern __shared__ __align__(16) unsigned char s_raw[];
     const int clip = blockIdx.x / a.blocks_per_clip;
