@@ -358,6 +358,26 @@ int v2v_nchw_to_nhwc_bf16_hip(const void *src, int src_dtype, int64_t B, int64_t
  * multiples of pad_to]; voxel [B,planes,H_in,W_in] (interior H x W valid), out [B,planes,Hp,Wp]; out == voxel allowed when the layouts
  * agree; scales NULL = copy / pad only.  A consumer that scales while it reads (v2v_to_nhwc8_bf16_scaled_hip) needs no such pass. */
 #define V2V_VOXEL_STATS_WORDS 516
+/* Optional extras of one simulator launch (v2v_esim_voxel_ex_hip = v2v_esim_voxel_padded_hip + this; NULL fields are off):
+ *   stats         as v2v_esim_voxel_stats_hip.
+ *   frame_index   int32 [B, N]: simulator frame f of clip b is STORED frame frame_index[b*N + f] -- the reference's pause-index gather
+ *                 (data/v2v_datasets.py:286-311: all_imgs = stack(raw_imgs[i] for i in img_idxes)) folded into the kernel's loads, so a
+ *                 clip whose video pauses is stored (and crosses PCIe) once per DECODED frame; results are those of the gathered clip.
+ *   clip_offsets  int64 [B]: clip b starts at element clip_offsets[b] of `frames` (clips of different stored lengths packed back to
+ *                 back); `clip_stride` then only states the alignment every offset keeps (in elements, e.g. 16).  Comes with frame_index.
+ * Indexed launches: uint8 clips, SUM bins, device-native noise, float32 grid, none of the NO_NOISE / NOISE_EXTERNAL / SYMMETRIC flags
+ * (V2V_ERR_MODE otherwise).  The indices are the caller's responsibility: a stored frame number beyond the clip reads past it. */
+typedef struct v2v_esim_extras {
+    uint32_t *stats;
+    const int32_t *frame_index;
+    const int64_t *clip_offsets;
+} v2v_esim_extras;
+int v2v_esim_voxel_ex_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W,
+                          int64_t clip_stride, int64_t frame_stride, const double *params, int64_t params_stride,
+                          uint32_t flags, int rng_mode, uint64_t seed, uint64_t clip_id0, const uint64_t *clip_keys,
+                          const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
+                          void *out_voxel, int out_dtype, int64_t out_row_pitch, int64_t out_plane_size, int64_t *out_counts,
+                          const v2v_esim_extras *extras, void *stream);
 int v2v_esim_voxel_stats_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W,
                              int64_t clip_stride, int64_t frame_stride, const double *params, int64_t params_stride,
                              uint32_t flags, int rng_mode, uint64_t seed, uint64_t clip_id0, const uint64_t *clip_keys,
@@ -378,6 +398,10 @@ int v2v_voxel_scales_select_hip(const float *voxel, int64_t B, int64_t planes, i
  * frame indices (NULL: frames 0..L-1); out float32 [B,L,C,H,W] contiguous.  C >= 1. */
 int v2v_clip_frames_f32_hip(const void *src, int64_t clip_stride, int64_t frame_stride, const int32_t *pick, int64_t B, int64_t L, int64_t H,
                             int64_t W, int64_t C, float *out, void *stream);
+/* the same for packed clips (v2v_esim_extras): clip b starts at clip_offsets[b] (NULL: b * clip_stride; with offsets clip_stride states
+ * their common alignment) and picks frame pick[b * pick_stride + l] (pick_stride 0: one row of picks for every clip) */
+int v2v_clip_frames_f32_ex_hip(const void *src, int64_t clip_stride, const int64_t *clip_offsets, int64_t frame_stride, const int32_t *pick,
+                               int64_t pick_stride, int64_t B, int64_t L, int64_t H, int64_t W, int64_t C, float *out, void *stream);
 
 #ifdef __cplusplus
 }

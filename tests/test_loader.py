@@ -29,47 +29,57 @@ def _make_ds(tmp_path, n_videos=6, **cfg):
 
 
 @pytest.mark.parametrize("extra", [{}, {"output_additional_frame": True}, {"output_additional_evs": True}, {"color_mode": "gray_in_bgr_out"},
-                                   {"shake_frames": 5, "shake_std": 2.0}, {"video_degrade": "hdr", "degrade_ratio": 1.0}, {"fixed_seed": 5}])
+                                   {"shake_frames": 5, "shake_std": 2.0}, {"video_degrade": "hdr", "degrade_ratio": 1.0}, {"fixed_seed": 5},
+                                   {"proba_pause_when_running": 0.2, "proba_pause_when_paused": 0.7}])
 def test_host_sample_into_equals_deferred_getitem(tmp_path, extra):
-    """The slot writer consumes np.random exactly like __getitem__(defer_sim) and leaves the same clip, parameters and key."""
-    from v2v_amd.loader import _SlotLayout
+    """The slot writer consumes np.random exactly like __getitem__(defer_sim) and leaves the same clip, parameters and key -- in the plain
+    form (the gathered clip) and in the PACKED form (every decoded frame once + the index row the simulator gathers through)."""
     ds = _make_ds(tmp_path, defer_sim=True, **extra)
     n, hw = ds.frames_per_seq + 1, ds.crop_size
     pick = ds.frame_pick()
-    lay = _SlotLayout(3, n, hw, hw, len(pick), ds.color_mode != "gray")
-    buf = np.zeros(lay.nbytes, dtype=np.uint8)
-    clips, cframes, params, keys = lay.views(buf)
-    for pos, idx in enumerate((4, 0, 2)):
+    colour = ds.color_mode != "gray"
+    for idx in (4, 0, 2):
         np.random.seed(100 + idx)
         want = ds[idx]
         state_after = np.random.get_state()[1].copy()
-        np.random.seed(100 + idx)
-        v2e = ds.host_sample_into(idx, clips[pos], params[pos], keys[pos], cframes[pos] if cframes is not None else None)
-        assert np.array_equal(np.random.get_state()[1], state_after)                 # same number of draws
-        assert np.array_equal(clips[pos], want["sim_frames"].numpy())
-        assert np.array_equal(params[pos], want["sim_params"].numpy()) and np.array_equal(keys[pos], want["sim_key"].numpy())
-        assert v2e == want["v2e_params"]
-        # the frames the loader will build on the device: clip[pick] / 255 (gray) or the colour frames / 255
-        if cframes is None:
-            got = torch.from_numpy(clips[pos][pick]).float().unsqueeze(1) / 255
-        else:
-            got = torch.from_numpy(cframes[pos]).float().permute(0, 3, 1, 2) / 255
-        assert torch.equal(got, want["frame"])
+        for packed in (False, True):
+            clip, params, key = np.full((n, hw, hw), 255, np.uint8), np.zeros(5), np.zeros(2, np.int64)
+            cframes = np.zeros((len(pick), hw, hw, 3), np.uint8) if colour else None
+            fidx = np.zeros(n, np.int32) if packed else None
+            np.random.seed(100 + idx)
+            res = ds.host_sample_into(idx, clip, params, key, cframes, fidx)
+            assert np.array_equal(np.random.get_state()[1], state_after)             # same number of draws
+            v2e, n_stored = res if packed else (res, n)
+            gathered = clip[fidx] if packed else clip
+            assert np.array_equal(gathered, want["sim_frames"].numpy())
+            if packed:
+                assert 1 <= n_stored <= n and fidx[0] == 0 and fidx[-1] == n_stored - 1 and set(np.diff(fidx)) <= {0, 1}
+                assert (clip[n_stored:] == 255).all()                                # nothing written past the stored frames
+            assert np.array_equal(params, want["sim_params"].numpy()) and np.array_equal(key, want["sim_key"].numpy())
+            assert v2e == want["v2e_params"]
+            # the frames the loader builds on the device: stored frame fidx[pick] / 255 (gray) or the colour frames / 255
+            if cframes is None:
+                got = torch.from_numpy(gathered[pick]).float().unsqueeze(1) / 255
+            else:
+                got = torch.from_numpy(cframes).float().permute(0, 3, 1, 2) / 255
+            assert torch.equal(got, want["frame"])
 
 
 def test_slot_layout_is_aligned_and_disjoint():
     from v2v_amd.loader import _SlotLayout
     lay = _SlotLayout(12, 201, 128, 128, 40, True)
-    offs = [lay.off_clips, lay.off_frames, lay.off_params, lay.off_keys, lay.nbytes]
-    assert all(o % 256 == 0 for o in offs) and offs == sorted(offs)
+    offs = [lay.off_offsets, lay.off_fidx, lay.off_pick, lay.off_params, lay.off_keys, lay.off_used, lay.off_cframes, lay.off_clips, lay.nbytes]
+    assert all(o % 256 == 0 for o in offs) and offs == sorted(offs) and len(set(offs)) == len(offs)
     buf = np.zeros(lay.nbytes, dtype=np.uint8)
-    clips, cframes, params, keys = lay.views(buf)
-    clips[:] = 1
-    cframes[:] = 2
-    params[:] = 3.0
-    keys[:] = 4
-    assert (clips == 1).all() and (cframes == 2).all() and (params == 3.0).all() and (keys == 4).all()
-    assert clips.shape == (12, 201, 128, 128) and cframes.shape == (12, 40, 128, 128, 3) and params.shape == (12, 5) and keys.shape == (12, 2)
+    views = lay.views(buf)
+    for i, v in enumerate(views):
+        v[...] = i + 1
+    for i, v in enumerate(views):
+        assert (v == i + 1).all()                                                    # no view overlaps another
+    offsets, fidx, pick, params, keys, used, cframes, clips = views
+    assert offsets.shape == (12,) and fidx.shape == (12, 201) and pick.shape == (12, 40) and params.shape == (12, 5) and keys.shape == (12, 2)
+    assert used.shape == (1,) and cframes.shape == (12, 40, 128, 128, 3) and clips.shape == (12 * 201 * 128 * 128,)
+    assert _SlotLayout(12, 201, 128, 128, 40, False).views(np.zeros(lay.nbytes, np.uint8))[6] is None
 
 
 def test_slot_batch_sampler_and_leaf_resolution(tmp_path):
@@ -94,6 +104,15 @@ def test_choose_normalize_method():
     assert ch(np.array([[0.02, 0.3, 0.0, 0.0, 0.0]]), 1, False) == "radix"     # 6.91 / 0.02 > 255
     assert ch(np.array([[0.2, 0.3, 0.0, 0.02, 1.0]]), 1, False) == "radix"     # 2 % hot pixels could reach the 1 % ranks
     assert ch(p, 8, False) == "radix"                            # 8 frames per bin
+
+
+def test_create_dataloader_falls_back_to_torch_for_other_datasets():
+    """train.py:52-65's signature; datasets that are not the simulator's (validation sets) get the reference's own DataLoader."""
+    from torch.utils.data import DataLoader, RandomSampler, TensorDataset
+    from v2v_amd.loader import create_dataloader
+    ds = TensorDataset(torch.arange(10).float())
+    dl = create_dataloader(ds, {"num_workers": 0, "pin_memory": False}, 2, None)
+    assert isinstance(dl, DataLoader) and isinstance(dl.sampler, RandomSampler) and dl.drop_last and len(dl) == 5
 
 
 # ----------------------------------------------------------------------------------------------------------------- GPU
@@ -168,3 +187,60 @@ def test_ring_loader_scales_mode_and_hot_pixels(tmp_path):
     neg = np.maximum(-flat[:, int(0.01 * m) - 1], 1).reshape(4, 1, 1, 1, 1)
     assert np.array_equal(done["events"].cpu().numpy(), np.where(v > 0, v / pos, v / neg).astype(np.float32))
     assert np.array_equal(raw["event_scales"].cpu().numpy(), np.concatenate([neg.reshape(4, 1), pos.reshape(4, 1)], 1).astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_create_dataloader_is_train_pys_with_a_ring_loader(tmp_path):
+    """The reference's create_dataloader(dataset, configs, batch_size, local_rank) (train.py:52-65) over the plugin loader's ConcatDataset
+    nesting: a RingLoader with the same sampler type, drop_last, len() and batch dict, batches on the GPU, epochs restartable."""
+    from torch.utils.data import ConcatDataset, RandomSampler
+    from v2v_amd.loader import RingLoader, create_dataloader
+    ds = ConcatDataset([ConcatDataset([_make_ds(tmp_path, n_videos=7)])])
+    dl = create_dataloader(ds, {"num_workers": 2, "persistent_workers": True, "pin_memory": True, "normalize_in_loader": True}, 3, None)
+    assert isinstance(dl, RingLoader) and isinstance(dl.sampler, RandomSampler) and len(dl) == 2 and dl.drop_last
+    for epoch in range(2):
+        seen = 0
+        for batch in dl:
+            assert batch["events"].shape == (3, 4, 5, 32, 32) and batch["events"].is_cuda and batch["frame"].shape == (3, 4, 1, 32, 32)
+            assert float(batch["events"].abs().max()) <= 1.0 + 1e-6 or float(batch["events"].abs().max()) > 0     # normalised by the 1 % / 99 % k-th values
+            assert batch["data_source_idx"].tolist() == [11, 11, 11] and set(batch["v2e_params"]) == {"pos_thres", "neg_thres", "base_noise_std", "hot_pixel_fraction", "hot_pixel_std"}
+            seen += 1
+        assert seen == 2
+    dl.close()
+
+
+@pytest.mark.gpu
+def test_packed_clips_launch_equals_the_gathered_launch():
+    """v2v_esim_voxel_ex_hip with a frame index and clip offsets (every decoded frame stored once, clips of different stored lengths
+    packed back to back) == v2v_esim_voxel_padded_hip on the gathered clips, bit for bit, for every work-item mapping, with the
+    writer's statistics; the packed frame assembly equals the plain one."""
+    from v2v_amd import _lib, esim
+    from v2v_amd.loader import clip_frames_f32, clip_frames_packed
+    g = np.random.default_rng(3)
+    b, n, h, w = 5, 21, 32, 48
+    stored = [int(g.integers(3, n + 1)) for _ in range(b)]
+    stored[0], stored[1] = n, 1                                                      # no pause at all / a video that never moves
+    clips_h = [g.integers(0, 256, (u, h, w), dtype=np.uint8) for u in stored]
+    fidx = np.stack([np.sort(np.concatenate([np.arange(u), g.integers(0, u, n - u)])) if u < n else np.arange(n) for u in stored]).astype(np.int32)
+    offs, flat, pos = [], [], 0
+    for c in clips_h:
+        offs.append(pos)
+        flat.append(c.ravel())
+        pad = (-c.size) % 16
+        flat.append(np.zeros(pad, np.uint8))
+        pos += c.size + pad
+    flat_d = torch.from_numpy(np.concatenate(flat)).cuda()
+    offs_d, fidx_d = torch.tensor(offs, dtype=torch.int64).cuda(), torch.from_numpy(fidx).cuda()
+    gathered = torch.from_numpy(np.stack([c[i] for c, i in zip(clips_h, fidx)])).cuda()
+    params = torch.tensor([[0.2 + 0.02 * i, 0.25, 0.05, 1e-3, 2.0] for i in range(b)], dtype=torch.float64).cuda()
+    keys = torch.tensor([[77 + i, 10 * i] for i in range(b)], dtype=torch.int64).cuda()
+    for mapping in ("4px", "2px", "1px", "auto"):
+        st_a = torch.zeros((b, _lib.VOXEL_STATS_WORDS), dtype=torch.int32, device="cuda")
+        st_b = torch.zeros_like(st_a)
+        want = esim.esim_voxel_batch(gathered, params, bin_mode="sum", num_bins=5, clip_keys=keys, no_noise=False, pad_to=16, stats=st_a, mapping=mapping)
+        got = esim.esim_voxel_packed(flat_d, offs_d, fidx_d, h, w, params, keys, num_bins=5, pad_to=16, stats=st_b, mapping=mapping)
+        assert torch.equal(got, want) and torch.equal(st_a, st_b) and float(want.abs().sum()) > 0
+    pick = torch.from_numpy(fidx[:, [5, 10, 20]].copy()).cuda()
+    assert torch.equal(clip_frames_packed(flat_d, offs_d, pick, h, w), clip_frames_f32(gathered, [5, 10, 20]))
+    with pytest.raises(ValueError):                                                   # indexed launches have no float64 / external-noise instances
+        esim.esim_voxel_packed(flat_d, offs_d, fidx_d.long(), h, w, params, keys)

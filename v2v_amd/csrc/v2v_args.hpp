@@ -28,6 +28,11 @@ struct EsimArgs {
     int32_t W;                             // row length (for the padded output layout)
     int64_t out_pitch, out_plane;          // output row pitch / plane size in elements (W, H*W when unpadded)
     unsigned int *stats;                   // optional [B, kStatWords] per-clip value histogram of the voxels written (SUM mode, float32 grid)
+    // optional (FIDX instances): simulator frame f of clip b is STORED frame frame_index[b * (K + 1) + f] (the reference's pause-index
+    // gather, data/v2v_datasets.py:286-311, folded into the loads: paused frames are stored once), and clip b starts at element
+    // clip_offsets[b] of `frames` instead of b * clip_stride (clips of different stored lengths packed back to back)
+    const int32_t *frame_index;
+    const int64_t *clip_offsets;
 };
 
 // Per-clip statistics the simulator's writer accumulates for the consumer's normalize_batch_voxel (model/train_utils.py:147-166):

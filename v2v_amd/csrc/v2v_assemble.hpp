@@ -12,13 +12,14 @@
 namespace v2v {
 
 // C == 1, HW % 4 == 0, 4-byte aligned rows: a work-item converts 4 pixels (one dword in, 16 bytes out)
-__global__ void __launch_bounds__(256) clip_frames4_kernel(const uint8_t *src, int64_t clip_stride, int64_t frame_stride, const int32_t *pick,
-                                                           int L, int HW4, float *out)
+// pick_stride: elements between the pick rows of consecutive clips (0: one row for every clip); clip_offsets: per-clip start (or b * clip_stride)
+__global__ void __launch_bounds__(256) clip_frames4_kernel(const uint8_t *src, int64_t clip_stride, const int64_t *clip_offsets, int64_t frame_stride,
+                                                           const int32_t *pick, int64_t pick_stride, int L, int HW4, float *out)
 {
     const int bl = blockIdx.y;                                   // b * L + l
     const int b = bl / L, l = bl - b * L;
-    const int f = pick ? pick[l] : l;
-    const uint32_t *s = reinterpret_cast<const uint32_t *>(src + (int64_t)b * clip_stride + (int64_t)f * frame_stride);
+    const int f = pick ? pick[(int64_t)b * pick_stride + l] : l;
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(src + (clip_offsets ? clip_offsets[b] : (int64_t)b * clip_stride) + (int64_t)f * frame_stride);
     float4 *o = reinterpret_cast<float4 *>(out + (int64_t)bl * HW4 * 4);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < HW4; i += gridDim.x * 256) {
         const uint32_t v = __builtin_nontemporal_load(s + i);
@@ -32,13 +33,13 @@ __global__ void __launch_bounds__(256) clip_frames4_kernel(const uint8_t *src, i
 }
 
 // any C (interleaved HWC source -> planar CHW output), any alignment: a work-item per (pixel, channel)
-__global__ void __launch_bounds__(256) clip_frames_kernel(const uint8_t *src, int64_t clip_stride, int64_t frame_stride, const int32_t *pick,
-                                                          int L, int HW, int C, float *out)
+__global__ void __launch_bounds__(256) clip_frames_kernel(const uint8_t *src, int64_t clip_stride, const int64_t *clip_offsets, int64_t frame_stride,
+                                                          const int32_t *pick, int64_t pick_stride, int L, int HW, int C, float *out)
 {
     const int bl = blockIdx.y;
     const int b = bl / L, l = bl - b * L;
-    const int f = pick ? pick[l] : l;
-    const uint8_t *s = src + (int64_t)b * clip_stride + (int64_t)f * frame_stride;
+    const int f = pick ? pick[(int64_t)b * pick_stride + l] : l;
+    const uint8_t *s = src + (clip_offsets ? clip_offsets[b] : (int64_t)b * clip_stride) + (int64_t)f * frame_stride;
     float *o = out + (int64_t)bl * HW * C;
     const int n = HW * C;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {

@@ -135,7 +135,7 @@ static int esim_launch_impl(const void *frames, int in_dtype, int64_t B, int64_t
                             uint32_t flags, int rng_mode, uint64_t seed, uint64_t clip_id0, const uint64_t *clip_keys,
                             const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
                             void *out_voxel, int out_dtype, int64_t out_row_pitch, int64_t out_plane_size, int64_t *out_counts, uint32_t *stats,
-                            void *stream);
+                            const int32_t *frame_index, const int64_t *clip_offsets, void *stream);
 
 int v2v_esim_voxel_padded_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W,
                               int64_t clip_stride, int64_t frame_stride, const double *params, int64_t params_stride,
@@ -144,7 +144,39 @@ int v2v_esim_voxel_padded_hip(const void *frames, int in_dtype, int64_t B, int64
                               void *out_voxel, int out_dtype, int64_t out_row_pitch, int64_t out_plane_size, int64_t *out_counts, void *stream)
 {
     return esim_launch_impl(frames, in_dtype, B, N, H, W, clip_stride, frame_stride, params, params_stride, flags, rng_mode, seed, clip_id0, clip_keys,
-                            replay, bin_mode, num_bins, frames_per_bin, out_voxel, out_dtype, out_row_pitch, out_plane_size, out_counts, nullptr, stream);
+                            replay, bin_mode, num_bins, frames_per_bin, out_voxel, out_dtype, out_row_pitch, out_plane_size, out_counts, nullptr, nullptr, nullptr, stream);
+}
+
+int v2v_esim_voxel_ex_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W,
+                          int64_t clip_stride, int64_t frame_stride, const double *params, int64_t params_stride,
+                          uint32_t flags, int rng_mode, uint64_t seed, uint64_t clip_id0, const uint64_t *clip_keys,
+                          const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
+                          void *out_voxel, int out_dtype, int64_t out_row_pitch, int64_t out_plane_size, int64_t *out_counts,
+                          const v2v_esim_extras *extras, void *stream)
+{
+    if (!extras) return v2v_esim_voxel_padded_hip(frames, in_dtype, B, N, H, W, clip_stride, frame_stride, params, params_stride, flags, rng_mode, seed, clip_id0,
+                                                  clip_keys, replay, bin_mode, num_bins, frames_per_bin, out_voxel, out_dtype, out_row_pitch, out_plane_size,
+                                                  out_counts, stream);
+    if ((extras->frame_index == nullptr) != (extras->clip_offsets == nullptr))
+        return fail(V2V_ERR_NULL, "v2v_esim_voxel_ex_hip: frame_index and clip_offsets come together");
+    if (extras->frame_index) {
+        if (in_dtype != V2V_U8 || bin_mode != V2V_BIN_SUM || out_dtype != V2V_F32 || rng_mode == V2V_RNG_REPLAY || rng_mode == V2V_RNG_NONE ||
+            (flags & (V2V_FLAG_NOISE_EXTERNAL | V2V_FLAG_NO_NOISE | V2V_FLAG_SYMMETRIC)))
+            return fail(V2V_ERR_MODE, "indexed frames: uint8 clips, SUM bins, device noise, float32 grid, no NO_NOISE / NOISE_EXTERNAL / SYMMETRIC flag");
+        if (!aligned(extras->frame_index, 4) || !aligned(extras->clip_offsets, 8)) return fail(V2V_ERR_ALIGN, "frame_index / clip_offsets misaligned");
+    }
+    if (extras->stats) {
+        if (bin_mode != V2V_BIN_SUM || out_dtype != V2V_F32 || (flags & V2V_FLAG_NOISE_EXTERNAL))
+            return fail(V2V_ERR_MODE, "voxel statistics are kept for SUM-mode float32 grids without external noise (integer counts)");
+        if (!aligned(extras->stats, 4)) return fail(V2V_ERR_ALIGN, "stats must be 4-byte aligned");
+        if (B > 0) {
+            const hipError_t e = hipMemsetAsync(extras->stats, 0, sizeof(uint32_t) * (size_t)B * V2V_VOXEL_STATS_WORDS, static_cast<hipStream_t>(stream));
+            if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(stats)");
+        }
+    }
+    return esim_launch_impl(frames, in_dtype, B, N, H, W, clip_stride, frame_stride, params, params_stride, flags, rng_mode, seed, clip_id0, clip_keys,
+                            replay, bin_mode, num_bins, frames_per_bin, out_voxel, out_dtype, out_row_pitch, out_plane_size, out_counts, extras->stats,
+                            extras->frame_index, extras->clip_offsets, stream);
 }
 
 int v2v_esim_voxel_stats_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W,
@@ -163,7 +195,7 @@ int v2v_esim_voxel_stats_hip(const void *frames, int in_dtype, int64_t B, int64_
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(stats)");
     }
     return esim_launch_impl(frames, in_dtype, B, N, H, W, clip_stride, frame_stride, params, params_stride, flags, rng_mode, seed, clip_id0, clip_keys,
-                            replay, bin_mode, num_bins, frames_per_bin, out_voxel, out_dtype, out_row_pitch, out_plane_size, out_counts, stats, stream);
+                            replay, bin_mode, num_bins, frames_per_bin, out_voxel, out_dtype, out_row_pitch, out_plane_size, out_counts, stats, nullptr, nullptr, stream);
 }
 
 int v2v_voxel_scales_hip(const uint32_t *stats, int64_t B, int64_t elems_per_sample, float *scales, void *stream)
@@ -213,14 +245,15 @@ static int esim_launch_impl(const void *frames, int in_dtype, int64_t B, int64_t
                             uint32_t flags, int rng_mode, uint64_t seed, uint64_t clip_id0, const uint64_t *clip_keys,
                             const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
                             void *out_voxel, int out_dtype, int64_t out_row_pitch, int64_t out_plane_size, int64_t *out_counts, uint32_t *stats,
-                            void *stream)
+                            const int32_t *frame_index, const int64_t *clip_offsets, void *stream)
 {
     if (out_row_pitch < W || out_plane_size < out_row_pitch * (H - 1) + W) return fail(V2V_ERR_SHAPE, "out_row_pitch / out_plane_size smaller than the frame");
     if (!frames || !params || !out_voxel) return fail(V2V_ERR_NULL, "v2v_esim_voxel_hip: frames/params/out_voxel is NULL");
     if (B < 0 || N < 2 || H < 1 || W < 1) return fail(V2V_ERR_SHAPE, "need B>=0, N>=2, H,W>=1 (got B=%lld N=%lld H=%lld W=%lld)", (long long)B, (long long)N, (long long)H, (long long)W);
     const int64_t HW = H * W, K = N - 1;
     if (HW > (int64_t)1 << 30 || K > (1 << 20) || B > (int64_t)1 << 31) return fail(V2V_ERR_SHAPE, "H*W, N or B too large");
-    if (frame_stride < HW || (B > 1 && clip_stride < (N - 1) * frame_stride + HW)) return fail(V2V_ERR_SHAPE, "strides smaller than the extent");
+    if (frame_stride < HW || (!clip_offsets && B > 1 && clip_stride < (N - 1) * frame_stride + HW)) return fail(V2V_ERR_SHAPE, "strides smaller than the extent");
+    if (clip_offsets && clip_stride < 1) return fail(V2V_ERR_SHAPE, "with clip_offsets, clip_stride states the alignment (in elements) every offset keeps");
     if (in_dtype != V2V_U8 && in_dtype != V2V_F32) return fail(V2V_ERR_DTYPE, "in_dtype must be V2V_U8 or V2V_F32");
     if (out_dtype != V2V_F32 && out_dtype != V2V_F64) return fail(V2V_ERR_DTYPE, "out_dtype must be V2V_F32 or V2V_F64");
     if (params_stride != 0 && params_stride < 5) return fail(V2V_ERR_PARAM, "params_stride must be 0 or >= 5");
@@ -289,6 +322,8 @@ static int esim_launch_impl(const void *frames, int in_dtype, int64_t B, int64_t
     a.out_pitch = out_row_pitch;
     a.out_plane = out_plane_size;
     a.stats = stats;
+    a.frame_index = frame_index;
+    a.clip_offsets = clip_offsets;
     const int64_t nblocks = B * a.blocks_per_clip;
     if (nblocks > 0x7FFFFFFF) return fail(V2V_ERR_SHAPE, "grid too large");
     const dim3 grid((unsigned)nblocks);
@@ -299,8 +334,9 @@ static int esim_launch_impl(const void *frames, int in_dtype, int64_t B, int64_t
     if (!noise && rng_mode == V2V_RNG_REPLAY) return fail(V2V_ERR_PARAM, "V2V_FLAG_NO_NOISE is not available in replay mode");
     // dynamic LDS: the bilinear weights per frame pair and the segment starts per bin; static: log table, thresholds, and the
     // Gaussian table of the instances that draw device-native noise
-    const size_t lds = bin_mode == V2V_BIN_BILINEAR ? (size_t)K * 2 * (out64 ? sizeof(double) : sizeof(float)) + (size_t)num_bins * sizeof(int) : 0;
-    const size_t lds_static = 256 * 8 + 32 + (noise && rng_mode != V2V_RNG_REPLAY && rng_mode != V2V_RNG_NONE ? (size_t)v2v::kIcdfBytes : 0);
+    const size_t lds = bin_mode == V2V_BIN_BILINEAR ? (size_t)K * 2 * (out64 ? sizeof(double) : sizeof(float)) + (size_t)num_bins * sizeof(int)
+                                                    : frame_index ? (size_t)(K + 1) * sizeof(int) : 0;
+    const size_t lds_static = 256 * 8 + 32 + (bin_mode == V2V_BIN_SUM && !out64 ? 2064 : 0) /* the writer's histogram */ + (noise && rng_mode != V2V_RNG_REPLAY && rng_mode != V2V_RNG_NONE ? (size_t)v2v::kIcdfBytes : 0);
     if (lds + lds_static > 64 * 1024) return fail(V2V_ERR_SHAPE, "too many frame pairs for the LDS tables (%zu bytes > 64 KiB): split the clip", lds + lds_static);
     hipStream_t s = static_cast<hipStream_t>(stream);
 
@@ -313,24 +349,35 @@ static int esim_launch_impl(const void *frames, int in_dtype, int64_t B, int64_t
 int v2v_clip_frames_f32_hip(const void *src, int64_t clip_stride, int64_t frame_stride, const int32_t *pick, int64_t B, int64_t L, int64_t H,
                             int64_t W, int64_t C, float *out, void *stream)
 {
+    return v2v_clip_frames_f32_ex_hip(src, clip_stride, nullptr, frame_stride, pick, 0, B, L, H, W, C, out, stream);
+}
+
+int v2v_clip_frames_f32_ex_hip(const void *src, int64_t clip_stride, const int64_t *clip_offsets, int64_t frame_stride, const int32_t *pick,
+                               int64_t pick_stride, int64_t B, int64_t L, int64_t H, int64_t W, int64_t C, float *out, void *stream)
+{
     if (!src || !out) return fail(V2V_ERR_NULL, "v2v_clip_frames_f32_hip: src/out is NULL");
     if (B < 0 || L < 1 || H < 1 || W < 1 || C < 1 || C > 4) return fail(V2V_ERR_SHAPE, "need B>=0, L,H,W>=1, 1<=C<=4");
     const int64_t HW = H * W;
     if (HW * C >= (int64_t)1 << 30 || B * L > 0x7FFFFFFF) return fail(V2V_ERR_SHAPE, "frame or batch too large");
-    if (frame_stride < HW * C || (B > 1 && clip_stride < frame_stride)) return fail(V2V_ERR_SHAPE, "strides smaller than the extent");
-    if (!aligned(out, 4)) return fail(V2V_ERR_ALIGN, "out must be 4-byte aligned");
+    if (frame_stride < HW * C || (!clip_offsets && B > 1 && clip_stride < frame_stride) || (clip_offsets && clip_stride < 1) || pick_stride < 0 ||
+        (pick_stride != 0 && (!pick || pick_stride < L)))
+        return fail(V2V_ERR_SHAPE, "strides smaller than the extent");
+    if (!aligned(out, 4) || !aligned(clip_offsets, 8) || !aligned(pick, 4)) return fail(V2V_ERR_ALIGN, "out / clip_offsets / pick misaligned");
     if (B == 0) return V2V_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint8_t *sp = static_cast<const uint8_t *>(src);
+    // with clip_offsets, clip_stride states the alignment (in bytes) every offset keeps
     const bool v4 = C == 1 && HW % 4 == 0 && frame_stride % 4 == 0 && (B == 1 || clip_stride % 4 == 0) && aligned(src, 4) && aligned(out, 16);
     if (v4) {
         const int hw4 = (int)(HW / 4);
         const unsigned gx = (unsigned)std::min<int64_t>((hw4 + 255) / 256, 64);
-        hipLaunchKernelGGL(v2v::clip_frames4_kernel, dim3(gx, (unsigned)(B * L)), dim3(256), 0, s, sp, clip_stride, frame_stride, pick, (int)L, hw4, out);
+        hipLaunchKernelGGL(v2v::clip_frames4_kernel, dim3(gx, (unsigned)(B * L)), dim3(256), 0, s, sp, clip_stride, clip_offsets, frame_stride, pick, pick_stride,
+                           (int)L, hw4, out);
     } else {
         const int64_t n = HW * C;
         const unsigned gx = (unsigned)std::min<int64_t>((n + 255) / 256, 256);
-        hipLaunchKernelGGL(v2v::clip_frames_kernel, dim3(gx, (unsigned)(B * L)), dim3(256), 0, s, sp, clip_stride, frame_stride, pick, (int)L, (int)HW, (int)C, out);
+        hipLaunchKernelGGL(v2v::clip_frames_kernel, dim3(gx, (unsigned)(B * L)), dim3(256), 0, s, sp, clip_stride, clip_offsets, frame_stride, pick, pick_stride,
+                           (int)L, (int)HW, (int)C, out);
     }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? V2V_OK : hip_fail(e, "clip_frames kernel launch");

@@ -120,9 +120,12 @@ __device__ __forceinline__ void pix_logs(const Raw<IN, VEC> &r, const typename L
 template <int VEC, int RNG, bool NOISE, bool OUT64, bool EXT, bool SYMONLY>
 constexpr bool esim_asym4() { return V2V_ESIM_ASYM4 && NOISE && RNG == kRngPhilox && VEC == 4 && !OUT64 && !EXT && !SYMONLY; }
 
-template <int IN, int VEC, int BIN, int RNG, bool NOISE, bool OUT64, bool EXT = false, bool SYMONLY = false>
+// FIDX   : the clip's frames are read through a per-clip index row (EsimArgs::frame_index, copied to LDS) and clips start at
+//          EsimArgs::clip_offsets -- the dataset's pause-index gather folded into the loads (instances: uint8 input, SUM bins, device noise).
+template <int IN, int VEC, int BIN, int RNG, bool NOISE, bool OUT64, bool EXT = false, bool SYMONLY = false, bool FIDX = false>
 __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE, OUT64, EXT, SYMONLY>()) ? 4 : V2V_MIN_WAVES) esim_voxel_kernel(const EsimArgs a)
 {
+    static_assert(!FIDX || BIN == kBinSum, "the frame index row uses the dynamic LDS region the bilinear tables live in");
     constexpr bool ASYM4 = esim_asym4<VEC, RNG, NOISE, OUT64, EXT, SYMONLY>();
     // SYMONLY (V2V_FLAG_SYMMETRIC: the caller guarantees C+ == C- for every clip): compiled without the asymmetric loop and with a
     // 2-frame ring, which fits 128 VGPRs = 4 waves per SIMD (-4.6 % on the headline, same box); a clip that breaks the
@@ -170,6 +173,15 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
     if constexpr (STATS) {
         if (want_stats) for (int i = threadIdx.x; i < kStatBins; i += kBlock) s_hist[i] = 0;
     }
+    int *s_fidx = reinterpret_cast<int *>(s_raw);              // FIDX: [K + 1] stored-frame numbers of this clip
+    if constexpr (FIDX) {
+        const int32_t *row = a.frame_index + (int64_t)(blockIdx.x / a.blocks_per_clip) * (a.K + 1);
+        for (int i = threadIdx.x; i <= a.K; i += kBlock) s_fidx[i] = row[i];
+    }
+    auto foff = [&](int f) -> int64_t {                        // element offset of simulator frame f inside the clip
+        if constexpr (FIDX) return (int64_t)s_fidx[f] * a.frame_stride;
+        else return (int64_t)f * a.frame_stride;
+    };
     if constexpr (BIN == kBinBilinear) {
         // Pair k contributes to bins seg(k) and seg(k)+1 with the float64 weights of event_utils.py:715-719:
         // t_norm = (k - 0)/((K-1) - 0)*(Tb-1), w_b = max(0, 1 - |t_norm - b|); every other bin's weight is exactly 0.
@@ -212,7 +224,7 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
     if constexpr (NOISE) { base_std = pp[2]; hot_frac = pp[3]; hot_std = pp[4]; }
     const uint64_t seed_ = a.clip_keys ? a.clip_keys[2 * clip] : a.seed;
     const uint32_t clip_id = a.clip_keys ? (uint32_t)a.clip_keys[2 * clip + 1] : (uint32_t)(a.clip_id0 + (uint64_t)clip);
-    const int64_t in_base = (int64_t)clip * a.clip_stride + p0;
+    const int64_t in_base = (FIDX ? a.clip_offsets[clip] : (int64_t)clip * a.clip_stride) + p0;
 
     // ---- per-pixel state
     double pot[VEC];
@@ -257,7 +269,7 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
 
     lut_t lprev[VEC];
     {
-        const Raw<IN, VEC> r0 = load_raw<IN, VEC>(a.frames, in_base);
+        const Raw<IN, VEC> r0 = load_raw<IN, VEC>(a.frames, in_base + foff(0));
         pix_logs<IN, VEC>(r0, s_lut, lprev);
     }
 
@@ -487,7 +499,7 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
 #pragma unroll
         for (int u = 0; u < kRing; ++u) {
             const int f = (1 + u <= a.K) ? 1 + u : a.K;
-            ring[u] = load_raw<IN, VEC>(a.frames, in_base + (int64_t)f * a.frame_stride);
+            ring[u] = load_raw<IN, VEC>(a.frames, in_base + foff(f));
         }
         int k0 = 0;
         for (; k0 + kRing <= a.K; k0 += kRing) {
@@ -496,7 +508,7 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
                 const int k = k0 + u;
                 step(sym_tag, hot_tag, std::integral_constant<int, (u & 1)>{}, k, ring[u]);
                 const int fn = k + 1 + kRing;
-                ring[u] = load_raw<IN, VEC>(a.frames, in_base + (int64_t)(fn <= a.K ? fn : a.K) * a.frame_stride);
+                ring[u] = load_raw<IN, VEC>(a.frames, in_base + foff(fn <= a.K ? fn : a.K));
             });
         }
         tail(sym_tag, hot_tag, k0, ring);

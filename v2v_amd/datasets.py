@@ -418,14 +418,17 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
             return [off + (i + 1) * self.frames_per_img for i in range(img_cnt)]                       # :329-333
         return [off + i * self.frames_per_img for i in range(img_cnt + 1)]                              # :334-338
 
-    def host_sample_into(self, sample_idx, clip_out, params_out, key_out, frames_out=None):
+    def host_sample_into(self, sample_idx, clip_out, params_out, key_out, frames_out=None, index_out=None):
         """The HOST half of a sample written straight into caller-owned arrays (v2v_amd.loader.RingLoader: slots of page-locked
         shared memory): same np.random draw order as __getitem__ with `defer_sim: true`, no intermediate stack, no float frames.
             clip_out   uint8 [N,H,W]    the simulator's frames (pause-index gather applied; gray)
             params_out float64 [5]      pos_thres, neg_thres, base_noise_std, hot_pixel_fraction, hot_pixel_std
             key_out    int64 [2]        {seed drawn from np.random, sample index}: the device RNG key of this sample
             frames_out uint8 [Lf,H,W,3] only for color_mode 'gray_in_bgr_out': the colour frames handed out as `frame`
-        Returns the v2e_params dict."""
+            index_out  int32 [N] or None.  Given: PACKED form -- clip_out[:U] receives the U DECODED frames once each (the video
+                       pauses, data/v2v_datasets.py:286-301, so U <= N) and index_out[f] the stored frame simulator frame f shows; the
+                       simulator gathers through it (v2v_esim_extras.frame_index) and the paused frames never cross PCIe twice
+        Returns the v2e_params dict (packed form: (v2e_params, U))."""
         if self.gpu_frontend:
             raise NotImplementedError("host_sample_into serves host-decoded clips; gpu_frontend samples are assembled on the device")
         old_state = None
@@ -440,7 +443,17 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
         assert (n - 1) % (self.num_bins * self.frames_per_bin) == 0                                      # :365
         if tuple(clip_out.shape) != (n,) + tuple(raw_imgs[0].shape[:2]):
             raise ValueError(f"clip_out is {tuple(clip_out.shape)}, the clip is {(n,) + tuple(raw_imgs[0].shape[:2])}")
-        if self.color_mode == "gray":
+        n_stored = img_idxes[-1] + 1                                     # the chain moves by 0 or 1: every decoded frame up to the last is shown
+        if index_out is not None:
+            index_out[:] = img_idxes
+            if self.color_mode == "gray":
+                for i in range(n_stored):
+                    clip_out[i] = raw_imgs[i][..., 0]
+            else:
+                stored = np.stack(raw_imgs[:n_stored])
+                clip_out[:n_stored] = bgr_to_gray(stored)
+                frames_out[:] = stored[[img_idxes[p] for p in self.frame_pick(img_cnt)]]
+        elif self.color_mode == "gray":
             for j, i in enumerate(img_idxes):
                 clip_out[j] = raw_imgs[i][..., 0]
         else:
@@ -457,7 +470,7 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
         key_out[1] = int(sample_idx)
         if old_state is not None:
             np.random.set_state(old_state)
-        return v2e_params
+        return v2e_params if index_out is None else (v2e_params, n_stored)
 
     def __getitem__(self, sample_idx):
         old_state = None

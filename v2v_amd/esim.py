@@ -152,6 +152,45 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
     return out
 
 
+def esim_voxel_packed(frames: torch.Tensor, clip_offsets: torch.Tensor, frame_index: torch.Tensor, h: int, w: int, params: torch.Tensor,
+                      clip_keys: torch.Tensor, *, num_bins: int = 5, frames_per_bin: int = 1, pad_to: int = 1, stats: Optional[torch.Tensor] = None,
+                      align: int = 16, mapping: Optional[str] = None) -> torch.Tensor:
+    """The batch launch over PACKED clips (v2v_esim_voxel_ex_hip with v2v_esim_extras): `frames` is one flat uint8 CUDA buffer, clip b starts
+    at element clip_offsets[b] (int64 [B], multiples of `align`) and holds its DECODED frames once each; frame_index int32 [B,N] names the
+    stored frame every simulator frame shows -- the reference's pause-index gather (data/v2v_datasets.py:286-311) done by the kernel's
+    loads.  SUM bins, device-native noise, float32 grid; params float64 [B,5] and clip_keys int64 [B,2] on the device.  Same results as
+    esim_voxel_batch on the gathered clips (tests/test_loader.py).  -> [B, L, num_bins, Hp, Wp]"""
+    _lib.require_gpu()
+    dev = frames.device
+    if frames.dtype != torch.uint8 or frames.ndim != 1 or not frames.is_cuda:
+        raise ValueError("frames must be a flat uint8 CUDA buffer")
+    b, n = frame_index.shape
+    for t, dt, shape in ((clip_offsets, torch.int64, (b,)), (frame_index, torch.int32, (b, n)), (params, torch.float64, (b, 5)), (clip_keys, torch.int64, (b, 2))):
+        if t.dtype != dt or tuple(t.shape) != shape or t.device != dev or not t.is_contiguous():
+            raise ValueError(f"expected a contiguous {dt} {shape} tensor on {dev}")
+    k = n - 1
+    assert k % (num_bins * frames_per_bin) == 0, "(N-1) % (num_bins*frames_per_bin) != 0"   # v2v_datasets.py:365
+    hp, wp = (h + pad_to - 1) // pad_to * pad_to, (w + pad_to - 1) // pad_to * pad_to
+    out = torch.empty((b, k // (num_bins * frames_per_bin), num_bins, hp, wp), dtype=torch.float32, device=dev)
+    if hp != h:
+        out[..., h:, :] = 0
+    if wp != w:
+        out[..., :h, w:] = 0
+    if b == 0:
+        return out
+    if stats is not None and (stats.dtype != torch.int32 or tuple(stats.shape) != (b, _lib.VOXEL_STATS_WORDS) or not stats.is_contiguous() or stats.device != dev):
+        raise ValueError(f"stats must be a contiguous int32 [{b},{_lib.VOXEL_STATS_WORDS}] tensor on the frames' device")
+    ex = _lib.EsimExtras(stats.data_ptr() if stats is not None else None, frame_index.data_ptr(), clip_offsets.data_ptr())
+    with torch.cuda.device(dev):
+        rc = _lib.lib().v2v_esim_voxel_ex_hip(
+            C.c_void_p(frames.data_ptr()), _lib.U8, b, n, h, w, align, h * w, C.c_void_p(params.data_ptr()), 5,
+            {"auto": 0, "4px": _lib.FLAG_MAP_4PX, "2px": _lib.FLAG_MAP_2PX, "1px": _lib.FLAG_MAP_1PX}[mapping or DEFAULT_MAPPING],
+            _lib.RNG_PHILOX, C.c_uint64(0), C.c_uint64(0), C.c_void_p(clip_keys.data_ptr()), None, _lib.BIN_SUM, num_bins, frames_per_bin,
+            C.c_void_p(out.data_ptr()), _lib.F32, wp, hp * wp, None, C.byref(ex), _lib.stream_ptr())
+    _lib.check(rc)
+    return out
+
+
 def algorithmic_bytes(frames_dtype: torch.dtype, b: int, n: int, h: int, w: int, bin_mode: str, num_bins: int,
                       frames_per_bin: int = 1, out_dtype: torch.dtype = torch.float32) -> int:
     """HBM bytes one launch must move: every input byte read once + every voxel byte written once."""

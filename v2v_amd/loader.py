@@ -9,8 +9,9 @@ Why not DataLoader + default_collate + SimulatingCollator (the round-2/3 path, k
 training samples that path moves 39.5 MB of uint8 clips and 31 MB of float frames through (worker) np.stack -> torch tensor ->
 default_collate copy -> shared-memory copy -> (main) page-locked copy -> H2D, builds the float frames on the host, and crosses
 PCIe with both.  Here:
-  * fork()ed DataLoader workers (they never touch HIP) write each sample's uint8 clip, its five simulator parameters and its
-    RNG key STRAIGHT into a slot of a ring of shared memory that the GPU process has page-locked (hipHostRegister): no stack,
+  * fork()ed DataLoader workers (they never touch HIP) write each sample's DECODED frames once each (the reference's pause schedule
+    repeats frames -- 27 % of a training clip, data/v2v_datasets.py:286-301; the simulator gathers through a per-clip index instead,
+    v2v_esim_extras), the sample's five simulator parameters and its RNG key STRAIGHT into a slot of a ring of shared memory that the GPU process has page-locked (hipHostRegister): no stack,
     no collate copy, no queue payload (a worker returns the slot number), no staging copy in the GPU process;
   * the GPU process issues ONE asynchronous H2D copy per batch (the whole slot: clips + parameters + keys) on a copy stream,
     one batch ahead of the compute stream;
@@ -64,6 +65,21 @@ def clip_frames_f32(src: torch.Tensor, pick=None, frames: int | None = None) -> 
     return out
 
 
+def clip_frames_packed(clips: torch.Tensor, clip_offsets: torch.Tensor, pick: torch.Tensor, h: int, w: int, align: int = 16) -> torch.Tensor:
+    """`frame` of a batch of PACKED gray clips (flat uint8 buffer, clip b at clip_offsets[b], stored frame pick[b, l] for output l):
+    float32 [B,L,1,H,W] = frame / 255, as clip_frames_f32."""
+    _lib.require_gpu()
+    b, n_l = pick.shape
+    out = torch.empty((b, n_l, 1, h, w), dtype=torch.float32, device=clips.device)
+    if b == 0 or n_l == 0:
+        return out
+    with torch.cuda.device(clips.device):
+        rc = _lib.lib().v2v_clip_frames_f32_ex_hip(C.c_void_p(clips.data_ptr()), align, C.c_void_p(clip_offsets.data_ptr()), h * w,
+                                                   C.c_void_p(pick.data_ptr()), n_l, b, n_l, h, w, 1, C.c_void_p(out.data_ptr()), _lib.stream_ptr())
+    _lib.check(rc)
+    return out
+
+
 def choose_normalize_method(params: np.ndarray, frames_per_bin: int, put_noise_external: bool) -> str:
     """'count' (exact counting select over the integers -255..255 with overflow bins) when the batch's own parameters bound every
     NON-hot pixel's |count| by 255 and hot pixels stay far below the 1 % the quantiles cut off; else 'radix' (any float32 content).
@@ -80,33 +96,44 @@ def choose_normalize_method(params: np.ndarray, frames_per_bin: int, put_noise_e
 
 # --------------------------------------------------------------------------------------------------------------------- ring
 class _SlotLayout:
-    """Byte layout of one slot: [clips u8 B*N*H*W][colour frames u8 B*Lf*H*W*3 (gray_in_bgr_out only)][params f64 B*5][keys i64 B*2]."""
+    """Byte layout of one slot.  Fixed head (always copied): [clip offsets i64 B][frame index i32 B*N][frame picks i32 B*Lf][params f64 B*5]
+    [keys i64 B*2][used bytes i64 1][colour frames u8 B*Lf*H*W*3 (gray_in_bgr_out only)]; then the clips, PACKED: clip b holds its decoded
+    frames once each at byte `offsets[b]` of the clip region (a multiple of 16), `used` bytes in all -- the H2D copy ends there."""
 
     def __init__(self, batch, n, h, w, lf, colour):
         self.batch, self.n, self.h, self.w, self.lf, self.colour = batch, n, h, w, lf, colour
         al = lambda v: (v + 255) // 256 * 256                           # noqa: E731
-        self.off_clips = 0
-        self.off_frames = al(batch * n * h * w)
-        self.off_params = self.off_frames + (al(batch * lf * h * w * 3) if colour else 0)
+        self.off_offsets = 0
+        self.off_fidx = al(batch * 8)
+        self.off_pick = self.off_fidx + al(batch * n * 4)
+        self.off_params = self.off_pick + al(batch * lf * 4)
         self.off_keys = self.off_params + al(batch * 5 * 8)
-        self.nbytes = self.off_keys + al(batch * 2 * 8)
+        self.off_used = self.off_keys + al(batch * 2 * 8)
+        self.off_cframes = self.off_used + 256
+        self.off_clips = self.off_cframes + (al(batch * lf * h * w * 3) if colour else 0)
+        self.nbytes = self.off_clips + al(batch * n * h * w)
+
+    @staticmethod
+    def _v(buf, off, count, dtype, shape):
+        return buf[off:off + count * np.dtype(dtype).itemsize].view(dtype).reshape(shape)
 
     def views(self, buf: np.ndarray):
-        """NumPy views of one slot (a uint8 array of nbytes)."""
-        b, n, h, w = self.batch, self.n, self.h, self.w
-        clips = buf[self.off_clips:self.off_clips + b * n * h * w].reshape(b, n, h, w)
-        frames = buf[self.off_frames:self.off_frames + b * self.lf * h * w * 3].reshape(b, self.lf, h, w, 3) if self.colour else None
-        params = buf[self.off_params:self.off_params + b * 40].view(np.float64).reshape(b, 5)
-        keys = buf[self.off_keys:self.off_keys + b * 16].view(np.int64).reshape(b, 2)
-        return clips, frames, params, keys
+        """NumPy views of one slot (a uint8 array of nbytes): offsets, fidx, pick, params, keys, used, colour frames, clip region."""
+        b, n, h, w, lf = self.batch, self.n, self.h, self.w, self.lf
+        return (self._v(buf, self.off_offsets, b, np.int64, (b,)), self._v(buf, self.off_fidx, b * n, np.int32, (b, n)),
+                self._v(buf, self.off_pick, b * lf, np.int32, (b, lf)), self._v(buf, self.off_params, b * 5, np.float64, (b, 5)),
+                self._v(buf, self.off_keys, b * 2, np.int64, (b, 2)), self._v(buf, self.off_used, 1, np.int64, (1,)),
+                self._v(buf, self.off_cframes, b * lf * h * w * 3, np.uint8, (b, lf, h, w, 3)) if self.colour else None,
+                buf[self.off_clips:self.off_clips + b * n * h * w])
 
     def device_views(self, dbuf: torch.Tensor):
-        b, n, h, w = self.batch, self.n, self.h, self.w
-        clips = dbuf[self.off_clips:self.off_clips + b * n * h * w].view(b, n, h, w)
-        frames = dbuf[self.off_frames:self.off_frames + b * self.lf * h * w * 3].view(b, self.lf, h, w, 3) if self.colour else None
-        params = dbuf[self.off_params:self.off_params + b * 40].view(torch.float64).view(b, 5)
-        keys = dbuf[self.off_keys:self.off_keys + b * 16].view(torch.int64).view(b, 2)
-        return clips, frames, params, keys
+        b, n, h, w, lf = self.batch, self.n, self.h, self.w, self.lf
+        v = lambda off, nbytes, dt, shape: dbuf[off:off + nbytes].view(dt).view(shape)       # noqa: E731
+        return (v(self.off_offsets, b * 8, torch.int64, (b,)), v(self.off_fidx, b * n * 4, torch.int32, (b, n)),
+                v(self.off_pick, b * lf * 4, torch.int32, (b, lf)), v(self.off_params, b * 40, torch.float64, (b, 5)),
+                v(self.off_keys, b * 16, torch.int64, (b, 2)),
+                dbuf[self.off_cframes:self.off_cframes + b * lf * h * w * 3].view(b, lf, h, w, 3) if self.colour else None,
+                dbuf[self.off_clips:self.off_clips + b * n * h * w])
 
 
 def _leaf(dataset, idx):
@@ -133,8 +160,8 @@ class _RingDataset(torch.utils.data.Dataset):
     """What the workers index: item = (sample index, slot, position in the batch).  The sample's host half is written into the
     slot; only the slot number travels back through the worker queue."""
 
-    def __init__(self, base, ring: np.ndarray, layout: _SlotLayout):
-        self.base, self.ring, self.layout = base, ring, layout
+    def __init__(self, base, ring: np.ndarray, layout: _SlotLayout, pick):
+        self.base, self.ring, self.layout, self.pick = base, ring, layout, np.asarray(pick, dtype=np.int64)
 
     def __len__(self):
         return len(self.base)
@@ -142,8 +169,15 @@ class _RingDataset(torch.utils.data.Dataset):
     def __getitem__(self, item):
         idx, slot, pos = item
         leaf, li = _leaf(self.base, idx)
-        clips, frames, params, keys = self.layout.views(self.ring[slot])
-        leaf.host_sample_into(li, clips[pos], params[pos], keys[pos], frames[pos] if frames is not None else None)
+        lay = self.layout
+        offsets, fidx, pick, params, keys, used, cframes, clips = lay.views(self.ring[slot])
+        # a DataLoader worker builds a whole batch, sample after sample: the clips are packed back to back as they come
+        start = 0 if pos == 0 else int(used[0])
+        room = clips[start:start + lay.n * lay.h * lay.w].reshape(lay.n, lay.h, lay.w)
+        _, n_stored = leaf.host_sample_into(li, room, params[pos], keys[pos], cframes[pos] if cframes is not None else None, fidx[pos])
+        offsets[pos] = start
+        pick[pos] = fidx[pos][self.pick]                                   # the stored frames handed out as `frame`
+        used[0] = start + (n_stored * lay.h * lay.w + 15) // 16 * 16
         return slot, leaf.data_source_idx
 
 
@@ -209,7 +243,9 @@ class RingLoader:
         self.layout = _SlotLayout(self.batch_size, n, hw, hw, len(self.pick), lf0.color_mode != "gray")
         if sampler is None:
             sampler = RandomSampler(dataset, generator=generator) if shuffle else SequentialSampler(dataset)
-        self.num_workers = int(num_workers)
+        self.sampler = sampler                                             # train loops call loader.sampler.set_epoch(epoch) under DDP
+        self.drop_last = drop_last
+        self.num_workers = int(num_workers or 0)
         self.depth = max(2, int(depth))
         in_flight = max(1, self.num_workers) * (prefetch_factor if self.num_workers else 1)
         self.slots = in_flight + self.depth + 1
@@ -223,12 +259,12 @@ class RingLoader:
         kw = dict(num_workers=self.num_workers, collate_fn=_ring_collate, worker_init_fn=worker_init_fn)
         if self.num_workers:
             kw.update(prefetch_factor=prefetch_factor, persistent_workers=persistent_workers, multiprocessing_context="fork")
-        self.loader = DataLoader(_RingDataset(dataset, self.ring, self.layout), batch_sampler=bs, **kw)
+        self.loader = DataLoader(_RingDataset(dataset, self.ring, self.layout, self.pick), batch_sampler=bs, **kw)
         self._it = None
+        self.bytes_copied, self.batches_copied = 0, 0                      # H2D bytes / batches so far (heads + packed clips)
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self._dev = [torch.empty(self.layout.nbytes, dtype=torch.uint8, device=self.device) for _ in range(self.depth)]
         self._dev_free = [torch.cuda.Event() for _ in range(self.depth)]          # the slot's last consumer is done
-        self._pick_d = torch.tensor(self.pick, dtype=torch.int32, device=self.device)
         self._ring_t = torch.from_numpy(self.ring)
 
     # ---- page-locking
@@ -260,21 +296,22 @@ class RingLoader:
             self.timers[key] = self.timers.get(key, 0.0) + (time.perf_counter() - t0)
 
     def _stage(self, item, k):
-        """Enqueue the H2D copy of ring slot `slot` into device slot k % depth; returns what _finish needs."""
+        """Enqueue the H2D copy of ring slot `slot` (its head + the packed clips: `used` bytes) into device slot k % depth."""
         slot, src_idx = item
         t0 = time.perf_counter()
         d = k % self.depth
-        cur = torch.cuda.current_stream(self.device)
+        lay = self.layout
+        _, _, _, params, _, used, _, _ = lay.views(self.ring[slot])
+        nbytes = lay.off_clips + int(used[0])
         ev = torch.cuda.Event()
         with torch.cuda.stream(self.copy_stream):
             # the launches that read this device slot `depth` batches ago (a host-side wait instead was measured: no faster)
             self.copy_stream.wait_event(self._dev_free[d])
-            self._dev[d].copy_(self._ring_t[slot], non_blocking=True)
+            self._dev[d][:nbytes].copy_(self._ring_t[slot, :nbytes], non_blocking=True)
             ev.record(self.copy_stream)
-        del cur
-        # host-side values of the batch, read before the ring slot can be recycled
-        _, _, params, _ = self.layout.views(self.ring[slot])
-        params = params.copy()
+        params = params.copy()                                            # host-side values of the batch, read before the slot is recycled
+        self.bytes_copied += nbytes
+        self.batches_copied += 1
         self._t("h2d_enqueue", t0)
         return d, ev, params, src_idx
 
@@ -283,20 +320,24 @@ class RingLoader:
         lay, leaf = self.layout, self.leaf
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ev)
-        clips, cframes, params_d, keys_d = lay.device_views(self._dev[d])
+        offsets_d, fidx_d, pick_d, params_d, keys_d, cframes, clips = lay.device_views(self._dev[d])
         t0 = time.perf_counter()
-        no_noise = bool((params[:, 2] == 0).all() and (params[:, 3] <= 0).all())
+        h, w = lay.h, lay.w
         method = choose_normalize_method(params, leaf.frames_per_bin, leaf.put_noise_external) if self.normalize else None
         stats = torch.empty((lay.batch, _lib.VOXEL_STATS_WORDS), dtype=torch.int32, device=self.device) if method == "count" else None
-        vox = esim.esim_voxel_batch(clips, params_d, bin_mode="sum", num_bins=leaf.num_bins, frames_per_bin=leaf.frames_per_bin,
-                                    rng_mode="philox", clip_keys=keys_d, put_noise_external=leaf.put_noise_external, no_noise=no_noise,
-                                    pad_to=self.pad_to, validate=False, stats=stats)
+        if leaf.put_noise_external:
+            # external noise has no indexed instance: gather the clips on the device first (an ablation configuration, not a training one)
+            gathered = torch.stack([clips[int(o):int(o) + lay.n * h * w].view(lay.n, h, w)[fi.long()] for o, fi in zip(offsets_d.tolist(), fidx_d)])
+            vox = esim.esim_voxel_batch(gathered, params_d, bin_mode="sum", num_bins=leaf.num_bins, frames_per_bin=leaf.frames_per_bin, rng_mode="philox",
+                                        clip_keys=keys_d, put_noise_external=True, pad_to=self.pad_to, validate=False)
+        else:
+            vox = esim.esim_voxel_packed(clips, offsets_d, fidx_d, h, w, params_d, keys_d, num_bins=leaf.num_bins, frames_per_bin=leaf.frames_per_bin,
+                                         pad_to=self.pad_to, stats=stats)
         self._t("sim", t0)
         t0 = time.perf_counter()
         batch = {}
         if self.normalize:
             from . import postops
-            h, w = lay.h, lay.w
             if method == "count":                                         # the writer's statistics -> exact scales, no pass over the tensor
                 scales = postops.scales_from_stats(stats, vox.shape[1] * vox.shape[2] * h * w)
             else:                                                         # counts beyond the counting range / external noise: radix select
@@ -308,7 +349,7 @@ class RingLoader:
         self._t("postops", t0)
         t0 = time.perf_counter()
         if cframes is None:
-            frame = clip_frames_f32(clips, self._pick_d)
+            frame = clip_frames_packed(clips, offsets_d, pick_d, h, w)
         else:
             frame = clip_frames_f32(cframes)
         self._dev_free[d].record(cur)                                     # everything that reads the device slot is enqueued
@@ -350,3 +391,29 @@ class RingLoader:
         while nxt is not None:
             cur, nxt = nxt, fetch()                                       # one batch of look-ahead: copy of k+1 under the compute of k
             yield self._finish(cur)
+
+
+def create_dataloader(dataset, configs, batch_size, local_rank):
+    """Drop-in for the reference's `create_dataloader` (train.py:52-65; same signature, same sampler choice, drop_last=True):
+
+        from v2v_amd.loader import create_dataloader          # the one line a maintainer changes in train.py
+
+    Training datasets made of v2v_amd.datasets.WebvidDatasetV2 (through any ConcatDataset nesting, data/data_interface.py:19-27) get a
+    RingLoader -- batches arrive on the GPU, `batch[k] = v.to(device)` (train.py:79-81) is then a no-op; anything else (the
+    TestH5Dataset validation sets) gets the reference's own DataLoader.  Extra keys of the `dataset:` block of the YAML:
+        normalize_in_loader   false | true | 'scales'   normalize_batch_voxel where the voxels are written (then normalize_voxels: false
+                                                        for the model, model/train_utils.py:200,319-320)
+        pad_events_to         1                         16 writes the x16-padded layout forward_sequence builds (:322-326) in place"""
+    from torch.utils.data import DistributedSampler
+    sampler = DistributedSampler(dataset) if local_rank is not None else RandomSampler(dataset)
+    num_workers = configs.get("num_workers")
+    persistent_workers = configs.get("persistent_workers", False)
+    leaves = list(_leaves(dataset))
+    ring_ok = all(hasattr(d, "host_sample_into") and not getattr(d, "gpu_frontend", False) for d in leaves) and torch.cuda.is_available()
+    if ring_ok:
+        device = torch.device("cuda", local_rank if local_rank is not None else torch.cuda.current_device())
+        return RingLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers or 0, drop_last=True,
+                          persistent_workers=bool(persistent_workers and num_workers), pad_to=configs.get("pad_events_to", 1),
+                          normalize=configs.get("normalize_in_loader", False), device=device)
+    return DataLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers or 0,
+                      persistent_workers=bool(persistent_workers and num_workers), pin_memory=configs.get("pin_memory", False), drop_last=True)
