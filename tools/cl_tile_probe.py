@@ -15,7 +15,7 @@ for (b,c,h,w) in ((8,64,128,128),(8,128,64,64),(8,256,32,32),(8,64,64,64),(8,128
     flops = 2.0*b*h*w*(18*c)*(4*c)
     row = {}
     ref = None
-    for tr in (0, 64, 128, 256, 129, 130, 257):
+    for tr in (0, 64, 128, 256):
         try:
             out = CL.convlstm_step(xn, hn, cn, packed, bias, nchw_dtype=None, tile_rows=tr)
             if ref is None: ref = out

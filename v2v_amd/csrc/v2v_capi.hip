@@ -810,9 +810,8 @@ int v2v_convlstm_step_hip(const void *x, const void *h_prev, const float *c_prev
     if (h_nchw && h_nchw_dtype != V2V_F32 && h_nchw_dtype != V2V_BF16) return fail(V2V_ERR_DTYPE, "h_nchw_dtype must be V2V_F32 or V2V_BF16");
     if (!x || !packed || !gates_bias || !h_state || !c_state) return fail(V2V_ERR_NULL, "v2v_convlstm_step_hip: x/packed/gates_bias/h_state/c_state is NULL");
     if (B < 1 || H < 1 || W < 1 || C < 64 || C % 64 != 0 || C > 4096) return fail(V2V_ERR_SHAPE, "need B,H,W >= 1 and C %% 64 == 0, C <= 4096");
-    const int tile_px = tile_rows == 129 || tile_rows == 130 ? 128 : tile_rows == 257 ? 256 : tile_rows;      // 129 / 130 / 257: one-wave-column tiles
-    if (tile_rows != 0 && tile_px != 64 && tile_px != 128 && tile_px != 256) return fail(V2V_ERR_PARAM, "tile_rows must be 0 (auto), 64, 128 or 256");
-    if ((B * H * W) % (tile_px ? tile_px : 64) != 0 || (H * W) % 4 != 0 || B * H * W * C > 0x7FFFFFFFLL)
+    if (tile_rows != 0 && tile_rows != 64 && tile_rows != 128 && tile_rows != 256) return fail(V2V_ERR_PARAM, "tile_rows must be 0 (auto), 64, 128 or 256");
+    if ((B * H * W) % (tile_rows ? tile_rows : 64) != 0 || (H * W) % 4 != 0 || B * H * W * C > 0x7FFFFFFFLL)
         return fail(V2V_ERR_SHAPE, "ConvLSTM kernel needs (B*H*W) %% 64 == 0 (%% tile_rows when given), (H*W) %% 4 == 0 and B*H*W*C < 2^31 (got %lldx%lldx%lldx%lld)",
                     (long long)B, (long long)H, (long long)W, (long long)C);
     if (h_state == h_prev || h_state == x) return fail(V2V_ERR_PARAM, "h_state must not alias h_prev or x (neighbouring tiles read them)");

@@ -28,7 +28,7 @@
 // on the SOURCE address of the LDS-DMA (its LDS destination is lane-linear) and on the ds_read_b128 address -- which makes
 // every 16-lane group of a fragment read hit 16 distinct (row parity, slot) pairs = all 64 banks once.
 // The launcher picks the largest tile that still gives every CU a workgroup (256 -> 128 -> 64 pixels).  Where a wave's cycles
-// go (tools/convlstm_phase_probe.py on a -DV2V_CL_TIMING build, 256-pixel tile): 7-16 % in the vmcnt wait, 16-17 % in the
+// go (cycle stamps of a -DV2V_CL_TIMING build: tools/experiments/convlstm_ablation_and_timing_switches.patch re-adds them; 256-pixel tile): 7-16 % in the vmcnt wait, 16-17 % in the
 // barrier, the rest in LDS-DMA issue + fragment reads + MFMA -- the 8 LDS-DMA instructions a wave issues per chunk cost about
 // as much issue time as half of its 32 MFMAs.
 #pragma once
@@ -51,9 +51,6 @@ typedef __attribute__((__vector_size__(16 * sizeof(float)))) float cl_f32x16;
 
 
 __device__ __attribute__((aligned(128))) unsigned char g_cl_zero_line[128];      // zero-initialised: the padding source
-#ifdef V2V_CL_TIMING
-__device__ unsigned long long g_cl_dbg[4];      // EXPERIMENT: per-wave cycle totals {vmcnt wait, barrier, everything else, waves}
-#endif
 
 // float -> bf16, round to nearest even, NaN stays NaN: gfx950's v_cvt_pk_bf16_f32 (two values per instruction)
 typedef __bf16 cl_hwbf16x2 __attribute__((ext_vector_type(2)));
@@ -138,11 +135,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
     const int64_t m0 = (int64_t)(blockIdx.x / n_ct) * kClBM;      // first pixel of the tile (flattened b,y,x)
     const int cc_x = TPC == 2 ? 1 : C / kClBK, cc_all = EPI == 0 ? 2 * cc_x : cc_x;
     const int cc_eff = (EPI == 0 && a.h_prev) ? cc_all : cc_x;    // zero state: skip h's chunks
-#ifdef V2V_CL_ABLATE_LOOP                                          // timing ablation (results invalid): prologue + ONE chunk + epilogue
-    const int n_chunks = 1;
-#else
     const int n_chunks = TPC == 2 ? (n_taps + 1) / 2 : n_taps * cc_eff;
-#endif
 
     // ---- staging plan: wave w issues A pieces NA*w.. (8 rows each) and B pieces NB*w.. per chunk ----------------------
     const int srow = lane >> 3, sslot = lane & 7;                 // this lane's (row in piece, LDS slot)
@@ -178,9 +171,6 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
     // the same box with two buffers AND with three (every piece issued between MFMAs stalls the wave's instruction stream for
     // its turn in the address unit)
     auto stage = [&](int ck, int buf, int part, int nparts) __attribute__((always_inline)) {
-#ifdef V2V_CL_ABLATE_STAGE                                         // timing ablation (results invalid): no LDS-DMA after the first chunk
-        if (ck > 1) return;
-#endif
         if constexpr (TPC == 2) {
             const int t0 = 2 * ck, t1 = 2 * ck + 1;
             const int dy0 = t0 / ks - pad, dx0 = t0 % ks - pad, dy1 = t1 / ks - pad, dx1 = t1 % ks - pad;
@@ -241,19 +231,10 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][g][r] = 0.0f;
 
-#ifdef V2V_CL_TIMING
-    unsigned long long t_wait = 0, t_bar = 0, t_rest = 0, t_prev = __builtin_readcyclecounter();
-#define CL_STAMP(acc) { const unsigned long long t_now = __builtin_readcyclecounter(); acc += t_now - t_prev; t_prev = t_now; }
-#else
-#define CL_STAMP(acc)
-#endif
     auto k_steps = [&](const unsigned char *base, auto &&before_step) __attribute__((always_inline)) {
         // fragments of k-step s+1 are read before the MFMAs of k-step s are issued (two register sets: +1..3 %)
         cl_bf16x8 af[2][MF], bf[2][NF];
         auto load = [&](int s, int slot) __attribute__((always_inline)) {
-#ifdef V2V_CL_ABLATE_READS                                         // timing ablation (results invalid): fragments read once per chunk
-            if (s > 0) { for (int i = 0; i < MF; ++i) af[slot][i] = af[0][i]; for (int g = 0; g < NF; ++g) bf[slot][g] = bf[0][g]; return; }
-#endif
 #pragma unroll
             for (int i = 0; i < MF; ++i) af[slot][i] = *reinterpret_cast<const cl_bf16x8 *>(base + a_row + i * (32 * 128) + koff[s]);
 #pragma unroll
@@ -267,11 +248,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
 #pragma unroll
             for (int i = 0; i < MF; ++i)
 #pragma unroll
-#ifdef V2V_CL_ABLATE_MFMA                                          // timing ablation (results invalid): the fragments stay live, no matrix work
-                for (int g = 0; g < NF; ++g) asm volatile("" :: "v"(af[s & 1][i]), "v"(bf[s & 1][g]));
-#else
                 for (int g = 0; g < NF; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], bf[s & 1][g], acc[i][g], 0, 0, 0);
-#endif
         }
     };
     // 64- and 128-pixel tiles (MF = 1): the previous cell state of this lane's outputs is fetched while the LAST chunk's MFMAs
@@ -298,13 +275,8 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
         if (kgrp < n_chunks) stage(kgrp, 0, 0, 1);
         for (int it = 0; it < n_it; ++it) {
             const int ck = it * KS + kgrp;
-            CL_STAMP(t_rest)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            CL_STAMP(t_wait)
-#ifndef V2V_CL_ABLATE_BARRIER                                      // timing ablation (results invalid): no barrier per chunk
             __syncthreads();                                     // chunk ck has landed; everyone is done with the other buffer
-#endif
-            CL_STAMP(t_bar)
             const bool more = ck + KS < n_chunks;
             if (it + 1 == n_it) prefetch_c();
             if (ck < n_chunks)
@@ -324,13 +296,10 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
         if (chunk_of(1) < n_chunks) stage(chunk_of(1), 1, 0, 1);
         int buf = 0, buf2 = 2;
         for (int it = 0; it < n_it; ++it) {
-            CL_STAMP(t_rest)
             if (chunk_of(it + 1) < n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPieces) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            CL_STAMP(t_wait)
             __builtin_amdgcn_s_barrier();                        // chunk `it` has landed for every wave; buffer buf2 is free
             asm volatile("" ::: "memory");
-            CL_STAMP(t_bar)
             const bool more2 = chunk_of(it + 2) < n_chunks;
             if (it + 1 == n_it) prefetch_c();
             if (chunk_of(it) < n_chunks)
@@ -361,12 +330,6 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][g][r] += red[((i * NF + g) * 16 + r) * 64];
     }
-#ifdef V2V_CL_TIMING
-    CL_STAMP(t_rest)
-    if (lane == 0) {
-        atomicAdd(&g_cl_dbg[0], t_wait); atomicAdd(&g_cl_dbg[1], t_bar); atomicAdd(&g_cl_dbg[2], t_rest); atomicAdd(&g_cl_dbg[3], 1ull);
-    }
-#endif
     if constexpr (EPI == 1) {
         cl_epilogue_conv<MF, NF>(a, acc, m0 + wm * 32 * MF, ct * kBN + wn * 32 * NF + fr, fh);
         return;
@@ -543,11 +506,7 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const ConvLstmArgs a,
     unsigned char *const a_lds = cl_lds, *const b_lds = cl_lds + a_bytes;    // ONE patch buffer (two workgroups per CU), two weight-group buffers
     const int tiles_x = W >> 4, tiles_y = H >> 4;
     const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, bimg = blockIdx.x / (tiles_x * tiles_y);
-#ifdef V2V_CL_ABLATE_LOOP
-    const int cc_x = C / kClBK, n_groups = (n_taps + tps - 1) / tps, n_chunks = 1;
-#else
     const int cc_x = C / kClBK, n_groups = (n_taps + tps - 1) / tps, n_chunks = cc_x * n_groups;
-#endif
     const int srow = lane >> 3, sslot = lane & 7;
 
     // ---- A staging plan: wave w stages patch pieces w, w + 4, ... (8 patch pixels each) ----------------------------------
@@ -577,9 +536,6 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const ConvLstmArgs a,
     };
     // weights of chunk (cc, tap group g) -> buffer `buf`: pieces of 8 columns, tap-major
     auto stage_b = [&](int ck, int buf) __attribute__((always_inline)) {
-#ifdef V2V_CL_ABLATE_STAGE                                         // timing ablation (results invalid): weights staged once
-        if (ck > 0) return;
-#endif
         const int cc = ck / n_groups, g = ck - cc * n_groups;
         const int tap0 = g * tps, nt = min(tps, n_taps - tap0), n_pb = nt * (kBN / 8);
         unsigned char *dst = b_lds + buf * b_bytes;
@@ -617,9 +573,6 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const ConvLstmArgs a,
         // 32 columns: fragments of tap t + 1 are read before the MFMAs of tap t are issued (two register sets)
         cl_bf16x8 af0[2][4], bf0[NF][4], af1[2][4], bf1[NF][4];
         auto load = [&](int tig, cl_bf16x8 (&af)[2][4], cl_bf16x8 (&bf)[NF][4]) __attribute__((always_inline)) {
-#ifdef V2V_CL_ABLATE_READS                                         // timing ablation (results invalid): one tap's fragments per group
-            if (tig > 0) return;
-#endif
             const int tap = tap0 + tig, dy = tap / ks, dx = tap - dy * ks;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -640,11 +593,7 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const ConvLstmArgs a,
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-#ifdef V2V_CL_ABLATE_MFMA                                          // timing ablation (results invalid)
-                    for (int q = 0; q < NF; ++q) asm volatile("" :: "v"(af[i][s]), "v"(bf[q][s]));
-#else
                     for (int q = 0; q < NF; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][s], bf[q][s], acc[i][q], 0, 0, 0);
-#endif
         };
         if constexpr (NF == 1) {                                          // wider column tiles run one tap per group: nothing to prefetch
             load(0, af0, bf0);

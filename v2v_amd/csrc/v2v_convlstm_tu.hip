@@ -42,10 +42,10 @@ hipError_t launch_convlstm_step(const ConvLstmArgs &a, int tile_rows, hipStream_
         // 128 ch @32^2 0.039 -> 0.033 ms, 256 ch @16^2 0.067 -> 0.053 ms; slower where more tiles exist: 0.115 -> 0.144 ms)
         if (tile_rows == 64 && m / 64 * ct <= cus) tile_rows = 65;
     }
-    // EXPERIMENT codes: one wave column (32 hidden channels x 4 gates = 128 columns per tile)
-    if (tile_rows == 129) return launch_step_t<1, 4, 2, 0, 1, 4>(a, s);        // 128 px x 32 ch, 4 waves, 64 KB: two workgroups per CU
-    if (tile_rows == 130) return launch_step_t<1, 4, 3, 0, 1, 4>(a, s);        // the same on three stages (96 KB: one workgroup)
-    if (tile_rows == 257) return launch_step_t<2, 4, 2, 0, 1, 4>(a, s);        // 256 px x 32 ch, 4 waves of 64 px, 96 KB
+    // (round 4, measured and not kept: tiles of ONE wave column -- 32 hidden channels x 4 gates -- so that two workgroups share a CU and
+    // one's epilogue runs under the other's main loop: launch_step_t<1, 4, 2, 0, 1, 4>, 128 px x 32 ch, 64 KB: 0.107 / 0.101 / 0.098 ms
+    // against 0.088 / 0.078 / 0.095 for the tiles below at 64@128^2 / 128@64^2 / 256@32^2, same box -- twice the LDS-DMA pieces per MFMA
+    // cost more than the overlap buys; the kernel template still takes WN = 1 for the step)
     if (tile_rows == 65) return launch_step_t<1, 2, 2, 0, 2, 4, 1, 2>(a, s);   // 64 px as two K groups of 4 waves (160 KB, internal code)
     // 256 px as 16 waves of 32 px x 128 columns (4 per SIMD, 114 VGPRs) instead of 8 of 64 x 128: bit-identical, -2...-4 % same box
     if (tile_rows == 256) return launch_step_t<1, 8, 2>(a, s);
@@ -216,12 +216,4 @@ hipError_t launch_upsample2x_nhwc(const uint16_t *x, const uint16_t *skip, uint1
     return hipGetLastError();
 }
 
-#ifdef V2V_CL_TIMING
-extern "C" int v2v_convlstm_debug_read(unsigned long long *out4, int reset)
-{
-    hipError_t e = hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_cl_dbg), 32);
-    if (e == hipSuccess && reset) { unsigned long long z[4] = {0, 0, 0, 0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_cl_dbg), z, 32); }
-    return (int)e;
-}
-#endif
 }  // namespace v2v
