@@ -69,13 +69,17 @@ WORKLOADS = {
     "cfg5_fused_convlstm_channels_last": dict(model="pipeline", b=8, n=41, h=256, w=256, dtype="uint8", bin="sum", tb=5, fpb=1,
                                               params=DATASET_STYLE, src_hw=(720, 1280), consumer="fused_cl"),
     "train_u8_12x201x128x128_sum5": dict(model="esim", b=12, n=201, h=128, w=128, dtype="uint8", bin="sum", tb=5, fpb=1, params=DATASET_STYLE),
+    # one training batch's device work as the loader issues it (v2v_amd/loader.py): simulator with the writer's statistics (SURVEY 8f-2
+    # "in the writer") -> exact k-th values -> [the one scaling pass, in place]; `scales`: the consumer scales while it reads
+    "train_batch_stats_scales_12x201x128x128": dict(model="train_batch", b=12, n=201, h=128, w=128, dtype="uint8", bin="sum", tb=5, fpb=1, params=DATASET_STYLE, apply=False),
+    "train_batch_normalised_12x201x128x128": dict(model="train_batch", b=12, n=201, h=128, w=128, dtype="uint8", bin="sum", tb=5, fpb=1, params=DATASET_STYLE, apply=True),
     "cfg1_plumbing_u8_1x8x128x128": dict(model="esim", b=1, n=8, h=128, w=128, dtype="uint8", bin="sum", tb=7, fpb=1, params=NOISE_FREE),
 }
 DEFAULT_WORKLOAD = "cfg2_esim_f32_256x32x256x256_bilinear5"
 ALSO_MEASURED = ["cfg2_noise_free", "cfg2_dataset_style", "cfg2_u8", "cfg3_v2e_f32_256x32x256x256_bilinear5", "cfg3_v2e_u8",
                  "cfg3_v2e_f32_per_frame_thresholds",
                  "cfg4_u8_256x41x256x256_sum5", "cfg4_pipeline_720p_to_256_41f_sum5", "cfg4_pipeline_720p_to_256_40f_bilinear5",
-                 "train_u8_12x201x128x128_sum5",
+                 "train_u8_12x201x128x128_sum5", "train_batch_stats_scales_12x201x128x128", "train_batch_normalised_12x201x128x128",
                  "cfg5_pipeline_plus_e2vid_bf16", "cfg5_fused_convlstm", "cfg5_channels_last", "cfg5_fused_convlstm_channels_last"]
 
 
@@ -87,7 +91,7 @@ def cpu_baseline(frames_host, wl, budget_s=12.0):
     n_done, t0 = 0, time.perf_counter()
     np.random.seed(0)
     for clip in frames_host:
-        if wl["model"] in ("esim", "pipeline"):
+        if wl["model"] in ("esim", "pipeline", "train_batch"):
             counts = O.esim_video_to_voxel(clip, *wl["params"], put_noise_external=False, rng=O.GlobalNumpyRNG, use_lut=False)
         else:
             counts = O.v2e_video_to_voxel(clip, *wl["params"], seed=None)
@@ -110,7 +114,7 @@ def _pool_clip(job):
     sys.path.insert(0, ROOT)
     from oracle import v2v_oracle as O
     np.random.seed(seed)
-    if wl["model"] in ("esim", "pipeline"):
+    if wl["model"] in ("esim", "pipeline", "train_batch"):
         counts = O.esim_video_to_voxel(clip, *wl["params"], put_noise_external=False, rng=O.GlobalNumpyRNG, use_lut=False)
     else:
         counts = O.v2e_video_to_voxel(clip, *wl["params"], seed=None)
@@ -144,7 +148,7 @@ def cpu_baseline_c(frames_host, wl):
     cores = os.cpu_count() or 1
     bm = clib.BIN_BILINEAR if wl["bin"] == "bilinear" else clib.BIN_SUM
     t0 = time.perf_counter()
-    if wl["model"] in ("esim", "pipeline"):
+    if wl["model"] in ("esim", "pipeline", "train_batch"):
         clib.esim_voxel(frames_host, wl["params"], O.load_luts(), rng_mode=clib.RNG_PHILOX, seed=1, bin_mode=bm,
                         num_bins=wl["tb"], frames_per_bin=wl["fpb"])
     else:
@@ -237,6 +241,23 @@ class Workload:
                 if consumer is not None:
                     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
                         forward_sequence(consumer, out, channels_last=c_last)
+        elif wl["model"] == "train_batch":
+            from v2v_amd import _lib, postops
+            ptensor = torch.tensor([params] * b, dtype=torch.float64, device=dev)
+            keys = torch.stack([torch.full((b,), 20240001, dtype=torch.int64), torch.arange(b, dtype=torch.int64) + clip_id0], 1).to(dev)
+            stats = torch.empty((b, _lib.VOXEL_STATS_WORDS), dtype=torch.int32, device=dev)
+            elems = shape[1] * tb * h * w
+            self.kernel_name = "esim_voxel_kernel (writer statistics) + count_pick_kernel" + (" + normalize_pad_rows_kernel" if wl["apply"] else "")
+            if wl["apply"]:
+                self.alg_bytes += 2 * out.numel() * 4                # the scaling pass reads and writes the grid once more
+            self.scales = None
+
+            def step():
+                esim.esim_voxel_batch(frames, ptensor, bin_mode=bin_mode, num_bins=tb, frames_per_bin=fpb, rng_mode="philox", clip_keys=keys, out=out,
+                                      validate=False, no_noise=False, stats=stats)
+                self.scales = postops.scales_from_stats(stats, elems)
+                if wl["apply"]:
+                    postops.apply_scales(out, self.scales, 1, inplace=True)
         elif wl["model"] == "esim":
             ptensor = torch.tensor(params, dtype=torch.float64, device=dev)
             self.kernel_name = "esim_voxel_kernel"
@@ -265,7 +286,19 @@ class Workload:
         verdicts = []
         for c in sorted({0, self.b // 2, self.b - 1}):
             host = self.frames[c:c + 1].cpu().numpy()
-            if wl["model"] in ("esim", "pipeline"):
+            if wl["model"] == "train_batch":
+                # the oracle's grid of this clip, its k-th values by sorting (model/train_utils.py:153-160), and -- normalised workload --
+                # where(v > 0, v / pos_max, v / neg_max); device side: the scales off the writer's statistics and the grid as it stands
+                want, _ = clib.esim_voxel(host, wl["params"], O.load_luts(), rng_mode=clib.RNG_PHILOX, seed=20240001, clip_id0=self.clip_id0 + c,
+                                          bin_mode=bm, num_bins=wl["tb"], frames_per_bin=wl["fpb"])
+                flat = np.sort(want.ravel())
+                neg, pos = max(-flat[int(0.01 * flat.size) - 1], 1.0), max(flat[int(0.99 * flat.size) - 1], 1.0)
+                ok = np.array_equal(self.scales[c].cpu().numpy(), np.array([neg, pos], dtype=np.float32))
+                ref = np.where(want > 0, want.astype(np.float32) / np.float32(pos), want.astype(np.float32) / np.float32(neg)) if wl["apply"] else want
+                ok = ok and np.array_equal(self.out[c:c + 1].cpu().numpy(), ref.astype(np.float32))
+                verdicts.append("ok" if ok else "MISMATCH")
+                continue
+            if wl["model"] in ("esim", "pipeline", "train_batch"):
                 want, _ = clib.esim_voxel(host, wl["params"], O.load_luts(), rng_mode=clib.RNG_PHILOX, seed=20240001,
                                           clip_id0=self.clip_id0 + c, bin_mode=bm, num_bins=wl["tb"], frames_per_bin=wl["fpb"])
             else:
@@ -436,7 +469,7 @@ def main():
     step = W.step
     for _ in range(args.warmup):
         step()
-    step, use_graph = maybe_graph(step, torch, dev, args.hip_graph == "on" or (args.hip_graph == "auto" and wl["model"] == "pipeline"))
+    step, use_graph = maybe_graph(step, torch, dev, args.hip_graph == "on" or (args.hip_graph == "auto" and wl["model"] in ("pipeline", "train_batch")))
     sharding.barrier(dist, local_rank)
     t0 = time.perf_counter()
     kern_trace = time_launches(step, args.steps, torch)
@@ -521,7 +554,7 @@ def main():
                 S = Workload(name, dev, 0, 1)
                 for _ in range(3):
                     S.step()
-                s_step, s_graph = maybe_graph(S.step, torch, dev, S.wl["model"] == "pipeline")
+                s_step, s_graph = maybe_graph(S.step, torch, dev, S.wl["model"] in ("pipeline", "train_batch"))
                 ms = sorted(time_launches(s_step, 12, torch))
                 avg = sum(ms) / len(ms)
                 ach = S.alg_bytes / (avg * 1e-3) / 1e9
