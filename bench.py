@@ -386,23 +386,27 @@ def convlstm_roofline(torch, dev):
 
 def load_valu(name, kernel_ms):
     """VALU-issue view of a launch, next to the HBM one (the noise-on kernels are issue-bound, not bandwidth-bound): the kernel's
-    dynamic vector-instruction count per launch (SQ_INSTS_VALU of the rocprofv3 --pmc pass in profiles/r03/<workload>/summary.json --
+    dynamic vector-instruction count per launch (SQ_INSTS_VALU of the rocprofv3 --pmc pass in profiles/r04|r03/<workload>/summary.json --
     static per binary, like `traffic`) over this run's kernel time, against what 4 SIMDs x 256 CUs can issue at the 2.4 GHz peak
     clock: one wave-instruction per 2 cycles for the cheap class (add/sub/mul/logic/shift/mov) and per 4 cycles for everything else
     (all float64, fma, convert, compare, select, packed: profiles/valu_rates_ubench.txt).  The true ceiling of a kernel lies between
     the two by its instruction mix and is lowered further by the clock the chip holds under load (~1.7-1.9 GHz here)."""
-    path = os.path.join(ROOT, "profiles", "r03", name, "summary.json")
-    try:
-        d = json.load(open(path))
-        insts = d["sq_counters_per_step"]["SQ_INSTS_VALU"]
-    except Exception:  # noqa: BLE001
+    insts = rel = None
+    for tag in ("r04", "r03"):                     # the latest profile of this workload's kernels
+        try:
+            rel = f"profiles/{tag}/{name}/summary.json"
+            insts = json.load(open(os.path.join(ROOT, rel)))["sq_counters_per_step"]["SQ_INSTS_VALU"]
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    if insts is None:
         return None
     simds, clock = 1024, 2.4e9
     rate = insts / (kernel_ms * 1e-3)
     return {"bound": "valu-issue", "wave_instructions_per_launch": insts, "achieved_Ginstr_per_s": rate / 1e9,
             "peak_Ginstr_per_s_2cycle_class": simds * clock / 2 / 1e9, "peak_Ginstr_per_s_4cycle_class": simds * clock / 4 / 1e9,
             "frac_of_2cycle_peak": rate / (simds * clock / 2), "frac_of_4cycle_peak": rate / (simds * clock / 4),
-            "source": f"static: profiles/r03/{name}/summary.json (SQ_INSTS_VALU, rocprofv3 --pmc pass) over this run's kernel time"}
+            "source": f"static: {rel} (SQ_INSTS_VALU, rocprofv3 --pmc pass) over this run's kernel time"}
 
 
 def load_traffic(name):

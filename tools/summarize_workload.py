@@ -9,7 +9,8 @@ import os
 import sys
 
 out_dir, workload = sys.argv[1], sys.argv[2]
-KEYS = ("esim_voxel_kernel", "v2e_voxel_kernel", "v2e_shot_sum_kernel", "frontend_tile_kernel", "frontend_kernel")   # the hot path's kernels
+KEYS = ("esim_voxel_kernel", "v2e_voxel_kernel", "v2e_shot_sum_kernel", "frontend_tile_kernel", "frontend_kernel", "count_pick_kernel",
+        "normalize_pad_rows_kernel", "normalize_pad_kernel", "count_hist4_kernel", "clip_frames4_kernel")   # the hot path's kernels
 
 
 def rows(pattern):
@@ -28,7 +29,7 @@ def short(name):
 
 # register / spill figures from the code objects' own metadata (tools/kernel_resources.py), keyed by the demangled kernel name
 RES = {}
-for cand in ("profiles/r03/kernel_resources.json", "profiles/kernel_resources.json"):
+for cand in ("profiles/r04/kernel_resources.json", "profiles/r03/kernel_resources.json", "profiles/kernel_resources.json"):
     rp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), cand)
     if os.path.exists(rp):
         RES = {v["demangled"]: v for v in json.load(open(rp)).values()}
