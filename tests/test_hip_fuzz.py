@@ -174,3 +174,55 @@ def test_random_frontend_modes(case):
     assert np.array_equal(imgs.cpu().numpy(), want_imgs)
     _, gray2 = frontend.prepare_clip(raw_d, cb, mi, mj, flip, crop, idxes, all_di=di, all_dj=dj, color_mode=mode, want_imgs=False, cv_version=ver)
     assert torch.equal(gray2, gray)                                   # the tiled kernel (gray clip only) and the one that also returns frames
+
+
+@pytest.mark.parametrize("case", range(16 * _SCALE))
+def test_random_packed_clips_with_statistics(oracle_c, luts, case):
+    """The loader's launch (v2v_esim_voxel_ex_hip: per-clip frame index, packed clip offsets, writer statistics) over random shapes, pause
+    patterns, parameters and mappings: grid == the scalar C oracle run on the GATHERED clips (exact: SUM bins hold integers), statistics
+    == the histogram of that grid, scales == its sorted k-th values."""
+    from v2v_amd import _lib, esim as E, postops
+    g = np.random.default_rng(9000 + case)
+    b = int(g.integers(1, 6))
+    h = int(g.integers(2, 40))
+    w = int(g.integers(1, 18)) * 4                             # rows of whole 4-pixel groups (the dataset's crops are multiples of 16)
+    nb, fpb = int(g.integers(1, 6)), int(g.integers(1, 3))
+    k = nb * fpb * int(g.integers(1, 5))
+    n = k + 1
+    stored = [int(g.integers(1, n + 1)) for _ in range(b)]
+    clips = [g.integers(0, 256, size=(u, h, w), dtype=np.uint8) if g.random() < 0.5 else
+             O.synth_clip_s1(u, h, w, seed=int(g.integers(1 << 30)), dtype=np.uint8) for u in stored]
+    fidx = np.stack([np.sort(np.concatenate([np.arange(u), g.integers(0, u, n - u)])) for u in stored]).astype(np.int32)
+    offs, parts, pos = [], [], 0
+    for c in clips:
+        offs.append(pos)
+        pad = (-c.size) % 16
+        parts += [c.ravel(), np.zeros(pad, np.uint8)]
+        pos += c.size + pad
+    gathered = np.stack([c[i] for c, i in zip(clips, fidx)])
+    params = np.stack([[g.uniform(0.05, 1.0), g.uniform(0.05, 1.0), g.uniform(0, 0.2), g.choice([0.0, g.uniform(0, 0.004)]), g.uniform(0, 30.0)]
+                       for _ in range(b)])
+    keys = np.stack([[int(g.integers(1 << 62)), int(g.integers(1 << 30))] for _ in range(b)]).astype(np.int64)
+    want = np.stack([oracle_c.esim_voxel(gathered[i:i + 1], params[i], luts, seed=int(keys[i, 0]), clip_id0=int(keys[i, 1]), bin_mode=oracle_c.BIN_SUM,
+                                         num_bins=nb, frames_per_bin=fpb)[0][0] for i in range(b)])
+    stats = torch.zeros((b, _lib.VOXEL_STATS_WORDS), dtype=torch.int32, device="cuda")
+    pad_to = int(g.choice([1, 16]))
+    got = E.esim_voxel_packed(torch.from_numpy(np.concatenate(parts)).cuda(), torch.tensor(offs, dtype=torch.int64).cuda(), torch.from_numpy(fidx).cuda(),
+                              h, w, torch.from_numpy(params).cuda(), torch.from_numpy(keys).cuda(), num_bins=nb, frames_per_bin=fpb, pad_to=pad_to,
+                              stats=stats, mapping=["4px", "2px", "1px", "auto"][int(g.integers(0, 4))])
+    assert np.array_equal(got[..., :h, :w].cpu().numpy(), want.astype(np.float32)), (b, n, h, w, stored)
+    assert not got[..., h:, :].any() and not got[..., :, w:].any()
+    st = stats.cpu().numpy()
+    for i in range(b):
+        iv = want[i].astype(np.int64).ravel()
+        hist = np.bincount(np.clip(iv, -256, 256) + 256, minlength=516)[:516]
+        hist[256] = 0
+        assert np.array_equal(st[i], hist), i
+    m = want[0].size
+    if m >= 100:
+        flat = np.sort(want.reshape(b, -1), axis=1)
+        lo, hi = flat[:, int(0.01 * m) - 1], flat[:, int(0.99 * m) - 1]
+        sc = postops.scales_from_stats(stats, m).cpu().numpy()
+        for i in range(b):                                     # exact inside the counting range, NaN (never a wrong value) beyond it
+            assert (np.isnan(sc[i, 0]) and lo[i] < -255) or sc[i, 0] == max(-lo[i], 1.0), (i, sc[i], lo[i])
+            assert (np.isnan(sc[i, 1]) and hi[i] > 255) or sc[i, 1] == max(hi[i], 1.0), (i, sc[i], hi[i])
