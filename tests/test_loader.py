@@ -244,3 +244,24 @@ def test_packed_clips_launch_equals_the_gathered_launch():
     assert torch.equal(clip_frames_packed(flat_d, offs_d, pick, h, w), clip_frames_f32(gathered, [5, 10, 20]))
     with pytest.raises(ValueError):                                                   # indexed launches have no float64 / external-noise instances
         esim.esim_voxel_packed(flat_d, offs_d, fidx_d.long(), h, w, params, keys)
+
+
+@pytest.mark.gpu
+def test_create_dataloader_under_two_ddp_ranks(tmp_path):
+    """train.py under torchrun: two processes, each `create_dataloader(dataset, configs, batch_size, local_rank)` -> DistributedSampler +
+    RingLoader.  The ranks receive disjoint halves of the samples, their union is the dataset, and set_epoch reshuffles."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29617",
+           os.path.join(root, "tests", "ddp_loader_rank.py"), str(tmp_path)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    r0, r1 = (json.load(open(tmp_path / f"rank{r}.json")) for r in (0, 1))
+    for epoch in range(2):
+        a, b = set(r0[epoch]), set(r1[epoch])
+        assert len(r0[epoch]) == 6 and len(r1[epoch]) == 6 and not (a & b) and len(a | b) == 12      # 12 samples, 2 ranks, drop_last, batch 3
+    assert r0[0] != r0[1]                                                                               # set_epoch changed the order
