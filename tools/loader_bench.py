@@ -147,6 +147,68 @@ def run_loader(make_iterable, n_batches, batch, dev, timers=None, gpu_ms_per_bat
     return out
 
 
+def run_with_consumer(ds, workers, batch, n_batches, dev):
+    """BASELINE config 5's "end-to-end dataloader throughput" at the training shape: RingLoader(normalize='scales') feeding the package's
+    E2VIDRecurrent (random init, the reference's module tree, every layer on the device kernels) over the sequence's 40 time steps, the
+    head applying normalize_batch_voxel's scales while it reads the raw voxels (model/train_utils.py:318-345, inference: no loss / backward)."""
+    from v2v_amd.loader import RingLoader
+    from v2v_amd.unet import E2VIDRecurrent
+    torch.manual_seed(0)
+    net = E2VIDRecurrent(dict(num_bins=5, skip_type="sum", recurrent_block_type="convlstm", num_encoders=3, base_num_channels=32,
+                              num_residual_blocks=2, use_upsample_conv=True, final_activation="", norm=None)).to(dev).eval()
+    loader = RingLoader(ds, batch_size=batch, num_workers=workers, drop_last=True, pad_to=16, normalize="scales")
+    it = iter(loader)
+
+    first = next(it)
+    ev_buf, sc_buf = torch.empty_like(first["events"]), torch.empty_like(first["event_scales"])
+
+    def forward_all():
+        net.reset_states()
+        with torch.no_grad():
+            for t in range(ev_buf.shape[1]):                    # forward_sequence's time loop (:339-345)
+                img = net(ev_buf[:, t], sc_buf)["image"]
+        return img
+    ev_buf.copy_(first["events"])
+    sc_buf.copy_(first["event_scales"])
+    forward_all()                                               # warm-up (weight packing, allocator)
+    torch.cuda.synchronize(dev)
+    # ~1,000 launches per batch: replayed from ONE hipGraph (the entry points only enqueue kernels), fed through two static buffers
+    graph, img_ref = None, None
+    try:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            forward_all()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            img_ref = forward_all()
+    except Exception:  # noqa: BLE001 - capture is an optimisation
+        graph = None
+
+    def consume(b):
+        ev_buf.copy_(b["events"])
+        sc_buf.copy_(b["event_scales"])
+        if graph is not None:
+            graph.replay()
+            return img_ref
+        return forward_all()
+    for _ in range(2):
+        consume(next(it))
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(n_batches):
+        last = consume(next(it))
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    del it
+    loader.close()
+    return {"samples_per_s": n_batches * batch / dt, "ms_per_batch": dt / n_batches * 1e3, "batches": n_batches, "time_steps_per_sample": 40,
+            "frames_reconstructed_per_s": n_batches * batch * 40 / dt, "image": f"{tuple(last.shape)} {last.dtype}", "launch": "hipGraph replay" if graph is not None else "eager",
+            "what": "RingLoader(normalize='scales') -> v2v_amd.unet.E2VIDRecurrent(event_tensor, event_scales) over 40 time steps per sample (inference); "
+                    "the consumer is the bound here, the loader idles"}
+
+
 def gpu_ms_of_batch(batch, dev, pad_to=16):
     """Kernel time of one batch's device work (simulator with the writer's statistics, scales, the scaling pass, the frame tensor) at
     this shape: HIP events around a hipGraph replay of exactly the launches the loader issues, device-resident inputs."""
@@ -183,7 +245,7 @@ def gpu_ms_of_batch(batch, dev, pad_to=16):
     return sum(ms) / len(ms)
 
 
-def measure(batches=200, workers=9, batch=12, modes=("ring", "simulating"), cpu_port=True, dev=None, cpu_port_budget_s=60.0, simulating_batches=None, ring_kw=None):
+def measure(batches=200, workers=9, batch=12, modes=("ring", "simulating"), cpu_port=True, dev=None, cpu_port_budget_s=60.0, simulating_batches=None, ring_kw=None, consumer=True):
     ring_kw = ring_kw or {}
     from torch.utils.data import DataLoader
     from v2v_amd.datasets import SimulatingCollator, SimulatingLoader
@@ -226,6 +288,11 @@ def measure(batches=200, workers=9, batch=12, modes=("ring", "simulating"), cpu_
             # fewer bytes cross PCIe than the gathered clips hold, so it may beat the gathered-clip floor above
             r["pcie_busy_fraction"] = r["h2d_bytes_per_batch"] / (res["pcie"]["h2d_GBps_page_locked"] * 1e9) / (r["ms_per_batch"] * 1e-3)
             r["vs_gathered_clip_pcie_floor"] = res["pcie"]["floor_ms_per_batch"] / r["ms_per_batch"]
+        if consumer:
+            try:
+                res["ring_loader_feeding_e2vid"] = run_with_consumer(ds, workers, batch, 20, dev)
+            except Exception as exc:  # noqa: BLE001 - a secondary figure
+                res["ring_loader_feeding_e2vid"] = {"error": f"{type(exc).__name__}: {exc}"}
         if cpu_port:
             res["cpu_port_in_workers"] = run_cpu_port(ds, workers, batch, budget_s=cpu_port_budget_s)
     best = max((res[k]["samples_per_s"] for k in ("ring_loader", "simulating_loader") if k in res), default=None)
@@ -241,9 +308,10 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--mode", default="both", choices=["ring", "simulating", "both"])
     ap.add_argument("--no-cpu-port", action="store_true")
+    ap.add_argument("--no-consumer", action="store_true")
     ap.add_argument("--depth", type=int, default=2)
     ap.add_argument("--normalize", default="True")
     a = ap.parse_args()
     modes = ("ring", "simulating") if a.mode == "both" else (a.mode,)
     kw = dict(depth=a.depth, normalize={"True": True, "False": False}.get(a.normalize, a.normalize))
-    print(json.dumps(measure(a.batches, a.workers, a.batch, modes, not a.no_cpu_port, ring_kw=kw), indent=1))
+    print(json.dumps(measure(a.batches, a.workers, a.batch, modes, not a.no_cpu_port, ring_kw=kw, consumer=not a.no_consumer), indent=1))
