@@ -265,3 +265,23 @@ def test_create_dataloader_under_two_ddp_ranks(tmp_path):
         a, b = set(r0[epoch]), set(r1[epoch])
         assert len(r0[epoch]) == 6 and len(r1[epoch]) == 6 and not (a & b) and len(a | b) == 12      # 12 samples, 2 ranks, drop_last, batch 3
     assert r0[0] != r0[1]                                                                               # set_epoch changed the order
+
+
+@pytest.mark.gpu
+def test_ring_loader_partial_last_batch(tmp_path):
+    """drop_last=False: the epoch's last batch is smaller; every sample still equals the per-sample path."""
+    from torch.utils.data import default_collate
+    from v2v_amd.datasets import SimulatingCollator
+    from v2v_amd.loader import RingLoader
+    ds = _make_ds(tmp_path, n_videos=7, defer_sim=True, fixed_seed=21)
+    col = SimulatingCollator.from_configs({"num_bins": 5}, output_device="cuda", pad_to=16, normalize=True)
+    loader = RingLoader(ds, batch_size=3, num_workers=2, drop_last=False, pad_to=16, normalize=True)
+    sizes = []
+    for bi, batch in enumerate(loader):
+        idx = list(range(3 * bi, min(3 * bi + 3, 7)))
+        want = col.simulate(default_collate([ds[i] for i in idx]))
+        sizes.append(batch["events"].shape[0])
+        assert torch.equal(batch["events"], want["events"]) and torch.equal(batch["frame"], want["frame"])
+        assert batch["data_source_idx"].shape == (len(idx),) and all(v.shape == (len(idx),) for v in batch["v2e_params"].values())
+    assert sizes == [3, 3, 1]
+    loader.close()

@@ -321,10 +321,15 @@ class RingLoader:
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ev)
         offsets_d, fidx_d, pick_d, params_d, keys_d, cframes, clips = lay.device_views(self._dev[d])
+        nb = len(src_idx)                                                 # < batch_size only for the last batch of an epoch with drop_last=False
+        if nb < lay.batch:
+            offsets_d, fidx_d, pick_d, params_d, keys_d = offsets_d[:nb], fidx_d[:nb], pick_d[:nb], params_d[:nb], keys_d[:nb]
+            cframes = cframes[:nb] if cframes is not None else None
+            params = params[:nb]
         t0 = time.perf_counter()
         h, w = lay.h, lay.w
         method = choose_normalize_method(params, leaf.frames_per_bin, leaf.put_noise_external) if self.normalize else None
-        stats = torch.empty((lay.batch, _lib.VOXEL_STATS_WORDS), dtype=torch.int32, device=self.device) if method == "count" else None
+        stats = torch.empty((nb, _lib.VOXEL_STATS_WORDS), dtype=torch.int32, device=self.device) if method == "count" else None
         if leaf.put_noise_external:
             # external noise has no indexed instance: gather the clips on the device first (an ablation configuration, not a training one)
             gathered = torch.stack([clips[int(o):int(o) + lay.n * h * w].view(lay.n, h, w)[fi.long()] for o, fi in zip(offsets_d.tolist(), fidx_d)])
