@@ -228,3 +228,57 @@ def test_cfg5_pipeline_feeds_the_consumer():
         assert err_f < 1.25 * err_s + 1e-3 and err_f < 0.5 * spread, f"step {t}: fused {err_f:.4g}, stock autocast {err_s:.4g}, spread {spread:.4g}"
         err_c = float((fcl.float() - w32).abs().max())
         assert err_c < 1.25 * err_s + 1e-3 and err_c < 0.5 * spread, f"step {t}: fused channels_last {err_c:.4g}, stock autocast {err_s:.4g}"
+
+
+@gpu
+def test_training_batch_packed_clips_with_statistics(oracle_c, luts):
+    """The reference's training shape (config/train_v2v_e2vid_10k.yaml:50-76: B = 12, 201 frames of 128 x 128, 40 x 5 SUM bins) as the
+    loader launches it: every decoded frame stored once + the pause-index row (proba_pause_when_running 0.0102 / _when_paused 0.9791),
+    per-clip parameters and RNG keys on the device, writer statistics.  First / middle / last clip against the scalar C oracle on the
+    GATHERED clip (exact), all twelve statistics rows against the histogram of the written grid, scales against its sorted k-th values."""
+    import torch
+    from v2v_amd import _lib, esim, postops
+    b, n, h, w, tb = 12, 201, 128, 128, 5
+    g = np.random.default_rng(77)
+    fidx = np.zeros((b, n), np.int32)
+    for c in range(b):                                             # the reference's pause chain (data/v2v_datasets.py:292-300)
+        idx, paused = 0, False
+        for f in range(n):
+            fidx[c, f] = idx
+            u = g.random()
+            if paused:
+                paused = not (u > 0.9791)
+            elif u < 0.0102:
+                paused = True
+            if not paused:
+                idx += 1
+    stored = fidx[:, -1] + 1
+    video = esim.synth_clips(b, n, h, w, dtype=torch.uint8, seed=SEED + 11, clip_id0=0)            # decoded frames: the first `stored` of each
+    offs = np.concatenate([[0], np.cumsum((stored * h * w + 15) // 16 * 16)])[:-1].astype(np.int64)
+    flat = torch.zeros(int(offs[-1] + stored[-1] * h * w), dtype=torch.uint8, device="cuda")
+    for c in range(b):
+        flat[offs[c]:offs[c] + stored[c] * h * w] = video[c, :stored[c]].reshape(-1)
+    params = np.stack([[g.uniform(0.05, 2), 0, g.uniform(0, 0.1), g.uniform(0, 1e-3), g.uniform(0, 10)] for _ in range(b)])
+    params[:, 1] = params[:, 0] * g.uniform(1, 1.5, size=b)
+    keys = np.ascontiguousarray(np.stack([g.integers(0, 1 << 62, size=b), np.arange(b) + 1000]).T.astype(np.int64))
+    stats = torch.zeros((b, _lib.VOXEL_STATS_WORDS), dtype=torch.int32, device="cuda")
+    got = esim.esim_voxel_packed(flat, torch.from_numpy(offs).cuda(), torch.from_numpy(fidx).cuda(), h, w, torch.from_numpy(params).cuda(),
+                                 torch.from_numpy(keys).cuda(), num_bins=tb, pad_to=16, stats=stats)
+    assert got.shape == (b, 40, tb, h, w) and stored.min() < n                                       # some clip did pause
+    vh = video.cpu().numpy()
+    for c in (0, b // 2, b - 1):
+        gathered = vh[c][fidx[c]][None]
+        want, _ = oracle_c.esim_voxel(gathered, params[c], luts, seed=int(keys[c, 0]), clip_id0=int(keys[c, 1]), bin_mode=oracle_c.BIN_SUM, num_bins=tb)
+        assert np.array_equal(got[c].cpu().numpy(), want[0].astype(np.float32)), c
+    iv = got.long().reshape(b, -1)
+    assert torch.equal(iv.float().reshape(got.shape), got)
+    m = iv.shape[1]
+    st = stats.cpu().numpy()
+    for c in range(b):
+        hist = torch.bincount(iv[c].clamp(-256, 256) + 256, minlength=516)[:516].cpu().numpy()
+        hist[256] = 0
+        assert np.array_equal(st[c], hist), c
+    srt = torch.sort(got.reshape(b, -1), dim=1).values
+    lo, hi = srt[:, int(0.01 * m) - 1].cpu().numpy(), srt[:, int(0.99 * m) - 1].cpu().numpy()
+    sc = postops.scales_from_stats(stats, m).cpu().numpy()
+    assert np.array_equal(sc, np.stack([np.maximum(-lo, 1), np.maximum(hi, 1)], 1).astype(np.float32))
