@@ -137,7 +137,8 @@ def test_clip_frames_equals_cpu_division_on_all_values():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("extra,workers", [({}, 2), ({"color_mode": "gray_in_bgr_out"}, 0), ({"output_additional_evs": True}, 2),
-                                           ({"output_additional_frame": True, "crop_size": 36}, 0)])
+                                           ({"output_additional_frame": True, "crop_size": 36}, 0), ({"put_noise_external": True}, 2),
+                                           ({"proba_pause_when_running": 0.3, "proba_pause_when_paused": 0.6, "shake_frames": 4, "shake_std": 1.5}, 2)])
 def test_ring_loader_equals_simulating_collator(tmp_path, extra, workers):
     """Whole batches: RingLoader == default_collate + SimulatingCollator over the deferred samples (hence == the per-sample path,
     tests/test_hip_dataset_events.py::test_simulating_collator_equals_per_sample_path), bit for bit, with forked workers too."""
@@ -285,3 +286,25 @@ def test_ring_loader_partial_last_batch(tmp_path):
         assert batch["data_source_idx"].shape == (len(idx),) and all(v.shape == (len(idx),) for v in batch["v2e_params"].values())
     assert sizes == [3, 3, 1]
     loader.close()
+
+
+@pytest.mark.gpu
+def test_ring_loader_survives_an_abandoned_epoch(tmp_path):
+    """The training loop breaks out of an epoch (validation, early stop): the next epoch starts clean -- no worker of the abandoned one
+    writes into a slot that is handed out again, every batch still equals the per-sample path."""
+    from torch.utils.data import default_collate
+    from v2v_amd.datasets import SimulatingCollator
+    from v2v_amd.loader import RingLoader
+    ds = _make_ds(tmp_path, n_videos=12, defer_sim=True, fixed_seed=9)
+    col = SimulatingCollator.from_configs({"num_bins": 5}, output_device="cuda")
+    for persistent in (False, True):
+        loader = RingLoader(ds, batch_size=2, num_workers=3, persistent_workers=persistent)
+        for bi, batch in enumerate(loader):
+            if bi == 1:
+                break                                                             # 4 more batches are in flight in the workers
+        for epoch in range(2):
+            for bi, batch in enumerate(loader):
+                want = col.simulate(default_collate([ds[2 * bi], ds[2 * bi + 1]]))
+                assert torch.equal(batch["events"], want["events"]) and torch.equal(batch["frame"], want["frame"]), (persistent, epoch, bi)
+            assert bi == 5
+        loader.close()

@@ -235,8 +235,8 @@ class RingLoader:
                 raise TypeError("RingLoader needs v2v_amd.datasets.WebvidDatasetV2 leaves")
             if shape(d) != shape(lf0):
                 raise ValueError("all datasets of a RingLoader must share clip length, crop size, colour mode and binning")
-            if d.shake_frames or d.gpu_frontend:
-                pass                                                       # shake crops back to crop_size on the host; gpu_frontend raises in host_sample_into
+            if d.gpu_frontend:
+                raise TypeError("RingLoader ships host-decoded clips: configure the dataset with gpu_frontend: false")
         self.leaf = lf0
         n, hw = lf0.frames_per_seq + 1, lf0.crop_size
         self.pick = lf0.frame_pick()
@@ -301,7 +301,7 @@ class RingLoader:
         t0 = time.perf_counter()
         d = k % self.depth
         lay = self.layout
-        _, _, _, params, _, used, _, _ = lay.views(self.ring[slot])
+        offsets, _, _, params, _, used, _, _ = lay.views(self.ring[slot])
         nbytes = lay.off_clips + int(used[0])
         ev = torch.cuda.Event()
         with torch.cuda.stream(self.copy_stream):
@@ -309,14 +309,14 @@ class RingLoader:
             self.copy_stream.wait_event(self._dev_free[d])
             self._dev[d][:nbytes].copy_(self._ring_t[slot, :nbytes], non_blocking=True)
             ev.record(self.copy_stream)
-        params = params.copy()                                            # host-side values of the batch, read before the slot is recycled
+        params, offsets = params.copy(), offsets.copy()                  # host-side values of the batch, read before the slot is recycled
         self.bytes_copied += nbytes
         self.batches_copied += 1
         self._t("h2d_enqueue", t0)
-        return d, ev, params, src_idx
+        return d, ev, params, src_idx, offsets
 
     def _finish(self, staged):
-        d, ev, params, src_idx = staged
+        d, ev, params, src_idx, offsets = staged
         lay, leaf = self.layout, self.leaf
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ev)
@@ -332,7 +332,7 @@ class RingLoader:
         stats = torch.empty((nb, _lib.VOXEL_STATS_WORDS), dtype=torch.int32, device=self.device) if method == "count" else None
         if leaf.put_noise_external:
             # external noise has no indexed instance: gather the clips on the device first (an ablation configuration, not a training one)
-            gathered = torch.stack([clips[int(o):int(o) + lay.n * h * w].view(lay.n, h, w)[fi.long()] for o, fi in zip(offsets_d.tolist(), fidx_d)])
+            gathered = torch.stack([clips[int(o):int(o) + lay.n * h * w].view(lay.n, h, w)[fi.long()] for o, fi in zip(offsets[:nb].tolist(), fidx_d)])
             vox = esim.esim_voxel_batch(gathered, params_d, bin_mode="sum", num_bins=leaf.num_bins, frames_per_bin=leaf.frames_per_bin, rng_mode="philox",
                                         clip_keys=keys_d, put_noise_external=True, pad_to=self.pad_to, validate=False)
         else:
@@ -371,6 +371,7 @@ class RingLoader:
         # an abandoned epoch's workers may still be writing into ring slots: end them (non-persistent workers are joined when their
         # iterator goes; persistent ones drain their queue when the DataLoader restarts them) before slots are handed out again
         self._it = None
+        self.copy_stream.synchronize()                                    # ... and no copy of an abandoned epoch still reads the ring
         it = self._it = iter(self.loader)
         k = 0
         copies = []                                                       # H2D events of the batches whose ring slot may still be read
