@@ -277,7 +277,8 @@ static int esim_launch_impl(const void *frames, int in_dtype, int64_t B, int64_t
 
     // 4 (or 2) pixels per work-item when every row segment a lane touches is 16-byte (8-byte) fp32 / 4-byte (2-byte) u8 aligned
     auto layout_ok = [&](int64_t v) {
-        return (HW % v == 0) && (frame_stride % v == 0) && (B == 1 || clip_stride % v == 0) && aligned(frames, (size_t)v * in_sz) &&
+        // (with clip_offsets, clip_stride is the alignment every offset keeps: it counts for a single clip too)
+        return (HW % v == 0) && (frame_stride % v == 0) && ((B == 1 && !clip_offsets) || clip_stride % v == 0) && aligned(frames, (size_t)v * in_sz) &&
                aligned(out_voxel, (size_t)v * 4) &&
                (out_row_pitch == W ? out_plane_size % v == 0 : (W % v == 0 && out_row_pitch % v == 0 && out_plane_size % v == 0));
     };
@@ -358,7 +359,7 @@ int v2v_clip_frames_f32_ex_hip(const void *src, int64_t clip_stride, const int64
     if (!src || !out) return fail(V2V_ERR_NULL, "v2v_clip_frames_f32_hip: src/out is NULL");
     if (B < 0 || L < 1 || H < 1 || W < 1 || C < 1 || C > 4) return fail(V2V_ERR_SHAPE, "need B>=0, L,H,W>=1, 1<=C<=4");
     const int64_t HW = H * W;
-    if (HW * C >= (int64_t)1 << 30 || B * L > 0x7FFFFFFF) return fail(V2V_ERR_SHAPE, "frame or batch too large");
+    if (HW * C >= (int64_t)1 << 30 || B * L > 65535) return fail(V2V_ERR_SHAPE, "frame too large or more than 65535 output frames in one call (split the batch)");
     if (frame_stride < HW * C || (!clip_offsets && B > 1 && clip_stride < frame_stride) || (clip_offsets && clip_stride < 1) || pick_stride < 0 ||
         (pick_stride != 0 && (!pick || pick_stride < L)))
         return fail(V2V_ERR_SHAPE, "strides smaller than the extent");
@@ -367,7 +368,7 @@ int v2v_clip_frames_f32_ex_hip(const void *src, int64_t clip_stride, const int64
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint8_t *sp = static_cast<const uint8_t *>(src);
     // with clip_offsets, clip_stride states the alignment (in bytes) every offset keeps
-    const bool v4 = C == 1 && HW % 4 == 0 && frame_stride % 4 == 0 && (B == 1 || clip_stride % 4 == 0) && aligned(src, 4) && aligned(out, 16);
+    const bool v4 = C == 1 && HW % 4 == 0 && frame_stride % 4 == 0 && ((B == 1 && !clip_offsets) || clip_stride % 4 == 0) && aligned(src, 4) && aligned(out, 16);
     if (v4) {
         const int hw4 = (int)(HW / 4);
         const unsigned gx = (unsigned)std::min<int64_t>((hw4 + 255) / 256, 64);
