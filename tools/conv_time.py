@@ -14,8 +14,12 @@ from tools.convlstm_time import timeit  # noqa: E402
 
 def main():
     # (name, B, Cin, Hin, Win, Cout, ks, stride)
-    shapes = [("enc1", 8, 32, 256, 256, 64, 5, 2), ("enc2", 8, 64, 128, 128, 128, 5, 2), ("enc3", 8, 128, 64, 64, 256, 5, 2), ("dec1", 8, 256, 64, 64, 128, 5, 1),
-              ("dec2", 8, 128, 128, 128, 64, 5, 1), ("dec3", 8, 64, 256, 256, 32, 5, 1), ("res", 8, 256, 32, 32, 256, 3, 1)]
+    if len(sys.argv) > 1 and sys.argv[1] == "train":      # the reference's training shape: 12 clips of 128^2 per time step
+        shapes = [("enc1", 12, 32, 128, 128, 64, 5, 2), ("enc2", 12, 64, 64, 64, 128, 5, 2), ("enc3", 12, 128, 32, 32, 256, 5, 2), ("dec1", 12, 256, 32, 32, 128, 5, 1),
+                  ("dec2", 12, 128, 64, 64, 64, 5, 1), ("dec3", 12, 64, 128, 128, 32, 5, 1), ("res", 12, 256, 16, 16, 256, 3, 1)]
+    else:
+      shapes = [("enc1", 8, 32, 256, 256, 64, 5, 2), ("enc2", 8, 64, 128, 128, 128, 5, 2), ("enc3", 8, 128, 64, 64, 256, 5, 2), ("dec1", 8, 256, 64, 64, 128, 5, 1),
+                ("dec2", 8, 128, 128, 128, 64, 5, 1), ("dec3", 8, 64, 256, 256, 32, 5, 1), ("res", 8, 256, 32, 32, 256, 3, 1)]
     for name, b, cin, h, w, cout, ks, stride in shapes:
         ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
         flops = 2.0 * b * ho * wo * cin * ks * ks * cout
