@@ -308,3 +308,19 @@ def test_ring_loader_survives_an_abandoned_epoch(tmp_path):
                 assert torch.equal(batch["events"], want["events"]) and torch.equal(batch["frame"], want["frame"]), (persistent, epoch, bi)
             assert bi == 5
         loader.close()
+
+
+@pytest.mark.gpu
+def test_ring_loader_retires_an_older_iterator(tmp_path):
+    """The ring's slots serve one epoch at a time: a second iter(loader) retires the first one loudly instead of sharing slots with it."""
+    from v2v_amd.loader import RingLoader
+    ds = _make_ds(tmp_path, n_videos=8, defer_sim=True, fixed_seed=4)
+    loader = RingLoader(ds, batch_size=2, num_workers=0)
+    first = iter(loader)
+    next(first)
+    second = iter(loader)
+    assert next(second)["events"].shape[0] == 2
+    with pytest.raises(RuntimeError, match="retired"):
+        next(first)
+    assert sum(1 for _ in second) == 3                                            # the newer iterator finishes its epoch
+    loader.close()

@@ -261,6 +261,7 @@ class RingLoader:
             kw.update(prefetch_factor=prefetch_factor, persistent_workers=persistent_workers, multiprocessing_context="fork")
         self.loader = DataLoader(_RingDataset(dataset, self.ring, self.layout, self.pick), batch_sampler=bs, **kw)
         self._it = None
+        self._generation = 0                                               # one live iterator: a newer __iter__ retires the older ones
         self.bytes_copied, self.batches_copied = 0, 0                      # H2D bytes / batches so far (heads + packed clips)
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self._dev = [torch.empty(self.layout.nbytes, dtype=torch.uint8, device=self.device) for _ in range(self.depth)]
@@ -371,6 +372,8 @@ class RingLoader:
         # an abandoned epoch's workers may still be writing into ring slots: end them (non-persistent workers are joined when their
         # iterator goes; persistent ones drain their queue when the DataLoader restarts them) before slots are handed out again
         self._it = None
+        self._generation += 1
+        gen = self._generation
         self.copy_stream.synchronize()                                    # ... and no copy of an abandoned epoch still reads the ring
         it = self._it = iter(self.loader)
         k = 0
@@ -378,6 +381,8 @@ class RingLoader:
 
         def fetch():
             nonlocal k
+            if gen != self._generation:                                   # the ring and its slot counter serve ONE iterator (torch's DataLoader allows several)
+                raise RuntimeError("this RingLoader iterator was retired by a newer iter(loader): the ring's slots serve one epoch at a time")
             # a ring slot is rewritten `slots` batches later, and a worker may start on it once the batch `in_flight` before it
             # has been handed out: make sure the H2D copy of the batch `depth + 1` back has left the ring before asking for more
             while len(copies) > self.depth:
