@@ -131,7 +131,9 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
     // 2-frame ring, which fits 128 VGPRs = 4 waves per SIMD (-4.6 % on the headline, same box); a clip that breaks the
     // guarantee gets NaN planes (loud, never a wrong count)
     // (uint8 frames are 4 bytes per lane and frame: their ring stays kDepth deep -- with 2 in flight config 4's shape lost 20 %)
-    constexpr int kRing = ((SYMONLY || ASYM4) && IN == kInF32) ? 2 : kDepth;
+    // (1 pixel per work-item: 8 frames in flight -- at 3 waves per SIMD a step is short and 4 frames of look-ahead do not cover the
+    // memory latency; -2 % at the training shape, same box)
+    constexpr int kRing = ((SYMONLY || ASYM4) && IN == kInF32) ? 2 : VEC == 1 ? 8 : kDepth;
     static_assert(NOISE || !EXT, "external noise needs the noise path");
     using lut_t = typename LutT<IN>::type;
     using acc_t = typename std::conditional<OUT64, double, float>::type;
@@ -320,6 +322,10 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
                 next_k = (cur_seg + 1 <= a.Tb - 2) ? __builtin_amdgcn_readfirstlane(s_kb[cur_seg + 1]) : 0x7FFFFFFF;
             }
         }
+        // 1 pixel per work-item: the log lookup goes first, so that its LDS round trip runs under the noise block (whose scalar branch
+        // the scheduler does not move loads across); with 4 pixels the lookups' registers would be live across that block for nothing
+        lut_t ln[VEC];
+        if constexpr (VEC == 1) pix_logs<IN, VEC>(raw, s_lut, ln);
         double base[NOISE ? VEC : 1];
         if constexpr (NOISE) {
 #pragma unroll
@@ -365,8 +371,7 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
         acc_t wl = 1, wh = 0;
         if constexpr (BIN == kBinBilinear) { wl = s_wlo[k]; wh = s_whi[k]; }
 
-        lut_t ln[VEC];
-        pix_logs<IN, VEC>(raw, s_lut, ln);
+        if constexpr (VEC != 1) pix_logs<IN, VEC>(raw, s_lut, ln);
 
         // Branch-free per pixel: q = np.floor_divide(|p|, C) is 0 exactly when |p| < C, so the reference's
         // `where(p >= C+ ...)` / `where(p <= -C- ...)` masks (v2v_core_esim.py:51-55) need no separate test,
