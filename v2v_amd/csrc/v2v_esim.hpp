@@ -311,7 +311,9 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
 
     // SYM (compile-time tag): C+ == C- for this clip (wave-uniform), so no per-lane threshold selection.
     // PAR (compile-time tag): k & 1 -- the time loop is unrolled by an even factor from an even k.
-    auto step = [&](auto sym_tag, auto hot_tag, auto par_tag, int k, const Raw<IN, VEC> &raw) __attribute__((always_inline)) {
+    // 1 pixel per work-item: log intensity of the frame the NEXT step consumes, looked up one step ahead (see the step)
+    lut_t ln_pre[VEC];
+    auto step = [&](auto sym_tag, auto hot_tag, auto par_tag, int k, const Raw<IN, VEC> &raw, const Raw<IN, VEC> &raw_next) __attribute__((always_inline)) {
         constexpr bool SYM = decltype(sym_tag)::value;
         constexpr bool HOT = decltype(hot_tag)::value;     // false: no work-item of this WAVE owns a hot pixel -> no hot-pixel add
         constexpr int PAR = decltype(par_tag)::value;
@@ -322,10 +324,14 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
                 next_k = (cur_seg + 1 <= a.Tb - 2) ? __builtin_amdgcn_readfirstlane(s_kb[cur_seg + 1]) : 0x7FFFFFFF;
             }
         }
-        // 1 pixel per work-item: the log lookup goes first, so that its LDS round trip runs under the noise block (whose scalar branch
-        // the scheduler does not move loads across); with 4 pixels the lookups' registers would be live across that block for nothing
+        // 1 pixel per work-item (small batches, 3 waves per SIMD, a wave issues in order): this step's log intensity was looked up during
+        // the previous step and the next step's lookup is issued here, so that its LDS round trip runs under a whole step instead of
+        // parking the wave in front of the potential update; with 4 pixels the lookups' registers would be live across the step for nothing
         lut_t ln[VEC];
-        if constexpr (VEC == 1) pix_logs<IN, VEC>(raw, s_lut, ln);
+        if constexpr (VEC == 1) {
+            ln[0] = ln_pre[0];
+            pix_logs<IN, VEC>(raw_next, s_lut, ln_pre);
+        }
         double base[NOISE ? VEC : 1];
         if constexpr (NOISE) {
 #pragma unroll
@@ -495,7 +501,7 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
         // up to kRing-1 remaining steps, with compile-time slot index (and parity)
         static_for(std::make_integer_sequence<int, kRing - 1>{}, [&](auto u_tag) {
             constexpr int u = decltype(u_tag)::value;
-            if (k0 + u < a.K) step(sym_tag, hot_tag, std::integral_constant<int, (u & 1)>{}, k0 + u, ring[u]);
+            if (k0 + u < a.K) step(sym_tag, hot_tag, std::integral_constant<int, (u & 1)>{}, k0 + u, ring[u], ring[u + 1]);
         });
     };
     auto run_hot = [&](auto sym_tag, auto hot_tag) {
@@ -506,12 +512,13 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
             const int f = (1 + u <= a.K) ? 1 + u : a.K;
             ring[u] = load_raw<IN, VEC>(a.frames, in_base + foff(f));
         }
+        if constexpr (VEC == 1) pix_logs<IN, VEC>(ring[0], s_lut, ln_pre);
         int k0 = 0;
         for (; k0 + kRing <= a.K; k0 += kRing) {
             static_for(std::make_integer_sequence<int, kRing>{}, [&](auto u_tag) {
                 constexpr int u = decltype(u_tag)::value;
                 const int k = k0 + u;
-                step(sym_tag, hot_tag, std::integral_constant<int, (u & 1)>{}, k, ring[u]);
+                step(sym_tag, hot_tag, std::integral_constant<int, (u & 1)>{}, k, ring[u], ring[(u + 1) % kRing]);
                 const int fn = k + 1 + kRing;
                 ring[u] = load_raw<IN, VEC>(a.frames, in_base + foff(fn <= a.K ? fn : a.K));
             });
