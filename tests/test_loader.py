@@ -65,6 +65,37 @@ def test_host_sample_into_equals_deferred_getitem(tmp_path, extra):
             assert torch.equal(got, want["frame"])
 
 
+def _frames_array(*args):
+    return np.stack(_frames(*args))
+
+
+@pytest.mark.parametrize("extra", [{}, {"color_mode": "gray_in_bgr_out"}, {"video_degrade": "hdr", "degrade_ratio": 1.0}, {"shake_frames": 5, "shake_std": 2.0}])
+def test_array_frame_source_equals_list_frame_source(tmp_path, extra):
+    """A frame source may hand out ONE [T,h,w,C] array instead of a list of frames (pre-decoded stores): same samples, through
+    __getitem__ and through the slot writer, with and without the per-frame paths (shake, degradations) in the way."""
+    a = _make_ds(tmp_path, defer_sim=True, **extra)
+    b = _make_ds(tmp_path, defer_sim=True, frame_source=_frames_array, **extra)
+    n, hw = a.frames_per_seq + 1, a.crop_size
+    colour = a.color_mode != "gray"
+    for idx in (1, 3):
+        np.random.seed(7 + idx)
+        sa = a[idx]
+        np.random.seed(7 + idx)
+        sb = b[idx]
+        assert torch.equal(sa["sim_frames"], sb["sim_frames"]) and torch.equal(sa["frame"], sb["frame"]) and sa["v2e_params"] == sb["v2e_params"]
+        outs = []
+        for ds in (a, b):
+            clip, params, key = np.zeros((n, hw, hw), np.uint8), np.zeros(5), np.zeros(2, np.int64)
+            cframes = np.zeros((len(ds.frame_pick()), hw, hw, 3), np.uint8) if colour else None
+            fidx = np.zeros(n, np.int32)
+            np.random.seed(7 + idx)
+            _, stored = ds.host_sample_into(idx, clip, params, key, cframes, fidx)
+            outs.append((clip, params, key, cframes, fidx, stored))
+        for x, y in zip(*outs):
+            assert np.array_equal(x, y) if isinstance(x, np.ndarray) else x == y
+        assert np.array_equal(outs[1][0][outs[1][4]], sa["sim_frames"].numpy())
+
+
 def test_slot_layout_is_aligned_and_disjoint():
     from v2v_amd.loader import _SlotLayout
     lay = _SlotLayout(12, 201, 128, 128, 40, True)

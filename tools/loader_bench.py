@@ -52,7 +52,7 @@ class PooledFrameSource:
         v = (self.flipped if flip else self.pool)[int(sample_idx) % len(self.pool)]
         n = end - start
         assert n <= v.shape[0] and need_h == v.shape[1] and need_w == v.shape[2]
-        return list(v[:n])
+        return v[:n]                               # one [T,H,W,1] array: the dataset moves it into the slot with one copy
 
 
 def make_dataset(tmpdir, n_samples, source, **extra):

@@ -300,6 +300,10 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
             cap.release()
         off_i = np.array(all_di) - min(all_di)
         off_j = np.array(all_dj) - min(all_dj)
+        if isinstance(imgs, np.ndarray) and imgs.ndim == 4 and self.shake_frames <= 0:
+            # a frame source that hands out ONE [T,h,w,C] array (pre-decoded stores): no shake means one crop for all frames -- a view,
+            # so that host_sample_into moves the clip with one copy instead of one per frame
+            return imgs[:, :self.crop_size, :self.crop_size, :]
         return [img[off_i[i]:off_i[i] + self.crop_size, off_j[i]:off_j[i] + self.crop_size, :] for i, img in enumerate(imgs)]
 
     def read_video_gpu(self, video_path, start_frame, end_frame, crop_size_before_resize, min_i, min_j, flip, img_idxes,
@@ -438,7 +442,7 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
         video_path, start_frame, end_frame, crop_before, min_i, min_j, flip, img_idxes, img_cnt = self._draw_geometry(sample_idx)
         raw_imgs = self.read_video(video_path, start_frame, end_frame, crop_before, min_i, min_j, flip, sample_idx)
         if self.video_degrade is not None and np.random.rand() < self.degrade_ratio:                    # :307-308
-            raw_imgs = self.degrade_video(raw_imgs)
+            raw_imgs = self.degrade_video(list(raw_imgs))
         n = len(img_idxes)
         assert (n - 1) % (self.num_bins * self.frames_per_bin) == 0                                      # :365
         if tuple(clip_out.shape) != (n,) + tuple(raw_imgs[0].shape[:2]):
@@ -447,10 +451,13 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
         if index_out is not None:
             index_out[:] = img_idxes
             if self.color_mode == "gray":
-                for i in range(n_stored):
-                    clip_out[i] = raw_imgs[i][..., 0]
+                if isinstance(raw_imgs, np.ndarray):
+                    clip_out[:n_stored] = raw_imgs[:n_stored, ..., 0]
+                else:
+                    for i in range(n_stored):
+                        clip_out[i] = raw_imgs[i][..., 0]
             else:
-                stored = np.stack(raw_imgs[:n_stored])
+                stored = np.stack(raw_imgs[:n_stored]) if not isinstance(raw_imgs, np.ndarray) else raw_imgs[:n_stored]
                 clip_out[:n_stored] = bgr_to_gray(stored)
                 frames_out[:] = stored[[img_idxes[p] for p in self.frame_pick(img_cnt)]]
         elif self.color_mode == "gray":
@@ -488,7 +495,7 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
         if self.video_degrade is not None and np.random.rand() < self.degrade_ratio:                    # v2v_datasets.py:307-308
             if self.gpu_frontend:
                 raise NotImplementedError("video_degrade acts on the decoded host frames: use gpu_frontend: false with it")
-            raw_imgs = self.degrade_video(raw_imgs)
+            raw_imgs = self.degrade_video(list(raw_imgs))
         if not self.gpu_frontend:
             all_imgs = np.stack([raw_imgs[i] for i in img_idxes])                                       # [N,H,W,C] uint8
             gray = all_imgs[..., 0] if self.color_mode == "gray" else bgr_to_gray(all_imgs)
