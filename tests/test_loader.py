@@ -386,3 +386,36 @@ def test_train_pys_loop_trains_a_stock_model_on_ring_loader_batches(tmp_path):
         losses.append(float(loss))
     assert len(losses) == 3 and all(np.isfinite(losses))
     dl.close()
+
+
+@pytest.mark.gpu
+def test_ring_loader_without_page_locking_still_delivers_the_same_batches(tmp_path, monkeypatch):
+    """RLIMIT_MEMLOCK too small for the ring: hipHostRegister fails, the loader warns and runs out of pageable shared memory (the runtime
+    stages the copies) -- slower, same batches."""
+    from torch.utils.data import default_collate
+    from v2v_amd.datasets import SimulatingCollator
+    from v2v_amd import loader as L
+    ds = _make_ds(tmp_path, n_videos=6, defer_sim=True, fixed_seed=3)
+    col = SimulatingCollator.from_configs({"num_bins": 5}, output_device="cuda")
+
+    class _NoPin:
+        def __init__(self, rt):
+            self.rt = rt
+
+        def cudaHostRegister(self, *a):
+            return 2                                                               # hipErrorOutOfMemory
+
+        def __getattr__(self, k):
+            return getattr(self.rt, k)
+
+    real = torch.cuda.cudart()
+    monkeypatch.setattr(torch.cuda, "cudart", lambda: _NoPin(real))
+    with pytest.warns(RuntimeWarning, match="stays pageable"):
+        loader = L.RingLoader(ds, batch_size=2, num_workers=2)
+    monkeypatch.undo()
+    assert not loader._registered
+    for bi, batch in enumerate(loader):
+        want = col.simulate(default_collate([ds[2 * bi], ds[2 * bi + 1]]))
+        assert torch.equal(batch["events"], want["events"]) and torch.equal(batch["frame"], want["frame"])
+    assert bi == 2
+    loader.close()

@@ -273,7 +273,12 @@ class RingLoader:
         with torch.cuda.device(self.device):
             rc = torch.cuda.cudart().cudaHostRegister(self.ring.ctypes.data, self.ring.nbytes, 0)
         if int(rc) != 0:
-            raise RuntimeError(f"hipHostRegister of the {self.ring.nbytes >> 20} MiB clip ring failed ({rc}): raise RLIMIT_MEMLOCK or lower num_workers / prefetch_factor")
+            # not fatal: out of pageable memory the runtime stages every copy itself (slower, and synchronous with the host) -- what the
+            # reference's DataLoader(pin_memory=False) lives with; say so once, loudly
+            import warnings
+            warnings.warn(f"hipHostRegister of the {self.ring.nbytes >> 20} MiB clip ring failed ({rc}): the ring stays pageable and H2D copies run "
+                          "at a fraction of the link rate -- raise RLIMIT_MEMLOCK or lower num_workers / prefetch_factor", RuntimeWarning, stacklevel=3)
+            return
         self._registered = True
 
     def close(self):
