@@ -10,9 +10,11 @@ already resident in HBM.  Workload at N=1: BASELINE configs[1] -- 256 clips of 3
 C+ = C- = 0.2, 5 temporal-bilinear voxel bins, simulated with the REFERENCE'S OWN EventEmulator constructor defaults
 (data/v2v_core_esim.py:8-16: base_noise_std 0.1, hot_pixel_fraction 1e-3, hot_pixel_std 0.1), i.e. with the noise the
 reference always applies.  With N>1 GPUs every rank gets its own 256 clips (global clip ids rank*256..), no data-path
-collective: weak scaling.  Rank 0 prints ONE JSON line.  The default run also times every other BASELINE config and
-variant once each (`also_measured`: own kernel time, algorithmic bytes, fraction of the HBM peak), outside the timed
-region; they are parity-test cases and secondary measurements, never the headline.
+collective: weak scaling.  Rank 0 prints ONE JSON line, last and alone on stdout, at most 4 KB: the contract keys only.  The
+default run also times one workload of every other BASELINE config (`also_measured`: own kernel time, algorithmic bytes,
+fraction of the HBM peak) and the loader at the training shape, outside the timed region and after the headline; those,
+the launch trace and the secondary CPU baselines go to the sidecar file the line names (`extra`: bench_extra.json).
+`--full` runs every variant.  They are parity-test cases and secondary measurements, never the headline.
 """
 import argparse
 import json
@@ -417,6 +419,120 @@ def load_traffic(name):
         return None
 
 
+MAX_LINE_BYTES = 4096      # the contract line stays far below what the driver's stdout tail keeps (round 4's 21.9 KB line was cut: parsed = null)
+
+# secondary workloads of the default run (one of each kind); --full adds the rest
+ALSO_DEFAULT = ["cfg2_dataset_style", "cfg2_u8", "cfg3_v2e_f32_256x32x256x256_bilinear5", "cfg4_pipeline_720p_to_256_40f_bilinear5",
+                "train_u8_12x201x128x128_sum5", "train_batch_normalised_12x201x128x128", "cfg5_fused_convlstm_channels_last"]
+
+
+def measure_secondary(torch, dev, full, lap):
+    """Rank 0 at N = 1, after the headline's launches have warmed the clocks and outside the timed region: each secondary workload's own
+    kernel time (3 warm-up + 12 timed launches), algorithmic bytes and fraction of the HBM peak; then the loader at the training
+    shape (tools/loader_bench.py) and the consumer's ConvLSTM step against the bf16 matrix peak.  Never the headline value."""
+    also = {}
+    for name in (ALSO_MEASURED if full else ALSO_DEFAULT):
+        try:
+            S = Workload(name, dev, 0, 1)
+            for _ in range(3):
+                S.step()
+            s_step, s_graph = maybe_graph(S.step, torch, dev, S.wl["model"] in ("pipeline", "train_batch"))
+            ms = sorted(time_launches(s_step, 12, torch))
+            avg = sum(ms) / len(ms)
+            ach = S.alg_bytes / (avg * 1e-3) / 1e9
+            also[name] = {"kernel": S.kernel_name, "kernel_ms_avg": avg, "kernel_ms_p50": ms[len(ms) // 2], "grids_per_s": S.grids_per_step / (avg * 1e-3),
+                          "algorithmic_bytes_per_launch": S.alg_bytes, "achieved_GBps": ach, "frac_of_hbm_peak": ach / HBM_PEAK_GBPS,
+                          "traffic_bytes_per_launch": load_traffic(name), "valu_issue": load_valu(name, avg), "sim_params": S.wl["params"], "input_dtype": S.wl["dtype"],
+                          "bin_mode": S.wl["bin"], "launch": "hipGraph replay" if s_graph else "eager", "parity_check": S.parity()}
+            S.free()
+            del S, s_step
+            torch.cuda.empty_cache()
+        except Exception as exc:  # noqa: BLE001 - a secondary figure must not take the headline down
+            also[name] = {"error": f"{type(exc).__name__}: {exc}"}
+        lap(name)
+    try:
+        also["convlstm_step_mfma"] = convlstm_roofline(torch, dev)
+    except Exception as exc:  # noqa: BLE001
+        also["convlstm_step_mfma"] = {"error": f"{type(exc).__name__}: {exc}"}
+    lap("convlstm_step_mfma")
+    try:
+        # what train.py receives at the reference's training shape (B = 12, 201 x 128 x 128 -> [12,40,5,128,128]) at each integration level:
+        # YAML only (train.py untouched), + one line of train.py (RingLoader), the reference's deployment (NumPy port in workers)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import loader_bench
+        also["train_loader_b12_201x128x128"] = loader_bench.measure(batches=200 if full else 60, workers=9, batch=12, dev=dev,
+                                                                    simulating_batches=40 if full else 0, cpu_port_budget_s=60.0 if full else 8.0,
+                                                                    consumer_batches=20 if full else 6)
+    except Exception as exc:  # noqa: BLE001
+        also["train_loader_b12_201x128x128"] = {"error": f"{type(exc).__name__}: {exc}"}
+    lap("train_loader")
+    return also
+
+
+def measure_host_input(torch, dev, W, wl, kern_avg_ms):
+    """Host-resident input: the boundary takes device pointers, so a host pipeline pays the PCIe copy first.  Pageable copy then launch
+    (no overlap), and page-locked double buffers on a copy stream (v2v_amd/staging.py).  Reported for context, never `value`."""
+    try:
+        n_host = min(W.b, 32)
+        host_batch = W.frames[:n_host].cpu()
+        t_h = time.perf_counter()
+        dev_copy = host_batch.to(dev)
+        torch.cuda.synchronize()
+        h2d_s = time.perf_counter() - t_h
+        h2d_gbps = host_batch.numel() * host_batch.element_size() / h2d_s / 1e9
+        per_batch_s = W.frames.numel() * W.frames.element_size() / (h2d_gbps * 1e9) + kern_avg_ms * 1e-3
+        pinned = host_batch.pin_memory()
+        t_h = time.perf_counter()
+        dev_copy = pinned.to(dev, non_blocking=True)
+        torch.cuda.synchronize()
+        pin_gbps = host_batch.numel() * host_batch.element_size() / (time.perf_counter() - t_h) / 1e9
+        from v2v_amd import esim, staging
+        stager = staging.HostStager(dev)
+        sub_out = torch.empty((n_host,) + tuple(W.out.shape[1:]), dtype=torch.float32, device=dev)
+        ptensor = torch.tensor(wl["params"], dtype=torch.float64, device=dev)
+
+        def sim(frames_d):
+            esim.esim_voxel_batch(frames_d, ptensor, bin_mode=wl["bin"], num_bins=wl["tb"], frames_per_bin=wl["fpb"], seed=20240001,
+                                  clip_id0=0, out=sub_out, validate=False, no_noise=False)
+        h = stager.stage(pinned)
+        sim(stager.ready(h))
+        torch.cuda.synchronize()
+        reps = 8
+        t_h = time.perf_counter()
+        h = stager.stage(pinned)
+        for _ in range(reps):
+            cur, h = h, stager.stage(pinned)
+            sim(stager.ready(cur))
+        torch.cuda.synchronize()
+        staged_s = (time.perf_counter() - t_h) / reps
+        del dev_copy
+        return {"h2d_GBps_pageable": h2d_gbps, "h2d_GBps_pinned": pin_gbps,
+                "pcie_inclusive_grids_per_s": W.grids_per_step / per_batch_s,
+                "pcie_inclusive_overlapped_grids_per_s": n_host * (W.grids_per_step // W.b) / staged_s,
+                "note": "host-resident float32 clips: `pcie_inclusive` = pageable copy then launch, no overlap; `overlapped` = page-locked "
+                        "double buffers on a copy stream (v2v_amd/staging.py), copy of batch k+1 under the launch on batch k, "
+                        f"{n_host}-clip batches; PCIe-bound either way; reported for context, never `value`"}
+    except Exception as exc:  # noqa: BLE001
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
+def write_sidecar(obj, path):
+    """Everything that is not the contract line: `bench_extra.json` next to bench.py (and a copy under gpurun_out/ when that exists, so
+    a gpurun call brings it home).  Returns the path named in the line, or None when nothing could be written."""
+    path = path or os.path.join(ROOT, "bench_extra.json")
+    written = None
+    for target in (path, os.path.join(ROOT, "gpurun_out", "bench_extra.json") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None):
+        if not target:
+            continue
+        try:
+            with open(target, "w") as f:
+                json.dump(obj, f, indent=1)
+            written = written or os.path.relpath(target, ROOT)
+        except OSError as exc:
+            print(f"[bench] could not write {target}: {exc}", file=sys.stderr, flush=True)
+    return written
+
+
 def self_launch(n_gpus):
     """Re-run this script as `n_gpus` ranks under torch.distributed.run (child process; this one never initialises the GPU)."""
     import socket
@@ -441,6 +557,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads of the default run")
+    ap.add_argument("--full", action="store_true", help="every secondary workload, 200-batch loader bench, NumPy process-pool baseline (minutes)")
+    ap.add_argument("--extra-out", default=None, help="sidecar file for everything that is not the contract line (default: bench_extra.json next to bench.py)")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses cuda:0 (tests the N>1 code path on a 1-GPU box)")
@@ -484,146 +602,92 @@ def main():
     per_rank_ms = sharding.gather_floats(dist, my_elapsed / args.steps * 1e3, dev)        # every rank's own ms per step
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
 
-    # parity guard outside the timed region (first + last clip of rank 0 against the C oracle) + the CPU baseline
-    parity = cpu = cpu_c = cpu_pool = None
+    # Everything below is outside the timed region.  Order: secondary kernel workloads first (the headline's launches have just
+    # warmed the clocks), then the parity guard and the CPU baselines (the GPU idles under those).
+    extra = {"seconds": {}}
+    t_sec = time.perf_counter()
+
+    def lap(name):
+        nonlocal t_sec
+        now = time.perf_counter()
+        extra["seconds"][name] = round(now - t_sec, 2)
+        t_sec = now
+
+    secondary = rank == 0 and world == 1 and args.workload == DEFAULT_WORKLOAD and not args.no_also and not args.batch
+    if secondary:
+        extra["also_measured"] = measure_secondary(torch, dev, args.full, lap)
+        extra["host_input"] = measure_host_input(torch, dev, W, wl, kern_avg_ms)
+        lap("host_input")
+
+    parity = cpu = None
     if rank == 0:
         try:
             from oracle import clib
             clib.build()
             parity = W.parity()
+            lap("parity")
             if world == 1 and not args.no_cpu_baseline:
                 sample = W.frames[: min(W.b, 256)].cpu().numpy()
                 cpu = cpu_baseline(sample, wl, budget_s=args.cpu_budget)
-                cpu_c = cpu_baseline_c(sample, wl)
-                try:
-                    cpu_pool = cpu_baseline_pool(sample, wl)
-                except Exception as exc:  # noqa: BLE001 - secondary figure
-                    cpu_pool = {"error": f"{type(exc).__name__}: {exc}"}
+                lap("cpu_baseline")
+                extra["cpu_baseline_c_omp"] = cpu_baseline_c(sample, wl)
+                lap("cpu_baseline_c_omp")
+                if args.full:
+                    try:
+                        extra["cpu_baseline_numpy_pool"] = cpu_baseline_pool(sample, wl)
+                    except Exception as exc:  # noqa: BLE001 - secondary figure
+                        extra["cpu_baseline_numpy_pool"] = {"error": f"{type(exc).__name__}: {exc}"}
+                    lap("cpu_baseline_numpy_pool")
                 del sample
         except Exception as exc:  # the oracle is a checker; never let it take the measurement down
             parity = f"unchecked ({type(exc).__name__}: {exc})"
 
-    # Secondary measurements on rank 0 at N=1, outside the timed region; never the headline value.
-    also, host_input = None, None
-    if rank == 0 and world == 1 and args.workload == DEFAULT_WORKLOAD and not args.no_cpu_baseline and not args.no_also and not args.batch:
-        try:
-            # host-resident input: the boundary takes device pointers, so a host pipeline pays the PCIe copy first
-            n_host = min(W.b, 32)
-            host_batch = W.frames[:n_host].cpu()
-            t_h = time.perf_counter()
-            dev_copy = host_batch.to(dev)
-            torch.cuda.synchronize()
-            h2d_s = time.perf_counter() - t_h
-            h2d_gbps = host_batch.numel() * host_batch.element_size() / h2d_s / 1e9
-            per_batch_s = W.frames.numel() * W.frames.element_size() / (h2d_gbps * 1e9) + kern_avg_ms * 1e-3
-            pinned = host_batch.pin_memory()
-            t_h = time.perf_counter()
-            dev_copy = pinned.to(dev, non_blocking=True)
-            torch.cuda.synchronize()
-            pin_gbps = host_batch.numel() * host_batch.element_size() / (time.perf_counter() - t_h) / 1e9
-            # double-buffered page-locked staging on a copy stream, copy of batch k+1 overlapped with the launch on batch k
-            # (v2v_amd/staging.py, what SimulatingLoader does per rank): the PCIe-inclusive steady state of a host pipeline
-            from v2v_amd import esim, staging
-            stager = staging.HostStager(dev)
-            sub_out = torch.empty((n_host,) + tuple(W.out.shape[1:]), dtype=torch.float32, device=dev)
-            ptensor = torch.tensor(wl["params"], dtype=torch.float64, device=dev)
-
-            def sim(frames_d):
-                esim.esim_voxel_batch(frames_d, ptensor, bin_mode=wl["bin"], num_bins=wl["tb"], frames_per_bin=wl["fpb"], seed=20240001,
-                                      clip_id0=0, out=sub_out, validate=False, no_noise=False)
-            h = stager.stage(pinned)
-            sim(stager.ready(h))
-            torch.cuda.synchronize()
-            reps = 8
-            t_h = time.perf_counter()
-            h = stager.stage(pinned)
-            for _ in range(reps):
-                cur, h = h, stager.stage(pinned)
-                sim(stager.ready(cur))
-            torch.cuda.synchronize()
-            staged_s = (time.perf_counter() - t_h) / reps
-            host_input = {"h2d_GBps_pageable": h2d_gbps, "h2d_GBps_pinned": pin_gbps,
-                          "pcie_inclusive_grids_per_s": W.grids_per_step / per_batch_s,
-                          "pcie_inclusive_overlapped_grids_per_s": n_host * (W.grids_per_step // W.b) / staged_s,
-                          "note": "host-resident float32 clips: `pcie_inclusive` = pageable copy then launch, no overlap; `overlapped` = page-locked "
-                                  "double buffers on a copy stream (v2v_amd/staging.py), copy of batch k+1 under the launch on batch k, "
-                                  f"{n_host}-clip batches; PCIe-bound either way; reported for context, never `value`"}
-            del sub_out, stager
-            del dev_copy, host_batch, pinned
-        except Exception as exc:  # noqa: BLE001
-            host_input = {"error": f"{type(exc).__name__}: {exc}"}
-        also = {}
-        for name in ALSO_MEASURED:
-            try:
-                S = Workload(name, dev, 0, 1)
-                for _ in range(3):
-                    S.step()
-                s_step, s_graph = maybe_graph(S.step, torch, dev, S.wl["model"] in ("pipeline", "train_batch"))
-                ms = sorted(time_launches(s_step, 12, torch))
-                avg = sum(ms) / len(ms)
-                ach = S.alg_bytes / (avg * 1e-3) / 1e9
-                also[name] = {"kernel": S.kernel_name, "kernel_ms_avg": avg, "kernel_ms_p50": ms[len(ms) // 2], "grids_per_s": S.grids_per_step / (avg * 1e-3),
-                              "algorithmic_bytes_per_launch": S.alg_bytes, "achieved_GBps": ach, "frac_of_hbm_peak": ach / HBM_PEAK_GBPS,
-                              "traffic_bytes_per_launch": load_traffic(name), "valu_issue": load_valu(name, avg), "sim_params": S.wl["params"], "input_dtype": S.wl["dtype"],
-                              "bin_mode": S.wl["bin"], "launch": "hipGraph replay" if s_graph else "eager", "parity_check": S.parity()}
-                S.free()
-                del S, s_step
-                torch.cuda.empty_cache()
-            except Exception as exc:  # noqa: BLE001 - a secondary figure must not take the headline down
-                also[name] = {"error": f"{type(exc).__name__}: {exc}"}
-        try:
-            # what train.py would receive through the drop-in loader at the reference's training shape (B = 12, 201 x 128 x 128 ->
-            # [12,40,5,128,128]): samples/s, host us per batch by stage, GPU-busy fraction, next to the round-2/3 loader and to the
-            # reference's deployment (NumPy port inside 9 DataLoader workers) on the same clips -- tools/loader_bench.py
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import loader_bench
-            also["train_loader_b12_201x128x128"] = loader_bench.measure(batches=200, workers=9, batch=12, dev=dev, simulating_batches=40)
-        except Exception as exc:  # noqa: BLE001
-            also["train_loader_b12_201x128x128"] = {"error": f"{type(exc).__name__}: {exc}"}
-        try:
-            also["convlstm_step_mfma"] = convlstm_roofline(torch, dev)
-        except Exception as exc:  # noqa: BLE001
-            also["convlstm_step_mfma"] = {"error": f"{type(exc).__name__}: {exc}"}
-
     if rank == 0:
         achieved = W.alg_bytes / (kern_avg_ms * 1e-3) / 1e9
+        hints = []
+        if wl["model"] == "esim" and wl["params"][0] == wl["params"][1]:
+            hints.append("V2V_FLAG_SYMMETRIC")
+        if wl["model"] == "esim" and wl["params"][2] == 0 and wl["params"][3] <= 0:
+            hints.append("V2V_FLAG_NO_NOISE")
+        # THE contract line: small (asserted <= 4 KB), printed last and alone on stdout.  Everything else goes to the sidecar file.
         line = {
             "metric": "voxel grids/sec", "value": W.grids_per_step * world * args.steps / elapsed, "unit": "voxel grids/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic", "dist_backend": backend, "dist_world_size": (dist.get_world_size() if dist is not None else 1),
-            "ms_per_step_per_rank": per_rank_ms,
-            "config": {"workload": args.workload, "model": wl["model"], "clips_per_gpu": W.b, "frames": wl["n"], "height": wl["h"], "width": wl["w"],
-                       "input_dtype": wl["dtype"], "output_dtype": "float32", "state_dtype": "float64 (potential, floor-divide)",
-                       "bin_mode": wl["bin"], "num_bins": wl["tb"], "frames_per_bin": wl["fpb"],
-                       "sim_params": wl["params"], "sim_params_note": "pos_thres, neg_thres, base_noise_std, hot_pixel_fraction, hot_pixel_std"
-                       + (" = EventEmulator() constructor defaults of the reference (noise on)" if wl["params"] == REF_DEFAULTS else ""),
-                       "rng": "philox4x32 on device (10 rounds per-clip fields, 7 rounds per-step noise fields), Gaussians by direct table inversion (2 per word)",
-                       "kernel_hints": (["V2V_FLAG_SYMMETRIC (pos_thres == neg_thres, known on the host as in EventEmulator(pos, neg))"] if wl["model"] == "esim" and wl["params"][0] == wl["params"][1] else [])
-                       + (["V2V_FLAG_NO_NOISE"] if wl["model"] == "esim" and wl["params"][2] == 0 and wl["params"][3] <= 0 else []),
-                       "sharding": f"batch over {world} GPU(s), no collective", "grid": [wl["tb"], wl["h"], wl["w"]],
-                       "launch": "hipGraph replay" if use_graph else "eager"},
+            "ms_per_step_per_rank": [round(v, 4) for v in per_rank_ms],
+            "config": {"workload": args.workload, "simulator": wl["model"], "clips_per_gpu": W.b, "frames": wl["n"], "height": wl["h"], "width": wl["w"],
+                       "input_dtype": wl["dtype"], "output_dtype": "float32", "state_dtype": "float64",
+                       "bin_mode": wl["bin"], "num_bins": wl["tb"], "frames_per_bin": wl["fpb"], "sim_params": wl["params"],
+                       "rng": "philox4x32", "kernel_hints": hints, "sharding": f"batch over {world} GPU(s), no collective",
+                       "grid": [wl["tb"], wl["h"], wl["w"]], "launch": "hipGraph replay" if use_graph else "eager"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(args.workload),
-                         "traffic_source": "static: profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
-                                           "collected separately; not re-measured in this run)",
                          "kernel": W.kernel_name, "algorithmic_bytes_per_launch": W.alg_bytes,
-                         "measured_ceilings_GBps": MEASURED_CEILINGS_GBPS,
                          "kernel_ms_avg": kern_avg_ms, "kernel_ms_p10": kern_ms[len(kern_ms) // 10],
-                         "kernel_ms_p50": kern_ms[len(kern_ms) // 2], "kernel_ms_p90": kern_ms[(len(kern_ms) * 9) // 10],
-                         # every timed launch in order: a monotone ramp after the warm-up launches = clocks settling, scatter = neighbours
-                         "kernel_ms_trace": [round(v, 4) for v in kern_trace],
-                         "valu_issue": load_valu(args.workload, kern_avg_ms),
-                         "note": "noise-on launches are VALU-issue-bound, not HBM-bound (DESIGN.md §4.1); `frac` is still quoted against the HBM peak; "
-                                 "`valu_issue` gives the same launch against the vector-issue ceilings"},
+                         "kernel_ms_p50": kern_ms[len(kern_ms) // 2], "kernel_ms_p90": kern_ms[(len(kern_ms) * 9) // 10]},
             "cpu_baseline": cpu,
-            "cpu_baseline_numpy_pool": cpu_pool,
-            "cpu_baseline_c_omp": cpu_c,
             "parity_check": parity,
-            "also_measured": also,
-            "host_input": host_input,
+            "extra": None,
         }
-        print(json.dumps(line))
+        extra["headline"] = {"kernel_ms_trace": [round(v, 4) for v in kern_trace], "valu_issue": load_valu(args.workload, kern_avg_ms),
+                             "measured_ceilings_GBps": MEASURED_CEILINGS_GBPS,
+                             "traffic_source": "static: profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, collected "
+                                               "separately; not re-measured in this run)",
+                             "sim_params_order": "pos_thres, neg_thres, base_noise_std, hot_pixel_fraction, hot_pixel_std"
+                             + (" = EventEmulator() constructor defaults of the reference (noise on)" if wl["params"] == REF_DEFAULTS else ""),
+                             "rng": "philox4x32 on device (10 rounds per-clip fields, 7 rounds per-step noise fields), Gaussians by direct table inversion (2 per word)",
+                             "note": "noise-on launches are VALU-issue-bound, not HBM-bound (DESIGN.md); `frac` is still quoted against the HBM peak; "
+                                     "`valu_issue` gives the same launch against the vector-issue ceilings"}
+        line["extra"] = write_sidecar(dict(line, **extra), args.extra_out)
+        text = json.dumps(line)
+        if len(text) > MAX_LINE_BYTES:                 # never hand the driver a line it cannot parse: shed the optional keys, keep the contract
+            for key in ("ms_per_step_per_rank", "parity_check", "extra"):
+                line.pop(key, None)
+            line["config"] = {"workload": args.workload, "clips_per_gpu": W.b}
+            text = json.dumps(line)
+        sys.stderr.flush()
+        print(text, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

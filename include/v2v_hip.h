@@ -32,8 +32,11 @@ extern "C" {
  *    front-end's `gray_first` was RE-MAPPED: 1 now selects OpenCV 4.x's 15-bit BGR2GRAY weights (3735 / 19235 / 9798, >> 15);
  *    the 14-bit OpenCV 2.x/3.x form that ABI 1 ran for gray_first = 1 moved to gray_first = 2 -- an ABI-1 caller passing 1 gets
  *    different gray values on some colours, with no error.  A client must re-query workspace sizes and cannot replay ABI-1
- *    native noise.  Replay-mode (V2V_RNG_REPLAY) results are unchanged. */
-#define V2V_ABI_VERSION 2
+ *    native noise.  Replay-mode (V2V_RNG_REPLAY) results are unchanged.
+ * 3: v2v_esim_extras grew two trailing fields (stored_frames, frames_elems: the bounds of the frame_index gather).  Every function
+ *    signature and every result of ABI 2 is unchanged; a caller that fills v2v_esim_extras must be recompiled (or zero the struct at
+ *    its new size): an ABI-2 struct is 16 bytes shorter. */
+#define V2V_ABI_VERSION 3
 
 typedef enum v2v_status {
     V2V_OK = 0,
@@ -365,12 +368,22 @@ int v2v_nchw_to_nhwc_bf16_hip(const void *src, int src_dtype, int64_t B, int64_t
  *                 clip whose video pauses is stored (and crosses PCIe) once per DECODED frame; results are those of the gathered clip.
  *   clip_offsets  int64 [B]: clip b starts at element clip_offsets[b] of `frames` (clips of different stored lengths packed back to
  *                 back); `clip_stride` then only states the alignment every offset keeps (in elements, e.g. 16).  Comes with frame_index.
+ *   stored_frames int32 [B] (with frame_index; NULL = the caller vouches for the rows): clip b holds stored_frames[b] frames.  The launch
+ *                 checks every row while it stages it through LDS: a clip whose row names a frame outside [0, stored_frames[b]) is NOT
+ *                 read -- its planes come out NaN and, with `stats`, its flag word (513) is set, so v2v_voxel_scales_hip hands out NaN
+ *                 scales for it -- the same loud failure as a broken V2V_FLAG_SYMMETRIC promise; the other clips are unaffected.  (The
+ *                 reference's gather, a Python list index at data/v2v_datasets.py:311, raises IndexError there.)
+ *   frames_elems  int64 (with stored_frames; 0 = not stated): elements in `frames`.  A clip with clip_offsets[b] < 0 or
+ *                 clip_offsets[b] + (stored_frames[b]-1)*frame_stride + H*W > frames_elems is poisoned the same way.
  * Indexed launches: uint8 clips, SUM bins, device-native noise, float32 grid, none of the NO_NOISE / NOISE_EXTERNAL / SYMMETRIC flags
- * (V2V_ERR_MODE otherwise).  The indices are the caller's responsibility: a stored frame number beyond the clip reads past it. */
+ * (V2V_ERR_MODE otherwise).  The index rows live on the device, so their check cannot return a status code without a synchronisation:
+ * it is reported through the data (NaN planes / the flag word), never by reading out of bounds. */
 typedef struct v2v_esim_extras {
     uint32_t *stats;
     const int32_t *frame_index;
     const int64_t *clip_offsets;
+    const int32_t *stored_frames;
+    int64_t frames_elems;
 } v2v_esim_extras;
 int v2v_esim_voxel_ex_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W,
                           int64_t clip_stride, int64_t frame_stride, const double *params, int64_t params_stride,

@@ -68,6 +68,43 @@ def test_bench_contract_json():
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     assert d["parity_check"] == "ok"
     assert abs(d["value"] - 8 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+    assert len(lines[0]) <= 4096 and res.stdout.strip().splitlines()[-1] == lines[0]
+
+
+def test_bench_default_command_prints_a_small_last_line_and_a_sidecar(tmp_path):
+    """The DRIVER's command, unabridged (`python bench.py --gpus 1 --steps 20 --warmup 5`: full batch, every default secondary
+    workload, the loader bench, the CPU baseline).  Round 4's line had grown to 21.9 KB and the driver could not parse it: the contract
+    line is the LAST non-empty stdout line, alone, at most 4 KB, and everything else sits in the sidecar file it names."""
+    import time
+    side = tmp_path / "bench_extra.json"
+    t0 = time.perf_counter()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--extra-out", str(side)],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    wall = time.perf_counter() - t0
+    assert res.returncode == 0, res.stderr[-3000:]
+    out_lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(out_lines) == 1, [l[:200] for l in out_lines]
+    assert len(out_lines[-1].encode()) <= 4096
+    d = json.loads(out_lines[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline", "parity_check", "dist_backend", "ms_per_step_per_rank"):
+        assert key in d, key
+    assert d["config"]["workload"] == "cfg2_esim_f32_256x32x256x256_bilinear5" and d["config"]["clips_per_gpu"] == 256 and d["steps"] == 20
+    assert d["parity_check"] == "ok" and d["cpu_baseline"]["value"] > 0
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "algorithmic_bytes_per_launch", "kernel_ms_avg", "kernel_ms_p50"):
+        assert key in r, key
+    assert d["ms_per_step"] * d["steps"] / 1e3 <= wall                                                 # the driver's own consistency check
+    extra = json.loads(side.read_text())
+    assert "also_measured" in extra and "headline" in extra and len(extra["headline"]["kernel_ms_trace"]) == 20
+    for name, rec in extra["also_measured"].items():
+        assert "error" not in rec, (name, rec)
+        if "parity_check" in rec:
+            assert rec["parity_check"] == "ok", name
+    lv = extra["also_measured"]["train_loader_b12_201x128x128"]["integration_levels_samples_per_s"]
+    assert all(lv[k] and lv[k] > 0 for k in ("yaml_only_num_workers_0", "yaml_only_spawned_workers", "one_line_of_train_py_ring_loader",
+                                             "reference_numpy_port_in_workers")), lv
+    assert wall < 240, f"the default run took {wall:.0f} s"
 
 
 def test_bench_two_ranks_under_torch_distributed_run():
@@ -90,7 +127,8 @@ def test_bench_two_ranks_under_torch_distributed_run():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["dist_backend"] == "gloo" and d["scaling"] == "weak" and d["steps"] == 4
     assert d["config"]["clips_per_gpu"] == 16 and "2 GPU(s)" in d["config"]["sharding"]
-    assert d["parity_check"] == "ok" and d["cpu_baseline"] is None and d["also_measured"] is None      # rank-0-at-N=1 extras stay off
+    assert d["parity_check"] == "ok" and d["cpu_baseline"] is None and "also_measured" not in d        # rank-0-at-N=1 extras stay off
+    assert len(lines[0].encode()) <= 4096 and res.stdout.strip().splitlines()[-1] == lines[0] and len(d["ms_per_step_per_rank"]) == 2
     assert abs(d["value"] - 2 * 16 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-6                 # whole-job aggregate over both ranks
     single = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--batch", "16",
                              "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)

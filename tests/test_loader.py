@@ -99,7 +99,7 @@ def test_array_frame_source_equals_list_frame_source(tmp_path, extra):
 def test_slot_layout_is_aligned_and_disjoint():
     from v2v_amd.loader import _SlotLayout
     lay = _SlotLayout(12, 201, 128, 128, 40, True)
-    offs = [lay.off_offsets, lay.off_fidx, lay.off_pick, lay.off_params, lay.off_keys, lay.off_used, lay.off_cframes, lay.off_clips, lay.nbytes]
+    offs = [lay.off_offsets, lay.off_fidx, lay.off_pick, lay.off_params, lay.off_keys, lay.off_used, lay.off_stored, lay.off_cframes, lay.off_clips, lay.nbytes]
     assert all(o % 256 == 0 for o in offs) and offs == sorted(offs) and len(set(offs)) == len(offs)
     buf = np.zeros(lay.nbytes, dtype=np.uint8)
     views = lay.views(buf)
@@ -107,10 +107,27 @@ def test_slot_layout_is_aligned_and_disjoint():
         v[...] = i + 1
     for i, v in enumerate(views):
         assert (v == i + 1).all()                                                    # no view overlaps another
-    offsets, fidx, pick, params, keys, used, cframes, clips = views
+    offsets, fidx, pick, params, keys, used, cframes, clips, stored = views
+    assert stored.shape == (12,) and stored.dtype == np.int32
     assert offsets.shape == (12,) and fidx.shape == (12, 201) and pick.shape == (12, 40) and params.shape == (12, 5) and keys.shape == (12, 2)
     assert used.shape == (1,) and cframes.shape == (12, 40, 128, 128, 3) and clips.shape == (12 * 201 * 128 * 128,)
     assert _SlotLayout(12, 201, 128, 128, 40, False).views(np.zeros(lay.nbytes, np.uint8))[6] is None
+    # every packed clip is rounded up to 16 bytes: the clip region holds `batch` ROUNDED clips (a crop size that is not a multiple of 4
+    # with no paused clip in the batch overflowed the region before round 5)
+    odd = _SlotLayout(7, 21, 30, 30, 4, False)
+    per_clip = (21 * 30 * 30 + 15) // 16 * 16
+    assert 21 * 30 * 30 % 16 != 0 and odd.views(np.zeros(odd.nbytes, np.uint8))[7].size >= 7 * per_clip
+    assert 6 * per_clip + 21 * 30 * 30 <= odd.views(np.zeros(odd.nbytes, np.uint8))[7].size            # the last clip's room, all clips unpaused
+
+
+def test_conv_layer_refuses_scales_it_would_drop():
+    """ConvLayer.forward(x, skip, scales) applies normalize_batch_voxel's scales in the head kernel only; a layer that is not the head
+    (more than 8 input channels, or another kernel size) must refuse them instead of running on raw events."""
+    from v2v_amd.convlstm import ConvLayer
+    layer = ConvLayer(64, 64, kernel_size=5, padding=2)
+    assert not layer.head
+    with torch.no_grad(), pytest.raises(ValueError, match="head kernel only"):
+        layer(torch.zeros(1, 64, 8, 8), None, torch.ones(1, 2))
 
 
 def test_slot_batch_sampler_and_leaf_resolution(tmp_path):
@@ -147,6 +164,102 @@ def test_create_dataloader_falls_back_to_torch_for_other_datasets():
 
 
 # ----------------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_ring_loader_with_a_crop_size_that_is_not_a_multiple_of_4_and_no_pauses(tmp_path):
+    """n*h*w % 16 != 0 and no clip of the batch pauses: every packed clip is rounded up to 16 bytes and the last sample's room must still
+    lie inside the clip region (it did not before round 5: a reshape error inside the worker)."""
+    from torch.utils.data import default_collate
+    from v2v_amd.datasets import SimulatingCollator
+    from v2v_amd.loader import RingLoader
+    ds = _make_ds(tmp_path, defer_sim=True, fixed_seed=3, crop_size=30, proba_pause_when_running=0.0)
+    assert ((ds.frames_per_seq + 1) * 30 * 30) % 16 != 0
+    col = SimulatingCollator.from_configs(dict(ds.__dict__, num_bins=5), output_device="cuda", pad_to=16, normalize=False)
+    for workers in (0, 2):
+        loader = RingLoader(ds, batch_size=6, num_workers=workers, drop_last=True, pad_to=16)
+        batch = next(iter(loader))
+        want = col.simulate(default_collate([ds[j] for j in range(6)]))
+        assert torch.equal(batch["events"], want["events"]) and torch.equal(batch["frame"], want["frame"])
+        loader.close()
+
+
+@pytest.mark.gpu
+def test_ring_loader_refuses_numpy_replay_datasets_and_create_dataloader_routes_them_to_torch(tmp_path):
+    """`sim_rng: numpy` (bit-exact replay of the reference's np.random stream) lives on the per-sample path; the ring always draws
+    device-native noise, so it must not accept such a dataset silently."""
+    from torch.utils.data import DataLoader
+    from v2v_amd.loader import RingLoader, create_dataloader
+    ds = _make_ds(tmp_path, sim_rng="numpy")
+    with pytest.raises(TypeError, match="sim_rng"):
+        RingLoader(ds, batch_size=2)
+    dl = create_dataloader(ds, {"num_workers": 0, "pin_memory": False}, 2, None)
+    assert isinstance(dl, DataLoader)
+    batch = next(iter(dl))
+    assert batch["events"].shape == (2, 4, 5, 32, 32)
+
+
+@pytest.mark.gpu
+def test_a_new_iter_retires_the_abandoned_epoch_at_once(tmp_path):
+    """iter(loader) is a plain method: the abandoned epoch's DataLoader iterator is shut down when the new one is requested, not at the
+    new iterator's first next(); the old generator then refuses to continue."""
+    from v2v_amd.loader import RingLoader
+    ds = _make_ds(tmp_path, n_videos=12, defer_sim=True, fixed_seed=1)
+    loader = RingLoader(ds, batch_size=2, num_workers=2, drop_last=True)
+    it1 = iter(loader)
+    first = next(it1)
+    old_dl_iter = loader._it
+    it2 = iter(loader)                                                   # no next() yet
+    assert loader._it is not old_dl_iter and getattr(old_dl_iter, "_shutdown", True)
+    with pytest.raises(RuntimeError, match="retired"):
+        next(it1)
+    again = next(it2)
+    assert torch.equal(first["events"], again["events"])                 # fixed_seed: the epoch restarts from sample 0
+    loader.close()
+
+
+@pytest.mark.gpu
+def test_packed_launch_checks_the_frame_index_rows():
+    """v2v_esim_voxel_ex_hip with stored_frames: a row that names a frame outside its clip (or a clip that does not fit the buffer) gives
+    NaN planes and the statistics' flag word for THAT clip -- no out-of-bounds read, the other clips bit-identical to the clean launch."""
+    from v2v_amd import _lib, esim, postops
+    g = np.random.default_rng(5)
+    b, n, h, w = 4, 11, 32, 32
+    stored = [n, 5, 7, n]
+    clips_h = [g.integers(0, 256, (u, h, w), dtype=np.uint8) for u in stored]
+    fidx = np.stack([np.sort(np.concatenate([np.arange(u), g.integers(0, u, n - u)])) for u in stored]).astype(np.int32)
+    offs = np.cumsum([0] + [c.size for c in clips_h[:-1]]).astype(np.int64)
+    flat_d = torch.from_numpy(np.concatenate([c.ravel() for c in clips_h])).cuda()
+    offs_d, stored_d = torch.from_numpy(offs).cuda(), torch.tensor(stored, dtype=torch.int32).cuda()
+    params = torch.tensor([[0.2, 0.25, 0.05, 1e-3, 2.0]] * b, dtype=torch.float64).cuda()
+    keys = torch.tensor([[7 + i, i] for i in range(b)], dtype=torch.int64).cuda()
+
+    def run(fi, st=stored_d, off=offs_d, mapping="auto"):
+        stats = torch.zeros((b, _lib.VOXEL_STATS_WORDS), dtype=torch.int32, device="cuda")
+        vox = esim.esim_voxel_packed(flat_d, off, torch.from_numpy(fi).cuda(), h, w, params, keys, num_bins=5, stats=stats, stored_frames=st, mapping=mapping)
+        return vox, stats
+    clean, st_clean = run(fidx)
+    assert not torch.isnan(clean).any() and int(st_clean[:, _lib.VOXEL_STATS_WORDS - 3].sum()) == 0
+    unchecked, _ = run(fidx, st=None)
+    assert torch.equal(clean, unchecked)                                 # the check changes nothing for valid rows
+    for mapping in ("auto", "4px", "2px", "1px"):
+        for bad_clip, bad_val in ((1, 5), (2, -1), (1, 2**31 - 1)):      # == stored, negative, huge
+            bad = fidx.copy()
+            bad[bad_clip, 6] = bad_val
+            vox, st = run(bad, mapping=mapping)
+            assert torch.isnan(vox[bad_clip]).all() and int(st[bad_clip, 513]) == 1
+            ok = [i for i in range(b) if i != bad_clip]
+            assert torch.equal(vox[ok], clean[ok]) and int(st[ok][:, 513].sum()) == 0
+            scales = postops.scales_from_stats(st, 10 * h * w)
+            assert torch.isnan(scales[bad_clip]).all() and not torch.isnan(scales[ok]).any()
+    # a clip that does not fit `frames` (offset + stored frames beyond the buffer; a negative offset)
+    for bad_off in (int(flat_d.numel()) - 3 * h * w, -16):
+        off2 = offs.copy()
+        off2[3] = bad_off
+        vox, st = run(fidx, off=torch.from_numpy(off2).cuda())
+        assert torch.isnan(vox[3]).all() and int(st[3, 513]) == 1 and torch.equal(vox[:3], clean[:3])
+    with pytest.raises(ValueError):
+        esim.esim_voxel_packed(flat_d, offs_d, torch.from_numpy(fidx).cuda(), h, w, params, keys, stored_frames=stored_d.long())
+
+
 @pytest.mark.gpu
 def test_clip_frames_equals_cpu_division_on_all_values():
     from v2v_amd.loader import clip_frames_f32
@@ -290,8 +403,12 @@ def test_create_dataloader_under_two_ddp_ranks(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import socket
+    with socket.socket() as sock:                                   # an ephemeral port, like bench.self_launch: no clash with a concurrent session
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29617",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "tests", "ddp_loader_rank.py"), str(tmp_path)]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert res.returncode == 0, res.stderr[-3000:]

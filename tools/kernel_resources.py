@@ -4,6 +4,11 @@ profiler field: compiles every translation unit of libv2v_hip.so with `-S --cuda
 reads .vgpr_count / .vgpr_spill_count / .sgpr_count / .sgpr_spill_count / .group_segment_fixed_size per kernel.
 
     python tools/kernel_resources.py [out.json]        (default: profiles/kernel_resources.json; ~3 minutes, no GPU needed)
+    python tools/kernel_resources.py --from-so [out.json]   the same fields out of the BUILT v2v_amd/libv2v_hip.so (carves the gfx950 code
+                                                       objects out of .hip_fatbin, reads their notes and disassembly; seconds)
+
+`from_so()` is what tests/test_kernel_resources.py runs: no kernel of the shipped library may use scratch memory or spill registers
+outside an explicit allow-list (round 4 shipped 560 bytes of scratch in one ESIM instance and nothing looked).
 """
 import json
 import os
@@ -41,7 +46,73 @@ def parse(path):
     return out
 
 
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def carve_code_objects(so_path):
+    """The device ELFs inside a host library's .hip_fatbin: a sequence of uncompressed clang offload bundles ('__CLANG_OFFLOAD_BUNDLE__',
+    u64 entry count, per entry {u64 offset, u64 size, u64 triple length, triple}); -> [(triple, bytes)] of the amdgcn entries."""
+    import struct
+    data = open(so_path, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out, pos = [], data.find(magic)
+    while pos >= 0:
+        n, = struct.unpack_from("<Q", data, pos + len(magic))
+        q = pos + len(magic) + 8
+        for _ in range(n):
+            off, size, tlen = struct.unpack_from("<QQQ", data, q)
+            triple = data[q + 24:q + 24 + tlen].decode()
+            q += 24 + tlen
+            if "amdgcn" in triple and size:
+                out.append((triple, data[pos + off:pos + off + size]))
+        pos = data.find(magic, pos + len(magic))
+    return out
+
+
+def from_so(so_path=None):
+    """{mangled kernel name: {vgpr, vgpr_spill, sgpr, sgpr_spill, lds_static_bytes, scratch_bytes, agpr, scratch_instructions, arch}} of the
+    built library, from the code objects' own notes (llvm-readelf --notes) and their disassembly (count of scratch_* instructions)."""
+    so_path = so_path or os.path.join(ROOT, "v2v_amd", "libv2v_hip.so")
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for i, (triple, blob) in enumerate(carve_code_objects(so_path)):
+            co = os.path.join(tmp, f"co{i}.elf")
+            open(co, "wb").write(blob)
+            notes = os.path.join(tmp, f"co{i}.notes")
+            open(notes, "w").write(subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout)
+            kernels = parse(notes)
+            # scratch_* instructions per function symbol of the disassembly
+            dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+            cur, scratch = None, {}
+            for line in dis.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+                if m:
+                    cur = m.group(1)
+                elif cur and re.search(r"\bscratch_(load|store)", line):
+                    scratch[cur] = scratch.get(cur, 0) + 1
+            for name, r in kernels.items():
+                r["arch"] = triple.split("--")[-1] if "--" in triple else triple
+                r["scratch_instructions"] = scratch.get(name, 0)
+                r["code_object"] = i
+                res[name] = r
+    names = list(res)
+    dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+    for n, d in zip(names, dem):
+        res[n]["demangled"] = d
+    return res
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--from-so":
+        res = from_so()
+        dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "kernel_resources.json")
+        json.dump(res, open(dst, "w"), indent=1, sort_keys=True)
+        bad = {r["demangled"]: (r.get("scratch_bytes", 0), r.get("vgpr_spill", 0), r["scratch_instructions"]) for r in res.values()
+               if r.get("scratch_bytes", 0) or r.get("vgpr_spill", 0) or r["scratch_instructions"]}
+        print(f"{len(res)} kernels of the built library -> {dst}; with scratch / VGPR spills: {len(bad)}")
+        for k, v in bad.items():
+            print(f"  scratch {v[0]} B, {v[1]} spilled VGPRs, {v[2]} scratch instructions  {k[:140]}")
+        return
     dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "kernel_resources.json")
     res = {}
     with tempfile.TemporaryDirectory() as tmp:
@@ -71,4 +142,5 @@ def main():
         print(f"  {v:4d}  {k[:150]}")
 
 
-main()
+if __name__ == "__main__":
+    main()

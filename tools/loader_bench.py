@@ -209,6 +209,31 @@ def run_with_consumer(ds, workers, batch, n_batches, dev):
                     "the consumer is the bound here, the loader idles"}
 
 
+def run_yaml_only(tmp, src, n_batches, batch, dev, workers=0, **cfg):
+    """The ZERO-EDIT integration level: train.py's own loader -- DataLoader(dataset, batch_size, sampler=RandomSampler,
+    num_workers, persistent_workers, pin_memory, drop_last=True), default collate, then `batch[k] = v.to(device)` (train.py:52-65,76-82) --
+    over v2v_amd.datasets.WebvidDatasetV2 selected by the YAML's class_name; every sample is simulated inside __getitem__ (one launch per
+    sample).  workers = 0: the process that owns the GPU does everything serially (`output_device: cuda`).  workers > 0: the YAML key
+    `worker_start_method: spawn` makes train.py's DataLoader start spawned workers, each with its own HIP context; samples return on the
+    host (`output_device: cpu`) through the worker queue, pin_memory thread and H2D copy like the reference's."""
+    from torch.utils.data import DataLoader, RandomSampler
+    spawn = workers > 0
+    ds = make_dataset(tmp, (n_batches + 8) * batch, src, defer_sim=False, output_device="cpu" if spawn else "cuda",
+                      **(dict(worker_start_method="spawn") if spawn else {}), **cfg)
+    mk = lambda: DataLoader(ds, batch_size=batch, sampler=RandomSampler(ds), num_workers=workers, persistent_workers=spawn,   # noqa: E731
+                            pin_memory=spawn, drop_last=True)
+    t0 = time.perf_counter()
+    out = run_loader(mk, n_batches, batch, dev)
+    out["seconds_with_startup"] = time.perf_counter() - t0
+    out["workers"] = workers
+    out["yaml"] = ("class_name: v2v_amd.datasets.WebvidDatasetV2, " + ("worker_start_method: spawn, output_device: cpu; num_workers: %d, persistent_workers: true, "
+                   "pin_memory: true" % workers if spawn else "output_device: cuda; num_workers: 0, persistent_workers: false, pin_memory: false"))
+    if spawn:
+        import multiprocessing as mp
+        mp.set_start_method("fork", force=True)                  # what the dataset's YAML key changed, put back for the other legs
+    return out
+
+
 def gpu_ms_of_batch(batch, dev, pad_to=16):
     """Kernel time of one batch's device work (simulator with the writer's statistics, scales, the scaling pass, the frame tensor) at
     this shape: HIP events around a hipGraph replay of exactly the launches the loader issues, device-resident inputs."""
@@ -245,7 +270,9 @@ def gpu_ms_of_batch(batch, dev, pad_to=16):
     return sum(ms) / len(ms)
 
 
-def measure(batches=200, workers=9, batch=12, modes=("ring", "simulating"), cpu_port=True, dev=None, cpu_port_budget_s=60.0, simulating_batches=None, ring_kw=None, consumer=True):
+def measure(batches=200, workers=9, batch=12, modes=("ring", "simulating"), cpu_port=True, dev=None, cpu_port_budget_s=60.0, simulating_batches=None, ring_kw=None, consumer=True,
+            consumer_batches=20, yaml_only_batches=10, yaml_only_spawn_batches=20):
+    """simulating_batches = 0 skips the round-2/3 collator leg; yaml_only_* = 0 skips the zero-edit legs."""
     ring_kw = ring_kw or {}
     from torch.utils.data import DataLoader
     from v2v_amd.datasets import SimulatingCollator, SimulatingLoader
@@ -272,7 +299,7 @@ def measure(batches=200, workers=9, batch=12, modes=("ring", "simulating"), cpu_
                        "note": "floor_* = the GATHERED uint8 clips (201 frames per sample, what default_collate ships) crossing PCIe once at the measured rate; "
                                "a host-fed loader's GPU-busy fraction is bounded by gpu_kernel_ms_per_batch / (its own bytes / rate)"}
         del pin, dst
-        if "simulating" in modes:
+        if "simulating" in modes and simulating_batches != 0:
             col = SimulatingCollator.from_configs(TRAIN_CFG, output_device="cuda", pad_to=16, normalize=True)
             col.timers = {}
             mk = lambda: SimulatingLoader(DataLoader(ds, batch_size=batch, num_workers=workers, drop_last=True, persistent_workers=False), col)   # noqa: E731
@@ -290,11 +317,25 @@ def measure(batches=200, workers=9, batch=12, modes=("ring", "simulating"), cpu_
             r["vs_gathered_clip_pcie_floor"] = res["pcie"]["floor_ms_per_batch"] / r["ms_per_batch"]
         if consumer:
             try:
-                res["ring_loader_feeding_e2vid"] = run_with_consumer(ds, workers, batch, 20, dev)
+                res["ring_loader_feeding_e2vid"] = run_with_consumer(ds, workers, batch, consumer_batches, dev)
             except Exception as exc:  # noqa: BLE001 - a secondary figure
                 res["ring_loader_feeding_e2vid"] = {"error": f"{type(exc).__name__}: {exc}"}
         if cpu_port:
             res["cpu_port_in_workers"] = run_cpu_port(ds, workers, batch, budget_s=cpu_port_budget_s)
+        for key, nb, wk in (("yaml_only_workers0", yaml_only_batches, 0), ("yaml_only_spawn_workers", yaml_only_spawn_batches, workers)):
+            if nb:
+                try:
+                    res[key] = run_yaml_only(tmp, src, nb, batch, dev, workers=wk)
+                except Exception as exc:  # noqa: BLE001 - a secondary figure
+                    res[key] = {"error": f"{type(exc).__name__}: {exc}"}
+    # one table, three integration levels (samples/s; decode excluded everywhere -- see `source`)
+    res["integration_levels_samples_per_s"] = {
+        "yaml_only_num_workers_0": res.get("yaml_only_workers0", {}).get("samples_per_s"),
+        "yaml_only_spawned_workers": res.get("yaml_only_spawn_workers", {}).get("samples_per_s"),
+        "one_line_of_train_py_ring_loader": res.get("ring_loader", {}).get("samples_per_s"),
+        "reference_numpy_port_in_workers": res.get("cpu_port_in_workers", {}).get("samples_per_s"),
+        "decode_caveat": "video decode (cv2.VideoCapture.read + resize, ~0.4 s per 201-frame sample per worker: ~22 samples/s with 9 workers) is NOT in "
+                         "any of these figures; with real decode every level is decode-bound unless decoded clips are cached"}
     best = max((res[k]["samples_per_s"] for k in ("ring_loader", "simulating_loader") if k in res), default=None)
     if best and cpu_port:
         res["speedup_vs_cpu_port"] = best / res["cpu_port_in_workers"]["samples_per_s"]

@@ -18,7 +18,7 @@ FLAG_NO_NOISE = 0x2
 FLAG_SYMMETRIC = 0x4
 FLAG_MAP_4PX, FLAG_MAP_1PX, FLAG_MAP_2PX = 0x8, 0x10, 0x20
 OK, ERR_NULL, ERR_SHAPE, ERR_BINS, ERR_DTYPE, ERR_MODE, ERR_ALIGN, ERR_HIP, ERR_PARAM = 0, -1, -2, -3, -4, -5, -6, -7, -8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EXPORTS = ("v2v_version", "v2v_last_error", "v2v_device_count", "v2v_lut_get", "v2v_lut_set",
            "v2v_esim_voxel_hip", "v2v_esim_voxel_keyed_hip", "v2v_esim_voxel_bytes", "v2v_synth_clips_hip", "v2v_events_to_voxel_hip", "v2v_events_to_voxel_segmented_hip",
@@ -38,7 +38,7 @@ class EsimReplay(C.Structure):
 
 
 class EsimExtras(C.Structure):
-    _fields_ = [("stats", C.c_void_p), ("frame_index", C.c_void_p), ("clip_offsets", C.c_void_p)]
+    _fields_ = [("stats", C.c_void_p), ("frame_index", C.c_void_p), ("clip_offsets", C.c_void_p), ("stored_frames", C.c_void_p), ("frames_elems", C.c_int64)]
 
 
 class V2EParams(C.Structure):

@@ -387,6 +387,11 @@ class ConvLayer(nn.Module):
         upsampling kernel -- layer(x, skip) == layer(x + skip)."""
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise RuntimeError("v2v_amd.convlstm.ConvLayer is inference-only (no autograd through the fused kernel)")
+        if scales is not None and not self.head:
+            # only the head kernel (<= 8 input channels, 3x3 / 5x5) divides by normalize_batch_voxel's scales while it reads; anything else
+            # would silently run on raw, un-normalised events (RingLoader(normalize='scales') hands out raw voxels)
+            raise ValueError("`scales` is applied by the head kernel only (in_channels <= 8, kernel 3 or 5): normalise the events first "
+                             "(v2v_amd.postops.apply_scales / RingLoader(normalize=True)) for this layer")
         if self.conv2d.kernel_size[0] == 1:                                           # prediction layer: pred(skip_sum(x, head)), model/unet.py:307
             nhwc = all(v is None or (v.dtype == torch.bfloat16 and v.dim() == 4 and v.is_contiguous(memory_format=torch.channels_last)
                                      and not v.is_contiguous()) for v in (x, skip))

@@ -33,6 +33,11 @@ struct EsimArgs {
     // clip_offsets[b] of `frames` instead of b * clip_stride (clips of different stored lengths packed back to back)
     const int32_t *frame_index;
     const int64_t *clip_offsets;
+    // bounds of the gather (optional): clip b holds stored_frames[b] frames; `frames` holds frames_elems elements in all (0 = not stated).
+    // A row that names a frame outside [0, stored_frames[b]) or a clip that does not fit the buffer poisons the clip (NaN planes,
+    // kStatBad) instead of reading out of bounds -- checked once per workgroup while the row is staged through LDS.
+    const int32_t *stored_frames;
+    int64_t frames_elems;
 };
 
 // Per-clip statistics the simulator's writer accumulates for the consumer's normalize_batch_voxel (model/train_utils.py:147-166):

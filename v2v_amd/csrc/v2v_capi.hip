@@ -135,7 +135,7 @@ static int esim_launch_impl(const void *frames, int in_dtype, int64_t B, int64_t
                             uint32_t flags, int rng_mode, uint64_t seed, uint64_t clip_id0, const uint64_t *clip_keys,
                             const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
                             void *out_voxel, int out_dtype, int64_t out_row_pitch, int64_t out_plane_size, int64_t *out_counts, uint32_t *stats,
-                            const int32_t *frame_index, const int64_t *clip_offsets, void *stream);
+                            const int32_t *frame_index, const int64_t *clip_offsets, const int32_t *stored_frames, int64_t frames_elems, void *stream);
 
 int v2v_esim_voxel_padded_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W,
                               int64_t clip_stride, int64_t frame_stride, const double *params, int64_t params_stride,
@@ -144,7 +144,7 @@ int v2v_esim_voxel_padded_hip(const void *frames, int in_dtype, int64_t B, int64
                               void *out_voxel, int out_dtype, int64_t out_row_pitch, int64_t out_plane_size, int64_t *out_counts, void *stream)
 {
     return esim_launch_impl(frames, in_dtype, B, N, H, W, clip_stride, frame_stride, params, params_stride, flags, rng_mode, seed, clip_id0, clip_keys,
-                            replay, bin_mode, num_bins, frames_per_bin, out_voxel, out_dtype, out_row_pitch, out_plane_size, out_counts, nullptr, nullptr, nullptr, stream);
+                            replay, bin_mode, num_bins, frames_per_bin, out_voxel, out_dtype, out_row_pitch, out_plane_size, out_counts, nullptr, nullptr, nullptr, nullptr, 0, stream);
 }
 
 int v2v_esim_voxel_ex_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W,
@@ -163,7 +163,11 @@ int v2v_esim_voxel_ex_hip(const void *frames, int in_dtype, int64_t B, int64_t N
         if (in_dtype != V2V_U8 || bin_mode != V2V_BIN_SUM || out_dtype != V2V_F32 || rng_mode == V2V_RNG_REPLAY || rng_mode == V2V_RNG_NONE ||
             (flags & (V2V_FLAG_NOISE_EXTERNAL | V2V_FLAG_NO_NOISE | V2V_FLAG_SYMMETRIC)))
             return fail(V2V_ERR_MODE, "indexed frames: uint8 clips, SUM bins, device noise, float32 grid, no NO_NOISE / NOISE_EXTERNAL / SYMMETRIC flag");
-        if (!aligned(extras->frame_index, 4) || !aligned(extras->clip_offsets, 8)) return fail(V2V_ERR_ALIGN, "frame_index / clip_offsets misaligned");
+        if (!aligned(extras->frame_index, 4) || !aligned(extras->clip_offsets, 8) || !aligned(extras->stored_frames, 4))
+            return fail(V2V_ERR_ALIGN, "frame_index / clip_offsets / stored_frames misaligned");
+        if (extras->frames_elems < 0) return fail(V2V_ERR_SHAPE, "frames_elems must be >= 0 (0: not stated)");
+    } else if (extras->stored_frames || extras->frames_elems) {
+        return fail(V2V_ERR_NULL, "v2v_esim_voxel_ex_hip: stored_frames / frames_elems bound the frame_index gather and come with it");
     }
     if (extras->stats) {
         if (bin_mode != V2V_BIN_SUM || out_dtype != V2V_F32 || (flags & V2V_FLAG_NOISE_EXTERNAL))
@@ -176,7 +180,7 @@ int v2v_esim_voxel_ex_hip(const void *frames, int in_dtype, int64_t B, int64_t N
     }
     return esim_launch_impl(frames, in_dtype, B, N, H, W, clip_stride, frame_stride, params, params_stride, flags, rng_mode, seed, clip_id0, clip_keys,
                             replay, bin_mode, num_bins, frames_per_bin, out_voxel, out_dtype, out_row_pitch, out_plane_size, out_counts, extras->stats,
-                            extras->frame_index, extras->clip_offsets, stream);
+                            extras->frame_index, extras->clip_offsets, extras->stored_frames, extras->frames_elems, stream);
 }
 
 int v2v_esim_voxel_stats_hip(const void *frames, int in_dtype, int64_t B, int64_t N, int64_t H, int64_t W,
@@ -195,7 +199,7 @@ int v2v_esim_voxel_stats_hip(const void *frames, int in_dtype, int64_t B, int64_
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(stats)");
     }
     return esim_launch_impl(frames, in_dtype, B, N, H, W, clip_stride, frame_stride, params, params_stride, flags, rng_mode, seed, clip_id0, clip_keys,
-                            replay, bin_mode, num_bins, frames_per_bin, out_voxel, out_dtype, out_row_pitch, out_plane_size, out_counts, stats, nullptr, nullptr, stream);
+                            replay, bin_mode, num_bins, frames_per_bin, out_voxel, out_dtype, out_row_pitch, out_plane_size, out_counts, stats, nullptr, nullptr, nullptr, 0, stream);
 }
 
 int v2v_voxel_scales_hip(const uint32_t *stats, int64_t B, int64_t elems_per_sample, float *scales, void *stream)
@@ -245,7 +249,7 @@ static int esim_launch_impl(const void *frames, int in_dtype, int64_t B, int64_t
                             uint32_t flags, int rng_mode, uint64_t seed, uint64_t clip_id0, const uint64_t *clip_keys,
                             const v2v_esim_replay *replay, int bin_mode, int num_bins, int frames_per_bin,
                             void *out_voxel, int out_dtype, int64_t out_row_pitch, int64_t out_plane_size, int64_t *out_counts, uint32_t *stats,
-                            const int32_t *frame_index, const int64_t *clip_offsets, void *stream)
+                            const int32_t *frame_index, const int64_t *clip_offsets, const int32_t *stored_frames, int64_t frames_elems, void *stream)
 {
     if (out_row_pitch < W || out_plane_size < out_row_pitch * (H - 1) + W) return fail(V2V_ERR_SHAPE, "out_row_pitch / out_plane_size smaller than the frame");
     if (!frames || !params || !out_voxel) return fail(V2V_ERR_NULL, "v2v_esim_voxel_hip: frames/params/out_voxel is NULL");
@@ -325,6 +329,8 @@ static int esim_launch_impl(const void *frames, int in_dtype, int64_t B, int64_t
     a.stats = stats;
     a.frame_index = frame_index;
     a.clip_offsets = clip_offsets;
+    a.stored_frames = stored_frames;
+    a.frames_elems = frames_elems;
     const int64_t nblocks = B * a.blocks_per_clip;
     if (nblocks > 0x7FFFFFFF) return fail(V2V_ERR_SHAPE, "grid too large");
     const dim3 grid((unsigned)nblocks);

@@ -176,9 +176,20 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
         if (want_stats) for (int i = threadIdx.x; i < kStatBins; i += kBlock) s_hist[i] = 0;
     }
     int *s_fidx = reinterpret_cast<int *>(s_raw);              // FIDX: [K + 1] stored-frame numbers of this clip
+    int fidx_bad = 0;                                          // this work-item saw an index / a clip extent out of bounds
     if constexpr (FIDX) {
-        const int32_t *row = a.frame_index + (int64_t)(blockIdx.x / a.blocks_per_clip) * (a.K + 1);
-        for (int i = threadIdx.x; i <= a.K; i += kBlock) s_fidx[i] = row[i];
+        const int cb = blockIdx.x / a.blocks_per_clip;
+        const int32_t *row = a.frame_index + (int64_t)cb * (a.K + 1);
+        const int stored = a.stored_frames ? a.stored_frames[cb] : 0x7FFFFFFF;
+        for (int i = threadIdx.x; i <= a.K; i += kBlock) {
+            const int f = row[i];
+            fidx_bad |= (int)((unsigned)f >= (unsigned)stored);            // negative or >= stored (the reference's gather cannot, v2v_datasets.py:286-311)
+            s_fidx[i] = f;
+        }
+        if (a.stored_frames && a.frames_elems > 0 && threadIdx.x == 0) {
+            const int64_t off = a.clip_offsets[cb];
+            fidx_bad |= (int)(stored < 1 || off < 0 || off + (int64_t)(stored - 1) * a.frame_stride + a.HW > a.frames_elems);
+        }
     }
     auto foff = [&](int f) -> int64_t {                        // element offset of simulator frame f inside the clip
         if constexpr (FIDX) return (int64_t)s_fidx[f] * a.frame_stride;
@@ -206,7 +217,9 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
             for (int b = bprev + 1; b <= b0; ++b) s_kb[b] = k;          // seg() is non-decreasing in k
         }
     }
-    __syncthreads();
+    bool clip_bad = false;
+    if constexpr (FIDX) clip_bad = __syncthreads_or(fidx_bad) != 0;       // every workgroup of the clip stages the same row: all agree
+    else __syncthreads();
 
     const int clip = blockIdx.x / a.blocks_per_clip;
     const int blk = blockIdx.x - clip * a.blocks_per_clip;
@@ -215,6 +228,23 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
     // output planes may be padded (row pitch >= W, plane size >= pitch * H: the consumer's x16 padding written in place); the
     // VEC pixels of a work-item share a row (VEC == 4 needs W % 4 == 0), and a plane is stored a handful of times per clip
     const int64_t pix_off = (a.out_pitch == a.W) ? (int64_t)p0 : (int64_t)(p0 / (uint32_t)a.W) * a.out_pitch + (p0 % (uint32_t)a.W);
+
+    // a clip whose inputs break a promise (V2V_FLAG_SYMMETRIC with C+ != C-; a frame index outside the clip): NaN planes + the
+    // statistics' kStatBad word -- loud, never a wrong count, never an out-of-bounds read
+    auto poison_clip = [&]() {
+        using pacc_t = typename std::conditional<OUT64, double, float>::type;
+        pacc_t bad[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) bad[j] = (pacc_t)__builtin_nanf("");
+        const int64_t planes = (BIN == kBinSum) ? (a.K / a.fpb) : a.Tb;
+        for (int64_t pl = 0; pl < planes; ++pl) store_vec<VEC, pacc_t>(a.out, (int64_t)clip * planes * a.out_plane + pl * a.out_plane + pix_off, bad);
+        if constexpr (BIN == kBinSum && !OUT64 && !EXT) {
+            if (a.stats != nullptr && p0 == 0) atomicExch(&a.stats[(int64_t)clip * kStatWords + kStatBad], 1u);
+        }
+    };
+    if constexpr (FIDX) {
+        if (clip_bad) { poison_clip(); return; }                       // workgroup-uniform
+    }
 
     const double *pp = a.params + (int64_t)clip * a.params_stride;
     // symmetric clips keep the threshold and its (slightly low) reciprocal in VGPRs; asymmetric ones read s_thr by polarity.
@@ -357,8 +387,14 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
                                 { const uint32_t y = xchg(upper ? w1 : w3, std::integral_constant<int, 0x4E>{}); if (upper) w1 = y; else w3 = y; }
                                 gw0 = w0; gw1 = w1; gw2 = w2; gw3 = w3;            // this pixel's word for couples c0 .. c0 + 3
                             }
-                            const int sel = (k >> 1) & 3;                          // wave-uniform
-                            icdf_pair(sel == 0 ? gw0 : sel == 1 ? gw1 : sel == 2 ? gw2 : gw3, s_icdf, g[0], g_pend[0]);
+                            // the couple's word is always gw0: the four words rotate by one after each use (plain moves the unrolled loop
+                            // renames away).  NOT `sel == 0 ? gw0 : sel == 1 ? gw1 : ...`: the compiler turned that chain over the by-reference
+                            // captures into a run-time index into the lambda's closure object, which pinned the closure and every captured
+                            // local -- the whole argument struct included -- to scratch memory (560 bytes, 2,262 scratch instructions in the
+                            // <float32, 1 pixel, SUM, device noise> instance of round 4; tests/test_kernel_resources.py refuses any scratch now)
+                            const uint32_t word = gw0;
+                            gw0 = gw1; gw1 = gw2; gw2 = gw3; gw3 = word;
+                            icdf_pair(word, s_icdf, g[0], g_pend[0]);
                         } else
                         field_gauss_pairs<VEC, kNoiseRounds>(seed_, clip_id, kFieldBase0 + (uint32_t)(k >> 1), kStreamEsim, p0, s_icdf, g, g_pend);
                     } else {
@@ -548,16 +584,7 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
         }
     };
     if constexpr (SYMONLY) {
-        if (pp[0] != pp[1]) {                                          // guarantee broken: poison this clip's planes
-            acc_t bad[VEC];
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) bad[j] = (acc_t)__builtin_nanf("");
-            for (int64_t pl = 0; pl < planes_per_clip; ++pl) store_vec<VEC, acc_t>(a.out, (int64_t)clip * planes_per_clip * a.out_plane + pl * a.out_plane + pix_off, bad);
-            if constexpr (STATS) {
-                if (want_stats && p0 == 0) atomicExch(&a.stats[(int64_t)clip * kStatWords + kStatBad], 1u);
-            }
-            return;
-        }
+        if (pp[0] != pp[1]) { poison_clip(); return; }                 // guarantee broken: poison this clip's planes
         run(std::true_type{});
     } else if constexpr (ASYM4) {
         run(std::false_type{});

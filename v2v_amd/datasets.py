@@ -100,6 +100,7 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
                        'gray', 3 for 'gray_in_bgr_out'); replaces OpenCV decoding (tests, synthetic benches).  Must be
                        picklable (a module-level function) when DataLoader workers are spawned; see synthetic_frame_source
         video_size     (width, height) reported for every video when frame_source is used
+        worker_start_method  'spawn': train.py's own DataLoader then starts spawned workers (each owns a HIP context) -- see load_configs
     """
 
     def load_configs(self, configs):
@@ -167,6 +168,15 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
         # decoded [T,Hs,Ws,3] uint8 frames instead of OpenCV.  Parity of the resize itself is unpinned (no cv2 here).
         self.gpu_frontend = g("gpu_frontend", False)
         self.raw_frame_source = g("raw_frame_source", None)
+        # worker_start_method: 'spawn' | 'forkserver' -- how train.py's OWN DataLoader (train.py:52-65 passes no multiprocessing_context)
+        # starts its workers: a fork()ed worker cannot use HIP, a spawned one owns a HIP context and simulates its samples itself.
+        # Set from the YAML, so `num_workers: 9` works with train.py untouched (each worker pays an interpreter start: use
+        # `persistent_workers: true` as the shipped YAML does).
+        self.worker_start_method = g("worker_start_method", None)
+        if self.worker_start_method is not None:
+            assert self.worker_start_method in ["spawn", "forkserver", "fork"]
+            import multiprocessing
+            multiprocessing.set_start_method(self.worker_start_method, force=True)
         assert not (self.gpu_frontend and self.defer_sim), "gpu_frontend runs in the process that owns the GPU; defer_sim is for fork()ed workers"
 
     def __init__(self, dataset_path, configs):

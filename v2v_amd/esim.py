@@ -154,12 +154,14 @@ def esim_voxel_batch(frames: torch.Tensor, params, *, bin_mode: str = "sum", num
 
 def esim_voxel_packed(frames: torch.Tensor, clip_offsets: torch.Tensor, frame_index: torch.Tensor, h: int, w: int, params: torch.Tensor,
                       clip_keys: torch.Tensor, *, num_bins: int = 5, frames_per_bin: int = 1, pad_to: int = 1, stats: Optional[torch.Tensor] = None,
-                      align: int = 16, mapping: Optional[str] = None) -> torch.Tensor:
+                      align: int = 16, mapping: Optional[str] = None, stored_frames: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The batch launch over PACKED clips (v2v_esim_voxel_ex_hip with v2v_esim_extras): `frames` is one flat uint8 CUDA buffer, clip b starts
     at element clip_offsets[b] (int64 [B], multiples of `align`) and holds its DECODED frames once each; frame_index int32 [B,N] names the
     stored frame every simulator frame shows -- the reference's pause-index gather (data/v2v_datasets.py:286-311) done by the kernel's
     loads.  SUM bins, device-native noise, float32 grid; params float64 [B,5] and clip_keys int64 [B,2] on the device.  Same results as
-    esim_voxel_batch on the gathered clips (tests/test_loader.py).  -> [B, L, num_bins, Hp, Wp]"""
+    esim_voxel_batch on the gathered clips (tests/test_loader.py).  stored_frames int32 [B] on the device = frames each clip holds: the
+    launch then checks every index row (and that the clip fits `frames`) while it stages it -- a clip that fails comes out as NaN planes with
+    its `stats` flag set, nothing is read out of bounds; None = the caller vouches for the rows.  -> [B, L, num_bins, Hp, Wp]"""
     _lib.require_gpu()
     dev = frames.device
     if frames.dtype != torch.uint8 or frames.ndim != 1 or not frames.is_cuda:
@@ -180,7 +182,10 @@ def esim_voxel_packed(frames: torch.Tensor, clip_offsets: torch.Tensor, frame_in
         return out
     if stats is not None and (stats.dtype != torch.int32 or tuple(stats.shape) != (b, _lib.VOXEL_STATS_WORDS) or not stats.is_contiguous() or stats.device != dev):
         raise ValueError(f"stats must be a contiguous int32 [{b},{_lib.VOXEL_STATS_WORDS}] tensor on the frames' device")
-    ex = _lib.EsimExtras(stats.data_ptr() if stats is not None else None, frame_index.data_ptr(), clip_offsets.data_ptr())
+    if stored_frames is not None and (stored_frames.dtype != torch.int32 or tuple(stored_frames.shape) != (b,) or stored_frames.device != dev or not stored_frames.is_contiguous()):
+        raise ValueError(f"stored_frames must be a contiguous int32 [{b}] tensor on {dev}")
+    ex = _lib.EsimExtras(stats.data_ptr() if stats is not None else None, frame_index.data_ptr(), clip_offsets.data_ptr(),
+                         stored_frames.data_ptr() if stored_frames is not None else None, frames.numel() if stored_frames is not None else 0)
     with torch.cuda.device(dev):
         rc = _lib.lib().v2v_esim_voxel_ex_hip(
             C.c_void_p(frames.data_ptr()), _lib.U8, b, n, h, w, align, h * w, C.c_void_p(params.data_ptr()), 5,

@@ -97,7 +97,7 @@ def choose_normalize_method(params: np.ndarray, frames_per_bin: int, put_noise_e
 # --------------------------------------------------------------------------------------------------------------------- ring
 class _SlotLayout:
     """Byte layout of one slot.  Fixed head (always copied): [clip offsets i64 B][frame index i32 B*N][frame picks i32 B*Lf][params f64 B*5]
-    [keys i64 B*2][used bytes i64 1][colour frames u8 B*Lf*H*W*3 (gray_in_bgr_out only)]; then the clips, PACKED: clip b holds its decoded
+    [keys i64 B*2][used bytes i64 1][stored frames i32 B][colour frames u8 B*Lf*H*W*3 (gray_in_bgr_out only)]; then the clips, PACKED: clip b holds its decoded
     frames once each at byte `offsets[b]` of the clip region (a multiple of 16), `used` bytes in all -- the H2D copy ends there."""
 
     def __init__(self, batch, n, h, w, lf, colour):
@@ -109,22 +109,26 @@ class _SlotLayout:
         self.off_params = self.off_pick + al(batch * lf * 4)
         self.off_keys = self.off_params + al(batch * 5 * 8)
         self.off_used = self.off_keys + al(batch * 2 * 8)
-        self.off_cframes = self.off_used + 256
+        self.off_stored = self.off_used + 256                           # frames each clip holds: the simulator bounds its gather with them
+        self.off_cframes = self.off_stored + al(batch * 4)
         self.off_clips = self.off_cframes + (al(batch * lf * h * w * 3) if colour else 0)
-        self.nbytes = self.off_clips + al(batch * n * h * w)
+        # every packed clip is rounded up to 16 bytes (see _RingDataset): room for that rounding when n*h*w % 16 != 0 (crop sizes that
+        # are not multiples of 4) and no clip of the batch pauses
+        self.clip_room = (n * h * w + 15) // 16 * 16
+        self.nbytes = self.off_clips + al(batch * self.clip_room)
 
     @staticmethod
     def _v(buf, off, count, dtype, shape):
         return buf[off:off + count * np.dtype(dtype).itemsize].view(dtype).reshape(shape)
 
     def views(self, buf: np.ndarray):
-        """NumPy views of one slot (a uint8 array of nbytes): offsets, fidx, pick, params, keys, used, colour frames, clip region."""
+        """NumPy views of one slot (a uint8 array of nbytes): offsets, fidx, pick, params, keys, used, colour frames, clip region, stored."""
         b, n, h, w, lf = self.batch, self.n, self.h, self.w, self.lf
         return (self._v(buf, self.off_offsets, b, np.int64, (b,)), self._v(buf, self.off_fidx, b * n, np.int32, (b, n)),
                 self._v(buf, self.off_pick, b * lf, np.int32, (b, lf)), self._v(buf, self.off_params, b * 5, np.float64, (b, 5)),
                 self._v(buf, self.off_keys, b * 2, np.int64, (b, 2)), self._v(buf, self.off_used, 1, np.int64, (1,)),
                 self._v(buf, self.off_cframes, b * lf * h * w * 3, np.uint8, (b, lf, h, w, 3)) if self.colour else None,
-                buf[self.off_clips:self.off_clips + b * n * h * w])
+                buf[self.off_clips:self.off_clips + b * self.clip_room], self._v(buf, self.off_stored, b, np.int32, (b,)))
 
     def device_views(self, dbuf: torch.Tensor):
         b, n, h, w, lf = self.batch, self.n, self.h, self.w, self.lf
@@ -133,7 +137,7 @@ class _SlotLayout:
                 v(self.off_pick, b * lf * 4, torch.int32, (b, lf)), v(self.off_params, b * 40, torch.float64, (b, 5)),
                 v(self.off_keys, b * 16, torch.int64, (b, 2)),
                 dbuf[self.off_cframes:self.off_cframes + b * lf * h * w * 3].view(b, lf, h, w, 3) if self.colour else None,
-                dbuf[self.off_clips:self.off_clips + b * n * h * w])
+                dbuf[self.off_clips:self.off_clips + b * self.clip_room], v(self.off_stored, b * 4, torch.int32, (b,)))
 
 
 def _leaf(dataset, idx):
@@ -170,12 +174,13 @@ class _RingDataset(torch.utils.data.Dataset):
         idx, slot, pos = item
         leaf, li = _leaf(self.base, idx)
         lay = self.layout
-        offsets, fidx, pick, params, keys, used, cframes, clips = lay.views(self.ring[slot])
+        offsets, fidx, pick, params, keys, used, cframes, clips, stored = lay.views(self.ring[slot])
         # a DataLoader worker builds a whole batch, sample after sample: the clips are packed back to back as they come
         start = 0 if pos == 0 else int(used[0])
         room = clips[start:start + lay.n * lay.h * lay.w].reshape(lay.n, lay.h, lay.w)
         _, n_stored = leaf.host_sample_into(li, room, params[pos], keys[pos], cframes[pos] if cframes is not None else None, fidx[pos])
         offsets[pos] = start
+        stored[pos] = n_stored
         pick[pos] = fidx[pos][self.pick]                                   # the stored frames handed out as `frame`
         used[0] = start + (n_stored * lay.h * lay.w + 15) // 16 * 16
         return slot, leaf.data_source_idx
@@ -203,7 +208,10 @@ def _ring_collate(items):
 
 class RingLoader:
     """See the module docstring.  Arguments as torch's DataLoader where they share a name; the dataset is a
-    v2v_amd.datasets.WebvidDatasetV2 (any `defer_sim` setting; not `gpu_frontend`) or ConcatDatasets of them with one clip shape.
+    v2v_amd.datasets.WebvidDatasetV2 (any `defer_sim` setting; not `gpu_frontend`; not `sim_rng: numpy` -- the ring always simulates with the
+    device-native Philox noise keyed by {seed drawn per sample, sample index}, the bit-exact np.random replay lives on the per-sample path
+    only; `sim_device` / `output_device` are not consulted either: batches are simulated and handed out on `device`) or ConcatDatasets of
+    them with one clip shape.
 
     pad_to / normalize   the consumer-side post-ops done where the voxels are produced (model/train_utils.py:147-166, 322-326): events
                          are written into the x`pad_to`-padded layout and, with normalize=True, normalize_batch_voxel is applied in
@@ -229,7 +237,7 @@ class RingLoader:
             raise ValueError("empty dataset")
         lf0 = leaves[0]
         shape = lambda d: (d.frames_per_seq + 1, d.crop_size, d.color_mode, len(d.frame_pick()), d.num_bins, d.frames_per_bin,   # noqa: E731
-                           d.put_noise_external, d.output_additional_evs)
+                           d.put_noise_external, d.output_additional_evs, d.sim_rng == "numpy")
         for d in leaves:
             if not hasattr(d, "host_sample_into"):
                 raise TypeError("RingLoader needs v2v_amd.datasets.WebvidDatasetV2 leaves")
@@ -237,6 +245,9 @@ class RingLoader:
                 raise ValueError("all datasets of a RingLoader must share clip length, crop size, colour mode and binning")
             if d.gpu_frontend:
                 raise TypeError("RingLoader ships host-decoded clips: configure the dataset with gpu_frontend: false")
+            if d.sim_rng == "numpy":
+                raise TypeError("RingLoader simulates with the device-native Philox noise; `sim_rng: numpy` (bit-exact replay of the reference's "
+                                "np.random stream) is served by the per-sample path: use torch's DataLoader (create_dataloader does)")
         self.leaf = lf0
         n, hw = lf0.frames_per_seq + 1, lf0.crop_size
         self.pick = lf0.frame_pick()
@@ -307,7 +318,7 @@ class RingLoader:
         t0 = time.perf_counter()
         d = k % self.depth
         lay = self.layout
-        offsets, _, _, params, _, used, _, _ = lay.views(self.ring[slot])
+        offsets, _, _, params, _, used, _, _, _ = lay.views(self.ring[slot])
         nbytes = lay.off_clips + int(used[0])
         ev = torch.cuda.Event()
         with torch.cuda.stream(self.copy_stream):
@@ -326,10 +337,10 @@ class RingLoader:
         lay, leaf = self.layout, self.leaf
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ev)
-        offsets_d, fidx_d, pick_d, params_d, keys_d, cframes, clips = lay.device_views(self._dev[d])
+        offsets_d, fidx_d, pick_d, params_d, keys_d, cframes, clips, stored_d = lay.device_views(self._dev[d])
         nb = len(src_idx)                                                 # < batch_size only for the last batch of an epoch with drop_last=False
         if nb < lay.batch:
-            offsets_d, fidx_d, pick_d, params_d, keys_d = offsets_d[:nb], fidx_d[:nb], pick_d[:nb], params_d[:nb], keys_d[:nb]
+            offsets_d, fidx_d, pick_d, params_d, keys_d, stored_d = offsets_d[:nb], fidx_d[:nb], pick_d[:nb], params_d[:nb], keys_d[:nb], stored_d[:nb]
             cframes = cframes[:nb] if cframes is not None else None
             params = params[:nb]
         t0 = time.perf_counter()
@@ -343,7 +354,7 @@ class RingLoader:
                                         clip_keys=keys_d, put_noise_external=True, pad_to=self.pad_to, validate=False)
         else:
             vox = esim.esim_voxel_packed(clips, offsets_d, fidx_d, h, w, params_d, keys_d, num_bins=leaf.num_bins, frames_per_bin=leaf.frames_per_bin,
-                                         pad_to=self.pad_to, stats=stats)
+                                         pad_to=self.pad_to, stats=stats, stored_frames=stored_d)
         self._t("sim", t0)
         t0 = time.perf_counter()
         batch = {}
@@ -374,13 +385,20 @@ class RingLoader:
         return batch
 
     def __iter__(self):
-        # an abandoned epoch's workers may still be writing into ring slots: end them (non-persistent workers are joined when their
-        # iterator goes; persistent ones drain their queue when the DataLoader restarts them) before slots are handed out again
-        self._it = None
+        """A plain method, not a generator: the previous epoch is retired HERE, when iter(loader) is called, not at the new iterator's first
+        next().  An abandoned epoch's workers may still be writing into ring slots: its DataLoader iterator is shut down explicitly (a
+        generator object someone still references would otherwise keep its non-persistent workers alive and writing), persistent workers
+        drain their queue when the DataLoader restarts them, and no copy of the old epoch may still read the ring."""
+        old, self._it = self._it, None
         self._generation += 1
-        gen = self._generation
-        self.copy_stream.synchronize()                                    # ... and no copy of an abandoned epoch still reads the ring
+        if old is not None and not getattr(self.loader, "persistent_workers", False) and hasattr(old, "_shutdown_workers"):
+            old._shutdown_workers()
+        del old
+        self.copy_stream.synchronize()
         it = self._it = iter(self.loader)
+        return self._batches(it, self._generation)
+
+    def _batches(self, it, gen):
         k = 0
         copies = []                                                       # H2D events of the batches whose ring slot may still be read
 
@@ -425,7 +443,8 @@ def create_dataloader(dataset, configs, batch_size, local_rank):
     num_workers = configs.get("num_workers")
     persistent_workers = configs.get("persistent_workers", False)
     leaves = list(_leaves(dataset))
-    ring_ok = all(hasattr(d, "host_sample_into") and not getattr(d, "gpu_frontend", False) for d in leaves) and torch.cuda.is_available()
+    ring_ok = all(hasattr(d, "host_sample_into") and not getattr(d, "gpu_frontend", False) and getattr(d, "sim_rng", "philox") != "numpy"
+                  for d in leaves) and torch.cuda.is_available()
     if ring_ok:
         device = torch.device("cuda", local_rank if local_rank is not None else torch.cuda.current_device())
         return RingLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers or 0, drop_last=True,
