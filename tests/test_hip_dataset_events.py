@@ -53,7 +53,10 @@ def _frames(ds, sample_idx, start, end, crop_before, min_i, min_j, flip, need_h,
     for _ in range(end - start):
         base = np.clip(base + g.normal(0, 6, size=base.shape), 0, 255)
         f = base.astype(np.uint8)
-        out.append((f[:, ::-1] if flip else f)[..., None].copy())
+        f = (f[:, ::-1] if flip else f)[..., None]
+        if ds.color_mode != "gray":                   # three different channels (a swapped weight must show)
+            f = np.concatenate([f, 255 - f, f // 2 + 30], axis=-1)
+        out.append(f.copy())
     return out
 
 
@@ -101,6 +104,37 @@ def test_dataset_sample_equals_oracle_replay(tmp_path, extra):
     fpi = ds.frames_per_img
     pick = [i * fpi for i in range(L + 1)] if extra.get("output_additional_frame") else [(i + 1) * fpi for i in range(L)]
     assert np.array_equal(sample["frame"][:, 0].numpy(), imgs[pick].astype(np.float32) / 255)
+
+
+@pytest.mark.parametrize("extra", [{}, {"output_additional_frame": True}, {"output_additional_evs": True}, {"color_mode": "gray_in_bgr_out"},
+                                   {"shake_frames": 5, "shake_std": 2.0}, {"video_degrade": "hdr", "degrade_ratio": 1.0}, {"fixed_seed": 5},
+                                   {"proba_pause_when_running": 0.3, "proba_pause_when_paused": 0.6, "frames_per_bin": 2}, {"crop_size": 30},
+                                   {"output_device": "cuda"}])
+def test_staged_getitem_equals_the_plain_per_sample_path(tmp_path, extra):
+    """Round 5: __getitem__ goes through page-locked slots, the packed-clip launch and the device-side `frame` assembly (the loader's
+    machinery with a batch of one).  Same np.random draws, same tensors, bit for bit, as the plain path (`staged_getitem: false`) -- over
+    more samples than there are slots, so slot reuse is exercised."""
+    fast = _make_ds(tmp_path, sim_rng="philox", **extra)
+    plain = _make_ds(tmp_path, sim_rng="philox", staged_getitem=False, **extra)
+    assert fast._staged_ok() and not plain._staged_ok()
+    got, want = [], []
+    np.random.seed(11)
+    for i in (0, 1, 0, 1, 1, 0, 1):
+        got.append(fast[i])
+    state_fast = np.random.get_state()[1].copy()
+    np.random.seed(11)
+    for i in (0, 1, 0, 1, 1, 0, 1):
+        want.append(plain[i])
+    assert np.array_equal(np.random.get_state()[1], state_fast)                   # the same number of global draws
+    for g, w in zip(got, want):
+        assert set(g) == set(w) == {"frame", "events", "data_source_idx", "v2e_params"}
+        assert g["events"].device == w["events"].device and g["frame"].device == w["frame"].device
+        assert g["events"].shape == w["events"].shape and torch.equal(g["events"], w["events"]) and float(w["events"].abs().sum()) > 0
+        assert g["frame"].shape == w["frame"].shape and g["frame"].dtype == torch.float32 and torch.equal(g["frame"], w["frame"])
+        assert g["v2e_params"] == w["v2e_params"] and torch.equal(g["data_source_idx"], w["data_source_idx"])
+        assert g["events"].is_contiguous() and g["frame"].is_contiguous()
+    import pickle
+    assert "_staging" in fast.__dict__ and "_staging" not in pickle.loads(pickle.dumps(fast)).__dict__     # slots stay with their process
 
 
 def test_dataset_default_collate_contract_g10(tmp_path):

@@ -172,6 +172,8 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
         # starts its workers: a fork()ed worker cannot use HIP, a spawned one owns a HIP context and simulates its samples itself.
         # Set from the YAML, so `num_workers: 9` works with train.py untouched (each worker pays an interpreter start: use
         # `persistent_workers: true` as the shipped YAML does).
+        # staged_getitem: false keeps the plain per-sample path (host-side gather, pageable copies) -- for A/B runs and the equality test
+        self.staged_getitem = g("staged_getitem", True)
         self.worker_start_method = g("worker_start_method", None)
         if self.worker_start_method is not None:
             assert self.worker_start_method in ["spawn", "forkserver", "fork"]
@@ -489,7 +491,66 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
             np.random.set_state(old_state)
         return v2e_params if index_out is None else (v2e_params, n_stored)
 
+    # ------------------------------------------------------------------ the per-sample path, staged (zero-edit integration level)
+    def _staged_ok(self):
+        """The per-sample launch can take the loader's route -- decoded frames written ONCE into a page-locked slot, one asynchronous H2D
+        copy, the simulator gathering through the pause index, `frame` built on the device -- whenever the ring loader could serve the
+        dataset: device-native noise inside the potential, host-decoded clips, a GPU to simulate on."""
+        return (self.staged_getitem and not self.defer_sim and not self.gpu_frontend and self.sim_rng != "numpy" and not self.put_noise_external
+                and torch.device(self.sim_device).type == "cuda" and self.crop_size is not None)
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_staging", None)                 # page-locked slots and device buffers belong to the process that made them
+        return state
+
+    def _getitem_staged(self, sample_idx):
+        """__getitem__ through three rotating page-locked slots (v2v_amd.loader._SlotLayout with a batch of one): same np.random draws,
+        same tensors as the plain path below (tests/test_hip_dataset_events.py), without its host-side gather (np.stack over the pause
+        index: 201 frames), its pageable synchronous copies and its float `frame` tensor built on the host.  Round 5, measured at the
+        training shape under train.py's own DataLoader(num_workers=0): tools/loader_bench.py `yaml_only_workers0`."""
+        from . import _lib
+        from .loader import _SlotLayout, clip_frames_f32, clip_frames_packed
+        _lib.require_gpu()                                                  # no CPU simulator fallback: fail as loudly as the plain path
+        dev = torch.device(self.sim_device)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        n, hw = self.frames_per_seq + 1, self.crop_size
+        st = self.__dict__.get("_staging")
+        if st is None or st["dev"] != dev:
+            pick = self.frame_pick()
+            lay = _SlotLayout(1, n, hw, hw, len(pick), self.color_mode != "gray")
+            slots = 3
+            host = torch.empty((slots, lay.nbytes), dtype=torch.uint8).pin_memory()
+            st = self._staging = {"dev": dev, "lay": lay, "pick": np.asarray(pick, dtype=np.int64), "host": host, "host_np": host.numpy(),
+                                  "dbuf": torch.empty((slots, lay.nbytes), dtype=torch.uint8, device=dev), "k": 0,
+                                  "copied": [torch.cuda.Event() for _ in range(slots)], "read": [torch.cuda.Event() for _ in range(slots)]}
+        lay, slot = st["lay"], st["k"] % 3
+        st["k"] += 1
+        st["copied"][slot].synchronize()                                   # the H2D copy that last read this page-locked slot has left it
+        offsets, fidx, pick, params, keys, used, cframes, clips, stored = lay.views(st["host_np"][slot])
+        v2e_params, n_stored = self.host_sample_into(sample_idx, clips[:n * hw * hw].reshape(n, hw, hw), params[0], keys[0],
+                                                     cframes[0] if cframes is not None else None, fidx[0])
+        offsets[0], stored[0] = 0, n_stored
+        pick[0] = fidx[0][st["pick"]]
+        nbytes = lay.off_clips + (n_stored * hw * hw + 15) // 16 * 16
+        with torch.cuda.device(dev):
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(st["read"][slot])                               # the launches that read this device slot three samples ago
+            dbuf = st["dbuf"][slot]
+            dbuf[:nbytes].copy_(st["host"][slot, :nbytes], non_blocking=True)
+            st["copied"][slot].record(cur)
+            offsets_d, fidx_d, pick_d, params_d, keys_d, cframes_d, clips_d, stored_d = lay.device_views(dbuf)
+            vox = esim.esim_voxel_packed(clips_d, offsets_d, fidx_d, hw, hw, params_d, keys_d, num_bins=self.num_bins,
+                                         frames_per_bin=self.frames_per_bin, stored_frames=stored_d)[0]          # [L(+1),Tb,H,W] f32
+            frame = (clip_frames_packed(clips_d, offsets_d, pick_d, hw, hw) if cframes_d is None else clip_frames_f32(cframes_d))[0]
+            st["read"][slot].record(cur)
+        out_dev = torch.device(self.output_device)
+        return {"frame": frame.to(out_dev), "events": vox.to(out_dev), "data_source_idx": torch.tensor(self.data_source_idx), "v2e_params": v2e_params}
+
     def __getitem__(self, sample_idx):
+        if self._staged_ok():
+            return self._getitem_staged(sample_idx)
         old_state = None
         if self.fixed_seed is not None:
             # the reference reads an unbound `idx` here (UnboundLocalError, SURVEY §4); the intended key is the sample index
