@@ -426,7 +426,7 @@ ALSO_DEFAULT = ["cfg2_dataset_style", "cfg2_u8", "cfg3_v2e_f32_256x32x256x256_bi
                 "train_u8_12x201x128x128_sum5", "train_batch_normalised_12x201x128x128", "cfg5_fused_convlstm_channels_last"]
 
 
-def measure_secondary(torch, dev, full, lap):
+def measure_secondary(torch, dev, full, lap, kernels_only=False):
     """Rank 0 at N = 1, after the headline's launches have warmed the clocks and outside the timed region: each secondary workload's own
     kernel time (3 warm-up + 12 timed launches), algorithmic bytes and fraction of the HBM peak; then the loader at the training
     shape (tools/loader_bench.py) and the consumer's ConvLSTM step against the bf16 matrix peak.  Never the headline value."""
@@ -450,6 +450,8 @@ def measure_secondary(torch, dev, full, lap):
         except Exception as exc:  # noqa: BLE001 - a secondary figure must not take the headline down
             also[name] = {"error": f"{type(exc).__name__}: {exc}"}
         lap(name)
+    if kernels_only:
+        return also
     try:
         also["convlstm_step_mfma"] = convlstm_roofline(torch, dev)
     except Exception as exc:  # noqa: BLE001
@@ -557,6 +559,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads of the default run")
+    ap.add_argument("--kernels-only", action="store_true", help="secondary workloads: kernel timings only (no loader bench, no ConvLSTM roofline, no host-input leg)")
     ap.add_argument("--full", action="store_true", help="every secondary workload, 200-batch loader bench, NumPy process-pool baseline (minutes)")
     ap.add_argument("--extra-out", default=None, help="sidecar file for everything that is not the contract line (default: bench_extra.json next to bench.py)")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -615,9 +618,10 @@ def main():
 
     secondary = rank == 0 and world == 1 and args.workload == DEFAULT_WORKLOAD and not args.no_also and not args.batch
     if secondary:
-        extra["also_measured"] = measure_secondary(torch, dev, args.full, lap)
-        extra["host_input"] = measure_host_input(torch, dev, W, wl, kern_avg_ms)
-        lap("host_input")
+        extra["also_measured"] = measure_secondary(torch, dev, args.full, lap, args.kernels_only)
+        if not args.kernels_only:
+            extra["host_input"] = measure_host_input(torch, dev, W, wl, kern_avg_ms)
+            lap("host_input")
 
     parity = cpu = None
     if rank == 0:

@@ -51,3 +51,11 @@ def test_the_single_clip_float32_instance_of_the_drop_in_emulator_is_scratch_fre
     hit = [r for r in resources.values() if "esim_voxel_kernel<1, 1, 0, 1, true, false, false, false, false>" in r["demangled"]]
     assert len(hit) == 1
     assert hit[0].get("scratch_bytes", 0) == 0 and hit[0]["scratch_instructions"] == 0 and hit[0]["vgpr"] <= 128
+
+
+def test_no_kernel_uses_packed_float32_instructions(resources):
+    """Round 5 (tools/pk_cohazard_probe.py): packed float32 instructions gave wrong values in lanes 48-63 whenever a matrix-core kernel of
+    another stream shared the CU -- in the x2 upsampling kernel and in the v2e simulator.  The library is built with
+    `-target-feature -packed-fp32-ops`; no v_pk_mul/add/fma_f32 may come back (an explicit builtin, a new translation unit without the flag)."""
+    bad = {r["demangled"][:120]: r["packed_f32_instructions"] for r in resources.values() if r["packed_f32_instructions"]}
+    assert not bad, bad

@@ -145,3 +145,58 @@ def test_unet_recurrent_three_steps_vs_reference(g18):
             img = net(vox[t].contiguous(memory_format=torch.channels_last))["image"]
             mx, rms = _err(img.float().cpu().numpy(), g18["unet__images"][t])
             assert img.dtype == torch.bfloat16 and mx <= 6e-2 and rms <= 1.2e-2, (t, mx, rms)     # + one bf16 rounding of the output (|img| < 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 7, 64, 64), (12, 6, 128, 128)])
+def test_forward_sequence_pipelined_over_two_streams_equals_the_step_loop(shape):
+    """E2VIDRecurrent.forward_sequence (the reference's time loop, model/train_utils.py:339-345, in one call): the decoder half of step t
+    on a second stream under the encoder half of step t + 1 gives bit-identical images and states to calling the network step by step --
+    eagerly and replayed from a captured hipGraph (fork / join through events).  (Round 5: the first version of this overlap exposed wrong
+    packed-float32 results under co-scheduling; the library carries no such instructions any more, tests/test_kernel_resources.py.)"""
+    import torch
+    from v2v_amd.unet import E2VIDRecurrent
+    n, t, h, w = shape
+    torch.manual_seed(1)
+    net = E2VIDRecurrent(dict(num_bins=5, skip_type="sum", recurrent_block_type="convlstm", num_encoders=3, base_num_channels=32,
+                              num_residual_blocks=2, use_upsample_conv=True, final_activation="", norm=None)).cuda().eval()
+    ev = torch.round(torch.randn((n, t, 5, h, w), device="cuda") * 2)
+    sc = torch.full((n, 2), 3.0, device="cuda")
+    with torch.no_grad():
+        net.reset_states()
+        want = torch.stack([net(ev[:, i], sc)["image"] for i in range(t)], 1)
+        want_states = net.states
+        for rep in range(3):                                               # a race shows up as run-to-run differences
+            net.reset_states()
+            got = net.forward_sequence(ev, sc)
+            assert got.shape == (n, t, 1, h, w) and got.dtype == ev.dtype and torch.equal(got, want), rep
+            for a, b in zip(net.states, want_states):
+                assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        net.reset_states()
+        assert torch.equal(net.forward_sequence(ev, sc, overlap=False), want)
+        # two calls continue the recurrence: states carry over
+        net.reset_states()
+        first = net.forward_sequence(ev[:, :3], sc)
+        second = net.forward_sequence(ev[:, 3:], sc)
+        assert torch.equal(torch.cat([first, second], 1), want)
+        # captured into one hipGraph
+        out = torch.empty_like(want)
+
+        def run():
+            net.reset_states()
+            net.forward_sequence(ev, sc, out=out)
+        run()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            run()
+        for rep in range(3):
+            out.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, want), rep

@@ -19,7 +19,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "v2v_amd", "csrc")
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-S", "--cuda-device-only"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-S", "--cuda-device-only"]
 TUS = ["v2v_v2e_tu", "v2v_v2e_spec_f32_tu", "v2v_v2e_spec_u8_tu", "v2v_esim_u8_tu", "v2v_esim_f32_tu", "v2v_convlstm_tu", "v2v_capi"]
 FIELDS = {".vgpr_count": "vgpr", ".vgpr_spill_count": "vgpr_spill", ".sgpr_count": "sgpr", ".sgpr_spill_count": "sgpr_spill",
           ".group_segment_fixed_size": "lds_static_bytes", ".private_segment_fixed_size": "scratch_bytes", ".agpr_count": "agpr"}
@@ -90,7 +90,15 @@ def from_so(so_path=None):
                     cur = m.group(1)
                 elif cur and re.search(r"\bscratch_(load|store)", line):
                     scratch[cur] = scratch.get(cur, 0) + 1
+            pk, curp = {}, None
+            for line in dis.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+                if m:
+                    curp = m.group(1)
+                elif curp and re.search(r"\bv_pk_(mul|add|fma)_f32", line):
+                    pk[curp] = pk.get(curp, 0) + 1
             for name, r in kernels.items():
+                r["packed_f32_instructions"] = pk.get(name, 0)
                 r["arch"] = triple.split("--")[-1] if "--" in triple else triple
                 r["scratch_instructions"] = scratch.get(name, 0)
                 r["code_object"] = i

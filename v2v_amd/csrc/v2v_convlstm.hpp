@@ -422,6 +422,9 @@ __device__ __forceinline__ void cl_unpack8(const uint4 v, float (&f)[8])
 // rows iy - 1, iy, iy + 1 (left / right output column) in registers and loads only row iy + 1 per step -- 3 (+3 skip) 16-byte
 // loads per input pixel instead of 9 (+9) when every pixel gathers its own 3 x 3 neighbourhood.  Same expressions in the
 // same order as before (horizontal 0.25 / 0.75 first, then vertical), so the output is bit-identical for any rs.
+// (Round 5: with packed float32 instructions -- the compiler's SLP pass had paired these blends into v_pk_mul_f32 / v_pk_add_f32 -- this
+// kernel returned wrong values in lanes 48-63 whenever a matrix-core kernel of another stream shared its CU; the whole library is now
+// built without packed float32 instructions, see the Makefile.)
 __global__ void __launch_bounds__(256) upsample2x_nhwc_bf16_kernel(const uint16_t *x, const uint16_t *skip, uint16_t *out, int B, int H, int W, int C, int rs)
 {
     const uint32_t c8n = (uint32_t)C >> 3, segs = (uint32_t)(H + rs - 1) / (uint32_t)rs;

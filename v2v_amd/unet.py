@@ -91,12 +91,8 @@ class UNetRecurrent(nn.Module):
         self.pred = ConvLayer(self.base_num_channels, self.num_output_channels, 1, activation=None, norm=self.norm)
         self.states = [None] * self.num_encoders
 
-    def forward(self, x, event_scales=None):
-        """x: [N, num_bins, H, W] float voxel grid (any layout), H and W multiples of 2^num_encoders -> {'image': [N,1,H,W]}.
-        event_scales (this implementation only): float32 [N,2] = (neg_max, pos_max) per sample, e.g. RingLoader(normalize='scales')'s
-        batch['event_scales'] -- normalize_batch_voxel (model/train_utils.py:147-166) is then applied by the head while it reads the
-        RAW voxel grid; None = x is used as it is."""
-        out_dtype = torch.bfloat16 if (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()) else x.dtype
+    def _encode(self, x, event_scales):
+        """head + the recurrent encoders of one time step (model/unet.py:287-296) -> (head, blocks): everything that touches the states."""
         with torch.autocast("cuda", dtype=torch.bfloat16):      # the head hands out bfloat16; every later layer keeps it
             x = self.head(x, scales=event_scales)               # reads any strides (its own layout kernel), bfloat16 NHWC out
         head = x
@@ -105,6 +101,11 @@ class UNetRecurrent(nn.Module):
             x, state = encoder(x, self.states[i])
             blocks.append(x)
             self.states[i] = state
+        return head, blocks
+
+    def _decode(self, head, blocks):
+        """residual blocks + decoders + prediction of one time step (model/unet.py:298-309): stateless."""
+        x = blocks[-1]
         for resblock in self.resblocks:
             x = resblock(x)
         for i, decoder in enumerate(self.decoders):
@@ -112,7 +113,61 @@ class UNetRecurrent(nn.Module):
         img = self.pred(x, head)                                 # pred(skip_sum(x, head)) in one pass (:307)
         if self.final_activation is not None:
             img = self.final_activation(img)
-        return {"image": img.to(out_dtype)}
+        return img
+
+    def forward_sequence(self, events, event_scales=None, out=None, overlap=True):
+        """The time loop of model/train_utils.py:339-345 (`for t in range(T): pred = model(events[:, t]); pred_imgs[:, t] = pred['image']`)
+        as ONE call: events [N,T,num_bins,H,W] -> images [N,T,1,H,W] (events' dtype, or `out`), the states advanced by T steps.
+
+        The recurrence only runs through the encoders' ConvLSTM states; residual blocks, decoders and prediction of step t are stateless.
+        With overlap=True they are issued on a second HIP stream, so step t's decoder half runs UNDER step t+1's encoder half: at the
+        training shape (12 x 128 x 128) no single layer fills 256 CUs (48-384 workgroups), and two half-filling kernels side by side
+        use what one leaves idle.  Same kernels on the same operands in the same per-tensor order: results are bit-identical to the
+        step-by-step loop.  Stream-ordering contract with torch's caching allocator: tensors made on the caller's stream and read on
+        the side stream (head, skip blocks) are kept alive until the caller's stream has waited for the side stream's event of that
+        step, so a freed block can never be handed out again while the side stream still reads it.  Captures into a hipGraph
+        (fork/join through events) like the single-stream loop."""
+        if events.dim() != 5:
+            raise ValueError("events must be [N, T, num_bins, H, W]")
+        n, t_steps = events.shape[:2]
+        out_dtype = torch.bfloat16 if (events.dtype == torch.bfloat16 or torch.is_autocast_enabled()) else events.dtype
+        if out is None:
+            out = torch.empty((n, t_steps, self.num_output_channels) + tuple(events.shape[-2:]), dtype=out_dtype, device=events.device)
+        if not overlap:
+            for t in range(t_steps):
+                head, blocks = self._encode(events[:, t], event_scales)
+                out[:, t] = self._decode(head, blocks)
+            return out
+        cur = torch.cuda.current_stream(events.device)
+        side = self.__dict__.get("_side_stream")
+        if side is None or side.device != events.device:
+            side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=events.device)
+        side.wait_stream(cur)                                   # `out`, the weights' packed copies, whatever the caller queued before
+        held = []                                               # (tensors of a step the side stream reads, its completion event)
+        for t in range(t_steps):
+            if len(held) == 2:                                  # two steps in flight: step t-2's operands may go once cur is ordered after their last reader
+                cur.wait_event(held[0][1])
+                held.pop(0)
+            head, blocks = self._encode(events[:, t], event_scales)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                out[:, t] = self._decode(head, blocks)
+                done = torch.cuda.Event()
+                done.record(side)
+            held.append(((head, blocks), done))
+        cur.wait_stream(side)
+        return out
+
+    def forward(self, x, event_scales=None):
+        """x: [N, num_bins, H, W] float voxel grid (any layout), H and W multiples of 2^num_encoders -> {'image': [N,1,H,W]}.
+        event_scales (this implementation only): float32 [N,2] = (neg_max, pos_max) per sample, e.g. RingLoader(normalize='scales')'s
+        batch['event_scales'] -- normalize_batch_voxel (model/train_utils.py:147-166) is then applied by the head while it reads the
+        RAW voxel grid; None = x is used as it is."""
+        out_dtype = torch.bfloat16 if (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()) else x.dtype
+        head, blocks = self._encode(x, event_scales)
+        return {"image": self._decode(head, blocks).to(out_dtype)}
 
 
 def copy_states(states):
@@ -144,3 +199,8 @@ class E2VIDRecurrent(nn.Module):
 
     def forward(self, event_tensor, event_scales=None):
         return self.unetrecurrent.forward(event_tensor, event_scales)
+
+    def forward_sequence(self, events, event_scales=None, out=None, overlap=True):
+        """[N,T,num_bins,H,W] -> [N,T,1,H,W]: the reference's time loop (model/train_utils.py:339-345) in one call, decoder half of step t
+        under the encoder half of step t+1 (UNetRecurrent.forward_sequence)."""
+        return self.unetrecurrent.forward_sequence(events, event_scales, out=out, overlap=overlap)
