@@ -228,6 +228,9 @@ class Workload:
 
                         def __call__(self, x):
                             return net(x)["image"]
+
+                        def forward_sequence(self, events):                  # the whole time loop in one call, two streams (v2v_amd/unet.py)
+                            return net.forward_sequence(events)
                     consumer = _Seq()
                 else:
                     consumer = E2VIDShapedConsumer(num_bins=tb, fused_convlstm=fused).to(dev).eval()
@@ -659,7 +662,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic", "dist_backend": backend, "dist_world_size": (dist.get_world_size() if dist is not None else 1),
-            "ms_per_step_per_rank": [round(v, 4) for v in per_rank_ms],
+            "ms_per_step_per_rank": [round(v, 6) for v in per_rank_ms],
             "config": {"workload": args.workload, "simulator": wl["model"], "clips_per_gpu": W.b, "frames": wl["n"], "height": wl["h"], "width": wl["w"],
                        "input_dtype": wl["dtype"], "output_dtype": "float32", "state_dtype": "float64",
                        "bin_mode": wl["bin"], "num_bins": wl["tb"], "frames_per_bin": wl["fpb"], "sim_params": wl["params"],

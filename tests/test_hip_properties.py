@@ -255,4 +255,4 @@ def test_bench_gpus_n_without_a_launcher_starts_the_ranks_itself():
     assert len(lines) == 1, res.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["dist_world_size"] == 2 and len(d["ms_per_step_per_rank"]) == 2 and d["dist_backend"] == "gloo"
-    assert max(d["ms_per_step_per_rank"]) <= d["ms_per_step"] * 1.0001 and d["parity_check"] == "ok"
+    assert max(d["ms_per_step_per_rank"]) <= d["ms_per_step"] * 1.001 and d["parity_check"] == "ok"

@@ -142,6 +142,8 @@ def forward_sequence(model, events, channels_last=False):
     """events [B,T,C,H,W] -> list of T predictions (the time loop of model/train_utils.py:339-345).  channels_last=True feeds
     every time step in torch.channels_last (the model should have been moved with .to(memory_format=torch.channels_last))."""
     model.reset_states()
+    if hasattr(model, "forward_sequence"):                                   # the package network: time loop + stream overlap inside
+        return model.forward_sequence(events)
     if channels_last and (isinstance(getattr(model, "head", None), _FusedConv) or getattr(model, "reads_any_layout", False)):
         return [model(events[:, t]) for t in range(events.shape[1])]       # the fused head reads any strides (its own layout kernel)
     if channels_last:

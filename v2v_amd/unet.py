@@ -122,11 +122,13 @@ class UNetRecurrent(nn.Module):
         The recurrence only runs through the encoders' ConvLSTM states; residual blocks, decoders and prediction of step t are stateless.
         With overlap=True they are issued on a second HIP stream, so step t's decoder half runs UNDER step t+1's encoder half: at the
         training shape (12 x 128 x 128) no single layer fills 256 CUs (48-384 workgroups), and two half-filling kernels side by side
-        use what one leaves idle.  Same kernels on the same operands in the same per-tensor order: results are bit-identical to the
-        step-by-step loop.  Stream-ordering contract with torch's caching allocator: tensors made on the caller's stream and read on
-        the side stream (head, skip blocks) are kept alive until the caller's stream has waited for the side stream's event of that
-        step, so a freed block can never be handed out again while the side stream still reads it.  Captures into a hipGraph
-        (fork/join through events) like the single-stream loop."""
+        use what one leaves idle (0.50 -> 0.37 ms per time step, tools/e2vid_pipeline_probe.py).  Same kernels on the same operands in
+        the same per-tensor order: results are bit-identical to the step-by-step loop (tests/test_unet_golden.py).
+        Stream-ordering contract with torch's caching allocator: tensors made on the caller's stream and read on the side stream
+        (head, skip blocks) are kept alive until the caller's stream has waited for the side stream's event of that step, so a freed
+        block can never be handed out again while the side stream still reads it.  Captures into a hipGraph (fork / join through
+        events) like the single-stream loop.  (A three-stage form -- the decoder half split over two side streams -- runs eagerly but
+        crashed hipGraph's capture_end on ROCm 7.2 and is not carried.)"""
         if events.dim() != 5:
             raise ValueError("events must be [N, T, num_bins, H, W]")
         n, t_steps = events.shape[:2]
