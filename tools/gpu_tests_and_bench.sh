@@ -4,8 +4,9 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 t0=$(date +%s)
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/drv_bench.json 2> gpurun_out/drv_bench.err
+brc=$?
 cp bench_extra.json gpurun_out/drv_bench_extra.json 2>/dev/null
-echo "bench rc=$? wall=$(( $(date +%s) - t0 ))s line_bytes=$(tail -n 1 gpurun_out/drv_bench.json | wc -c) stdout_lines=$(wc -l < gpurun_out/drv_bench.json)"
+echo "bench rc=$brc wall=$(( $(date +%s) - t0 ))s line_bytes=$(tail -n 1 gpurun_out/drv_bench.json | wc -c) stdout_lines=$(wc -l < gpurun_out/drv_bench.json)"
 python - <<'PY'
 import json
 try:
