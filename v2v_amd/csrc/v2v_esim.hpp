@@ -88,10 +88,11 @@ __device__ __forceinline__ void pix_logs(const Raw<IN, VEC> &r, const typename L
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float v = raw_f32<VEC>(r, j);
-            // v + 2^23 puts an integer v in 0..255 into the low mantissa byte (one cheap add instead of a
-            // convert); the byte is always a valid index, and converting it back exposes every other input
-            const uint32_t b = __float_as_uint(v + 8388608.0f);
-            const float2 e = at((b << kSh) & kMask);
+            // v + 2^20 puts an integer v in 0..255 into mantissa bits 3..10 (ulp = 1/8): masked, that IS the byte offset of the
+            // 8-byte table entry -- one cheap add and one and, no convert, no shift; the bits are always a valid offset, and the
+            // index that comes back with the entry exposes every other input (non-integer, negative, > 255, NaN)
+            const uint32_t b = __float_as_uint(v + 1048576.0f);
+            const float2 e = at(b & kMask);
             out[j] = e.x;
             bad |= __ballot(e.y != v);                         // e.y = (float)(b & 255): non-integer, negative, > 255, NaN
         }
@@ -99,7 +100,7 @@ __device__ __forceinline__ void pix_logs(const Raw<IN, VEC> &r, const typename L
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const float v = raw_f32<VEC>(r, j);
-                if ((float)(__float_as_uint(v + 8388608.0f) & 255u) != v) out[j] = log_generic_f32(v);
+                if ((float)((__float_as_uint(v + 1048576.0f) >> 3) & 255u) != v) out[j] = log_generic_f32(v);
             }
         }
     }
@@ -157,11 +158,12 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
     // a wave-level branch, zeros not at all (derived from the element count) -- 3 compares per stored voxel instead of a 157 MB pass.
     constexpr bool STATS = BIN == kBinSum && !OUT64 && !EXT;
     __shared__ unsigned int s_hist[STATS ? kStatBins : 1];
-    const bool want_stats = STATS && a.stats != nullptr;                    // wave-uniform (kernel argument)
+    // (kernel-argument tests go through readfirstlane: as plain bools the compiler kept them as lane masks and re-materialised them
+    // with a v_cndmask + v_cmp pair in every step of the time loop)
+    const bool want_stats = STATS && __builtin_amdgcn_readfirstlane((int)(a.stats != nullptr)) != 0;
     uint32_t st_p1 = 0, st_m1 = 0;                                          // wave totals of +1 / -1 (scalar registers)
-    acc_t *s_wlo = reinterpret_cast<acc_t *>(s_raw);
-    acc_t *s_whi = s_wlo + a.K;
-    int *s_kb = reinterpret_cast<int *>(s_whi + a.K);      // [Tb] first pair index of each bin segment
+    acc_t *s_w = reinterpret_cast<acc_t *>(s_raw);         // BILINEAR: {lower-bin weight, upper-bin weight} of pair k at s_w[2k], s_w[2k + 1] (one LDS read per step)
+    int *s_kb = reinterpret_cast<int *>(s_w + 2 * a.K);    // [Tb] first pair index of each bin segment
 
     // ---- workgroup prologue: tables into LDS
     if constexpr (ICDF) icdf_to_lds(s_icdf);
@@ -211,8 +213,8 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
             const int b0 = seg_of(t_norm);
             const double wl = 1.0 - fabs(t_norm - (double)b0);
             const double wh = 1.0 - fabs(t_norm - (double)(b0 + 1));
-            s_wlo[k] = (acc_t)(wl > 0.0 ? wl : 0.0);
-            s_whi[k] = (acc_t)(wh > 0.0 ? wh : 0.0);
+            s_w[2 * k] = (acc_t)(wl > 0.0 ? wl : 0.0);
+            s_w[2 * k + 1] = (acc_t)(wh > 0.0 ? wh : 0.0);
             const int bprev = k > 0 ? seg_of(t_of(k - 1)) : 0;
             for (int b = bprev + 1; b <= b0; ++b) s_kb[b] = k;          // seg() is non-decreasing in k
         }
@@ -367,7 +369,9 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
 #pragma unroll
             for (int j = 0; j < VEC; ++j) base[j] = 0.0;
             if constexpr (RNG == kRngPhilox) {
-                if (has_base) {                                        // uniform (scalar); 0*g adds nothing
+                // (internal noise: no `base_std != 0` branch -- 0 * g is +-0 and p + (+-0) is p bit for bit, because p = pot + d is never
+                // -0.0; the branch cost four register clears per step.  External noise adds to the voxel, where -0.0 occurs: branch kept)
+                if (!EXT || has_base) {
                     float g[VEC];
                     if constexpr (PAR == 0) {
                         if (VEC == 1 && share_quads) {
@@ -411,7 +415,12 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
             }
         }
         acc_t wl = 1, wh = 0;
-        if constexpr (BIN == kBinBilinear) { wl = s_wlo[k]; wh = s_whi[k]; }
+        if constexpr (BIN == kBinBilinear) {
+            typedef acc_t w2_t __attribute__((ext_vector_type(2)));
+            const w2_t w2 = *reinterpret_cast<const w2_t *>(s_w + 2 * k);
+            wl = w2.x;
+            wh = w2.y;
+        }
 
         if constexpr (VEC != 1) pix_logs<IN, VEC>(raw, s_lut, ln);
 
@@ -420,7 +429,6 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
         // and `p -= q*C` with q = 0 leaves p untouched bit for bit.  The VEC pixels are independent chains.
         // Phase A: new potential, polarity, reciprocal quotient estimate and its sign-exact fma residual.
         double mag[VEC], thr[VEC], q[VEC], r[VEC];
-        uint32_t sgn[VEC];
         unsigned long long fix = 0;                                    // wave-level mask in an SGPR pair (no per-lane bool)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -431,26 +439,31 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
             // which a round-to-nearest sum with the never-negative-zero log difference cannot be -- but the scalar branch
             // costs more than the four adds: +2.5 % on the same box, round 2.)
             if constexpr (NOISE && !EXT) { p = p + base[j]; if constexpr (HOT) p = p + hot[j]; }
-            sgn[j] = (uint32_t)__double2hiint(p) & 0x80000000u;
-            mag[j] = fabs(p);
+            // The whole chain in SIGNED form: trunc, the rounded product, the fma and the subtraction are odd functions under
+            // round-to-nearest, so q = sign(p) * floor(|p| / C), the residual and the new potential come out with p's sign and the
+            // magnitudes of the unsigned form bit for bit -- no sign extraction for the arithmetic, no sign re-insertion into the
+            // potential and the count (round 5: -3 vector instructions per pixel-step with C+ == C-, -2 otherwise).  An exact-zero
+            // residual is +0.0 here (as in NumPy's `potential += neg * C`) where the unsigned form gave -0.0 for negative p:
+            // invisible either way, pot + d is the same sum for both (d is never -0.0).
             double inv;
             if constexpr (SYM) { thr[j] = pos; inv = inv_pos; }
-            else {
-                const double2 ti = *reinterpret_cast<const double2 *>(reinterpret_cast<const unsigned char *>(s_thr) + (sgn[j] >> 27));
+            else {                                                     // {C, 1/C} of the polarity: one 16-byte LDS read at (sign bit) * 16
+                const double2 ti = *reinterpret_cast<const double2 *>(reinterpret_cast<const unsigned char *>(s_thr) + (((uint32_t)__double2hiint(p) >> 27) & 16u));
                 thr[j] = ti.x;
                 inv = ti.y;
             }
-            // inv is biased low, so the estimate never exceeds the true quotient; it is short by one only when
-            // |p|/C sits within ~1e-15 above an integer -- and then (or for a NaN potential) r < C fails
-            q[j] = floor(mag[j] * inv);
-            r[j] = __builtin_fma(-q[j], thr[j], mag[j]);
-            fix |= __ballot(!(r[j] < thr[j]));
+            mag[j] = p;
+            // inv is biased low, so the estimate never exceeds the true quotient in magnitude; it is short by one only when
+            // |p|/C sits within ~1e-15 above an integer -- and then (or for a NaN potential) |r| < C fails
+            q[j] = trunc(p * inv);
+            r[j] = __builtin_fma(-q[j], thr[j], p);
+            fix |= __ballot(!(fabs(r[j]) < thr[j]));
         }
         if (__builtin_expect(fix != 0, 0)) {                                // rare: exact multiples, NaN
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                if (r[j] >= thr[j]) q[j] += 1.0;
-                else if (!(r[j] < thr[j])) q[j] = 0.0;                 // NaN potential: NumPy's compares are false -> no events
+                if (fabs(r[j]) >= thr[j]) q[j] += __builtin_copysign(1.0, r[j]);
+                else if (!(fabs(r[j]) < thr[j])) q[j] = 0.0;           // NaN potential: NumPy's compares are false -> no events
             }
         }
         // Phase B: reset the potential (v2v_core_esim.py:57-58), signed count, binning.
@@ -460,10 +473,10 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
         for (int j = 0; j < VEC; ++j) {
             const double qt = q[j] * thr[j];
             const double m2 = mag[j] - qt;                             // product rounded, then subtracted (no fma)
-            pot[j] = __hiloint2double((int)((uint32_t)__double2hiint(m2) ^ sgn[j]), __double2loint(m2));
+            pot[j] = m2;
             if constexpr (OUT64) {
-                double vox = __hiloint2double((int)((uint32_t)__double2hiint(q[j]) ^ sgn[j]), __double2loint(q[j]));
-                qabs[j] = (float)q[j];
+                double vox = q[j];
+                qabs[j] = __builtin_fabsf((float)q[j]);
                 if constexpr (EXT) { vox = vox + base[j]; vox = vox + hot[j]; }   // :64-65
                 if constexpr (BIN == kBinBilinear) {
                     const double cl = vox * wl, ch = vox * wh;         // bincount adds ps*w (no fma)
@@ -474,8 +487,8 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
                 }
             } else {
                 const float qf = (float)q[j];
-                qabs[j] = qf;
-                float vf = __uint_as_float(__float_as_uint(qf) ^ sgn[j]);
+                qabs[j] = __builtin_fabsf(qf);
+                float vf = qf;
                 if constexpr (EXT) { double vox = (double)vf; vox = vox + base[j]; vox = vox + hot[j]; vf = (float)vox; }
                 if constexpr (PK) {
                     vfs[j] = vf;
@@ -496,12 +509,14 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
                 acc_lo[j] = lo.x; acc_lo[j + 1] = lo.y; acc_hi[j] = hi.x; acc_hi[j + 1] = hi.y;
             }
         }
-        if (want_counts) {                                             // wave-uniform
+        const unsigned long long *cp = a.counts;                       // the kernel argument (a scalar register pair), re-tested in every step: as a
+        asm("" : "+s"(cp));                                            // bool hoisted out of the loop it lived as a lane mask and cost a v_cndmask +
+        if (cp != nullptr) {                                           // v_cmp per step.  Wave-uniform
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const uint32_t n = (uint32_t)qabs[j];
                 n_all += n;
-                n_off += sgn[j] ? n : 0u;
+                n_off += q[j] < 0.0 ? n : 0u;
             }
         }
         if constexpr (BIN == kBinSum) {
