@@ -172,8 +172,9 @@ def test_forward_sequence_pipelined_over_two_streams_equals_the_step_loop(shape)
             assert got.shape == (n, t, 1, h, w) and got.dtype == ev.dtype and torch.equal(got, want), rep
             for a, b in zip(net.states, want_states):
                 assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-        net.reset_states()
-        assert torch.equal(net.forward_sequence(ev, sc, overlap=False), want)
+        for ov in (False, 1, 2):                                          # the plain loop; one / two side streams (True = three)
+            net.reset_states()
+            assert torch.equal(net.forward_sequence(ev, sc, overlap=ov), want), ov
         # two calls continue the recurrence: states carry over
         net.reset_states()
         first = net.forward_sequence(ev[:, :3], sc)

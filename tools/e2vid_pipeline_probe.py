@@ -41,11 +41,11 @@ for (b, t, h, w) in ((12, 40, 128, 128), (8, 8, 256, 256)):
     sc = torch.ones((b, 2), device="cuda") * 3
     res = {}
     with torch.no_grad():
-        for name, overlap in (("loop", False), ("two_streams", True), ("loop", False), ("two_streams", True)):
+        for name, overlap in (("loop", False), ("one_side", 1), ("two_sides", 2), ("three_sides", 3), ("loop", False), ("one_side", 1), ("two_sides", 2), ("three_sides", 3)):
             def run():
                 net.reset_states()
                 return net.forward_sequence(ev, sc, overlap=overlap)
             ms, img = timed_graph(run)
             res[name] = img.clone()
             print(f"{b}x{t}x5x{h}x{w}  {name:12s} {ms:8.3f} ms / sequence   {ms / t:6.3f} ms / step   {b / (ms * 1e-3):8.0f} samples/s")
-    print("identical:", torch.equal(res["loop"], res["two_streams"]), float(res["loop"].float().abs().mean()))
+    print("identical:", [torch.equal(res["loop"], res[k]) for k in ("one_side", "two_sides", "three_sides")], float(res["loop"].float().abs().mean()))

@@ -120,15 +120,16 @@ class UNetRecurrent(nn.Module):
         as ONE call: events [N,T,num_bins,H,W] -> images [N,T,1,H,W] (events' dtype, or `out`), the states advanced by T steps.
 
         The recurrence only runs through the encoders' ConvLSTM states; residual blocks, decoders and prediction of step t are stateless.
-        With overlap=True they are issued on a second HIP stream, so step t's decoder half runs UNDER step t+1's encoder half: at the
-        training shape (12 x 128 x 128) no single layer fills 256 CUs (48-384 workgroups), and two half-filling kernels side by side
-        use what one leaves idle (0.50 -> 0.37 ms per time step, tools/e2vid_pipeline_probe.py).  Same kernels on the same operands in
+        With overlap they are issued on side HIP streams (overlap=True: three, taken in turn by consecutive steps; an int: that many),
+        so step t's decoder half runs UNDER step t+1's encoder half and beside its neighbours' decoder halves: at the training shape
+        (12 x 128 x 128) no single layer fills 256 CUs (48-384 workgroups), and half-filling kernels side by side use what one leaves
+        idle (ms per time step, hipGraph replay, tools/e2vid_pipeline_probe.py: loop 0.50, one side stream 0.37, two 0.355, three 0.34).  Same kernels on the same operands in
         the same per-tensor order: results are bit-identical to the step-by-step loop (tests/test_unet_golden.py).
         Stream-ordering contract with torch's caching allocator: tensors made on the caller's stream and read on the side stream
         (head, skip blocks) are kept alive until the caller's stream has waited for the side stream's event of that step, so a freed
         block can never be handed out again while the side stream still reads it.  Captures into a hipGraph (fork / join through
-        events) like the single-stream loop.  (A three-stage form -- the decoder half split over two side streams -- runs eagerly but
-        crashed hipGraph's capture_end on ROCm 7.2 and is not carried.)"""
+        events) like the single-stream loop.  (A three-STAGE form -- the decoder half itself split over two chained side streams -- ran
+        eagerly but crashed hipGraph's capture_end on ROCm 7.2; whole decoder halves on alternating streams capture fine.)"""
         if events.dim() != 5:
             raise ValueError("events must be [N, T, num_bins, H, W]")
         n, t_steps = events.shape[:2]
@@ -141,25 +142,31 @@ class UNetRecurrent(nn.Module):
                 out[:, t] = self._decode(head, blocks)
             return out
         cur = torch.cuda.current_stream(events.device)
-        side = self.__dict__.get("_side_stream")
-        if side is None or side.device != events.device:
-            side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=events.device)
-        side.wait_stream(cur)                                   # `out`, the weights' packed copies, whatever the caller queued before
-        held = []                                               # (tensors of a step the side stream reads, its completion event)
+        n_side = 3 if overlap is True else max(1, int(overlap))  # decoder halves of consecutive steps alternate between the side streams
+        pool = self.__dict__.setdefault("_side_streams", {})
+        key = (events.device, n_side)
+        if key not in pool:
+            pool[key] = [torch.cuda.Stream(device=events.device) for _ in range(n_side)]
+        sides = pool[key]
+        for side in sides:
+            side.wait_stream(cur)                               # `out`, the weights' packed copies, whatever the caller queued before
+        held = []                                               # (tensors of a step a side stream reads, its completion event)
         for t in range(t_steps):
-            if len(held) == 2:                                  # two steps in flight: step t-2's operands may go once cur is ordered after their last reader
+            if len(held) == n_side + 1:                         # the oldest step's operands may go once cur is ordered after their last reader
                 cur.wait_event(held[0][1])
                 held.pop(0)
             head, blocks = self._encode(events[:, t], event_scales)
             ready = torch.cuda.Event()
             ready.record(cur)
+            side = sides[t % n_side]
             with torch.cuda.stream(side):
                 side.wait_event(ready)
                 out[:, t] = self._decode(head, blocks)
                 done = torch.cuda.Event()
                 done.record(side)
             held.append(((head, blocks), done))
-        cur.wait_stream(side)
+        for side in sides:
+            cur.wait_stream(side)
         return out
 
     def forward(self, x, event_scales=None):
