@@ -538,6 +538,53 @@ def write_sidecar(obj, path):
     return written
 
 
+def contract_line(*, workload, wl, clips_per_gpu, grids_per_step, alg_bytes, kernel_name, world, steps, warmup, elapsed_s, per_rank_ms, kern_ms_sorted,
+                  backend, dist_world, use_graph, traffic, cpu, parity):
+    """THE contract line as a dict (pure function: tests/test_host_logic.py builds it for 8 ranks without a GPU): small, the contract's
+    keys + `config` (shape keys, no prose) + `roofline` + `cpu_baseline` + `parity_check`; everything else goes to the sidecar file."""
+    kern_avg_ms = sum(kern_ms_sorted) / len(kern_ms_sorted)
+    achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
+    hints = []
+    if wl["model"] == "esim" and wl["params"][0] == wl["params"][1]:
+        hints.append("V2V_FLAG_SYMMETRIC")
+    if wl["model"] == "esim" and wl["params"][2] == 0 and wl["params"][3] <= 0:
+        hints.append("V2V_FLAG_NO_NOISE")
+    n = len(kern_ms_sorted)
+    return {
+        "metric": "voxel grids/sec", "value": grids_per_step * world * steps / elapsed_s, "unit": "voxel grids/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed_s / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic", "dist_backend": backend, "dist_world_size": dist_world,
+        "ms_per_step_per_rank": [round(v, 6) for v in per_rank_ms],
+        "config": {"workload": workload, "simulator": wl["model"], "clips_per_gpu": clips_per_gpu, "frames": wl["n"], "height": wl["h"], "width": wl["w"],
+                   "input_dtype": wl["dtype"], "output_dtype": "float32", "state_dtype": "float64",
+                   "bin_mode": wl["bin"], "num_bins": wl["tb"], "frames_per_bin": wl["fpb"], "sim_params": wl["params"],
+                   "rng": "philox4x32", "kernel_hints": hints, "sharding": f"batch over {world} GPU(s), no collective",
+                   "grid": [wl["tb"], wl["h"], wl["w"]], "launch": "hipGraph replay" if use_graph else "eager"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "kernel": kernel_name, "algorithmic_bytes_per_launch": alg_bytes,
+                     "kernel_ms_avg": kern_avg_ms, "kernel_ms_p10": kern_ms_sorted[n // 10],
+                     "kernel_ms_p50": kern_ms_sorted[n // 2], "kernel_ms_p90": kern_ms_sorted[(n * 9) // 10]},
+        "cpu_baseline": cpu,
+        "parity_check": parity,
+        "extra": None,
+    }
+
+
+def line_text(line):
+    """JSON text of the contract line, never above MAX_LINE_BYTES: a line the driver cannot parse is worth nothing, so the optional keys
+    are shed first (they stay in the sidecar)."""
+    text = json.dumps(line)
+    if len(text) > MAX_LINE_BYTES:
+        line = dict(line)
+        for key in ("ms_per_step_per_rank", "parity_check", "extra"):
+            line.pop(key, None)
+        line["config"] = {"workload": line["config"]["workload"], "clips_per_gpu": line["config"]["clips_per_gpu"]}
+        text = json.dumps(line)
+    return text
+
+
 def self_launch(n_gpus):
     """Re-run this script as `n_gpus` ranks under torch.distributed.run (child process; this one never initialises the GPU)."""
     import socket
@@ -650,33 +697,10 @@ def main():
             parity = f"unchecked ({type(exc).__name__}: {exc})"
 
     if rank == 0:
-        achieved = W.alg_bytes / (kern_avg_ms * 1e-3) / 1e9
-        hints = []
-        if wl["model"] == "esim" and wl["params"][0] == wl["params"][1]:
-            hints.append("V2V_FLAG_SYMMETRIC")
-        if wl["model"] == "esim" and wl["params"][2] == 0 and wl["params"][3] <= 0:
-            hints.append("V2V_FLAG_NO_NOISE")
-        # THE contract line: small (asserted <= 4 KB), printed last and alone on stdout.  Everything else goes to the sidecar file.
-        line = {
-            "metric": "voxel grids/sec", "value": W.grids_per_step * world * args.steps / elapsed, "unit": "voxel grids/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic", "dist_backend": backend, "dist_world_size": (dist.get_world_size() if dist is not None else 1),
-            "ms_per_step_per_rank": [round(v, 6) for v in per_rank_ms],
-            "config": {"workload": args.workload, "simulator": wl["model"], "clips_per_gpu": W.b, "frames": wl["n"], "height": wl["h"], "width": wl["w"],
-                       "input_dtype": wl["dtype"], "output_dtype": "float32", "state_dtype": "float64",
-                       "bin_mode": wl["bin"], "num_bins": wl["tb"], "frames_per_bin": wl["fpb"], "sim_params": wl["params"],
-                       "rng": "philox4x32", "kernel_hints": hints, "sharding": f"batch over {world} GPU(s), no collective",
-                       "grid": [wl["tb"], wl["h"], wl["w"]], "launch": "hipGraph replay" if use_graph else "eager"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(args.workload),
-                         "kernel": W.kernel_name, "algorithmic_bytes_per_launch": W.alg_bytes,
-                         "kernel_ms_avg": kern_avg_ms, "kernel_ms_p10": kern_ms[len(kern_ms) // 10],
-                         "kernel_ms_p50": kern_ms[len(kern_ms) // 2], "kernel_ms_p90": kern_ms[(len(kern_ms) * 9) // 10]},
-            "cpu_baseline": cpu,
-            "parity_check": parity,
-            "extra": None,
-        }
+        line = contract_line(workload=args.workload, wl=wl, clips_per_gpu=W.b, grids_per_step=W.grids_per_step, alg_bytes=W.alg_bytes, kernel_name=W.kernel_name,
+                             world=world, steps=args.steps, warmup=args.warmup, elapsed_s=elapsed, per_rank_ms=per_rank_ms, kern_ms_sorted=kern_ms,
+                             backend=backend, dist_world=(dist.get_world_size() if dist is not None else 1), use_graph=use_graph,
+                             traffic=load_traffic(args.workload), cpu=cpu, parity=parity)
         extra["headline"] = {"kernel_ms_trace": [round(v, 4) for v in kern_trace], "valu_issue": load_valu(args.workload, kern_avg_ms),
                              "measured_ceilings_GBps": MEASURED_CEILINGS_GBPS,
                              "traffic_source": "static: profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, collected "
@@ -687,14 +711,8 @@ def main():
                              "note": "noise-on launches are VALU-issue-bound, not HBM-bound (DESIGN.md); `frac` is still quoted against the HBM peak; "
                                      "`valu_issue` gives the same launch against the vector-issue ceilings"}
         line["extra"] = write_sidecar(dict(line, **extra), args.extra_out)
-        text = json.dumps(line)
-        if len(text) > MAX_LINE_BYTES:                 # never hand the driver a line it cannot parse: shed the optional keys, keep the contract
-            for key in ("ms_per_step_per_rank", "parity_check", "extra"):
-                line.pop(key, None)
-            line["config"] = {"workload": args.workload, "clips_per_gpu": W.b}
-            text = json.dumps(line)
         sys.stderr.flush()
-        print(text, flush=True)
+        print(line_text(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -140,3 +140,35 @@ def test_pause_chain_draws_equal_the_scalar_loop(tmp_path):
             st = np.random.get_state()
             assert got == img_idxes and end - start == idx + 1
             assert np.array_equal(st[1], want_state[1]) and st[2:] == want_state[2:]
+
+
+def test_bench_contract_line_for_eight_ranks_is_small_and_complete():
+    """The line bench.py prints is built by a pure function: for 8 ranks (no multi-GPU node has run it yet) it carries the contract's keys,
+    one time per rank, a whole-job aggregate over all ranks, and stays far below the 4 KB the driver's stdout tail keeps; an over-long
+    line sheds its optional keys instead of becoming unparseable (round 4's 21.9 KB line was `parsed: null`)."""
+    import json
+    import bench
+    wl = bench.WORKLOADS[bench.DEFAULT_WORKLOAD]
+    kern = sorted(0.57 + 0.001 * i for i in range(20))
+    cpu = {"value": 11.2, "unit": "voxel grids/s", "cores": 1, "kind": "port", "sample": "3 of the batch's clips (32x256x256 float32), NumPy port, single thread, 12.3 s"}
+    line = bench.contract_line(workload=bench.DEFAULT_WORKLOAD, wl=wl, clips_per_gpu=256, grids_per_step=256, alg_bytes=2483027968, kernel_name="esim_voxel_kernel",
+                               world=8, steps=20, warmup=5, elapsed_s=0.0118, per_rank_ms=[0.58 + 0.002 * r for r in range(8)], kern_ms_sorted=kern,
+                               backend="nccl", dist_world=8, use_graph=False, traffic=2491741150.0, cpu=None, parity="ok")
+    text = bench.line_text(line)
+    d = json.loads(text)
+    assert len(text.encode()) <= 2048 and "\n" not in text
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline", "parity_check", "dist_backend", "dist_world_size", "ms_per_step_per_rank"):
+        assert key in d, key
+    assert d["n_gpus"] == 8 and len(d["ms_per_step_per_rank"]) == 8 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert abs(d["value"] - 8 * 256 * 20 / 0.0118) < 1e-6 and abs(d["ms_per_step"] - 0.59) < 1e-9          # whole-job aggregate over all ranks
+    assert d["roofline"]["bound"] == "hbm" and abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / 8000.0) < 1e-12
+    assert d["config"]["workload"] == bench.DEFAULT_WORKLOAD and "8 GPU(s)" in d["config"]["sharding"]
+    # N = 1 with the CPU baseline, and a pathological line that would not fit
+    one = bench.contract_line(workload=bench.DEFAULT_WORKLOAD, wl=wl, clips_per_gpu=256, grids_per_step=256, alg_bytes=2483027968, kernel_name="esim_voxel_kernel",
+                              world=1, steps=20, warmup=5, elapsed_s=0.0117, per_rank_ms=[0.585], kern_ms_sorted=kern, backend=None, dist_world=1, use_graph=False,
+                              traffic=2491741150.0, cpu=cpu, parity="ok")
+    assert len(bench.line_text(one).encode()) <= 2048
+    fat = dict(one, parity_check="x" * 10000)
+    slim = json.loads(bench.line_text(fat))
+    assert len(bench.line_text(fat).encode()) <= bench.MAX_LINE_BYTES and "parity_check" not in slim and slim["value"] == one["value"] and "roofline" in slim
