@@ -10,7 +10,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from v2v_amd import esim, frontend  # noqa: E402
 
-b, n, sh, sw, crop = 24, 41, 720, 1280, 256
+b, n, sh, sw, crop = 24, int(os.environ.get("V2V_FT_N", "41")), 720, 1280, 256
 gray_video = esim.synth_clips(b, n, sh, sw, dtype=torch.uint8, seed=20240001, clip_id0=0)
 raw = torch.stack([gray_video, gray_video.flip(-1), 255 - gray_video], dim=-1).contiguous()
 del gray_video

@@ -579,6 +579,9 @@ static hipError_t launch_frontend(const v2v::FrontendArgs &a, int64_t B, int64_t
 #define V2V_FRONTEND_FPB 4
 #endif
                 int fpb = a.di ? 1 : V2V_FRONTEND_FPB;
+#ifdef V2V_TUNING_KNOBS                                                           // tuning builds only (tools/frontend_time.py): never in the product launch path
+                if (const char *e = getenv("V2V_FPB")) { if (!a.di && atoi(e) > 0) fpb = atoi(e); }
+#endif
                 while (fpb > 1 && (int64_t)ta.tiles_x * ta.tiles_y * ((a.N + fpb - 1) / fpb) * B < 4096) fpb >>= 1;
                 ta.frames_per_block = fpb;
                 const int64_t nblocks = (int64_t)ta.tiles_x * ta.tiles_y * ((a.N + fpb - 1) / fpb);
