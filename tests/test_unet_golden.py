@@ -180,7 +180,19 @@ def test_forward_sequence_pipelined_over_two_streams_equals_the_step_loop(shape)
         first = net.forward_sequence(ev[:, :3], sc)
         second = net.forward_sequence(ev[:, 3:], sc)
         assert torch.equal(torch.cat([first, second], 1), want)
-        # captured into one hipGraph
+        # the built-in graph cache: captured on the first call, replayed afterwards, new inputs flow through the static buffers
+        ev2 = torch.round(torch.randn((n, t, 5, h, w), device="cuda") * 2)
+        net.reset_states()
+        want2 = torch.stack([net(ev2[:, i], sc)["image"] for i in range(t)], 1)
+        want2_states = net.states
+        for rep in range(2):
+            assert torch.equal(net.forward_sequence(ev, sc, graph=True), want), rep
+            got2 = net.forward_sequence(ev2, sc, graph=True)
+            assert torch.equal(got2, want2), rep
+            for a, b in zip(net.states, want2_states):
+                assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert len(net._sequence_graphs) == 1
+        # captured into one hipGraph by hand
         out = torch.empty_like(want)
 
         def run():

@@ -160,37 +160,15 @@ def run_with_consumer(ds, workers, batch, n_batches, dev):
     it = iter(loader)
 
     first = next(it)
-    ev_buf, sc_buf = torch.empty_like(first["events"]), torch.empty_like(first["event_scales"])
-
-    def forward_all():
-        net.reset_states()
-        with torch.no_grad():                                   # forward_sequence's time loop (:339-345) in one call: decoder half of step t
-            return net.forward_sequence(ev_buf, sc_buf)         # on a second stream under the encoder half of step t + 1 (v2v_amd/unet.py)
-    ev_buf.copy_(first["events"])
-    sc_buf.copy_(first["event_scales"])
-    forward_all()                                               # warm-up (weight packing, allocator)
-    torch.cuda.synchronize(dev)
-    # ~1,000 launches per batch: replayed from ONE hipGraph (the entry points only enqueue kernels), fed through two static buffers
-    graph, img_ref = None, None
-    try:
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            forward_all()
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            img_ref = forward_all()
-    except Exception:  # noqa: BLE001 - capture is an optimisation
-        graph = None
 
     def consume(b):
-        ev_buf.copy_(b["events"])
-        sc_buf.copy_(b["event_scales"])
-        if graph is not None:
-            graph.replay()
-            return img_ref
-        return forward_all()
+        # the whole 40-step sequence as one call: reset_states + time loop, decoder halves on side streams, replayed from the hipGraph the
+        # network captured on its first call (v2v_amd/unet.py: forward_sequence(graph=True))
+        with torch.no_grad():
+            return net.forward_sequence(b["events"], b["event_scales"], graph=True)
+    consume(first)
+    torch.cuda.synchronize(dev)
+    graph = getattr(net, "_sequence_graphs", None)
     for _ in range(2):
         consume(next(it))
     torch.cuda.synchronize(dev)
@@ -204,7 +182,7 @@ def run_with_consumer(ds, workers, batch, n_batches, dev):
     return {"samples_per_s": n_batches * batch / dt, "ms_per_batch": dt / n_batches * 1e3, "ms_per_time_step": dt / n_batches * 1e3 / 40, "batches": n_batches, "time_steps_per_sample": 40,
             "frames_reconstructed_per_s": n_batches * batch * 40 / dt, "image": f"{tuple(last.shape)} {last.dtype}", "launch": "hipGraph replay" if graph is not None else "eager",
             "what": "RingLoader(normalize='scales') -> v2v_amd.unet.E2VIDRecurrent.forward_sequence(events, event_scales): 40 time steps per sample (inference), "
-                    "decoder half of step t on a second stream under the encoder half of step t + 1; the consumer is the bound here, the loader idles"}
+                    "replayed from the hipGraph the network captures on its first call, decoder halves on three alternating side streams; the consumer is the bound here, the loader idles"}
 
 
 def run_yaml_only(tmp, src, n_batches, batch, dev, workers=0, **cfg):

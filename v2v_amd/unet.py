@@ -209,7 +209,52 @@ class E2VIDRecurrent(nn.Module):
     def forward(self, event_tensor, event_scales=None):
         return self.unetrecurrent.forward(event_tensor, event_scales)
 
-    def forward_sequence(self, events, event_scales=None, out=None, overlap=True):
+    def forward_sequence(self, events, event_scales=None, out=None, overlap=True, graph=False):
         """[N,T,num_bins,H,W] -> [N,T,1,H,W]: the reference's time loop (model/train_utils.py:339-345) in one call, decoder half of step t
-        under the encoder half of step t+1 (UNetRecurrent.forward_sequence)."""
-        return self.unetrecurrent.forward_sequence(events, event_scales, out=out, overlap=overlap)
+        under the encoder half of step t+1 (UNetRecurrent.forward_sequence).
+
+        graph=True: the whole sequence -- reset_states() first, as forward_sequence(reset_states=True) does (model/train_utils.py:309-313),
+        then T steps on the overlapped streams -- is captured ONCE per (shape, dtype, device, weights) into a hipGraph and replayed from
+        then on: ~20 launches per time step cost the host ~12 ms per 40-step sequence when issued one by one, about what the GPU needs to
+        run them.  Inputs are copied into the graph's static buffers; the returned tensor is the graph's static output (overwritten by
+        the next call with the same shapes -- clone it to keep it); the states after the call are those of the sequence's last step.
+        Inference only, like every layer here."""
+        if not graph:
+            return self.unetrecurrent.forward_sequence(events, event_scales, out=out, overlap=overlap)
+        if out is not None:
+            raise ValueError("graph=True returns the captured graph's own output buffer; `out` is not supported")
+        params = list(self.parameters())
+        key = (tuple(events.shape), events.dtype, events.device, event_scales is not None, overlap,
+               tuple(p.data_ptr() for p in params), sum(p._version for p in params))
+        cache = self.__dict__.setdefault("_sequence_graphs", {})
+        entry = cache.get(key)
+        if entry is None:
+            cache.clear()                                       # one live graph: a new shape or new weights retire the old one and its buffers
+            ev = torch.empty_like(events, memory_format=torch.contiguous_format)
+            sc = torch.empty_like(event_scales, memory_format=torch.contiguous_format) if event_scales is not None else None
+
+            def run():
+                self.reset_states()
+                return self.unetrecurrent.forward_sequence(ev, sc, overlap=overlap)
+            ev.copy_(events)
+            if sc is not None:
+                sc.copy_(event_scales)
+            with torch.no_grad():
+                run()                                           # eager once: weight packing, LDS-size attributes, allocator warm-up
+                torch.cuda.synchronize(events.device)
+                warm = torch.cuda.Stream(device=events.device)
+                warm.wait_stream(torch.cuda.current_stream(events.device))
+                with torch.cuda.stream(warm):
+                    run()
+                torch.cuda.current_stream(events.device).wait_stream(warm)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    res = run()
+            entry = cache[key] = (g, ev, sc, res, self.unetrecurrent.states)
+        g, ev, sc, res, states = entry
+        ev.copy_(events)
+        if sc is not None:
+            sc.copy_(event_scales)
+        g.replay()
+        self.unetrecurrent.states = states                      # the graph's own state tensors: what the last captured step wrote
+        return res
