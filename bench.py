@@ -397,7 +397,7 @@ def load_valu(name, kernel_ms):
     (all float64, fma, convert, compare, select, packed: profiles/valu_rates_ubench.txt).  The true ceiling of a kernel lies between
     the two by its instruction mix and is lowered further by the clock the chip holds under load (~1.7-1.9 GHz here)."""
     insts = rel = None
-    for tag in ("r04", "r03"):                     # the latest profile of this workload's kernels
+    for tag in ("r05", "r04", "r03"):              # the latest profile of this workload's kernels
         try:
             rel = f"profiles/{tag}/{name}/summary.json"
             insts = json.load(open(os.path.join(ROOT, rel)))["sq_counters_per_step"]["SQ_INSTS_VALU"]

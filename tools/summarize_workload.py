@@ -29,7 +29,7 @@ def short(name):
 
 # register / spill figures from the code objects' own metadata (tools/kernel_resources.py), keyed by the demangled kernel name
 RES = {}
-for cand in ("profiles/r04/kernel_resources.json", "profiles/r03/kernel_resources.json", "profiles/kernel_resources.json"):
+for cand in ("profiles/r05/kernel_resources.json", "profiles/r04/kernel_resources.json", "profiles/r03/kernel_resources.json", "profiles/kernel_resources.json"):
     rp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), cand)
     if os.path.exists(rp):
         RES = {v["demangled"]: v for v in json.load(open(rp)).values()}
