@@ -172,3 +172,28 @@ def test_bench_contract_line_for_eight_ranks_is_small_and_complete():
     fat = dict(one, parity_check="x" * 10000)
     slim = json.loads(bench.line_text(fat))
     assert len(bench.line_text(fat).encode()) <= bench.MAX_LINE_BYTES and "parity_check" not in slim and slim["value"] == one["value"] and "roofline" in slim
+
+
+def test_worker_start_method_yaml_key_sets_how_train_pys_dataloader_starts_workers(tmp_path):
+    """`worker_start_method: spawn` in the dataset's YAML block: train.py's own DataLoader (train.py:52-65 passes no multiprocessing_context)
+    then spawns its workers -- each owns a HIP context and simulates its samples itself -- with train.py untouched."""
+    import multiprocessing
+    from torch.utils.data import DataLoader
+    from v2v_amd.datasets import WebvidDatasetV2, synthetic_frame_source
+    lst = tmp_path / "videos.txt"
+    lst.write_text("clip_a.mp4 450 0.2 0.3\n")
+    cfg = {"video_list_file": str(lst), "sequence_length": 4, "crop_size": 32, "data_source_name": "webvid", "frame_source": synthetic_frame_source,
+           "video_size": (1280, 720), "video_reader": "opencv"}
+    before = multiprocessing.get_start_method()
+    try:
+        ds = WebvidDatasetV2(str(tmp_path), dict(cfg, worker_start_method="spawn"))
+        assert multiprocessing.get_start_method() == "spawn"
+        it = iter(DataLoader(ds, batch_size=1, num_workers=1))               # what train.py builds: the default context is now spawn
+        assert "popen_spawn" in type(it._workers[0]._popen).__module__
+        it._shutdown_workers()
+        with pytest.raises(AssertionError):
+            WebvidDatasetV2(str(tmp_path), dict(cfg, worker_start_method="threads"))
+    finally:
+        multiprocessing.set_start_method(before, force=True)
+    assert multiprocessing.get_start_method() == before
+    assert WebvidDatasetV2(str(tmp_path), cfg).worker_start_method is None and multiprocessing.get_start_method() == before
