@@ -710,6 +710,15 @@ def main():
                              "rng": "philox4x32 on device (10 rounds per-clip fields, 7 rounds per-step noise fields), Gaussians by direct table inversion (2 per word)",
                              "note": "noise-on launches are VALU-issue-bound, not HBM-bound (DESIGN.md); `frac` is still quoted against the HBM peak; "
                                      "`valu_issue` gives the same launch against the vector-issue ceilings"}
+        # the training-shape loader figures by integration level (BASELINE.md quotes the reference's deployment there): four numbers in
+        # the line itself, the rest of tools/loader_bench.py's output in the sidecar
+        lv = ((extra.get("also_measured") or {}).get("train_loader_b12_201x128x128") or {}).get("integration_levels_samples_per_s")
+        if lv:
+            line["train_loader_samples_per_s"] = {k: (round(v, 1) if isinstance(v, float) else v) for k, v in lv.items() if k != "decode_caveat"}
+            line["train_loader_samples_per_s"]["note"] = "B=12, 201x128x128 -> [12,40,5,128,128]; video decode excluded at every level"
+            e2 = (extra["also_measured"]["train_loader_b12_201x128x128"].get("ring_loader_feeding_e2vid") or {}).get("samples_per_s")
+            if e2:
+                line["train_loader_samples_per_s"]["ring_loader_feeding_e2vid"] = round(e2, 1)
         line["extra"] = write_sidecar(dict(line, **extra), args.extra_out)
         sys.stderr.flush()
         print(line_text(line), flush=True)
