@@ -578,7 +578,7 @@ def line_text(line):
     text = json.dumps(line)
     if len(text) > MAX_LINE_BYTES:
         line = dict(line)
-        for key in ("ms_per_step_per_rank", "parity_check", "extra"):
+        for key in ("train_loader_samples_per_s", "ms_per_step_per_rank", "parity_check", "extra"):
             line.pop(key, None)
         line["config"] = {"workload": line["config"]["workload"], "clips_per_gpu": line["config"]["clips_per_gpu"]}
         text = json.dumps(line)
