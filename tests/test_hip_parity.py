@@ -110,30 +110,36 @@ def test_g7_bilinear_weights_through_kernel(E, golden, k):
     np.testing.assert_allclose(out32[0].cpu().numpy(), want, rtol=RTOL, atol=ATOL)
 
 
-def test_g5_floor_divide_near_ties_through_kernel(E, golden):
-    """Each (a,b) near-tie becomes one pixel: potential init = a exactly (u_init chosen so), C+ = b."""
+@pytest.mark.parametrize("sign,asym", [(1, False), (-1, False), (1, True), (-1, True)])
+def test_g5_floor_divide_near_ties_through_kernel(E, golden, sign, asym):
+    """Each (a,b) near-tie of the reference's np.floor_divide becomes one pixel whose potential is +-a exactly and whose threshold on that
+    side is b: the kernel must report +-q.  Both polarities and both threshold selections (C+ == C-: registers; C+ != C-: the LDS pair by
+    polarity) -- round 5 runs the whole quotient chain in signed form, so the OFF side and its +-1 fix-up are exercised like the ON side."""
     g = golden("g5_floor_divide.npz")
     a, b, q = g["a"], g["b"], g["q"]
     sel = a >= b
     a, b, q = a[sel], b[sel], q[sel]
     n = a.size
-    video = np.full((2, 1, n), 77, dtype=np.uint8)      # constant: diff = 0, so potential stays a
-    got = np.empty(n)
-    # one launch per distinct threshold would be slow; batch as B=n clips of 1x... use H*W=4 minimum vector
-    frames = torch.from_numpy(np.full((n, 2, 1, 4), 77, dtype=np.uint8)).cuda()
-    params = np.stack([b, b, np.ones(n), np.zeros(n), np.zeros(n)], axis=1)
-    # potential init = u*(pos+neg) - neg = a  -> cannot hit a exactly through u; inject a through base noise:
-    # potential = (0.5*2b - b) + 0 ; += 1.0 * g_base with g_base = a  -> 0 + a = a exactly
-    u_init = np.full((n, 1, 4), 0.5)
-    u_hot = np.ones((n, 1, 4))
-    g_hot = np.zeros((n, 1, 4))
-    g_base = np.broadcast_to(a[:, None, None, None], (n, 1, 1, 4)).copy()
+    frames = torch.from_numpy(np.full((n, 2, 1, 4), 77, dtype=np.uint8)).cuda()      # constant video: diff = 0, the potential stays what the noise makes it
+    other = b * 1.75 if asym else b                                                    # the threshold of the side that does not fire
+    pos, neg = (b, other) if sign > 0 else (other, b)
+    params = np.stack([pos, neg, np.ones(n), np.zeros(n), np.zeros(n)], axis=1)
+    # potential init = u * (pos + neg) - neg = 0 with u = neg / (pos + neg) is not exact in general; inject +-a through the base noise on top of
+    # an init that IS exact: u = 0.5 with pos == neg gives 0; for the asymmetric case start from u = 0 (potential = -neg) and add neg back
+    if asym:
+        u_init = np.zeros((n, 1, 4))
+        g_base = np.broadcast_to((sign * a + neg)[:, None, None, None], (n, 1, 1, 4)).copy()   # -neg + (neg + sign*a): exact only if it rounds back
+        exact = (-neg + (sign * a + neg)) == sign * a
+    else:
+        u_init = np.full((n, 1, 4), 0.5)
+        g_base = np.broadcast_to((sign * a)[:, None, None, None], (n, 1, 1, 4)).copy()
+        exact = np.ones(n, dtype=bool)
+    assert exact.sum() > 0.4 * n                                                        # enough ties survive the asymmetric construction
     out = E.esim_voxel_batch(frames, params, bin_mode="sum", num_bins=1, rng_mode="replay",
-                             replay=[torch.from_numpy(x) for x in (u_init, u_hot, g_hot, g_base)],
+                             replay=[torch.from_numpy(x) for x in (u_init, np.ones((n, 1, 4)), np.zeros((n, 1, 4)), g_base)],
                              out_dtype=torch.float64)
     got = out[:, 0, 0, 0, 0].cpu().numpy()
-    assert np.array_equal(got, q)
-    del video
+    assert np.array_equal(got[exact], sign * q[exact])
 
 
 # ------------------------------------------------------------------ HIP vs C oracle, seeded inputs
