@@ -415,6 +415,13 @@ int v2v_clip_frames_f32_hip(const void *src, int64_t clip_stride, int64_t frame_
  * their common alignment) and picks frame pick[b * pick_stride + l] (pick_stride 0: one row of picks for every clip) */
 int v2v_clip_frames_f32_ex_hip(const void *src, int64_t clip_stride, const int64_t *clip_offsets, int64_t frame_stride, const int32_t *pick,
                                int64_t pick_stride, int64_t B, int64_t L, int64_t H, int64_t W, int64_t C, float *out, void *stream);
+/* the same with the gather's bounds (ABI 3, round 5; what the loader calls): stored_frames int32 [B] = frames clip b holds, src_elems =
+ * bytes in `src` (0: not stated).  A picked frame outside [0, stored_frames[b]), or one that does not fit `src`, is not read: its output
+ * frame is NaN -- like v2v_esim_extras.stored_frames for the simulator (the picks live on the device: no status code without a
+ * synchronisation).  stored_frames NULL = v2v_clip_frames_f32_ex_hip (the caller vouches for the picks). */
+int v2v_clip_frames_f32_bounded_hip(const void *src, int64_t clip_stride, const int64_t *clip_offsets, int64_t frame_stride, const int32_t *pick,
+                                    int64_t pick_stride, const int32_t *stored_frames, int64_t src_elems, int64_t B, int64_t L, int64_t H, int64_t W,
+                                    int64_t C, float *out, void *stream);
 
 #ifdef __cplusplus
 }

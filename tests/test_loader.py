@@ -258,6 +258,18 @@ def test_packed_launch_checks_the_frame_index_rows():
         assert torch.isnan(vox[3]).all() and int(st[3, 513]) == 1 and torch.equal(vox[:3], clean[:3])
     with pytest.raises(ValueError):
         esim.esim_voxel_packed(flat_d, offs_d, torch.from_numpy(fidx).cuda(), h, w, params, keys, stored_frames=stored_d.long())
+    # the `frame` assembly gathers through picks too (v2v_clip_frames_f32_bounded_hip): a pick outside its clip -> that output frame is NaN
+    from v2v_amd.loader import clip_frames_packed
+    pick = np.stack([fidx[:, 2], fidx[:, 7], fidx[:, 10]], 1).astype(np.int32)
+    good = clip_frames_packed(flat_d, offs_d, torch.from_numpy(pick).cuda(), h, w, stored_frames=stored_d)
+    assert torch.equal(good, clip_frames_packed(flat_d, offs_d, torch.from_numpy(pick).cuda(), h, w)) and not torch.isnan(good).any()
+    bad_pick = pick.copy()
+    bad_pick[1, 1], bad_pick[2, 0] = 5, -3                              # clip 1 holds 5 frames, clip 2 seven
+    got = clip_frames_packed(flat_d, offs_d, torch.from_numpy(bad_pick).cuda(), h, w, stored_frames=stored_d)
+    assert torch.isnan(got[1, 1]).all() and torch.isnan(got[2, 0]).all()
+    mask = torch.ones(got.shape[:2], dtype=torch.bool)
+    mask[1, 1] = mask[2, 0] = False
+    assert torch.equal(got[mask], good[mask])
 
 
 @pytest.mark.gpu

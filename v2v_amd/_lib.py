@@ -27,7 +27,7 @@ EXPORTS = ("v2v_version", "v2v_last_error", "v2v_device_count", "v2v_lut_get", "
            "v2v_convlstm_packed_bytes", "v2v_convlstm_pack_weights_hip", "v2v_convlstm_step_hip", "v2v_nchw_to_nhwc_bf16_hip",
            "v2v_conv3x3_pack_weights_hip", "v2v_conv3x3_nhwc_hip", "v2v_conv_pack_weights_hip", "v2v_conv_nhwc_hip", "v2v_upsample2x_nhwc_hip", "v2v_conv1x1_nhwc_hip", "v2v_conv_packed_elems", "v2v_conv_head_packed_elems", "v2v_conv_head_pack_weights_hip",
            "v2v_to_nhwc8_bf16_hip", "v2v_conv_head_nhwc_hip", "v2v_clip_frames_f32_hip",
-           "v2v_esim_voxel_stats_hip", "v2v_voxel_scales_hip", "v2v_voxel_apply_scales_hip", "v2v_voxel_scales_select_hip", "v2v_to_nhwc8_bf16_scaled_hip", "v2v_esim_voxel_ex_hip", "v2v_clip_frames_f32_ex_hip")
+           "v2v_esim_voxel_stats_hip", "v2v_voxel_scales_hip", "v2v_voxel_apply_scales_hip", "v2v_voxel_scales_select_hip", "v2v_to_nhwc8_bf16_scaled_hip", "v2v_esim_voxel_ex_hip", "v2v_clip_frames_f32_ex_hip", "v2v_clip_frames_f32_bounded_hip")
 EV_MAKE_VOXEL_DISCRETE, EV_MAKE_VOXEL_INTERP, EV_BILINEAR = 0, 1, 2
 NORM_NONE, NORM_RADIX, NORM_COUNT = 0, 1, 2
 VOXEL_STATS_WORDS = 516
@@ -100,6 +100,8 @@ def lib():
     L.v2v_clip_frames_f32_ex_hip.restype = C.c_int
     L.v2v_clip_frames_f32_ex_hip.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                              C.c_int64, C.c_void_p, C.c_void_p]
+    L.v2v_clip_frames_f32_bounded_hip.restype = C.c_int
+    L.v2v_clip_frames_f32_bounded_hip.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64] + [C.c_int64] * 5 + [C.c_void_p, C.c_void_p]
     L.v2v_esim_voxel_ex_hip.restype = C.c_int
     L.v2v_esim_voxel_ex_hip.argtypes = L.v2v_esim_voxel_padded_hip.argtypes[:-1] + [C.POINTER(EsimExtras), C.c_void_p]
     L.v2v_voxel_scales_hip.restype = C.c_int

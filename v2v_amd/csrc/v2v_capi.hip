@@ -362,6 +362,13 @@ int v2v_clip_frames_f32_hip(const void *src, int64_t clip_stride, int64_t frame_
 int v2v_clip_frames_f32_ex_hip(const void *src, int64_t clip_stride, const int64_t *clip_offsets, int64_t frame_stride, const int32_t *pick,
                                int64_t pick_stride, int64_t B, int64_t L, int64_t H, int64_t W, int64_t C, float *out, void *stream)
 {
+    return v2v_clip_frames_f32_bounded_hip(src, clip_stride, clip_offsets, frame_stride, pick, pick_stride, nullptr, 0, B, L, H, W, C, out, stream);
+}
+
+int v2v_clip_frames_f32_bounded_hip(const void *src, int64_t clip_stride, const int64_t *clip_offsets, int64_t frame_stride, const int32_t *pick,
+                                    int64_t pick_stride, const int32_t *stored_frames, int64_t src_elems, int64_t B, int64_t L, int64_t H, int64_t W,
+                                    int64_t C, float *out, void *stream)
+{
     if (!src || !out) return fail(V2V_ERR_NULL, "v2v_clip_frames_f32_hip: src/out is NULL");
     if (B < 0 || L < 1 || H < 1 || W < 1 || C < 1 || C > 4) return fail(V2V_ERR_SHAPE, "need B>=0, L,H,W>=1, 1<=C<=4");
     const int64_t HW = H * W;
@@ -369,22 +376,25 @@ int v2v_clip_frames_f32_ex_hip(const void *src, int64_t clip_stride, const int64
     if (frame_stride < HW * C || (!clip_offsets && B > 1 && clip_stride < frame_stride) || (clip_offsets && clip_stride < 1) || pick_stride < 0 ||
         (pick_stride != 0 && (!pick || pick_stride < L)))
         return fail(V2V_ERR_SHAPE, "strides smaller than the extent");
-    if (!aligned(out, 4) || !aligned(clip_offsets, 8) || !aligned(pick, 4)) return fail(V2V_ERR_ALIGN, "out / clip_offsets / pick misaligned");
+    if (!aligned(out, 4) || !aligned(clip_offsets, 8) || !aligned(pick, 4) || !aligned(stored_frames, 4))
+        return fail(V2V_ERR_ALIGN, "out / clip_offsets / pick / stored_frames misaligned");
+    if (src_elems < 0 || (!stored_frames && src_elems != 0)) return fail(V2V_ERR_SHAPE, "src_elems comes with stored_frames and is >= 0 (0: not stated)");
     if (B == 0) return V2V_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint8_t *sp = static_cast<const uint8_t *>(src);
+    const v2v::ClipBounds cb{stored_frames, src_elems};
     // with clip_offsets, clip_stride states the alignment (in bytes) every offset keeps
     const bool v4 = C == 1 && HW % 4 == 0 && frame_stride % 4 == 0 && ((B == 1 && !clip_offsets) || clip_stride % 4 == 0) && aligned(src, 4) && aligned(out, 16);
     if (v4) {
         const int hw4 = (int)(HW / 4);
         const unsigned gx = (unsigned)std::min<int64_t>((hw4 + 255) / 256, 64);
         hipLaunchKernelGGL(v2v::clip_frames4_kernel, dim3(gx, (unsigned)(B * L)), dim3(256), 0, s, sp, clip_stride, clip_offsets, frame_stride, pick, pick_stride,
-                           (int)L, hw4, out);
+                           (int)L, hw4, out, cb);
     } else {
         const int64_t n = HW * C;
         const unsigned gx = (unsigned)std::min<int64_t>((n + 255) / 256, 256);
         hipLaunchKernelGGL(v2v::clip_frames_kernel, dim3(gx, (unsigned)(B * L)), dim3(256), 0, s, sp, clip_stride, clip_offsets, frame_stride, pick, pick_stride,
-                           (int)L, (int)HW, (int)C, out);
+                           (int)L, (int)HW, (int)C, out, cb);
     }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? V2V_OK : hip_fail(e, "clip_frames kernel launch");

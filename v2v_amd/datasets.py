@@ -543,7 +543,7 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
             offsets_d, fidx_d, pick_d, params_d, keys_d, cframes_d, clips_d, stored_d = lay.device_views(dbuf)
             vox = esim.esim_voxel_packed(clips_d, offsets_d, fidx_d, hw, hw, params_d, keys_d, num_bins=self.num_bins,
                                          frames_per_bin=self.frames_per_bin, stored_frames=stored_d)[0]          # [L(+1),Tb,H,W] f32
-            frame = (clip_frames_packed(clips_d, offsets_d, pick_d, hw, hw) if cframes_d is None else clip_frames_f32(cframes_d))[0]
+            frame = (clip_frames_packed(clips_d, offsets_d, pick_d, hw, hw, stored_frames=stored_d) if cframes_d is None else clip_frames_f32(cframes_d))[0]
             st["read"][slot].record(cur)
         out_dev = torch.device(self.output_device)
         return {"frame": frame.to(out_dev), "events": vox.to(out_dev), "data_source_idx": torch.tensor(self.data_source_idx), "v2e_params": v2e_params}

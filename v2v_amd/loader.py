@@ -65,17 +65,22 @@ def clip_frames_f32(src: torch.Tensor, pick=None, frames: int | None = None) -> 
     return out
 
 
-def clip_frames_packed(clips: torch.Tensor, clip_offsets: torch.Tensor, pick: torch.Tensor, h: int, w: int, align: int = 16) -> torch.Tensor:
+def clip_frames_packed(clips: torch.Tensor, clip_offsets: torch.Tensor, pick: torch.Tensor, h: int, w: int, align: int = 16,
+                       stored_frames: torch.Tensor | None = None) -> torch.Tensor:
     """`frame` of a batch of PACKED gray clips (flat uint8 buffer, clip b at clip_offsets[b], stored frame pick[b, l] for output l):
-    float32 [B,L,1,H,W] = frame / 255, as clip_frames_f32."""
+    float32 [B,L,1,H,W] = frame / 255, as clip_frames_f32.  stored_frames int32 [B] (frames each clip holds): a pick outside its clip, or a
+    frame that does not fit `clips`, is not read -- its output frame is NaN (v2v_clip_frames_f32_bounded_hip)."""
     _lib.require_gpu()
     b, n_l = pick.shape
     out = torch.empty((b, n_l, 1, h, w), dtype=torch.float32, device=clips.device)
     if b == 0 or n_l == 0:
         return out
     with torch.cuda.device(clips.device):
-        rc = _lib.lib().v2v_clip_frames_f32_ex_hip(C.c_void_p(clips.data_ptr()), align, C.c_void_p(clip_offsets.data_ptr()), h * w,
-                                                   C.c_void_p(pick.data_ptr()), n_l, b, n_l, h, w, 1, C.c_void_p(out.data_ptr()), _lib.stream_ptr())
+        rc = _lib.lib().v2v_clip_frames_f32_bounded_hip(C.c_void_p(clips.data_ptr()), align, C.c_void_p(clip_offsets.data_ptr()), h * w,
+                                                        C.c_void_p(pick.data_ptr()), n_l,
+                                                        C.c_void_p(stored_frames.data_ptr()) if stored_frames is not None else None,
+                                                        clips.numel() if stored_frames is not None else 0,
+                                                        b, n_l, h, w, 1, C.c_void_p(out.data_ptr()), _lib.stream_ptr())
     _lib.check(rc)
     return out
 
@@ -371,7 +376,7 @@ class RingLoader:
         self._t("postops", t0)
         t0 = time.perf_counter()
         if cframes is None:
-            frame = clip_frames_packed(clips, offsets_d, pick_d, h, w)
+            frame = clip_frames_packed(clips, offsets_d, pick_d, h, w, stored_frames=stored_d)
         else:
             frame = clip_frames_f32(cframes)
         self._dev_free[d].record(cur)                                     # everything that reads the device slot is enqueued
