@@ -188,6 +188,35 @@ def test_dataset_under_spawned_dataloader_workers_like_train_py(tmp_path):
             assert float(batch["v2e_params"]["pos_thres"][j]) == ref["v2e_params"]["pos_thres"]
 
 
+def test_spawned_workers_hand_over_cuda_tensors_without_a_host_round_trip(tmp_path):
+    """The YAML-only path WITH workers and without the host round trip: `worker_start_method: spawn` + `output_device: cuda` -- every
+    spawned worker simulates on its own HIP context, default_collate stacks on the GPU inside the worker, and the batch reaches the
+    training process as CUDA IPC handles (pin_memory off).  Batches equal the in-process samples bit for bit."""
+    import multiprocessing
+    from torch.utils.data import ConcatDataset, DataLoader
+    from v2v_amd.datasets import WebvidDatasetV2, synthetic_frame_source
+    lst = tmp_path / "videos.txt"
+    lst.write_text("clip_a.mp4 450 0.2 0.3\nclip_b.mp4 300 0.25 0.25\n")
+    configs = {"video_list_file": str(lst), "sequence_length": 4, "crop_size": 32, "data_source_name": "webvid", "video_size": (1280, 720),
+               "video_reader": "opencv", "fixed_seed": 31, "max_samples_per_shot": 2, "step_size": 20, "frame_source": synthetic_frame_source,
+               "worker_start_method": "spawn", "output_device": "cuda"}
+    before = multiprocessing.get_start_method()
+    try:
+        ds = WebvidDatasetV2(str(tmp_path), configs)
+        wrapped = ConcatDataset([ConcatDataset([ds])])
+        loader = DataLoader(wrapped, batch_size=2, shuffle=False, num_workers=2, persistent_workers=True, pin_memory=False, drop_last=True)   # train.py:52-65
+        got = [{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()} for batch in loader]    # clone: release the producers' blocks
+        assert len(got) == 2
+        for bi, batch in enumerate(got):
+            assert batch["events"].is_cuda and batch["frame"].is_cuda and batch["events"].shape == (2, 4, 5, 32, 32)
+            for j in range(2):
+                ref = wrapped[2 * bi + j]
+                assert torch.equal(batch["events"][j], ref["events"]) and torch.equal(batch["frame"][j], ref["frame"])
+        del loader
+    finally:
+        multiprocessing.set_start_method(before, force=True)
+
+
 def test_dataset_fixed_seed_is_deterministic_and_restores_state(tmp_path):
     ds = _make_ds(tmp_path, fixed_seed=123, sim_rng="philox")
     np.random.seed(1)

@@ -185,7 +185,7 @@ def run_with_consumer(ds, workers, batch, n_batches, dev):
                     "replayed from the hipGraph the network captures on its first call, decoder halves on three alternating side streams; the consumer is the bound here, the loader idles"}
 
 
-def run_yaml_only(tmp, src, n_batches, batch, dev, workers=0, **cfg):
+def run_yaml_only(tmp, src, n_batches, batch, dev, workers=0, worker_output="cpu", **cfg):
     """The ZERO-EDIT integration level: train.py's own loader -- DataLoader(dataset, batch_size, sampler=RandomSampler,
     num_workers, persistent_workers, pin_memory, drop_last=True), default collate, then `batch[k] = v.to(device)` (train.py:52-65,76-82) --
     over v2v_amd.datasets.WebvidDatasetV2 selected by the YAML's class_name; every sample is simulated inside __getitem__ (one launch per
@@ -194,16 +194,16 @@ def run_yaml_only(tmp, src, n_batches, batch, dev, workers=0, **cfg):
     host (`output_device: cpu`) through the worker queue, pin_memory thread and H2D copy like the reference's."""
     from torch.utils.data import DataLoader, RandomSampler
     spawn = workers > 0
-    ds = make_dataset(tmp, (n_batches + 8) * batch, src, defer_sim=False, output_device="cpu" if spawn else "cuda",
+    ds = make_dataset(tmp, (n_batches + 8) * batch, src, defer_sim=False, output_device=worker_output if spawn else "cuda",
                       **(dict(worker_start_method="spawn") if spawn else {}), **cfg)
     mk = lambda: DataLoader(ds, batch_size=batch, sampler=RandomSampler(ds), num_workers=workers, persistent_workers=spawn,   # noqa: E731
-                            pin_memory=spawn, drop_last=True)
+                            pin_memory=spawn and worker_output == "cpu", drop_last=True)
     t0 = time.perf_counter()
     out = run_loader(mk, n_batches, batch, dev)
     out["seconds_with_startup"] = time.perf_counter() - t0
     out["workers"] = workers
-    out["yaml"] = ("class_name: v2v_amd.datasets.WebvidDatasetV2, " + ("worker_start_method: spawn, output_device: cpu; num_workers: %d, persistent_workers: true, "
-                   "pin_memory: true" % workers if spawn else "output_device: cuda; num_workers: 0, persistent_workers: false, pin_memory: false"))
+    out["yaml"] = ("class_name: v2v_amd.datasets.WebvidDatasetV2, " + ("worker_start_method: spawn, output_device: %s; num_workers: %d, persistent_workers: true, "
+                   "pin_memory: %s" % (worker_output, workers, "true" if worker_output == "cpu" else "false") if spawn else "output_device: cuda; num_workers: 0, persistent_workers: false, pin_memory: false"))
     if spawn:
         import multiprocessing as mp
         mp.set_start_method("fork", force=True)                  # what the dataset's YAML key changed, put back for the other legs
@@ -298,16 +298,18 @@ def measure(batches=200, workers=9, batch=12, modes=("ring", "simulating"), cpu_
                 res["ring_loader_feeding_e2vid"] = {"error": f"{type(exc).__name__}: {exc}"}
         if cpu_port:
             res["cpu_port_in_workers"] = run_cpu_port(ds, workers, batch, budget_s=cpu_port_budget_s)
-        for key, nb, wk in (("yaml_only_workers0", yaml_only_batches, 0), ("yaml_only_spawn_workers", yaml_only_spawn_batches, workers)):
+        for key, nb, wk, wo in (("yaml_only_workers0", yaml_only_batches, 0, "cuda"), ("yaml_only_spawn_workers", yaml_only_spawn_batches, workers, "cuda"),
+                                ("yaml_only_spawn_workers_host_return", min(yaml_only_spawn_batches, 10), workers, "cpu")):
             if nb:
                 try:
-                    res[key] = run_yaml_only(tmp, src, nb, batch, dev, workers=wk)
+                    res[key] = run_yaml_only(tmp, src, nb, batch, dev, workers=wk, worker_output=wo)
                 except Exception as exc:  # noqa: BLE001 - a secondary figure
                     res[key] = {"error": f"{type(exc).__name__}: {exc}"}
     # one table, three integration levels (samples/s; decode excluded everywhere -- see `source`)
     res["integration_levels_samples_per_s"] = {
         "yaml_only_num_workers_0": res.get("yaml_only_workers0", {}).get("samples_per_s"),
         "yaml_only_spawned_workers": res.get("yaml_only_spawn_workers", {}).get("samples_per_s"),
+        "yaml_only_spawned_workers_host_return": res.get("yaml_only_spawn_workers_host_return", {}).get("samples_per_s"),
         "one_line_of_train_py_ring_loader": res.get("ring_loader", {}).get("samples_per_s"),
         "reference_numpy_port_in_workers": res.get("cpu_port_in_workers", {}).get("samples_per_s"),
         "decode_caveat": "video decode (cv2.VideoCapture.read + resize, ~0.4 s per 201-frame sample per worker: ~22 samples/s with 9 workers) is NOT in "
