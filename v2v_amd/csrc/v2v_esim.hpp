@@ -285,11 +285,18 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
             if constexpr (RNG == kRngPhilox) {
                 if (hot_frac > 0.0) {                                  // uniform: skipping is exact (u >= 0)
                     double u1[VEC];
-                    float gh[VEC], gh_unused[VEC];
                     field_uniform53<VEC>(seed_, clip_id, kFieldHotMask, kStreamEsim, p0, u1);
-                    field_gauss_pairs<VEC>(seed_, clip_id, kFieldHotGauss, kStreamEsim, p0, s_icdf, gh, gh_unused);
+                    bool mine = false;
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) hot[j] = (u1[j] < hot_frac) ? hot_std * (double)gh[j] : 0.0;   // :37-39
+                    for (int j = 0; j < VEC; ++j) mine = mine || (u1[j] < hot_frac);
+                    // the Gaussian field of the hot pixels (a Philox-10 block + table lookups) only in waves that own one: with the
+                    // reference's hot_pixel_fraction of 1e-3 that is one wave in four; the others keep hot = 0 exactly as before
+                    if (__builtin_amdgcn_ballot_w64(mine) != 0) {
+                        float gh[VEC], gh_unused[VEC];
+                        field_gauss_pairs<VEC>(seed_, clip_id, kFieldHotGauss, kStreamEsim, p0, s_icdf, gh, gh_unused);
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) hot[j] = (u1[j] < hot_frac) ? hot_std * (double)gh[j] : 0.0;   // :37-39
+                    }
                 }
             } else if constexpr (RNG == kRngReplay) {
 #pragma unroll
