@@ -548,3 +548,30 @@ def test_ring_loader_without_page_locking_still_delivers_the_same_batches(tmp_pa
         assert torch.equal(batch["events"], want["events"]) and torch.equal(batch["frame"], want["frame"])
     assert bi == 2
     loader.close()
+
+
+@pytest.mark.gpu
+def test_ring_loader_batches_through_the_network_in_one_graphed_call(tmp_path):
+    """BASELINE config 5 at miniature size, as tools/loader_bench.py runs it: RingLoader(normalize='scales') -> E2VIDRecurrent.forward_sequence
+    (events, event_scales, graph=True) -- the reference's reset + time loop (model/train_utils.py:309-345) captured once and replayed -- gives,
+    for every batch, the images of the step-by-step loop on the normalised events."""
+    from v2v_amd import postops
+    from v2v_amd.loader import RingLoader
+    from v2v_amd.unet import E2VIDRecurrent
+    ds = _make_ds(tmp_path, n_videos=8, defer_sim=True, fixed_seed=3)
+    torch.manual_seed(0)
+    net = E2VIDRecurrent(dict(num_bins=5, skip_type="sum", recurrent_block_type="convlstm", num_encoders=3, base_num_channels=32,
+                              num_residual_blocks=2, use_upsample_conv=True, final_activation="", norm=None)).cuda().eval()
+    loader = RingLoader(ds, batch_size=4, num_workers=2, drop_last=True, pad_to=16, normalize="scales")
+    n = 0
+    with torch.no_grad():
+        for batch in loader:
+            ev, sc = batch["events"], batch["event_scales"]
+            got = net.forward_sequence(ev, sc, graph=True).clone()
+            normed = postops.apply_scales(ev, sc, 16)                          # what the head divides by while it reads the raw events
+            net.reset_states()
+            want = torch.stack([net(normed[:, t])["image"] for t in range(ev.shape[1])], 1)
+            assert got.shape == (4, ev.shape[1], 1, 32, 32) and torch.equal(got, want)
+            n += 1
+    assert n == 2 and len(net._sequence_graphs) == 1
+    loader.close()
