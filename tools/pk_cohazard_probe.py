@@ -73,7 +73,7 @@ for vname, victim in victims.items():
     row = [f"alone {again}/10"]
     for dname, dist in disturbers.items():
         bad = worst = 0
-        for rep in range(8):
+        for rep in range(int(os.environ.get("PK_PROBE_ROUNDS", "8"))):
             with torch.cuda.stream(side):
                 for _ in range(24):
                     dist()
@@ -83,5 +83,5 @@ for vname, victim in victims.items():
                 n = int((o != solo).sum())
                 bad += n > 0
                 worst = max(worst, n)
-        row.append(f"{dname}: {bad}/32 launches differ (worst {worst} elements)")
+        row.append(f"{dname}: {bad}/{4 * int(os.environ.get('PK_PROBE_ROUNDS', '8'))} launches differ (worst {worst} elements)")
     print(f"{vname:34s} | " + " | ".join(row))
