@@ -359,6 +359,34 @@ def test_dataset_gpu_frontend_equals_host_path(tmp_path, cfg):
         assert torch.equal(a["frame"], b["frame"]) and torch.equal(a["events"], b["events"])      # incl. gray_in_bgr_out: exact (G15)
 
 
+@pytest.mark.parametrize("extra", [{}, {"color_mode": "gray_in_bgr_out"}, {"shake_frames": 4, "shake_std": 1.5}])
+def test_opencv_decode_branches_end_to_end_with_a_stand_in_cv2(tmp_path, monkeypatch, extra):
+    """The two `video_reader: opencv` branches that decode with cv2.VideoCapture -- the host path (read_video) and `gpu_frontend: true`
+    (read_video_gpu: host decodes, the GPU converts / crops / resizes / flips / gathers) -- run end to end on tests/fake_cv2.py (no OpenCV in
+    this image) and give the same sample: frames and simulated events, for the same np.random stream."""
+    import sys
+    import fake_cv2
+    from v2v_amd.datasets import WebvidDatasetV2
+    monkeypatch.setitem(sys.modules, "cv2", fake_cv2)
+    g = np.random.default_rng(5)
+    for i in range(2):
+        base = g.integers(0, 256, size=(1, 96, 160, 3)).astype(np.int16)
+        np.save(tmp_path / f"clip_{i}.npy", np.clip(base + np.cumsum(g.integers(-5, 6, size=(60, 96, 160, 3)), axis=0), 0, 255).astype(np.uint8))
+    (tmp_path / "videos.txt").write_text("clip_0.npy 60 0.2 0.3\nclip_1.npy 60 0.25 0.25\n")
+    cfg = {"video_list_file": str(tmp_path / "videos.txt"), "sequence_length": 3, "crop_size": 32, "data_source_name": "webvid", "video_reader": "opencv",
+           "keep_top_percentile": 1.0, "proba_pause_when_running": 0.2, "proba_pause_when_paused": 0.6, "sim_rng": "philox"}
+    cfg.update(extra)
+    host = WebvidDatasetV2(str(tmp_path), cfg)
+    gpu = WebvidDatasetV2(str(tmp_path), dict(cfg, gpu_frontend=True))
+    for idx in (0, 1):
+        np.random.seed(9 + idx)
+        a = host[idx]
+        np.random.seed(9 + idx)
+        b = gpu[idx]
+        assert a["v2e_params"] == b["v2e_params"] and a["events"].shape == (3, 5, 32, 32)
+        assert torch.equal(a["frame"], b["frame"]) and torch.equal(a["events"], b["events"]) and float(a["events"].abs().sum()) > 0
+
+
 @pytest.mark.gpu
 def test_neg_pos_voxel_wrappers_compose_like_the_reference():
     """events_to_neg_pos_voxel(_torch) (utils/event_utils.py:730-759, :509-541): the two grids are the bilinear voxeliser

@@ -5,6 +5,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -197,3 +198,62 @@ def test_worker_start_method_yaml_key_sets_how_train_pys_dataloader_starts_worke
         multiprocessing.set_start_method(before, force=True)
     assert multiprocessing.get_start_method() == before
     assert WebvidDatasetV2(str(tmp_path), cfg).worker_start_method is None and multiprocessing.get_start_method() == before
+
+
+def _npy_videos(tmp_path, n=3, t=60, h=96, w=160):
+    g = np.random.default_rng(5)
+    names = []
+    for i in range(n):
+        base = g.integers(0, 256, size=(1, h, w, 3)).astype(np.int16)
+        walk = np.clip(base + np.cumsum(g.integers(-5, 6, size=(t, h, w, 3)), axis=0), 0, 255).astype(np.uint8)
+        np.save(tmp_path / f"clip_{i}.npy", walk)
+        names.append(f"clip_{i}.npy")
+    (tmp_path / "videos.txt").write_text("".join(f"{nm} {t} 0.2 0.3\n" for nm in names))
+    return names
+
+
+def _oracle_frame_source(ds, sample_idx, start, end, crop_before, min_i, min_j, flip, need_h, need_w):
+    """The reference's decode loop (data/v2v_datasets.py:188-213) written out on the OpenCV restatement: what the cv2 branch must equal."""
+    from oracle import frontend_oracle as FO
+    video = np.load(os.path.join(ds.dataset_path, ds.sample_video_name[sample_idx]))
+    out = []
+    for f in video[start:end]:
+        if ds.color_mode == "gray":
+            f = FO.cv_bgr2gray_u8(f, "cv4")
+        f = f[min_i:min_i + crop_before, min_j:min_j + crop_before, ...]
+        f = FO.cv_resize_linear_u8(f, need_w, need_h)
+        if flip:
+            f = np.ascontiguousarray(f[:, ::-1])
+        out.append(f[..., None] if ds.color_mode == "gray" else f)
+    return out
+
+
+@pytest.mark.parametrize("extra", [{}, {"color_mode": "gray_in_bgr_out"}, {"shake_frames": 4, "shake_std": 1.5}, {"max_resize_scale": 1.3, "min_resize_scale": 0.4}])
+def test_opencv_decode_branch_runs_against_a_stand_in_cv2(tmp_path, monkeypatch, extra):
+    """`video_reader: opencv` without a frame_source -- the branch a real V2V installation takes (cv2.VideoCapture: seek, read loop, cvtColor
+    BEFORE the crop, resize to need_w x need_h, flip after the resize, the trailing axis, release; _probe_size for the geometry draws).  No
+    OpenCV in this image: tests/fake_cv2.py stands in (OpenCV's algorithms as restated in oracle/), and the samples must equal those of a
+    frame_source that writes the reference's loop out -- same np.random consumption, same clip, same frames."""
+    import sys
+    import fake_cv2
+    from v2v_amd.datasets import WebvidDatasetV2
+    monkeypatch.setitem(sys.modules, "cv2", fake_cv2)
+    fake_cv2.calls.clear()
+    _npy_videos(tmp_path)
+    cfg = {"video_list_file": str(tmp_path / "videos.txt"), "sequence_length": 3, "crop_size": 32, "data_source_name": "webvid", "video_reader": "opencv",
+           "defer_sim": True, "proba_pause_when_running": 0.2, "proba_pause_when_paused": 0.6}
+    cfg.update(extra)
+    via_cv2 = WebvidDatasetV2(str(tmp_path), cfg)
+    via_src = WebvidDatasetV2(str(tmp_path), dict(cfg, frame_source=_oracle_frame_source, video_size=(160, 96)))
+    assert via_cv2._probe_size(str(tmp_path / "clip_0.npy")) == (160, 96)
+    for idx in (0, 2, 1):
+        np.random.seed(40 + idx)
+        a = via_cv2[idx]
+        state = np.random.get_state()[1].copy()
+        np.random.seed(40 + idx)
+        b = via_src[idx]
+        assert np.array_equal(np.random.get_state()[1], state)
+        assert torch.equal(a["sim_frames"], b["sim_frames"]) and torch.equal(a["frame"], b["frame"]) and a["v2e_params"] == b["v2e_params"]
+        assert a["sim_frames"].shape == (16, 32, 32) and a["sim_frames"].dtype == torch.uint8 and float(a["sim_frames"].float().std()) > 1
+    names = [c[0] for c in fake_cv2.calls]
+    assert names.count("VideoCapture") == names.count("release") and "set_pos" in names      # every capture is released; the clip is sought, not read from frame 0
