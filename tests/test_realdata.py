@@ -111,3 +111,59 @@ def test_event_kernels_edge_semantics():
     assert bool(torch.isnan(t32[:, 1, 2]).all()) and int(torch.isnan(t32).sum()) == nb
     t32 = voxel.events_to_voxel_torch(torch.tensor([-1, 2]), torch.tensor([-1, 0]), torch.tensor([0.0, 1.0]), torch.tensor([1.0, 1.0]), nb, sensor_size=(h, w))
     assert float(t32[0, h - 1, w - 1]) == 1.0 and float(t32[nb - 1, 0, 2]) == 1.0                    # index_put_ wraps
+
+
+def _h5_copy(tmp_path, monkeypatch):
+    """The fixture sequence under an .h5 name + tests/fake_h5py.py injected as `h5py` (none in this image)."""
+    import shutil
+    import sys
+    import fake_h5py
+    monkeypatch.setitem(sys.modules, "h5py", fake_h5py)
+    path = tmp_path / "g16_monash_sequence.h5"
+    shutil.copy(FIX, path)
+    return str(path)
+
+
+def test_h5_branch_of_the_monash_store_equals_the_npz_form(tmp_path, monkeypatch, golden):
+    """v2v_amd/monash.py:H5Sequence (the branch real Monash .h5 files take) through a stand-in h5py: the same access pattern gives the same
+    arrays, attributes and image keys as the .npz form the other tests pin, and TestH5Dataset builds the same sample table from it."""
+    from v2v_amd import monash
+    from v2v_amd.testh5 import TestH5Dataset
+    path = _h5_copy(tmp_path, monkeypatch)
+    with monash.open_sequence(path) as h, monash.open_sequence(FIX) as z:
+        assert isinstance(h, monash.H5Sequence) and isinstance(z, monash.NpzSequence)
+        assert h.image_keys == z.image_keys and not h.has_flow()
+        for key in h.image_keys:
+            assert np.array_equal(h.image(key), z.image(key)) and int(h.image_attr(key, "event_idx")) == int(z.image_attr(key, "event_idx"))
+            assert float(h.image_attr(key, "timestamp")) == float(z.image_attr(key, "timestamp"))
+        for name in ("ts", "xs", "ys", "ps"):
+            assert np.array_equal(h.events(name), z.events(name)) and np.array_equal(h.events(name, 7, 31), z.events(name, 7, 31))
+        assert h.attr("source") == z.attr("source") and list(h.attr("sensor_resolution")) == list(z.attr("sensor_resolution"))
+        assert h.attr("no_such_attribute", 5) == 5
+    for tag in ("a", "b"):
+        a, b = TestH5Dataset(path, CFGS[tag]), TestH5Dataset(FIX, CFGS[tag])
+        assert len(a) == len(b) and a.samples == b.samples and (a.H, a.W) == (b.H, b.W) and a.sequence_name == b.sequence_name
+
+
+@pytest.mark.gpu
+def test_h5_branches_end_to_end(tmp_path, monkeypatch, golden):
+    """TestH5Dataset.__getitem__ and the cached-voxel writer over the .h5 container (stand-in h5py): same samples / same file contents as the
+    .npz form that golden G16 pins."""
+    from v2v_amd import voxel_cache
+    from v2v_amd.testh5 import TestH5Dataset
+    path = _h5_copy(tmp_path, monkeypatch)
+    a, b = TestH5Dataset(path, CFGS["a"]), TestH5Dataset(FIX, CFGS["a"])
+    for i in range(len(a)):
+        sa, sb = a[i], b[i]
+        assert set(sa) == set(sb)
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]) if isinstance(sa[k], torch.Tensor) else sa[k] == sb[k], k
+    out_h5, out_npz = tmp_path / "cache.h5", tmp_path / "cache.npz"
+    d1 = voxel_cache.convert(path, str(out_h5), temporal_bilinear=False)
+    d2 = voxel_cache.convert(FIX, str(out_npz), temporal_bilinear=False)
+    import fake_h5py
+    with fake_h5py.File(str(out_h5), "r") as f:
+        z = np.load(out_npz)
+        for k in ("frames", "flow", "events", "timestamps", "dt"):
+            assert f[k][()].dtype == np.float32 and np.array_equal(f[k][()], z[k]) and np.array_equal(d1[k], d2[k])
+        assert f.attrs["source"] == "esim" and list(f.attrs["sensor_resolution"]) == [36, 48]
