@@ -247,7 +247,7 @@ def gpu_ms_of_batch(batch, dev, pad_to=16):
 
 
 def measure(batches=200, workers=9, batch=12, modes=("ring", "simulating"), cpu_port=True, dev=None, cpu_port_budget_s=60.0, simulating_batches=None, ring_kw=None, consumer=True,
-            consumer_batches=20, yaml_only_batches=10, yaml_only_spawn_batches=20):
+            consumer_batches=20, yaml_only_batches=10, yaml_only_spawn_batches=40):
     """simulating_batches = 0 skips the round-2/3 collator leg; yaml_only_* = 0 skips the zero-edit legs."""
     ring_kw = ring_kw or {}
     from torch.utils.data import DataLoader
