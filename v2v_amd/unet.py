@@ -128,8 +128,9 @@ class UNetRecurrent(nn.Module):
         With overlap they are issued on side HIP streams (overlap=True: three, taken in turn by consecutive steps; an int: that many),
         so step t's decoder half runs UNDER step t+1's encoder half and beside its neighbours' decoder halves: at the training shape
         (12 x 128 x 128) no single layer fills 256 CUs (48-384 workgroups), and half-filling kernels side by side use what one leaves
-        idle (ms per time step, hipGraph replay, tools/e2vid_pipeline_probe.py: loop 0.50, one side stream 0.37, two 0.355, three 0.34).  Same kernels on the same operands in
-        the same per-tensor order: results are bit-identical to the step-by-step loop (tests/test_unet_golden.py).
+        idle (ms per time step, hipGraph replay, tools/e2vid_pipeline_probe.py: loop 0.50, one side stream 0.37, two 0.355, three 0.34;
+        0.316 with the state-free layers batched over time, below).  Same kernels on the same operands in the same per-tensor order:
+        results are bit-identical to the step-by-step loop (tests/test_unet_golden.py).
         Stream-ordering contract with torch's caching allocator: tensors made on the caller's stream and read on the side stream
         (head, skip blocks) are kept alive until the caller's stream has waited for the side stream's event of that step, so a freed
         block can never be handed out again while the side stream still reads it.  Captures into a hipGraph (fork / join through
