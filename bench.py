@@ -666,6 +666,12 @@ def main():
         extra["seconds"][name] = round(now - t_sec, 2)
         t_sec = now
 
+    # the same step again, OUTSIDE the timed region, once the clocks have settled (the chip ramps for ~30 ms after idle: the K timed launches
+    # of a short run sit in that ramp): 100 more launches, their median -- context for `frac`, never `value`
+    settled_ms = None
+    if rank == 0 and world == 1 and not args.no_also:
+        tail = sorted(time_launches(step, 100, torch))
+        settled_ms = tail[len(tail) // 2]
     secondary = rank == 0 and world == 1 and args.workload == DEFAULT_WORKLOAD and not args.no_also and not args.batch
     if secondary:
         extra["also_measured"] = measure_secondary(torch, dev, args.full, lap, args.kernels_only)
@@ -701,6 +707,9 @@ def main():
                              world=world, steps=args.steps, warmup=args.warmup, elapsed_s=elapsed, per_rank_ms=per_rank_ms, kern_ms_sorted=kern_ms,
                              backend=backend, dist_world=(dist.get_world_size() if dist is not None else 1), use_graph=use_graph,
                              traffic=load_traffic(args.workload), cpu=cpu, parity=parity)
+        if settled_ms:
+            line["roofline"]["kernel_ms_settled_p50"] = settled_ms          # median of 100 launches after the timed region (clocks settled)
+            line["roofline"]["frac_settled"] = W.alg_bytes / (settled_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
         extra["headline"] = {"kernel_ms_trace": [round(v, 4) for v in kern_trace], "valu_issue": load_valu(args.workload, kern_avg_ms),
                              "measured_ceilings_GBps": MEASURED_CEILINGS_GBPS,
                              "traffic_source": "static: profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, collected "
