@@ -43,8 +43,9 @@ from v2v_amd.unet import E2VIDRecurrent  # noqa: E402
 torch.manual_seed(0)
 net = E2VIDRecurrent(dict(num_bins=5, skip_type="sum", recurrent_block_type="convlstm", num_encoders=3, base_num_channels=32,
                           num_residual_blocks=2, use_upsample_conv=True, final_activation="", norm=None)).cuda().eval()
-ev = torch.round(torch.randn((12, 40, 5, 128, 128), device="cuda") * 2)
-sc = torch.ones((12, 2), device="cuda") * 3
+B, T, HW = (int(v) for v in os.environ.get("OVL_SHAPE", "12,40,128").split(","))    # config 5: OVL_SHAPE=8,8,256
+ev = torch.round(torch.randn((B, T, 5, HW, HW), device="cuda") * 2)
+sc = torch.ones((B, 2), device="cuda") * 3
 with torch.no_grad():
     for _ in range(4):
         net.forward_sequence(ev, sc, graph=True)
