@@ -23,11 +23,17 @@ def _disturbers():
 
 
 def _victims():
-    from v2v_amd import convlstm as CL, esim, v2e
+    import numpy as np
+    from v2v_amd import convlstm as CL, esim, frontend, loader, postops, v2e
     g = torch.Generator().manual_seed(6)
     ux, usk = torch.randn((12, 64, 64, 64), generator=g).bfloat16().cuda(), torch.randn((12, 64, 64, 64), generator=g).bfloat16().cuda()
     f32 = esim.synth_clips(32, 32, 256, 256, dtype=torch.float32)
     u8 = esim.synth_clips(32, 41, 256, 256, dtype=torch.uint8)
+    train = esim.synth_clips(12, 201, 128, 128, dtype=torch.uint8)
+    raw = torch.randint(0, 256, (6, 44, 360, 640, 3), generator=g, dtype=torch.uint8).cuda()
+    table = np.array([[10 * i, 30 * i, 200 + 20 * i, i & 1] for i in range(6)], dtype=np.int32)
+    idx = np.tile(np.arange(41, dtype=np.int32), (6, 1))
+    grid = torch.round(torch.randn((12, 40, 5, 120, 120), generator=g) * 3).cuda()
     vp = v2e.make_params(24, "pn_related", 0.5, 0.1, 0.0, 0.1, 30, 0.1, 0, 5.0, 0.1, 0.1)
     return {
         "upsample2x": lambda: CL.upsample2x_nhwc(ux, usk),
@@ -35,11 +41,16 @@ def _victims():
         "esim_f32_2px": lambda: esim.esim_voxel_batch(f32[:24], [0.2, 0.3, 0.1, 0.001, 0.1], bin_mode="bilinear", num_bins=5, seed=3, mapping="2px"),
         "esim_u8_sum": lambda: esim.esim_voxel_batch(u8, [0.2, 0.3, 0.05, 5e-4, 1.0], bin_mode="sum", num_bins=5, seed=3),
         "v2e_u8": lambda: v2e.v2e_voxel_batch(u8, vp, bin_mode="sum", num_bins=5, rng_mode="philox", seed=3),
+        "esim_u8_1px_quad_shared_noise": lambda: esim.esim_voxel_batch(train, [0.2, 0.3, 0.05, 5e-4, 1.0], bin_mode="sum", num_bins=5, seed=3, mapping="1px"),
+        "frontend_720p_crop_resize_gray": lambda: frontend.prepare_clips_batch(raw, table, idx, 128, "gray")[1],
+        "normalize_and_pad": lambda: postops.normalize_and_pad(grid, normalize=True),
+        "clip_frames_f32": lambda: loader.clip_frames_f32(u8[:, :, :, :, None], list(range(1, 41, 5))),
         "v2e_f32": lambda: v2e.v2e_voxel_batch(f32, vp, bin_mode="bilinear", num_bins=5, rng_mode="philox", seed=3),
     }
 
 
-@pytest.mark.parametrize("victim", ["upsample2x", "esim_f32_bilinear", "esim_f32_2px", "esim_u8_sum", "v2e_u8", "v2e_f32"])
+@pytest.mark.parametrize("victim", ["upsample2x", "esim_f32_bilinear", "esim_f32_2px", "esim_u8_sum", "v2e_u8", "v2e_f32", "esim_u8_1px_quad_shared_noise",
+                                    "frontend_720p_crop_resize_gray", "normalize_and_pad", "clip_frames_f32"])
 def test_kernel_results_do_not_depend_on_what_shares_the_cu(victim):
     run = _victims()[victim]
     side = torch.cuda.Stream()
