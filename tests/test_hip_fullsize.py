@@ -49,6 +49,51 @@ def test_cfg2_full_batch_256x32x256x256(oracle_c, luts, dt_name, params):
 
 
 @gpu
+@pytest.mark.parametrize("dt_name", ["float32", "uint8"])
+def test_batch_beyond_2_to_31_elements(oracle_c, luts, dt_name):
+    """MAXIMUM sizes: a batch sized for 288 GB of HBM rather than for config 2 -- 1,056 clips of 32 x 256 x 256 = 2.21e9 input elements
+    (8.9 GB as float32), so clip 1,024 STARTS at element 2^31 and every index past it needs 64-bit arithmetic (config 2's 2^29 elements
+    only take the byte offsets to 2^31).  One launch; the clips either side of the boundary and the last one against the C oracle,
+    and the tail of the batch against the same clips run as their own small batch."""
+    import torch
+    from v2v_amd import esim
+    b, n, h, w, tb = 1056, 32, 256, 256, 5
+    params = [0.2, 0.3, 0.05, 5e-4, 1.0]
+    assert b * n * h * w > 2 ** 31
+    frames = esim.synth_clips(b, n, h, w, dtype=getattr(torch, dt_name), seed=SEED, clip_id0=0)
+    counts = torch.zeros((b, 2), dtype=torch.int64, device="cuda")
+    out = esim.esim_voxel_batch(frames, params, bin_mode="bilinear", num_bins=tb, seed=SEED, clip_id0=0, counts=counts)
+    torch.cuda.synchronize()
+    assert out.shape == (b, tb, h, w) and bool(torch.isfinite(out[-40:]).all())
+    for c in (0, 1023, 1024, b - 1):
+        host = frames[c:c + 1].cpu().numpy()
+        want, tot = oracle_c.esim_voxel(host, params, luts, seed=SEED, clip_id0=c, bin_mode=oracle_c.BIN_BILINEAR, num_bins=tb)
+        np.testing.assert_allclose(out[c].cpu().numpy().astype(np.float64), want[0], rtol=1e-5, atol=1e-5, err_msg=f"clip {c}")
+        assert np.array_equal(counts[c].cpu().numpy(), tot[0]), f"clip {c} ON/OFF totals"
+    tail = esim.esim_voxel_batch(frames[-33:], params, bin_mode="bilinear", num_bins=tb, seed=SEED, clip_id0=b - 33)
+    assert torch.equal(tail, out[-33:])
+    # SUM bins through the 1-pixel mapping (its own index arithmetic) on the same buffer: 31 pairs do not divide by 5, so 30 of them
+    sub = frames[:, :31]                                           # a strided view: the launcher takes the clip stride from the tensor or copies
+    s4 = esim.esim_voxel_batch(sub, params, bin_mode="sum", num_bins=5, frames_per_bin=3, seed=SEED, clip_id0=0)
+    s1 = esim.esim_voxel_batch(sub[-12:], params, bin_mode="sum", num_bins=5, frames_per_bin=3, seed=SEED, clip_id0=b - 12, mapping="1px")
+    assert torch.equal(s4[-12:], s1)
+    if dt_name == "uint8":
+        # the `frame` assembly (v / 255 of picked frames) and the normalise + pad pass over the same oversized batch: every sample is
+        # independent, so the tail must equal the tail run alone
+        from v2v_amd import loader, postops
+        pick = list(range(3, 32, 4))
+        fr = loader.clip_frames_f32(frames, pick)
+        assert fr.shape == (b, len(pick), 1, h, w) and torch.equal(fr[-5:], loader.clip_frames_f32(frames[-5:], pick))
+        assert torch.equal(fr[1024, 2, 0].cpu(), frames[1024, pick[2]].cpu().float() / 255)    # torch's CPU division (the GPU op multiplies by 1/255)
+        del fr
+        grid = s4.reshape(b, 2, 5, h, w)                                                   # 1,056 samples x 2 x 5 x 256 x 256: 6.9e8 voxels
+        big = torch.cat([grid, grid, grid, grid])                                            # 4,224 samples: 2.77e9 voxels
+        nrm = postops.normalize_and_pad(big, normalize=True, method="count")
+        assert torch.equal(nrm[-7:], postops.normalize_and_pad(big[-7:].contiguous(), normalize=True, method="count"))
+        assert torch.equal(nrm[3 * b + 5], nrm[5])
+
+
+@gpu
 def test_cfg2_full_batch_sum_mode_exact(oracle_c, luts):
     """Same batch, N = 31 frames -> (N-1) = 30 = 2 x 5 x 3: SUM binning (the voxel grid V2V trains on), bit-exact integers."""
     import torch
@@ -122,6 +167,27 @@ def test_cfg3_v2e_full_batch_256x32x256x256(oracle_c, luts, dt_name):
     want, _ = oracle_c.v2e_voxel(frames[c:c + 1].cpu().numpy(), oracle_c.v2e_params(*V2E_NOISY), luts, seed=SEED, clip_id0=c,
                                  bin_mode=oracle_c.BIN_SUM, num_bins=n - 1)
     assert np.array_equal(sub.cpu().numpy(), want)
+
+
+@gpu
+def test_v2e_batch_beyond_2_to_31_elements(oracle_c, luts):
+    """The v2e model on 1,056 uint8 clips of 32 x 256 x 256 (2.21e9 input elements; the frame-sum pre-pass and the simulator both index
+    past 2^31): the clips either side of element 2^31 and the last one against the C oracle, the tail against its own small batch."""
+    import torch
+    from v2v_amd import esim, v2e
+    b, n, h, w, tb = 1056, 32, 256, 256, 5
+    frames = esim.synth_clips(b, n, h, w, dtype=torch.uint8, seed=SEED, clip_id0=0)
+    vp = v2e.make_params(*V2E_NOISY)
+    counts = torch.zeros((b, 2), dtype=torch.int64, device="cuda")
+    out = v2e.v2e_voxel_batch(frames, vp, bin_mode="bilinear", num_bins=tb, seed=SEED, clip_id0=0, counts=counts)
+    torch.cuda.synchronize()
+    for c in (1023, 1024, b - 1):
+        want, tot = oracle_c.v2e_voxel(frames[c:c + 1].cpu().numpy(), oracle_c.v2e_params(*V2E_NOISY), luts, seed=SEED, clip_id0=c,
+                                       bin_mode=oracle_c.BIN_BILINEAR, num_bins=tb)
+        assert np.array_equal(counts[c].cpu().numpy(), tot[0]), f"clip {c}: ON/OFF totals"
+        np.testing.assert_allclose(out[c].cpu().numpy().astype(np.float64), want[0], rtol=1e-5, atol=1e-5, err_msg=f"clip {c}")
+    tail = v2e.v2e_voxel_batch(frames[-20:], vp, bin_mode="bilinear", num_bins=tb, seed=SEED, clip_id0=b - 20)
+    assert torch.equal(tail, out[-20:])
 
 
 @gpu
