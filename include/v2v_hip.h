@@ -245,7 +245,8 @@ int v2v_frontend_batch_hip(const uint8_t *src, int64_t B, int64_t T, int64_t Hs,
  * Replaces normalize_batch_voxel (model/train_utils.py:147-166: per-sample torch.kthvalue at int(0.01*M) / int(0.99*M),
  * clamp(min=1), where(v > 0, v/pos_max, v/neg_max)) fused with the zero padding of H,W to multiples of `pad_to`
  * (model/train_utils.py:322-326).  voxel float32 [B,planes,H,W] (planes = T*C); out float32 [B,planes,Hp,Wp].
- * The k-th values are exact (3-pass radix select); workspace of v2v_postops_workspace_bytes(B) needed iff normalize. */
+ * The k-th values are exact (3-pass radix select); workspace of v2v_postops_workspace_bytes(B) needed iff normalize.
+ * B <= 65535 samples per call for every post-op entry point (one grid row per sample; V2V_ERR_SHAPE beyond). */
 int64_t v2v_postops_workspace_bytes(int64_t B);
 int v2v_normalize_pad_hip(const float *voxel, int64_t B, int64_t planes, int64_t H, int64_t W, int normalize, int pad_to,
                           float *out, void *workspace, void *stream);
@@ -418,7 +419,8 @@ int v2v_clip_frames_f32_ex_hip(const void *src, int64_t clip_stride, const int64
 /* the same with the gather's bounds (ABI 3, round 5; what the loader calls): stored_frames int32 [B] = frames clip b holds, src_elems =
  * bytes in `src` (0: not stated).  A picked frame outside [0, stored_frames[b]), or one that does not fit `src`, is not read: its output
  * frame is NaN -- like v2v_esim_extras.stored_frames for the simulator (the picks live on the device: no status code without a
- * synchronisation).  stored_frames NULL = v2v_clip_frames_f32_ex_hip (the caller vouches for the picks). */
+ * synchronisation).  stored_frames NULL = v2v_clip_frames_f32_ex_hip (the caller vouches for the picks).  Any B: more than 65,535
+ * output frames go out as several launches of whole clips on `stream`; L <= 65535. */
 int v2v_clip_frames_f32_bounded_hip(const void *src, int64_t clip_stride, const int64_t *clip_offsets, int64_t frame_stride, const int32_t *pick,
                                     int64_t pick_stride, const int32_t *stored_frames, int64_t src_elems, int64_t B, int64_t L, int64_t H, int64_t W,
                                     int64_t C, float *out, void *stream);

@@ -289,6 +289,13 @@ def test_clip_frames_equals_cpu_division_on_all_values():
     assert torch.equal(clip_frames_f32(sub, [3, 1]).cpu(), col[:, [4, 2]].float().permute(0, 1, 4, 2, 3) / 255)
     with pytest.raises(IndexError):
         clip_frames_f32(src.cuda(), [5])
+    # more output frames than one grid holds rows (65,535): the entry point sends whole clips out in several launches
+    many = torch.randint(0, 256, (9000, 9, 4, 8), dtype=torch.uint8, generator=g)
+    pick8 = [8, 0, 3, 3, 5, 1, 7, 2]
+    got = clip_frames_f32(many.cuda(), pick8).cpu()
+    assert got.shape == (9000, 8, 1, 4, 8) and torch.equal(got, (many[:, pick8].float() / 255).unsqueeze(2))
+    odd = many.reshape(9000, 9, 32)[:, :, :31].reshape(9000, 9, 1, 31).contiguous()          # 31 bytes per frame: the byte-wise kernel
+    assert torch.equal(clip_frames_f32(odd.cuda(), pick8).cpu(), (odd[:, pick8].float() / 255).unsqueeze(2))
 
 
 @pytest.mark.gpu

@@ -49,6 +49,10 @@ def test_hip_pad_and_fused(golden):
     assert np.array_equal(postops.normalize_batch_voxel(big).cpu().numpy(), want)
     with pytest.raises(ValueError):
         postops.normalize_batch_voxel(torch.zeros((1, 1, 1, 3, 3), device="cuda"))      # < 100 elements: kthvalue(0) raises in torch
+    with pytest.raises(ValueError, match="65535"):                                       # one grid row per sample: a clear refusal, not a launch error
+        postops.normalize_and_pad(torch.zeros((65536, 1, 1, 10, 10), device="cuda"), True, 16)
+    many = torch.round(torch.randn((65535, 1, 1, 10, 12), device="cuda") * 3)
+    assert torch.equal(postops.normalize_and_pad(many, True, 16)[-3:], postops.normalize_and_pad(many[-3:].contiguous(), True, 16))
 
 
 @pytest.mark.gpu

@@ -223,6 +223,7 @@ int v2v_voxel_apply_scales_hip(const float *voxel, int64_t B, int64_t planes, in
 {
     if (!voxel || !out) return fail(V2V_ERR_NULL, "v2v_voxel_apply_scales_hip: voxel/out is NULL");
     if (B < 0 || planes < 1 || H < 1 || W < 1 || pad_to < 1 || H_in < H || W_in < W) return fail(V2V_ERR_SHAPE, "need B>=0, planes,H,W,pad_to>=1, H_in>=H, W_in>=W");
+    if (B > 65535) return fail(V2V_ERR_SHAPE, "more than 65535 samples in one call (one grid row per sample): split the batch");
     if (!aligned(voxel, 4) || !aligned(out, 4) || (scales && !aligned(scales, 4))) return fail(V2V_ERR_ALIGN, "buffers misaligned");
     if (B == 0) return V2V_OK;
     const int Hp = (int)((H + pad_to - 1) / pad_to * pad_to), Wp = (int)((W + pad_to - 1) / pad_to * pad_to);
@@ -372,7 +373,7 @@ int v2v_clip_frames_f32_bounded_hip(const void *src, int64_t clip_stride, const 
     if (!src || !out) return fail(V2V_ERR_NULL, "v2v_clip_frames_f32_hip: src/out is NULL");
     if (B < 0 || L < 1 || H < 1 || W < 1 || C < 1 || C > 4) return fail(V2V_ERR_SHAPE, "need B>=0, L,H,W>=1, 1<=C<=4");
     const int64_t HW = H * W;
-    if (HW * C >= (int64_t)1 << 30 || B * L > 65535) return fail(V2V_ERR_SHAPE, "frame too large or more than 65535 output frames in one call (split the batch)");
+    if (HW * C >= (int64_t)1 << 30 || L > 65535) return fail(V2V_ERR_SHAPE, "frame too large or more than 65535 picked frames per clip");
     if (frame_stride < HW * C || (!clip_offsets && B > 1 && clip_stride < frame_stride) || (clip_offsets && clip_stride < 1) || pick_stride < 0 ||
         (pick_stride != 0 && (!pick || pick_stride < L)))
         return fail(V2V_ERR_SHAPE, "strides smaller than the extent");
@@ -381,20 +382,28 @@ int v2v_clip_frames_f32_bounded_hip(const void *src, int64_t clip_stride, const 
     if (src_elems < 0 || (!stored_frames && src_elems != 0)) return fail(V2V_ERR_SHAPE, "src_elems comes with stored_frames and is >= 0 (0: not stated)");
     if (B == 0) return V2V_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const uint8_t *sp = static_cast<const uint8_t *>(src);
-    const v2v::ClipBounds cb{stored_frames, src_elems};
     // with clip_offsets, clip_stride states the alignment (in bytes) every offset keeps
     const bool v4 = C == 1 && HW % 4 == 0 && frame_stride % 4 == 0 && ((B == 1 && !clip_offsets) || clip_stride % 4 == 0) && aligned(src, 4) && aligned(out, 16);
-    if (v4) {
-        const int hw4 = (int)(HW / 4);
-        const unsigned gx = (unsigned)std::min<int64_t>((hw4 + 255) / 256, 64);
-        hipLaunchKernelGGL(v2v::clip_frames4_kernel, dim3(gx, (unsigned)(B * L)), dim3(256), 0, s, sp, clip_stride, clip_offsets, frame_stride, pick, pick_stride,
-                           (int)L, hw4, out, cb);
-    } else {
-        const int64_t n = HW * C;
-        const unsigned gx = (unsigned)std::min<int64_t>((n + 255) / 256, 256);
-        hipLaunchKernelGGL(v2v::clip_frames_kernel, dim3(gx, (unsigned)(B * L)), dim3(256), 0, s, sp, clip_stride, clip_offsets, frame_stride, pick, pick_stride,
-                           (int)L, (int)HW, (int)C, out, cb);
+    // the grid's y dimension (one output frame each) holds 65,535: larger batches go out as several launches of whole clips
+    const int64_t group = std::max<int64_t>(1, 65535 / L);
+    for (int64_t b0 = 0; b0 < B; b0 += group) {
+        const int64_t nb = std::min(group, B - b0);
+        const uint8_t *sp = static_cast<const uint8_t *>(src) + (clip_offsets ? 0 : b0 * clip_stride);
+        const int64_t *offs = clip_offsets ? clip_offsets + b0 : nullptr;
+        const int32_t *pk = pick ? pick + b0 * pick_stride : nullptr;
+        const v2v::ClipBounds cb{stored_frames ? stored_frames + b0 : nullptr, (src_elems > 0 && !clip_offsets) ? std::max<int64_t>(1, src_elems - b0 * clip_stride) : src_elems};
+        float *o = out + b0 * L * HW * C;
+        if (v4) {
+            const int hw4 = (int)(HW / 4);
+            const unsigned gx = (unsigned)std::min<int64_t>((hw4 + 255) / 256, 64);
+            hipLaunchKernelGGL(v2v::clip_frames4_kernel, dim3(gx, (unsigned)(nb * L)), dim3(256), 0, s, sp, clip_stride, offs, frame_stride, pk, pick_stride,
+                               (int)L, hw4, o, cb);
+        } else {
+            const int64_t n = HW * C;
+            const unsigned gx = (unsigned)std::min<int64_t>((n + 255) / 256, 256);
+            hipLaunchKernelGGL(v2v::clip_frames_kernel, dim3(gx, (unsigned)(nb * L)), dim3(256), 0, s, sp, clip_stride, offs, frame_stride, pk, pick_stride,
+                               (int)L, (int)HW, (int)C, o, cb);
+        }
     }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? V2V_OK : hip_fail(e, "clip_frames kernel launch");
@@ -733,6 +742,7 @@ int v2v_voxel_scales_select_hip(const float *voxel, int64_t B, int64_t planes, i
 {
     if (!voxel || !scales || !workspace) return fail(V2V_ERR_NULL, "v2v_voxel_scales_select_hip: voxel/scales/workspace is NULL");
     if (B < 0 || planes < 1 || H < 1 || W < 1 || H_in < H || W_in < W) return fail(V2V_ERR_SHAPE, "need B>=0, planes,H,W>=1, H_in>=H, W_in>=W");
+    if (B > 65535) return fail(V2V_ERR_SHAPE, "more than 65535 samples in one call (one grid row per sample): split the batch");
     if (method != V2V_NORM_RADIX && method != V2V_NORM_COUNT) return fail(V2V_ERR_MODE, "method must be V2V_NORM_RADIX or V2V_NORM_COUNT");
     if (method == V2V_NORM_RADIX && (H_in != H || W_in != W)) return fail(V2V_ERR_MODE, "the radix select reads unpadded input; use V2V_NORM_COUNT for padded input");
     if (!aligned(voxel, 4) || !aligned(scales, 4) || !aligned(workspace, 16)) return fail(V2V_ERR_ALIGN, "buffers misaligned");
@@ -745,6 +755,7 @@ int v2v_normalize_pad_ex_hip(const float *voxel, int64_t B, int64_t planes, int6
 {
     if (!voxel || !out) return fail(V2V_ERR_NULL, "v2v_normalize_pad_hip: voxel/out is NULL");
     if (B < 0 || planes < 1 || H < 1 || W < 1 || pad_to < 1 || H_in < H || W_in < W) return fail(V2V_ERR_SHAPE, "need B>=0, planes,H,W,pad_to>=1, H_in>=H, W_in>=W");
+    if (B > 65535) return fail(V2V_ERR_SHAPE, "more than 65535 samples in one call (one grid row per sample): split the batch");
     if (method < V2V_NORM_NONE || method > V2V_NORM_COUNT) return fail(V2V_ERR_MODE, "unknown normalisation method %d", method);
     const bool normalize = method != V2V_NORM_NONE;
     if (normalize && !workspace) return fail(V2V_ERR_NULL, "normalisation needs a workspace of v2v_postops_workspace_bytes(B)");
