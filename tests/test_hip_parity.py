@@ -189,6 +189,26 @@ def test_strided_input_view(E, oracle_c, luts):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
+def test_long_clips(E, oracle_c, luts):
+    """MAXIMUM clip lengths: 3,001 (float32 grid) / 1,501 (float64) frames into 5 bilinear bins (the per-pair weight table and segment starts
+    fill LDS next to the Gaussian table), 10,001 frames into SUM bins (no per-pair table), both against the C oracle; one pair more than the tables hold is refused with
+    the status the header names (V2V_ERR_SHAPE -> ValueError), not mis-run."""
+    p = [0.2, 0.3, 0.05, 5e-3, 1.0]
+    for n, dt, tol in ((3001, torch.float32, dict(rtol=RTOL, atol=ATOL)), (1501, torch.float64, dict(rtol=1e-12, atol=1e-9))):   # 8 / 16 bytes of weights per pair
+        v = O.synth_clip_s1(n, 8, 12, seed=4, dtype=np.uint8)[None]
+        want, tot = oracle_c.esim_voxel(v, p, luts, seed=8, clip_id0=2, bin_mode=oracle_c.BIN_BILINEAR, num_bins=5)
+        counts = torch.zeros((1, 2), dtype=torch.int64, device="cuda")
+        got = E.esim_voxel_batch(torch.from_numpy(v).cuda(), p, bin_mode="bilinear", num_bins=5, seed=8, clip_id0=2, out_dtype=dt, counts=counts)
+        assert np.array_equal(counts.cpu().numpy(), tot)
+        np.testing.assert_allclose(got.cpu().numpy(), want, **tol)
+    v = O.synth_clip_s1(10001, 4, 8, seed=5, dtype=np.uint8)[None]
+    want, _ = oracle_c.esim_voxel(v, p, luts, seed=8, clip_id0=3, bin_mode=oracle_c.BIN_SUM, num_bins=5, frames_per_bin=4)
+    got = E.esim_voxel_batch(torch.from_numpy(v).cuda(), p, bin_mode="sum", num_bins=5, frames_per_bin=4, seed=8, clip_id0=3, out_dtype=torch.float64)
+    assert got.shape == (1, 500, 5, 4, 8) and np.array_equal(got.cpu().numpy(), want)
+    with pytest.raises(ValueError, match="split the clip"):
+        E.esim_voxel_batch(torch.zeros((1, 20001, 4, 4), dtype=torch.uint8, device="cuda"), p, bin_mode="bilinear", num_bins=5)
+
+
 def test_shard_invariance_and_batch_independence(E):
     """Clip b of a batch == the same clip run alone with clip_id0 = b: what makes 8-GPU sharding exact."""
     frames = E.synth_clips(6, 11, 32, 64, dtype=torch.uint8, seed=77)
