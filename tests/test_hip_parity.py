@@ -169,7 +169,7 @@ def test_hip_vs_c_oracle_philox(E, oracle_c, luts, dt, bin_mode, nb, fpb, n, ext
         np.testing.assert_allclose(got32.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
 
 
-@pytest.mark.parametrize("h,w", [(1, 1), (3, 5), (7, 9), (16, 18), (33, 31)])
+@pytest.mark.parametrize("h,w", [(1, 1), (3, 5), (7, 9), (16, 18), (33, 31), (1080, 1920), (719, 1279)])
 def test_ragged_sizes_scalar_path(E, oracle_c, luts, h, w):
     video = O.synth_clip_s1(6, h, w, seed=9, dtype=np.uint8)[None]
     p = [0.15, 0.25, 0.04, 0.02, 0.5]
