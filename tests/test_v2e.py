@@ -251,6 +251,23 @@ def test_hip_philox_equals_c_oracle(oracle_c, luts, dt, model, cutoff, leak, ref
 
 
 @gpu
+@pytest.mark.parametrize("h,w", [(1, 1), (3, 5), (33, 31), (16, 18), (719, 1279)])
+def test_hip_v2e_ragged_and_large_frames(oracle_c, luts, h, w):
+    """Frame sizes that are not multiples of the 4-pixel work-item or of the workgroup (the scalar tail paths, a partly empty last
+    workgroup, the per-frame sums of the shot-noise pre-pass over a ragged frame), up to an odd near-720p frame: C oracle, exact counts."""
+    import torch
+    from v2v_amd import v2e
+    args = [24, "pn_related", 0.5, 0.1, 0.0, 0.1, 30, 0.1, 0, 5.0, 0.1, 0.1]
+    for dt in (np.uint8, np.float32):
+        video = O.synth_clip_s1(7, h, w, seed=41, dtype=dt)[None]
+        want, totals = oracle_c.v2e_voxel(video, oracle_c.v2e_params(*args), luts, seed=77, clip_id0=9, bin_mode=oracle_c.BIN_SUM, num_bins=3, frames_per_bin=2)
+        counts = torch.zeros((1, 2), dtype=torch.int64, device="cuda")
+        got = v2e.v2e_voxel_batch(torch.from_numpy(video).cuda(), v2e.make_params(*args), bin_mode="sum", num_bins=3, frames_per_bin=2, seed=77, clip_id0=9,
+                                  out_dtype=torch.float64, counts=counts)
+        assert np.array_equal(got.cpu().numpy(), want) and np.array_equal(counts.cpu().numpy(), totals)
+
+
+@gpu
 def test_hip_v2e_errors():
     import torch
     from v2v_amd import v2e
