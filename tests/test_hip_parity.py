@@ -221,6 +221,37 @@ def test_shard_invariance_and_batch_independence(E):
     assert torch.equal(again, frames[3:5])
 
 
+def test_non_finite_and_out_of_range_float_frames(E):
+    """Degenerate float32 frames -- NaN, +-inf, negative, beyond 255, huge -- behave as in the reference's NumPy arithmetic
+    (data/v2v_core_esim.py:33-58): a NaN log value silences the pixel (every compare is false), an infinite potential passes the compare and
+    np.floor_divide(inf, C) is NaN, so that step's count is NaN and the pixel is silent afterwards.  NaN-aware equality on every voxel; the
+    neighbouring pixels of the same work-item are untouched."""
+    import warnings
+    v = O.synth_clip_s1(9, 4, 8, seed=4, dtype=np.float32)
+    v[3, 0, 0] = np.nan; v[2, 0, 1] = np.inf; v[4, 0, 2] = -np.inf; v[5, 0, 3] = -3.0; v[1, 0, 4] = 300.0; v[6, 0, 5] = 1e30; v[2, 0, 6] = 0.0
+    v[2:4, 2, 3] = np.inf; v[7, 3, 7] = np.nan
+    np.random.seed(3)
+    fields = O.draw_replay_fields(*v.shape)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = O.esim_video_to_voxel(v, 0.2, 0.3, 0.0, 0.0, 0.0, rng=O.ReplayRNG(fields[:2], [fields[2]] + list(fields[3])))
+    assert np.isnan(want).sum() >= 3
+    got = E.esim_voxel_batch(torch.from_numpy(v)[None].cuda(), [0.2, 0.3, 0, 0, 0], bin_mode="sum", num_bins=8, rng_mode="replay",
+                             replay=_replay_tensors(fields), out_dtype=torch.float64)[0, 0].cpu().numpy()
+    assert np.array_equal(got, want, equal_nan=True), np.argwhere(~((got == want) | (np.isnan(got) & np.isnan(want))))
+    got32 = E.esim_voxel_batch(torch.from_numpy(v)[None].cuda(), [0.2, 0.3, 0, 0, 0], bin_mode="sum", num_bins=8, rng_mode="replay",
+                               replay=_replay_tensors(fields))[0, 0].cpu().numpy()
+    assert np.array_equal(got32.astype(np.float64), want, equal_nan=True)
+    # the same frames with the reference's noise on (replayed fields), internal and external
+    for ext in (False, True):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            wantn = O.esim_video_to_voxel(v, 0.2, 0.3, 0.05, 5e-3, 1.0, put_noise_external=ext, rng=O.ReplayRNG(fields[:2], [fields[2]] + list(fields[3])))
+        gotn = E.esim_voxel_batch(torch.from_numpy(v)[None].cuda(), [0.2, 0.3, 0.05, 5e-3, 1.0], bin_mode="sum", num_bins=8, rng_mode="replay",
+                                  replay=_replay_tensors(fields), put_noise_external=ext, out_dtype=torch.float64)[0, 0].cpu().numpy()
+        assert np.isnan(wantn).any() and np.array_equal(gotn, wantn, equal_nan=True), ext
+
+
 def test_generic_fp32_content_tolerance(E):
     """Non-integer float32 content: the oracle's float32 pow/log are NumPy SIMD kernels that device
     powf/logf match only to 1-2 ulp, so counts may flip on <= 1e-5 of pixel-steps (SURVEY §7 hard part 4)."""

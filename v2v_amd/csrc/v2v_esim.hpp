@@ -470,7 +470,10 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 if (fabs(r[j]) >= thr[j]) q[j] += __builtin_copysign(1.0, r[j]);
-                else if (!(fabs(r[j]) < thr[j])) q[j] = 0.0;           // NaN potential: NumPy's compares are false -> no events
+                // NaN potential: NumPy's compares are false -> no events.  INFINITE potential (a +-inf or overflowing frame value): the compare
+                // passes and np.floor_divide(inf, C) is NaN (fmod(inf, C)), so the reference counts NaN in this step and the potential is NaN
+                // from then on (v2v_core_esim.py:51-58) -- q = NaN reproduces both through q * C and the accumulate
+                else if (!(fabs(r[j]) < thr[j])) q[j] = __builtin_isinf(mag[j]) ? __builtin_nan("") : 0.0;
             }
         }
         // Phase B: reset the potential (v2v_core_esim.py:57-58), signed count, binning.
