@@ -65,3 +65,51 @@ def test_kernel_results_do_not_depend_on_what_shares_the_cu(victim):
             torch.cuda.synchronize()
             for o in outs:
                 assert torch.equal(o, solo), f"{victim} differs from its stand-alone result while {name} runs on another stream ({int((o != solo).sum())} elements)"
+
+
+def test_entry_points_from_several_host_threads():
+    """The C ABI from several HOST threads at once (ctypes drops the GIL for the call), each on its own HIP stream: a data-loader thread next
+    to a training thread is the normal deployment.  Status text is thread-local, launch attributes are cached with atomics, nothing else is
+    shared: every thread must get its stand-alone results on every iteration, and an error raised in one thread must not leak into another's
+    status."""
+    import threading
+    from v2v_amd import esim, v2e, postops
+    u8 = esim.synth_clips(12, 41, 128, 128, dtype=torch.uint8)
+    f32 = esim.synth_clips(8, 32, 128, 128, dtype=torch.float32)
+    vp = v2e.make_params(24, "pn_related", 0.5, 0.1, 0.0, 0.1, 30, 0.1, 0, 5.0, 0.1, 0.1)
+    jobs = [
+        lambda: esim.esim_voxel_batch(u8, [0.2, 0.3, 0.05, 5e-4, 1.0], bin_mode="sum", num_bins=5, seed=3),
+        lambda: esim.esim_voxel_batch(f32, [0.2, 0.2, 0.1, 1e-3, 0.1], bin_mode="bilinear", num_bins=5, seed=4),
+        lambda: v2e.v2e_voxel_batch(u8, vp, bin_mode="sum", num_bins=5, seed=5),
+        lambda: postops.normalize_and_pad(esim.esim_voxel_batch(u8[:, :, :120, :120].contiguous(), [0.2, 0.3, 0.05, 5e-4, 1.0], bin_mode="sum", num_bins=5, seed=6),
+                                          normalize=True, method="count"),
+    ]
+    solo = [j() for j in jobs]
+    torch.cuda.synchronize()
+    errors, bad_frames = [], torch.zeros((1, 20, 8, 8), dtype=torch.uint8, device="cuda")
+
+    def work(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for it in range(25):
+                    out = jobs[i]()
+                    torch.cuda.current_stream().synchronize()
+                    if not torch.equal(out, solo[i]):
+                        errors.append(f"thread {i} iteration {it}: result differs from the stand-alone run")
+                        return
+                    if i == 0 and it % 5 == 0:                      # a refused call in THIS thread: its text stays here
+                        try:
+                            esim.esim_voxel_batch(bad_frames, [0.2, 0.2, 0, 0, 0], num_bins=5)
+                            errors.append("19 pairs into 5 bins was not refused")
+                        except AssertionError as e:
+                            if "num_bins" not in str(e) and "multiple" not in str(e):
+                                errors.append(f"foreign status text: {e}")
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"thread {i}: {type(e).__name__}: {e}")
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
