@@ -189,6 +189,23 @@ def test_strided_input_view(E, oracle_c, luts):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("bin_mode,nb,fpb,n", [("bilinear", 1, 1, 9), ("bilinear", 2, 1, 9), ("bilinear", 2, 1, 3), ("bilinear", 12, 1, 6), ("bilinear", 64, 1, 4),
+                                               ("sum", 1, 1, 2), ("sum", 1, 8, 9), ("sum", 8, 1, 9), ("sum", 1, 1, 9)])
+def test_bin_count_extremes(E, oracle_c, luts, bin_mode, nb, fpb, n):
+    """The ends of the binning parameters: one or two temporal-bilinear bins (no interior segment), more bins than frame pairs (most bins
+    empty), two frame pairs only; SUM with a single pair, a single plane of 8 pairs, one bin per pair -- HIP == C oracle, float64 exact."""
+    video = np.stack([O.synth_clip_s1(n, 24, 36, seed=60 + i, dtype=np.uint8) for i in range(2)])
+    p = [0.15, 0.22, 0.05, 5e-3, 1.0]
+    bm = oracle_c.BIN_SUM if bin_mode == "sum" else oracle_c.BIN_BILINEAR
+    want, tot = oracle_c.esim_voxel(video, p, luts, seed=21, clip_id0=7, bin_mode=bm, num_bins=nb, frames_per_bin=fpb)
+    counts = torch.zeros((2, 2), dtype=torch.int64, device="cuda")
+    got = E.esim_voxel_batch(torch.from_numpy(video).cuda(), p, bin_mode=bin_mode, num_bins=nb, frames_per_bin=fpb, seed=21, clip_id0=7,
+                             out_dtype=torch.float64, counts=counts)
+    assert got.shape == want.shape and np.array_equal(got.cpu().numpy(), want) and np.array_equal(counts.cpu().numpy(), tot)
+    got32 = E.esim_voxel_batch(torch.from_numpy(video.astype(np.float32)).cuda(), p, bin_mode=bin_mode, num_bins=nb, frames_per_bin=fpb, seed=21, clip_id0=7)
+    np.testing.assert_allclose(got32.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+
+
 def test_long_clips(E, oracle_c, luts):
     """MAXIMUM clip lengths: 3,001 (float32 grid) / 1,501 (float64) frames into 5 bilinear bins (the per-pair weight table and segment starts
     fill LDS next to the Gaussian table), 10,001 frames into SUM bins (no per-pair table), both against the C oracle; one pair more than the tables hold is refused with
