@@ -268,6 +268,23 @@ def test_hip_v2e_ragged_and_large_frames(oracle_c, luts, h, w):
 
 
 @gpu
+@pytest.mark.parametrize("bin_mode,nb,fpb,n", [("bilinear", 1, 1, 9), ("bilinear", 2, 1, 3), ("bilinear", 12, 1, 6), ("sum", 1, 1, 2), ("sum", 1, 8, 9), ("sum", 8, 1, 9)])
+def test_hip_v2e_bin_count_extremes(oracle_c, luts, bin_mode, nb, fpb, n):
+    """The v2e kernel's own binning at the ends of its parameters (one / two bilinear bins, more bins than pairs, a single pair, one plane
+    of 8 pairs, a bin per pair): C oracle, float64 exact."""
+    import torch
+    from v2v_amd import v2e
+    args = [24, "pn_related", 0.5, 0.1, 0.0, 0.1, 30, 0.1, 0, 5.0, 0.1, 0.1]
+    video = np.stack([O.synth_clip_s1(n, 24, 36, seed=70 + i, dtype=np.uint8) for i in range(2)])
+    bm = oracle_c.BIN_SUM if bin_mode == "sum" else oracle_c.BIN_BILINEAR
+    want, tot = oracle_c.v2e_voxel(video, oracle_c.v2e_params(*args), luts, seed=31, clip_id0=2, bin_mode=bm, num_bins=nb, frames_per_bin=fpb)
+    counts = torch.zeros((2, 2), dtype=torch.int64, device="cuda")
+    got = v2e.v2e_voxel_batch(torch.from_numpy(video).cuda(), v2e.make_params(*args), bin_mode=bin_mode, num_bins=nb, frames_per_bin=fpb, seed=31, clip_id0=2,
+                              out_dtype=torch.float64, counts=counts)
+    assert got.shape == want.shape and np.array_equal(got.cpu().numpy(), want) and np.array_equal(counts.cpu().numpy(), tot)
+
+
+@gpu
 def test_hip_v2e_errors():
     import torch
     from v2v_amd import v2e
