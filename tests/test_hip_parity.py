@@ -206,6 +206,25 @@ def test_bin_count_extremes(E, oracle_c, luts, bin_mode, nb, fpb, n):
     np.testing.assert_allclose(got32.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("dt", [np.uint8, np.float32])
+@pytest.mark.parametrize("ext", [False, True])
+def test_parameter_extremes(E, oracle_c, luts, dt, ext):
+    """Per-clip parameters at the ends of what the arithmetic takes: thresholds of 1e-3 (thousands of events per step, quotients far from
+    0 / 1), of 5 and 7 (a few hot-pixel events only), every pixel hot with a standard deviation of 50, base noise larger than any signal, and a clean
+    asymmetric clip beside them in the same launch -- HIP == C oracle, float64 counts exact, ON/OFF totals exact."""
+    params = np.array([[1e-3, 1.3e-3, 0.0, 0.0, 0.0], [5.0, 7.0, 0.05, 1e-3, 1.0], [0.2, 0.2, 2.0, 1.0, 50.0], [1e-3, 1e-3, 0.5, 0.5, 5.0],
+                       [0.31, 0.47, 0.0, 0.0, 0.0], [0.05, 0.9, 0.3, 0.02, 20.0]])
+    b = len(params)
+    video = np.stack([O.synth_clip_s1(11, 24, 40, seed=80 + i, dtype=dt) for i in range(b)])
+    for bin_mode, bm, nb, fpb in (("sum", oracle_c.BIN_SUM, 5, 2), ("bilinear", oracle_c.BIN_BILINEAR, 5, 1)):
+        want, tot = oracle_c.esim_voxel(video, params, luts, noise_external=ext, seed=0x5EED, clip_id0=3, bin_mode=bm, num_bins=nb, frames_per_bin=fpb)
+        counts = torch.zeros((b, 2), dtype=torch.int64, device="cuda")
+        got = E.esim_voxel_batch(torch.from_numpy(video).cuda(), params, bin_mode=bin_mode, num_bins=nb, frames_per_bin=fpb, seed=0x5EED, clip_id0=3,
+                                 put_noise_external=ext, out_dtype=torch.float64, counts=counts)
+        assert np.array_equal(got.cpu().numpy(), want), bin_mode
+        assert np.array_equal(counts.cpu().numpy(), tot) and tot[1].sum() < 1000 and tot[0].sum() > 1e5
+
+
 def test_long_clips(E, oracle_c, luts):
     """MAXIMUM clip lengths: 3,001 (float32 grid) / 1,501 (float64) frames into 5 bilinear bins (the per-pair weight table and segment starts
     fill LDS next to the Gaussian table), 10,001 frames into SUM bins (no per-pair table), both against the C oracle; one pair more than the tables hold is refused with
