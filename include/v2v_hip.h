@@ -174,6 +174,8 @@ int v2v_events_to_voxel_segmented_hip(const double *ts, const int64_t *xs, const
  * uint8_wrap = 1 reproduces the reference's uint8 wrap in (frame+20)/275 for uint8 input (v2v_core_v2e.py:184-190).
  * rng_mode: V2V_RNG_PHILOX (device-native fields; needs `workspace` of v2v_v2e_workspace_bytes() when
  * shot_noise_rate_hz > 0) or V2V_RNG_REPLAY (fields drawn by NumPy in the reference's order: bit-exact replay).
+ * The native shot-noise sampler inverts the Poisson law up to 64 events per pixel, frame and polarity: shot_noise_rate_hz <= 32 fps
+ * (16 expected events; the reference's default is 0.1), V2V_ERR_PARAM beyond -- REPLAY takes np.random.poisson's counts at any rate.
  * Output / binning / counts exactly as v2v_esim_voxel_hip. */
 typedef enum v2v_v2e_threshold_model {
     V2V_V2E_PN_RELATED = 0,                  /* "pn_related"                    */

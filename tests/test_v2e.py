@@ -285,6 +285,50 @@ def test_hip_v2e_bin_count_extremes(oracle_c, luts, bin_mode, nb, fpb, n):
 
 
 @gpu
+@pytest.mark.parametrize("dt", [np.uint8, np.float32])
+@pytest.mark.parametrize("name,args", [
+    ("tiny_thresholds_wide_spread", [24, "pn_related", 0.02, 0.05, 0.0, 0.02, 0, 0, 0, 0, 0.1, 0.1]),
+    ("shot_rate_100hz_low_fps", [5, "pn_related", 0.5, 0.1, 0.0, 0.1, 30, 0.1, 0, 100.0, 0.1, 1.0]),
+    ("leak_50hz_full_jitter", [24, "spatial_independent", 0.3, 0.05, 0.1, 0.05, 0, 50.0, 0, 0.0, 1.0, 0.1]),
+    ("refractory_longer_than_the_clip", [24, "spatial_temporal_independent", 0.2, 0.05, 0.0, 0.05, 200, 0.1, 10.0, 5.0, 0.1, 0.1]),
+    ("lowpass_1hz_at_240fps", [240, "pn_related", 0.1, 0.02, 0.05, 0.02, 1, 0.1, 1 / 480, 1.0, 0.1, 0.1]),
+])
+def test_hip_v2e_parameter_extremes(oracle_c, luts, dt, name, args):
+    """The v2e model's parameters at the ends of what its arithmetic takes (thresholds of a few hundredths with a spread larger than the mean,
+    a shot-noise rate of 100 Hz at 5 fps -- 10 expected noise events per pixel, frame and polarity -- a 50 Hz leak with full jitter, a
+    refractory period longer than the clip, a 1 Hz low-pass at 240 fps): HIP == C oracle, float64 counts and ON/OFF totals exact."""
+    import torch
+    from v2v_amd import v2e
+    video = np.stack([O.synth_clip_s1(13, 20, 28, seed=90 + i, dtype=dt) for i in range(2)])
+    want, tot = oracle_c.v2e_voxel(video, oracle_c.v2e_params(*args), luts, seed=0xFACE, clip_id0=4, bin_mode=oracle_c.BIN_SUM, num_bins=4, frames_per_bin=3)
+    counts = torch.zeros((2, 2), dtype=torch.int64, device="cuda")
+    got = v2e.v2e_voxel_batch(torch.from_numpy(video).cuda(), v2e.make_params(*args), bin_mode="sum", num_bins=4, frames_per_bin=3, seed=0xFACE, clip_id0=4,
+                              out_dtype=torch.float64, counts=counts)
+    assert np.array_equal(got.cpu().numpy(), want), name
+    assert np.array_equal(counts.cpu().numpy(), tot), name
+
+
+@gpu
+def test_hip_native_shot_noise_at_large_rates_and_its_refusal():
+    """The native Poisson sampler inverts up to 64 events per pixel, frame and polarity.  Inside its stated domain (shot_noise_rate_hz <= 32 fps,
+    i.e. <= 16 expected events) the per-pixel mean is the law's; beyond it the entry point refuses (V2V_ERR_PARAM -> ValueError) instead of
+    truncating silently -- the replay mode takes np.random.poisson's counts at any rate."""
+    import torch
+    from v2v_amd import v2e
+    b, n, h, w = 16, 2, 128, 128
+    video = torch.full((b, n, h, w), 90, dtype=torch.uint8, device="cuda")
+    for rate, fps in ((40.0, 5), (160.0, 5)):                                     # 4 and 16 expected events per pixel, frame and polarity
+        args = [fps, "pn_related", 0.5, 0.1, 0.0, 0.1, 0, 0, 0, rate, 0.1, 0.1]
+        counts = torch.zeros((b, 2), dtype=torch.int64, device="cuda")
+        v2e.v2e_voxel_batch(video, v2e.make_params(*args), bin_mode="sum", num_bins=1, seed=7, counts=counts)
+        lam, samples = rate / 2 / fps, b * h * w
+        for t in counts.cpu().numpy().sum(axis=0) / samples:
+            assert abs(t - lam) < 5 * np.sqrt(lam / samples) + 2e-3 * lam, (rate, t, lam)
+    with pytest.raises(ValueError, match="REPLAY"):
+        v2e.v2e_voxel_batch(video, v2e.make_params(5, "pn_related", 0.5, 0.1, 0.0, 0.1, 0, 0, 0, 161.0, 0.1, 0.1), bin_mode="sum", num_bins=1, seed=7)
+
+
+@gpu
 def test_hip_v2e_errors():
     import torch
     from v2v_amd import v2e

@@ -466,6 +466,12 @@ int v2v_v2e_voxel_hip(const void *frames, int in_dtype, int64_t B, int64_t N, in
     }
     const bool presum = shot && rng_mode == V2V_RNG_PHILOX;
     if (presum && !workspace) return fail(V2V_ERR_NULL, "native shot noise needs a workspace of v2v_v2e_workspace_bytes()");
+    // the native sampler inverts the Poisson distribution up to a count of 64 per pixel, frame and polarity: exact in distribution while the
+    // expected count stays small against that (frame mean rate / (2 fps) <= 16; the reference's default is 0.1), silently truncated beyond --
+    // refuse instead (np.random.poisson, i.e. REPLAY with host-drawn counts, has no such limit)
+    if (presum && params->shot_noise_rate_hz > 32.0 * params->fps)
+        return fail(V2V_ERR_PARAM, "native shot noise covers up to 16 expected noise events per pixel, frame and polarity (shot_noise_rate_hz <= 32 fps; got %g Hz at %g fps): "
+                                   "use V2V_RNG_REPLAY with host-drawn counts beyond", params->shot_noise_rate_hz, params->fps);
     if (bin_mode == V2V_BIN_SUM) {
         if (K % ((int64_t)num_bins * frames_per_bin) != 0)
             return fail(V2V_ERR_BINS, "(N-1)=%lld is not a multiple of num_bins*frames_per_bin=%d", (long long)K, num_bins * frames_per_bin);
