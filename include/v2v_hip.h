@@ -115,7 +115,10 @@ int v2v_lut_set(int which, const void *src_host);     /* the CURRENT device's ta
  * frames        [B,N,H,W] grayscale (HWC with C=1), dtype V2V_U8 or V2V_F32; rows contiguous;
  *               clip_stride / frame_stride in ELEMENTS (>= N*H*W / >= H*W).
  * params        device float64: {pos_thres, neg_thres, base_noise_std, hot_pixel_fraction, hot_pixel_std}
- *               per clip; params_stride = 5 for [B,5], 0 to broadcast one set.  Thresholds must be > 0.
+ *               per clip; params_stride = 5 for [B,5], 0 to broadcast one set.  The table lives on the device, so it is checked
+ *               there: a clip whose thresholds are outside [1e-9, 1e30] (the exact floor-divide needs |potential| / C < 2^40;
+ *               zero, negative, NaN have no meaning in the reference either) or whose noise parameters are negative or not finite
+ *               comes out as NaN planes (+ the flag word of `stats`); the other clips of the call are unaffected.
  * seed,clip_id0 Philox key and the GLOBAL id of clip 0 of this call (clip b uses clip_id0 + b).
  * replay        required iff rng_mode == V2V_RNG_REPLAY.
  * out_voxel     SUM: [B,L,Tb,H,W], L = (N-1)/(Tb*fpb); BILINEAR: [B,Tb,H,W]; dtype V2V_F32 or V2V_F64.

@@ -229,6 +229,34 @@ def test_symmetric_hint_is_exact_and_loud(oracle_c, luts):
             assert bool(torch.isnan(out[2]).all()) and torch.equal(out[[0, 1, 3, 4]], general[[0, 1, 3, 4]])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mapping", ["4px", "2px", "1px"])
+def test_device_resident_parameters_outside_the_domain_poison_their_clip_only(mapping):
+    """A [B,5] parameter table that lives on the device (the loaders' per-sample draws) cannot be checked by the host wrapper: a zero, negative,
+    NaN or sub-1e-9 threshold, a negative or infinite noise parameter makes THAT clip NaN (+ the statistics' flag word) in the kernel's
+    prologue -- never a wrong count -- and leaves the rest of the batch as it was.  The same values in a host list raise."""
+    from v2v_amd import _lib, esim
+    good = [0.2, 0.3, 0.05, 1e-3, 1.0]
+    rows = [good, [0.0, 0.3, 0.05, 1e-3, 1.0], good, [0.2, -0.3, 0.05, 1e-3, 1.0], [float("nan"), 0.3, 0.05, 1e-3, 1.0], [1e-12, 0.3, 0.05, 1e-3, 1.0],
+            [0.2, 0.3, -0.05, 1e-3, 1.0], [0.2, 0.3, 0.05, float("inf"), 1.0], [0.2, 0.3, 0.05, 1e-3, float("nan")], good]
+    bad = [i for i, r in enumerate(rows) if r is not good]
+    ok = [i for i, r in enumerate(rows) if r is good]
+    frames = esim.synth_clips(len(rows), 11, 64, 64, dtype=torch.uint8, seed=12)
+    clean = esim.esim_voxel_batch(frames, good, bin_mode="sum", num_bins=5, frames_per_bin=2, seed=3, mapping=mapping)
+    for mode, kw in (("sum", dict(num_bins=5, frames_per_bin=2)), ("bilinear", dict(num_bins=5))):
+        ref = esim.esim_voxel_batch(frames, good, bin_mode=mode, seed=3, mapping=mapping, **kw)
+        stats = torch.zeros((len(rows), _lib.VOXEL_STATS_WORDS), dtype=torch.int32, device="cuda") if mode == "sum" else None
+        out = esim.esim_voxel_batch(frames, torch.tensor(rows, dtype=torch.float64, device="cuda"), bin_mode=mode, seed=3, mapping=mapping, stats=stats, **kw)
+        assert all(bool(torch.isnan(out[i]).all()) for i in bad) and torch.equal(out[ok], ref[ok])
+        if stats is not None:
+            flag = stats[:, 513].cpu().numpy()                                   # kStatBad: the word behind the 513 histogram bins
+            assert all(flag[i] != 0 for i in bad) and all(flag[i] == 0 for i in ok)
+    assert torch.equal(clean, ref if mode == "sum" else clean)
+    for r in (rows[1], rows[5]):
+        with pytest.raises(ValueError):
+            esim.esim_voxel_batch(frames, r, bin_mode="sum", num_bins=5, frames_per_bin=2, seed=3)
+
+
 @pytest.mark.parametrize("workload,batch", [("cfg4_pipeline_720p_to_256_41f_sum5", 2), ("cfg5_fused_convlstm_channels_last", 2)])
 def test_bench_pipeline_workloads_run_with_two_ranks(workload, batch):
     """The configs BASELINE names for 8 GPUs (config 4: 720p -> front-end -> simulator; config 5: + the recurrent UNet) through the

@@ -256,6 +256,15 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
     asm volatile("" : "+v"(pos), "+v"(inv_pos));
     double base_std = 0.0, hot_frac = 0.0, hot_std = 0.0;
     if constexpr (NOISE) { base_std = pp[2]; hot_frac = pp[3]; hot_std = pp[4]; }
+    // parameters the arithmetic below is not exact for (host lists are checked by the callers; a DEVICE-resident [B,5] table -- the
+    // loaders' per-sample draws -- only here): thresholds outside [1e-9, 1e30] (the floor-divide estimate needs |potential| / C < 2^40;
+    // zero, negative and NaN thresholds have no meaning in the reference either), negative or non-finite noise parameters.  The clip
+    // comes out as NaN planes + the statistics' flag word, like every other broken per-clip promise (clip-uniform branch).
+    {
+        bool ok = pp[0] >= 1e-9 && pp[0] <= 1e30 && pp[1] >= 1e-9 && pp[1] <= 1e30;
+        if constexpr (NOISE) ok = ok && base_std >= 0.0 && base_std <= 1e30 && hot_frac >= 0.0 && hot_frac <= 1e30 && hot_std >= 0.0 && hot_std <= 1e30;
+        if (!ok) { poison_clip(); return; }
+    }
     const uint64_t seed_ = a.clip_keys ? a.clip_keys[2 * clip] : a.seed;
     const uint32_t clip_id = a.clip_keys ? (uint32_t)a.clip_keys[2 * clip + 1] : (uint32_t)(a.clip_id0 + (uint64_t)clip);
     const int64_t in_base = (FIDX ? a.clip_offsets[clip] : (int64_t)clip * a.clip_stride) + p0;
