@@ -241,7 +241,10 @@ int v2v_frontend_hip(const uint8_t *src, int64_t T, int64_t Hs, int64_t Ws, int6
 /* Batch form: src [B,T,Hs,Ws,Cs], frame_idx [B,N], clip_table device int32 [B,4] = {min_i, min_j, crop_before, flip}
  * per clip (no shake: the resize target is crop x crop); outputs [B,N,crop,crop(,C)].  One launch for the batch.
  * max_crop_before: upper bound of the table's crop_before column if the host knows it (sizes the LDS tile of the
- * gray-only path; clips above it still produce the same bytes through a slower path), 0 = bounded by the frame only. */
+ * gray-only path; clips above it still produce the same bytes through a slower path), 0 = bounded by the frame only.
+ * The tables live on the device and are not validated by this call: whatever they hold is CLAMPED into bounds on the device (frame
+ * numbers into [0, T), crop_before into [1, min(Hs, Ws)], the corner so that the rectangle lies inside the frame) -- a clamped crop,
+ * never an out-of-bounds read; the Python wrappers validate host tables and raise. */
 int v2v_frontend_batch_hip(const uint8_t *src, int64_t B, int64_t T, int64_t Hs, int64_t Ws, int64_t Cs, const int32_t *clip_table,
                            int64_t max_crop_before, int64_t crop, int gray_first, const int32_t *frame_idx, int64_t N,
                            uint8_t *out_imgs, uint8_t *out_gray, void *stream);

@@ -126,6 +126,31 @@ def test_hip_frontend_batch_equals_single_clip_calls():
         frontend.prepare_clips_batch(raw, np.array([[0, 0, 200, 0]] * 3), idx, crop)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["gray", "gray_in_bgr_out"])
+def test_hip_frontend_device_resident_tables_are_clamped_into_bounds(mode):
+    """Tables that live on the device (validate=False: no host round trip, the hipGraph-captured pipeline) were never seen by the host.  Whatever
+    they hold -- negative corners, a rectangle past the frame, a crop larger than the frame (and than the bound the LDS tile was sized for), frame numbers outside
+    the decoded clip -- every read stays inside the clip's frames: the result is that of the table clamped into bounds, never an
+    out-of-bounds access.  Valid rows of the same call are untouched."""
+    import torch
+    from v2v_amd import frontend
+    g = np.random.default_rng(5)
+    b, t, hs, ws, crop, cb_max = 5, 6, 90, 120, 32, 80
+    raw = torch.from_numpy(g.integers(0, 256, size=(b, t, hs, ws, 3), dtype=np.uint8)).cuda()
+    bad = np.array([[-5, 10, 64, 0], [70, 100, 64, 1], [3, 4, 5000, 0], [20, 30, 0, 1], [5, 7, 64, 0]], dtype=np.int32)
+    idx_bad = np.array([[0, 1, -3, 3, 4, 5, 99]] * b, dtype=np.int32)
+    cb = np.clip(bad[:, 2], 1, min(hs, ws))                     # the bound only sizes the LDS tile: larger crops take the unstaged path
+    fixed = np.stack([np.clip(bad[:, 0], 0, hs - cb), np.clip(bad[:, 1], 0, ws - cb), cb, bad[:, 3]], axis=1).astype(np.int32)
+    idx_fixed = np.clip(idx_bad, 0, t - 1)
+    want_imgs, want = frontend.prepare_clips_batch(raw, fixed, idx_fixed, crop, mode, want_imgs=True, max_crop_before=cb_max)
+    dev = lambda a: torch.from_numpy(a).cuda().contiguous()   # noqa: E731
+    got_imgs, got = frontend.prepare_clips_batch(raw, dev(bad), dev(idx_bad), crop, mode, want_imgs=True, validate=False, max_crop_before=cb_max)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want) and torch.equal(got_imgs, want_imgs)
+    assert torch.equal(got[4, :2], frontend.prepare_clip(raw[4], 64, 5, 7, False, crop, [0, 1], color_mode=mode)[1])
+
+
 # ---- LDS-tiled kernel (gray output only, no shake): same bits as the oracle and as the per-pixel gather kernel
 @pytest.mark.gpu
 @pytest.mark.parametrize("flip", [False, True])

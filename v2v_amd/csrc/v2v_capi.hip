@@ -559,8 +559,11 @@ int v2v_events_to_voxel_segmented_hip(const double *ts, const int64_t *xs, const
 // Front-end dispatch: the LDS-tiled kernel for the training configuration (BGR source, gray output only, no shake),
 // the per-pixel gather kernel otherwise.  LDS is sized for the largest crop rectangle the frame allows (the batch form
 // keeps the rectangles on the device); tiles that do not fit fall back to global reads inside the kernel.
-static hipError_t launch_frontend(const v2v::FrontendArgs &a, int64_t B, int64_t max_crop_before, hipStream_t s)
+static hipError_t launch_frontend(const v2v::FrontendArgs &a_in, int64_t B, int64_t max_crop_before, hipStream_t s)
 {
+    v2v::FrontendArgs a = a_in;
+    const int64_t frame_min = a.Hs < a.Ws ? a.Hs : a.Ws;
+    a.cb_max = (int32_t)frame_min;            // what a device-resident table is clamped to (a crop cannot exceed the frame's short side)
 #ifdef V2V_FRONTEND_FORCE_GATHER   // kernel-tuning builds only: always the gather kernel
     const bool force_gather = true;
 #else
@@ -571,8 +574,7 @@ static hipError_t launch_frontend(const v2v::FrontendArgs &a, int64_t B, int64_t
     const bool tiled = !force_gather && a.Cs == 3 && (bgr_mode || !a.out_imgs) && (a.di != nullptr || (a.need_h == a.crop && a.need_w == a.crop)) &&
                        a.Hs <= 32767 && a.Ws <= 32767;                        // 16-bit source coordinates in the LDS coefficient tables
     if (tiled) {
-        const int64_t frame_min = a.Hs < a.Ws ? a.Hs : a.Ws;
-        const int64_t cb_max = (max_crop_before > 0 && max_crop_before < frame_min) ? max_crop_before : frame_min;
+        const int64_t cb_max = (max_crop_before > 0 && max_crop_before < frame_min) ? max_crop_before : frame_min;   // sizes the LDS tile; larger crops take the unstaged path
         const double s_max = (double)cb_max / (double)a.crop;
         // tile = (4 waves x rows_per_wave) rows x (64 lanes x cpl) columns; shrink until the worst-case source rectangle fits
         for (int cpl = a.crop > 128 ? 4 : 2; cpl >= 2; cpl -= 2) {

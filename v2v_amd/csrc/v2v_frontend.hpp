@@ -28,6 +28,7 @@ struct FrontendArgs {
     // batch form: blockIdx.y = clip; every pointer above advances by one clip; per-clip crop parameters
     const int32_t *clip_table;              // [B,4] {min_i, min_j, crop_before, flip} or nullptr (scalars above)
     const uint8_t *src_end;                 // one past the last source byte (bounds the 8-byte neighbour loads)
+    int32_t cb_max;                         // the frame's short side: a device-resident table's crop_before is clamped to it
 };
 
 struct Coef { int s0, s1, a0, a1; };
@@ -106,12 +107,15 @@ __global__ void __launch_bounds__(256) frontend_kernel(const FrontendArgs a_in)
         if (a.clip_table) {
             const int32_t *t4 = a.clip_table + clip * 4;
             a.min_i = t4[0]; a.min_j = t4[1]; a.crop_before = t4[2]; a.flip = t4[3];
+            a.crop_before = min(max(a.crop_before, 1), a.cb_max);                 // device-resident table: clamped into the frame
+            a.min_i = min(max(a.min_i, 0), a.Hs - a.crop_before);
+            a.min_j = min(max(a.min_j, 0), a.Ws - a.crop_before);
         }
     }
     const int n = (int)(gid / ((int64_t)a.crop * qpr));
     const int rem = (int)(gid - (int64_t)n * a.crop * qpr);
     const int y = rem / qpr, x0 = (rem - y * qpr) * kFrontPx;
-    const int t = a.frame_idx[n];
+    const int t = min(max(a.frame_idx[n], 0), a.T - 1);
     const int Y = y + (a.di ? a.di[t] : 0);
     const int dj = a.dj ? a.dj[t] : 0;
     const uint8_t *frame = a.src + ((int64_t)t * a.Hs * a.Ws + (int64_t)a.min_i * a.Ws + a.min_j) * a.Cs;
@@ -287,11 +291,17 @@ __global__ void __launch_bounds__(256) frontend_tile_kernel(const FrontendTileAr
     const int ncol = min(kCols, a.crop - x0), nrow = min(tile_rows, a.crop - y0);
     int min_i = a.min_i, min_j = a.min_j, cb = a.crop_before, flip = a.flip;
     if (a.clip_table) { const int32_t *t4 = a.clip_table + (int64_t)clip * 4; min_i = t4[0]; min_j = t4[1]; cb = t4[2]; flip = t4[3]; }
+    // a table that lives on the device was not seen by the host: keep every read inside the clip's frames whatever it holds (no effect
+    // on a valid table; an invalid one gives a clamped crop, never an out-of-bounds access; a rectangle larger than the LDS tile was
+    // sized for takes the unstaged path below)
+    cb = min(max(cb, 1), a.cb_max);
+    min_i = min(max(min_i, 0), a.Hs - cb);
+    min_j = min(max(min_j, 0), a.Ws - cb);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform: steers scalar loops
     for (int n = n_first; n <= n_last; ++n) {
     if (n > n_first) __syncthreads();                    // everyone is done with the previous frame's rows (and tables, with shake)
-    const int t = a.frame_idx[(int64_t)clip * a.N + n];
+    const int t = min(max(a.frame_idx[(int64_t)clip * a.N + n], 0), a.T - 1);     // clamped like the crop rectangle
     const uint8_t *frame = a.src + (((int64_t)clip * a.T + t) * a.Hs * a.Ws + (int64_t)min_i * a.Ws + min_j) * 3;
     uint8_t *out = a.out_gray + ((int64_t)clip * a.N + n) * a.crop * a.crop;
     uint8_t *out3 = (BGR && a.out_imgs) ? a.out_imgs + ((int64_t)clip * a.N + n) * a.crop * a.crop * 3 : nullptr;
