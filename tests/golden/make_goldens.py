@@ -500,6 +500,53 @@ class _FakeH5:
         return False
 
 
+def g19_event_and_fps_loaders():
+    """The other two real-data loaders of data/testh5.py that sit on the event-list voxeliser's data, run by the REFERENCE on golden G16's
+    sequence (served through _FakeH5 like G16): TestH5EventDataset.__getitem__ (:305-381: raw [n,5] event rows per image interval, no
+    voxelisation) and FPS_H5Dataset (:448-520: a frame-less stream cut at a fixed rate, one make_voxel per cut).  Inputs are G16's
+    arrays (not stored again); only the reference's outputs are."""
+    z = np.load(os.path.join(HERE, "g16_monash_sequence.npz"))
+    keys = [str(k) for k in z["images/keys"]]
+    _FakeH5.store = {"events": {k: z[f"events/{k}"] for k in ("ts", "xs", "ys", "ps")},
+                     "images": {k: (z["images/stack"][i], {"event_idx": z["images/event_idx"][i], "timestamp": z["images/timestamp"][i]}) for i, k in enumerate(keys)},
+                     "attrs": {"sensor_resolution": z["attrs/sensor_resolution"], "num_events": int(z["attrs/num_events"]), "num_imgs": int(z["attrs/num_imgs"]), "source": "hqf"}}
+    sys.modules["h5py"].File = _FakeH5
+    out = {}
+    cfgs = {"a": {"sequence_length": 4, "num_bins": 5, "dataset_name": "hqf"},
+            "b": {"sequence_length": 5, "warm_up_length": 1, "num_bins": 3, "output_additional_frame": True, "image_range": 1, "dataset_name": "evaid"}}
+    for tag, cfg in cfgs.items():
+        ds = ref_th5.TestH5EventDataset("/fake/hqf_h5/bike_bay_hdr.h5", cfg)
+        out[f"ev_{tag}__len"] = np.array(len(ds))
+        for i in range(len(ds)):
+            s = ds[i]
+            assert s["sequence_name"] == ["bike_bay_hdr"] * len(s["frame_idx"])
+            out[f"ev_{tag}__{i}__frame"] = s["frame"].numpy()
+            out[f"ev_{tag}__{i}__n"] = np.array(len(s["events"]))
+            for j, e in enumerate(s["events"]):
+                assert e.dtype == torch_mod().float64
+                out[f"ev_{tag}__{i}__events{j}"] = e.numpy()
+            out[f"ev_{tag}__{i}__meta"] = np.stack([s["real_begin_idx"].numpy(), s["frame_idx"].numpy()])
+            out[f"ev_{tag}__{i}__source"] = np.array(int(s["data_source_idx"]))
+    fcfgs = {"a": {"sequence_length": 6, "num_bins": 5, "FPS": 100, "H": 36, "W": 48, "dataset_name": "evbird"},
+             "b": {"sequence_length": 80, "num_bins": 3, "interpolate_bins": True, "FPS": 40, "H": 40, "W": 50, "dataset_name": "evbird"}}
+    for tag, cfg in fcfgs.items():
+        ds = ref_th5.FPS_H5Dataset("/fake/evbird/lhy_0.h5", cfg)
+        out[f"fps_{tag}__len"] = np.array(len(ds))
+        out[f"fps_{tag}__samples"] = np.array(ds.samples)
+        out[f"fps_{tag}__event_idx"] = np.asarray(ds.event_idx)
+        for i in range(len(ds)):
+            s = ds[i]
+            assert set(s) == {"events", "data_source_idx", "sequence_name"} and s["sequence_name"] == ["lhy_0"] * s["events"].shape[0]
+            out[f"fps_{tag}__{i}__events"] = s["events"].numpy()
+            out[f"fps_{tag}__{i}__source"] = np.array(int(s["data_source_idx"]))
+    save("g19_event_and_fps_loaders.npz", **out)
+
+
+def torch_mod():
+    import torch
+    return torch
+
+
 def g16_monash_sequence():
     """A small event sequence in the Monash HDF5 layout + what the REFERENCE's own loaders make of it:
     TestH5Dataset.__getitem__ (data/testh5.py:96-173, two configurations) and DynamicH5Dataset.__getitem__ as
@@ -575,9 +622,9 @@ def g17_degrade_video():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
     fns = {"g1": g1_luts, "g2": g2_g3_esim_clean, "g4": g4_esim_noisy, "g5": g5_floor_divide,
-           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g15": g15_bgr_to_gray, "g16": g16_monash_sequence, "g17": g17_degrade_video, "g18": g18_unet_modules, "g12": g12_events_to_voxel_torch,
+           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g15": g15_bgr_to_gray, "g16": g16_monash_sequence, "g19": g19_event_and_fps_loaders, "g17": g17_degrade_video, "g18": g18_unet_modules, "g12": g12_events_to_voxel_torch,
            "g13": g13_normalize_batch_voxel}
     for w in which:
         fns[w]()

@@ -167,3 +167,59 @@ def test_h5_branches_end_to_end(tmp_path, monkeypatch, golden):
         for k in ("frames", "flow", "events", "timestamps", "dt"):
             assert f[k][()].dtype == np.float32 and np.array_equal(f[k][()], z[k]) and np.array_equal(d1[k], d2[k])
         assert f.attrs["source"] == "esim" and list(f.attrs["sensor_resolution"]) == [36, 48]
+
+
+# ---- the other two loaders of data/testh5.py on the same sequence: golden G19 = the reference's TestH5EventDataset / FPS_H5Dataset
+EV_CFGS = {"a": {"sequence_length": 4, "num_bins": 5, "dataset_name": "hqf"},
+           "b": {"sequence_length": 5, "warm_up_length": 1, "num_bins": 3, "output_additional_frame": True, "image_range": 1, "dataset_name": "evaid"}}
+FPS_CFGS = {"a": {"sequence_length": 6, "num_bins": 5, "FPS": 100, "H": 36, "W": 48, "dataset_name": "evbird"},
+            "b": {"sequence_length": 80, "num_bins": 3, "interpolate_bins": True, "FPS": 40, "H": 40, "W": 50, "dataset_name": "evbird"}}
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_event_dataset_equals_reference(golden, tag):
+    """TestH5EventDataset (data/testh5.py:305-381) returns raw event rows, no voxel grids: host logic only, exact (no GPU needed) --
+    [x, y, t, p in {-1,+1}, 0] in float64 per image interval, one row of zeros for the empty interval, frames as TestH5Dataset."""
+    from v2v_amd.testh5 import TestH5EventDataset
+    g = golden("g19_event_and_fps_loaders.npz")
+    ds = TestH5EventDataset(FIX, EV_CFGS[tag])
+    assert len(ds) == int(g[f"ev_{tag}__len"])
+    for i in range(len(ds)):
+        s = ds[i]
+        assert set(s) == {"frame", "events", "data_source_idx", "sequence_name", "real_begin_idx", "frame_idx"}
+        assert s["frame"].dtype == torch.float32 and np.array_equal(s["frame"].numpy(), g[f"ev_{tag}__{i}__frame"])
+        assert isinstance(s["events"], list) and len(s["events"]) == int(g[f"ev_{tag}__{i}__n"])
+        for j, e in enumerate(s["events"]):
+            assert e.dtype == torch.float64 and np.array_equal(e.numpy(), g[f"ev_{tag}__{i}__events{j}"]), (i, j)
+        assert np.array_equal(np.stack([s["real_begin_idx"].numpy(), s["frame_idx"].numpy()]), g[f"ev_{tag}__{i}__meta"])
+        assert int(s["data_source_idx"]) == int(g[f"ev_{tag}__{i}__source"]) and s["data_source_idx"].dtype == torch.int64
+    assert any(e.shape == (1, 5) and not e.any() for i in range(len(ds)) for e in ds[i]["events"])      # the fixture's empty interval
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_fps_dataset_cut_table_equals_reference(golden, tag):
+    """FPS_H5Dataset's constructor (data/testh5.py:452-481): number of cuts, np.searchsorted borders, sample table -- host logic only."""
+    from v2v_amd.testh5 import FPS_H5Dataset
+    g = golden("g19_event_and_fps_loaders.npz")
+    ds = FPS_H5Dataset(FIX, FPS_CFGS[tag])
+    assert len(ds) == int(g[f"fps_{tag}__len"]) and np.array_equal(np.array(ds.samples), g[f"fps_{tag}__samples"])
+    assert np.array_equal(np.asarray(ds.event_idx), g[f"fps_{tag}__event_idx"]) and (ds.H, ds.W) == (FPS_CFGS[tag]["H"], FPS_CFGS[tag]["W"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_fps_dataset_getitem_equals_reference(golden, tag):
+    """Every sample: the reference's dict (events [L,Tb,H,W] float32, data_source_idx, sequence_name), one segmented launch per sample.
+    Discrete bins exact; interpolated bins to 1e-6 (float64 atomics in another order, then the reference's float32 cast)."""
+    from v2v_amd.testh5 import FPS_H5Dataset
+    g = golden("g19_event_and_fps_loaders.npz")
+    ds = FPS_H5Dataset(FIX, FPS_CFGS[tag])
+    for i in range(len(ds)):
+        s = ds[i]
+        want = g[f"fps_{tag}__{i}__events"]
+        assert set(s) == {"events", "data_source_idx", "sequence_name"} and s["events"].dtype == torch.float32 and s["events"].shape == want.shape
+        if FPS_CFGS[tag].get("interpolate_bins"):
+            np.testing.assert_allclose(s["events"].numpy(), want, rtol=1e-6, atol=1e-6)
+        else:
+            assert np.array_equal(s["events"].numpy(), want)
+        assert int(s["data_source_idx"]) == int(g[f"fps_{tag}__{i}__source"]) and s["sequence_name"] == ["g16_monash_sequence"] * want.shape[0]

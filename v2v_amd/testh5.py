@@ -1,4 +1,4 @@
-"""`TestH5Dataset` -- drop-in for data/testh5.py:14-173 (the real-data validation loader around `make_voxel`).
+"""`TestH5Dataset`, `TestH5EventDataset`, `FPS_H5Dataset` -- drop-ins for data/testh5.py:14-173, :305-381, :448-520 (the real-data validation loaders around `make_voxel`).
 
 Same constructor `(h5_path, configs)`, config keys and defaults (:17-58), sample table (:43-52), `make_voxel(evs)` (:60-90)
 and `__getitem__` dict (:96-173: frame [L(+1),1,H,W] float32, events [L(+1),Tb,H,W] float32, data_source_idx, sequence_name,
@@ -88,4 +88,86 @@ class TestH5Dataset(torch.utils.data.Dataset, voxel.MakeVoxelMixin):
             "sequence_name": [self.sequence_name] * n,
             "real_begin_idx": torch.tensor([real_begin] * n, dtype=torch.int64),
             "frame_idx": torch.tensor(list(range(begin, end)), dtype=torch.int64),
+        }
+
+
+class TestH5EventDataset(TestH5Dataset):
+    """data/testh5.py:305-381: the same samples, but `events` is the list of RAW event rows per image interval -- float64 [n,5] =
+    [x, y, t, p in {-1,+1}, 0] (one [1,5] row of zeros for an empty interval) -- instead of voxel grids.  No voxelisation, so no device
+    work: host IO only.  (`output_additional_evs` is not read by the reference's method either.)"""
+    __test__ = False
+
+    def __getitem__(self, idx):
+        begin, real_begin, end = self.samples[idx]
+        with monash.open_sequence(self.h5_path) as f:
+            frames = [torch.tensor(self.get_img(f, i + 1), dtype=torch.float32).unsqueeze(0) for i in range(begin, end)]
+            ev_idx = [int(f.image_attr(self.img_keys[i], "event_idx")) for i in range(begin, end + 1)]
+            lo, hi = ev_idx[0], max(ev_idx[-1], ev_idx[0])
+            ts, xs, ys, ps = (np.asarray(f.events(k, lo, hi)).astype(np.float64) for k in ("ts", "xs", "ys", "ps"))   # float64: :329-333
+            first_frame = self.get_img(f, begin) if self.output_additional_frame else None
+        ps = ps * 2 - 1                                                                  # :334
+        rows = np.stack([xs, ys, ts, ps, np.zeros_like(ps)], axis=1)
+        all_events = []
+        for a, b in zip(ev_idx[:-1], ev_idx[1:]):
+            ev = torch.tensor(rows[a - lo:max(b, a) - lo].copy(), dtype=torch.float64)
+            all_events.append(ev if ev.shape[0] else torch.zeros((1, 5), dtype=torch.float64))   # :342-343
+        all_frames = torch.stack(frames, dim=0)
+        if self.output_additional_frame:
+            ff = torch.tensor(first_frame, dtype=torch.float32).unsqueeze(0).unsqueeze(0)
+            all_frames = torch.cat([ff, all_frames], dim=0)
+        if self.image_range == 1:
+            all_frames = all_frames / 255.0
+        n = end - begin
+        return {
+            "frame": all_frames,
+            "events": all_events,
+            "data_source_idx": torch.tensor(data_sources.index(self.dataset_name.lower()), dtype=torch.int64),
+            "sequence_name": [self.sequence_name] * n,
+            "real_begin_idx": torch.tensor([real_begin] * n, dtype=torch.int64),
+            "frame_idx": torch.tensor(list(range(begin, end)), dtype=torch.int64),
+        }
+
+
+class FPS_H5Dataset(TestH5Dataset):
+    """data/testh5.py:448-520: a frame-less event stream cut at a fixed rate -- `FPS` cuts per second between the first and the last
+    timestamp (np.linspace borders, np.searchsorted into events/ts), `sequence_length` consecutive cuts per sample, one voxel grid per cut
+    on an H x W sensor given by the configuration.  Returns {events [L,Tb,H,W] float32, data_source_idx, sequence_name}.  All grids of a
+    sample go through ONE segmented launch of the scatter kernel."""
+    __test__ = False
+
+    def __init__(self, h5_path, configs):  # noqa: D107 - the reference does not call its parent's constructor either
+        self.h5_path = h5_path
+        self.sequence_name = os.path.basename(h5_path).split(".")[0]
+        self.configs = configs
+        self.dataset_name = configs.get("dataset_name", "hqf")
+        self.sequence_length = configs.get("sequence_length", 40)
+        self.warm_up_length = configs.get("warm_up_length", 0)
+        self.num_bins = configs.get("num_bins", 5)
+        self.interpolate_bins = configs.get("interpolate_bins", False)
+        self.FPS = configs.get("FPS", 100)
+        self.H = configs.get("H", 260)
+        self.W = configs.get("W", 346)
+        self.device = configs.get("sim_device", "cuda")                                  # this implementation only
+        with monash.open_sequence(h5_path) as f:
+            ts = np.asarray(f.events("ts"))
+            min_t, max_t = ts[0], ts[-1]
+            self.total_frame_cnt = int((max_t - min_t) * self.FPS)                       # :470
+            border_timestamps = np.linspace(min_t, max_t, self.total_frame_cnt + 1)
+            self.event_idx = np.searchsorted(ts, border_timestamps)                      # :473
+        self.samples = []                                                                # (begin, end), :475-480
+        for i in range(0, self.total_frame_cnt - 1, self.sequence_length):
+            self.samples.append((i, min(self.total_frame_cnt - 1, i + self.sequence_length)))
+
+    def __getitem__(self, idx):
+        begin, end = self.samples[idx]
+        seg = np.asarray(self.event_idx[begin:end + 1], dtype=np.int64)
+        lo, hi = int(seg[0]), int(seg[-1])
+        with monash.open_sequence(self.h5_path) as f:
+            evs = [f.events(k, lo, hi) for k in ("ts", "xs", "ys", "ps")]
+        grids = voxel.make_voxels_segmented([np.asarray(evs[0], dtype=np.float64), evs[1], evs[2], evs[3]], seg - lo, self.H, self.W, self.num_bins,
+                                            self.interpolate_bins, device=self.device)
+        return {
+            "events": torch.as_tensor(grids).to(torch.float32).cpu(),                   # torch.tensor(voxel, dtype=float32), :503
+            "data_source_idx": torch.tensor(data_sources.index(self.dataset_name.lower()), dtype=torch.int64),
+            "sequence_name": [self.sequence_name] * (end - begin),
         }
