@@ -16,6 +16,10 @@ class _Dataset:
     def __len__(self):
         return len(self._a)
 
+    @property
+    def shape(self):
+        return self._a.shape
+
 
 class _Group(dict):
     attrs = None
@@ -38,6 +42,11 @@ class File:
                 for i, key in enumerate(z["images/keys"]):
                     imgs[str(key)] = _Dataset(z["images/stack"][i], {"event_idx": z["images/event_idx"][i], "timestamp": z["images/timestamp"][i]})
                 self._root["images"] = imgs
+            if "flow/keys" in z.files:                           # MVSEC-style sequences: a group of optic-flow maps with event_idx / image_idx attrs
+                fl = _Group()
+                for i, key in enumerate(z["flow/keys"]):
+                    fl[str(key)] = _Dataset(z["flow/stack"][i], {"event_idx": z["flow/event_idx"][i], "image_idx": z["flow/image_idx"][i]})
+                self._root["flow"] = fl
             for k in z.files:                                   # flat datasets of a cached-voxel file (frames, flow, events, timestamps, dt)
                 if "/" not in k:
                     self._root[k] = _Dataset(z[k])

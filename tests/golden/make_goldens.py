@@ -481,8 +481,15 @@ class _FakeH5:
     def __init__(self, path, mode="r"):
         s = _FakeH5.store
         self.attrs = dict(s["attrs"])
-        self._groups = {"events": _FakeH5._Group({k: _FakeH5._Dset(v) for k, v in s["events"].items()}),
-                        "images": _FakeH5._Group({k: _FakeH5._Dset(a, at) for k, (a, at) in sorted(s["images"].items())})}
+        self._groups = {}
+        if "images" in s:
+            self._groups = {"events": _FakeH5._Group({k: _FakeH5._Dset(v) for k, v in s["events"].items()}),
+                            "images": _FakeH5._Group({k: _FakeH5._Dset(a, at) for k, (a, at) in sorted(s["images"].items())})}
+        if "flow" in s:
+            self._groups["flow"] = _FakeH5._Group({k: _FakeH5._Dset(a, at) for k, (a, at) in sorted(s["flow"].items())})
+        for k in ("frames", "events_cache"):                  # a voxel cache (TestH5CacheDataset): top-level datasets `frames`, `events`
+            if k in s:
+                self._groups["events" if k == "events_cache" else k] = _FakeH5._Dset(s[k])
 
     def keys(self):
         return self._groups.keys()
@@ -540,6 +547,59 @@ def g19_event_and_fps_loaders():
             out[f"fps_{tag}__{i}__events"] = s["events"].numpy()
             out[f"fps_{tag}__{i}__source"] = np.array(int(s["data_source_idx"]))
     save("g19_event_and_fps_loaders.npz", **out)
+
+
+def g20_flow_and_cache_loaders():
+    """TestH5FlowDataset (data/testh5.py:175-303: MVSEC-style sequences, one sample item per optic-flow map: the events between two flow
+    maps' `event_idx`, the image named by the map's `image_idx`, the map itself) and TestH5CacheDataset (:383-446: pre-built voxel
+    caches) run by the REFERENCE.  The flow sequence is G16's events and images + seven random flow maps (stored here: the one new input);
+    the cache is what TestH5Dataset produced for G16's configuration "a" (frames [n,H,W] and events [n,Tb,H,W] + the two attributes)."""
+    import torch
+    z = np.load(os.path.join(HERE, "g16_monash_sequence.npz"))
+    keys = [str(k) for k in z["images/keys"]]
+    g = np.random.default_rng(2020)
+    H, W = int(z["attrs/sensor_resolution"][0]), int(z["attrs/sensor_resolution"][1])
+    n_flow = 7
+    flow = g.normal(0, 2.0, size=(n_flow, 2, H, W)).astype(np.float32)
+    n_ev = int(z["attrs/num_events"])
+    flow_event_idx = np.array([0, 300, 1350, 1350, 1353, 2900, n_ev], dtype=np.int64)              # an empty and a 3-event interval
+    flow_image_idx = np.array([0, 1, 2, 4, 5, 7, 11], dtype=np.int64)                             # the last one beyond the images: clamped (:236)
+    fkeys = ["flow{:09d}".format(i) for i in range(n_flow)]
+    store = {"events": {k: z[f"events/{k}"] for k in ("ts", "xs", "ys", "ps")},
+             "images": {k: (z["images/stack"][i], {"event_idx": z["images/event_idx"][i], "timestamp": z["images/timestamp"][i]}) for i, k in enumerate(keys)},
+             "flow": {k: (flow[i], {"event_idx": flow_event_idx[i], "image_idx": flow_image_idx[i]}) for i, k in enumerate(fkeys)},
+             "attrs": {"sensor_resolution": z["attrs/sensor_resolution"], "num_events": n_ev, "num_imgs": int(z["attrs/num_imgs"]), "source": "mvsec"}}
+    _FakeH5.store = store
+    sys.modules["h5py"].File = _FakeH5
+    out = {"flow/stack": flow, "flow/keys": np.array(fkeys), "flow/event_idx": flow_event_idx, "flow/image_idx": flow_image_idx}
+    cfgs = {"a": {"sequence_length": 4, "num_bins": 5, "dataset_name": "mvsec"},
+            "b": {"sequence_length": 3, "num_bins": 3, "interpolate_bins": True, "output_additional_frame": True, "output_additional_evs": True, "image_range": 1,
+                  "dataset_name": "mvsec", "max_samples": 2}}
+    for tag, cfg in cfgs.items():
+        ds = ref_th5.TestH5FlowDataset("/fake/mvsec/indoor_flying1.h5", cfg)
+        out[f"flow_{tag}__len"] = np.array(len(ds))
+        out[f"flow_{tag}__samples"] = np.array(ds.samples)
+        for i in range(len(ds)):
+            s = ds[i]
+            assert set(s) == {"frame", "events", "flow", "data_source_idx", "sequence_name", "frame_idx"} and s["sequence_name"] == ["indoor_flying1"] * len(s["frame_idx"])
+            for k in ("frame", "events", "flow", "frame_idx"):
+                out[f"flow_{tag}__{i}__{k}"] = s[k].numpy()
+            out[f"flow_{tag}__{i}__source"] = np.array(int(s["data_source_idx"]))
+    # the cache: every item of TestH5Dataset(config a with one long sample) stacked, as a converter would store it
+    _FakeH5.store = {k: store[k] for k in ("events", "images", "attrs")}
+    full = ref_th5.TestH5Dataset("/fake/hqf_h5/bike_bay_hdr.h5", {"sequence_length": 100, "num_bins": 5, "dataset_name": "hqf"})[0]
+    cache = {"frames": full["frame"].numpy()[:, 0], "events_cache": full["events"].numpy(), "attrs": {"num_bins": 5, "interpolate_bins": False}}
+    _FakeH5.store = cache
+    ds = ref_th5.TestH5CacheDataset("/fake/cache/bike_bay_hdr.h5", {"sequence_length": 3, "num_bins": 5, "dataset_name": "hqf"})
+    out["cache__frames"], out["cache__events"] = cache["frames"], cache["events_cache"]
+    out["cache__len"] = np.array(len(ds))
+    out["cache__samples"] = np.array(ds.samples)
+    for i in range(len(ds)):
+        s = ds[i]
+        assert set(s) == {"frame", "events", "data_source_idx", "sequence_name"} and s["sequence_name"] == ["bike_bay_hdr"] * len(s["data_source_idx"])
+        out[f"cache__{i}__frame"], out[f"cache__{i}__events"] = s["frame"].numpy(), s["events"].numpy()
+        out[f"cache__{i}__source"] = s["data_source_idx"].numpy()
+    save("g20_flow_and_cache_loaders.npz", **out)
 
 
 def torch_mod():
@@ -622,9 +682,9 @@ def g17_degrade_video():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
     fns = {"g1": g1_luts, "g2": g2_g3_esim_clean, "g4": g4_esim_noisy, "g5": g5_floor_divide,
-           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g15": g15_bgr_to_gray, "g16": g16_monash_sequence, "g19": g19_event_and_fps_loaders, "g17": g17_degrade_video, "g18": g18_unet_modules, "g12": g12_events_to_voxel_torch,
+           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g15": g15_bgr_to_gray, "g16": g16_monash_sequence, "g19": g19_event_and_fps_loaders, "g20": g20_flow_and_cache_loaders, "g17": g17_degrade_video, "g18": g18_unet_modules, "g12": g12_events_to_voxel_torch,
            "g13": g13_normalize_batch_voxel}
     for w in which:
         fns[w]()

@@ -223,3 +223,109 @@ def test_fps_dataset_getitem_equals_reference(golden, tag):
         else:
             assert np.array_equal(s["events"].numpy(), want)
         assert int(s["data_source_idx"]) == int(g[f"fps_{tag}__{i}__source"]) and s["sequence_name"] == ["g16_monash_sequence"] * want.shape[0]
+
+
+# ---- MVSEC-style flow sequences and voxel caches: golden G20 = the reference's TestH5FlowDataset / TestH5CacheDataset
+FLOW_CFGS = {"a": {"sequence_length": 4, "num_bins": 5, "dataset_name": "mvsec"},
+             "b": {"sequence_length": 3, "num_bins": 3, "interpolate_bins": True, "output_additional_frame": True, "output_additional_evs": True, "image_range": 1,
+                   "dataset_name": "mvsec", "max_samples": 2}}
+
+
+def _flow_fixture(tmp_path, golden):
+    """G16's events and images + G20's flow maps as one .npz sequence (the layout v2v_amd.monash documents)."""
+    g16, g20 = golden("g16_monash_sequence.npz"), golden("g20_flow_and_cache_loaders.npz")
+    path = tmp_path / "indoor_flying1.npz"
+    np.savez(path, **{k: g16[k] for k in g16 if k.split("/")[0] in ("events", "images", "attrs")}, **{k: g20[k] for k in g20 if k.startswith("flow/")})
+    return str(path), g20
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_flow_dataset_sample_table_equals_reference(tmp_path, golden, tag):
+    from v2v_amd.testh5 import TestH5FlowDataset
+    path, g = _flow_fixture(tmp_path, golden)
+    ds = TestH5FlowDataset(path, FLOW_CFGS[tag])
+    assert len(ds) == int(g[f"flow_{tag}__len"]) and np.array_equal(np.array(ds.samples), g[f"flow_{tag}__samples"]) and (ds.H, ds.W) == (36, 48)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_flow_dataset_getitem_equals_reference(tmp_path, golden, tag):
+    """TestH5FlowDataset.__getitem__ (data/testh5.py:218-303): frames by the maps' image_idx (clamped), voxel grids of the events between
+    consecutive maps (an empty and a 3-event interval in the fixture), the maps, the extra leading frame / grid of configuration b."""
+    from v2v_amd.testh5 import TestH5FlowDataset
+    path, g = _flow_fixture(tmp_path, golden)
+    ds = TestH5FlowDataset(path, FLOW_CFGS[tag])
+    for i in range(len(ds)):
+        s = ds[i]
+        assert set(s) == {"frame", "events", "flow", "data_source_idx", "sequence_name", "frame_idx"}
+        assert s["frame"].dtype == torch.float32 and np.array_equal(s["frame"].numpy(), g[f"flow_{tag}__{i}__frame"])
+        assert np.array_equal(s["flow"].numpy(), g[f"flow_{tag}__{i}__flow"]) and np.array_equal(s["frame_idx"].numpy(), g[f"flow_{tag}__{i}__frame_idx"])
+        want = g[f"flow_{tag}__{i}__events"]
+        assert s["events"].dtype == torch.float32 and s["events"].shape == want.shape
+        if FLOW_CFGS[tag].get("interpolate_bins"):
+            np.testing.assert_allclose(s["events"].numpy(), want, rtol=1e-6, atol=1e-6)
+        else:
+            assert np.array_equal(s["events"].numpy(), want)
+        assert int(s["data_source_idx"]) == int(g[f"flow_{tag}__{i}__source"]) and s["sequence_name"] == ["indoor_flying1"] * s["frame_idx"].numel()
+
+
+def test_cache_dataset_equals_reference(tmp_path, golden):
+    """TestH5CacheDataset (data/testh5.py:383-446) over a cache in the .npz form: sample table, slices, per-item source indices; a
+    configuration that disagrees with the cache's attributes is refused by the same asserts."""
+    from v2v_amd.testh5 import TestH5CacheDataset
+    g = golden("g20_flow_and_cache_loaders.npz")
+    path = tmp_path / "bike_bay_hdr.npz"
+    np.savez(path, frames=g["cache__frames"], events=g["cache__events"], **{"attrs/num_bins": np.array(5), "attrs/interpolate_bins": np.array(False)})
+    ds = TestH5CacheDataset(str(path), {"sequence_length": 3, "num_bins": 5, "dataset_name": "hqf"})
+    assert len(ds) == int(g["cache__len"]) and np.array_equal(np.array(ds.samples), g["cache__samples"]) and (ds.H, ds.W) == (36, 48)
+    for i in range(len(ds)):
+        s = ds[i]
+        assert set(s) == {"frame", "events", "data_source_idx", "sequence_name"}
+        assert np.array_equal(s["frame"].numpy(), g[f"cache__{i}__frame"]) and np.array_equal(s["events"].numpy(), g[f"cache__{i}__events"])
+        assert np.array_equal(s["data_source_idx"].numpy(), g[f"cache__{i}__source"]) and s["sequence_name"] == ["bike_bay_hdr"] * len(s["data_source_idx"])
+    with pytest.raises(AssertionError):
+        TestH5CacheDataset(str(path), {"num_bins": 3})
+    with pytest.raises(AssertionError):
+        TestH5CacheDataset(str(path), {"num_bins": 5, "interpolate_bins": True})
+
+
+@pytest.mark.gpu
+def test_cache_writer_produces_what_the_reference_reader_was_given(tmp_path, golden):
+    """v2v_amd.voxel_cache.testh5_to_cache on G16's sequence == the cache golden G20 fed to the reference's reader (= the reference's
+    TestH5Dataset items, stacked), and reading it back through TestH5CacheDataset gives the golden samples."""
+    from v2v_amd.testh5 import TestH5CacheDataset
+    from v2v_amd.voxel_cache import testh5_to_cache
+    g = golden("g20_flow_and_cache_loaders.npz")
+    out = tmp_path / "bike_bay_hdr.npz"
+    d = testh5_to_cache(FIX, str(out), {"num_bins": 5, "dataset_name": "hqf"})
+    assert np.array_equal(d["frames"], g["cache__frames"]) and np.array_equal(d["events"], g["cache__events"])
+    ds = TestH5CacheDataset(str(out), {"sequence_length": 3, "num_bins": 5})
+    assert all(np.array_equal(ds[i]["events"].numpy(), g[f"cache__{i}__events"]) for i in range(len(ds)))
+
+
+@pytest.mark.gpu
+def test_flow_and_cache_loaders_over_the_h5_container(tmp_path, monkeypatch, golden):
+    """The .h5 branches of the flow and cache loaders (stand-in h5py): same samples as over the .npz form that golden G20 pins; the cache
+    written as .h5 reads back through TestH5CacheDataset."""
+    import shutil
+    import sys
+    import fake_h5py
+    from v2v_amd.testh5 import TestH5CacheDataset, TestH5FlowDataset
+    from v2v_amd.voxel_cache import testh5_to_cache
+    npz, g = _flow_fixture(tmp_path, golden)
+    monkeypatch.setitem(sys.modules, "h5py", fake_h5py)
+    h5 = tmp_path / "indoor_flying1.h5"
+    shutil.copy(npz, h5)
+    a, b = TestH5FlowDataset(str(h5), FLOW_CFGS["b"]), TestH5FlowDataset(npz, FLOW_CFGS["b"])
+    assert len(a) == len(b) and a.samples == b.samples and a.flow_keys == b.flow_keys
+    for i in range(len(a)):
+        sa, sb = a[i], b[i]
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]) if isinstance(sa[k], torch.Tensor) else sa[k] == sb[k], k
+    seq = tmp_path / "bike_bay_hdr.h5"
+    shutil.copy(FIX, seq)
+    out = tmp_path / "cache" / "bike_bay_hdr.h5"
+    out.parent.mkdir()
+    testh5_to_cache(str(seq), str(out), {"num_bins": 5, "dataset_name": "hqf"})
+    ds = TestH5CacheDataset(str(out), {"sequence_length": 3, "num_bins": 5})
+    assert len(ds) == int(g["cache__len"]) and all(np.array_equal(ds[i]["events"].numpy(), g[f"cache__{i}__events"]) for i in range(len(ds)))

@@ -11,6 +11,8 @@
         "events/ts" ...            the event arrays
         "images/stack"             [n, H, W] uint8, "images/keys" the image names, "images/event_idx", "images/timestamp"
         "attrs/sensor_resolution", "attrs/num_events", "attrs/num_imgs", "attrs/source"
+        "flow/stack" [m, 2, H, W], "flow/keys", "flow/event_idx", "flow/image_idx"      (MVSEC-style sequences with optic flow, optional)
+    and voxel caches (data/testh5.py:383-446): top-level datasets "frames" [n,H,W], "events" [n,Tb,H,W], attrs num_bins, interpolate_bins
 Host-side IO only; the voxelisation itself is v2v_amd/voxel.py -> HIP.
 """
 from __future__ import annotations
@@ -22,7 +24,7 @@ class NpzSequence:
     def __init__(self, path):
         z = np.load(path, allow_pickle=False)
         self._z = {k: z[k] for k in z.files}
-        self.image_keys = [str(k) for k in self._z["images/keys"]]
+        self.image_keys = [str(k) for k in self._z["images/keys"]] if "images/keys" in self._z else []
         self._idx = {k: i for i, k in enumerate(self.image_keys)}
 
     def image(self, key):
@@ -41,7 +43,24 @@ class NpzSequence:
         return str(v) if v.dtype.kind in "US" else (v if v.ndim else v[()])
 
     def has_flow(self):
-        return False
+        return "flow/stack" in self._z and len(self._z["flow/stack"]) > 0
+
+    @property
+    def flow_keys(self):
+        return [str(k) for k in self._z["flow/keys"]]
+
+    def flow(self, key):
+        return self._z["flow/stack"][self.flow_keys.index(key)]
+
+    def flow_attr(self, key, name):
+        return self._z[f"flow/{name}"][self.flow_keys.index(key)]
+
+    def dataset(self, name, a=None, b=None):
+        """A top-level dataset (voxel caches: `frames`, `events`)."""
+        return self._z[name][a:b]
+
+    def dataset_len(self, name):
+        return len(self._z[name])
 
     def close(self):
         pass
@@ -57,7 +76,7 @@ class H5Sequence:
     def __init__(self, path):
         import h5py                                           # absent from this image; present where real data lives
         self._f = h5py.File(path, "r")
-        self.image_keys = sorted(self._f["images"].keys())
+        self.image_keys = sorted(self._f["images"].keys()) if "images" in self._f.keys() else []
 
     def image(self, key):
         return self._f["images"][key][()]
@@ -73,6 +92,22 @@ class H5Sequence:
 
     def has_flow(self):
         return "flow" in self._f.keys() and len(self._f["flow"]) > 0
+
+    @property
+    def flow_keys(self):
+        return sorted(self._f["flow"].keys())
+
+    def flow(self, key):
+        return self._f["flow"][key][()]
+
+    def flow_attr(self, key, name):
+        return self._f["flow"][key].attrs[name]
+
+    def dataset(self, name, a=None, b=None):
+        return self._f[name][a:b]
+
+    def dataset_len(self, name):
+        return self._f[name].shape[0]
 
     def close(self):
         self._f.close()

@@ -75,3 +75,26 @@ def convert(in_path, out_path, temporal_bilinear, num_bins=5, device="cuda"):
             for k, v in data.items():
                 f.create_dataset(k, data=v, dtype=np.float32)
     return data
+
+
+def testh5_to_cache(in_path, out_path, configs):
+    """Write the voxel cache TestH5CacheDataset reads (data/testh5.py:383-446: datasets `frames` [n,H,W] float32 and `events`
+    [n,Tb,H,W] float32, attributes num_bins / interpolate_bins) from a Monash-format sequence: every item of
+    v2v_amd.testh5.TestH5Dataset(in_path, configs) -- one segmented launch of the scatter kernel for the whole sequence.  The reference's
+    docstring names scripts/testh5_to_voxel_cache.py for this; the script is not in the repository, the reader defines the format."""
+    from .testh5 import TestH5Dataset
+    cfg = dict(configs, sequence_length=1 << 30, warm_up_length=0, max_samples=None, output_additional_frame=False, output_additional_evs=False)
+    ds = TestH5Dataset(in_path, cfg)
+    s = ds[0]
+    frames = s["frame"].numpy()[:, 0].astype(np.float32)
+    events = s["events"].numpy().astype(np.float32)
+    if str(out_path).endswith(".npz"):
+        np.savez_compressed(out_path, frames=frames, events=events, **{"attrs/num_bins": np.array(ds.num_bins), "attrs/interpolate_bins": np.array(bool(ds.interpolate_bins))})
+    else:
+        import h5py
+        with h5py.File(out_path, "w") as f:
+            f.attrs["num_bins"] = ds.num_bins
+            f.attrs["interpolate_bins"] = bool(ds.interpolate_bins)
+            f.create_dataset("frames", data=frames)
+            f.create_dataset("events", data=events)
+    return {"frames": frames, "events": events}
