@@ -487,9 +487,9 @@ class _FakeH5:
                             "images": _FakeH5._Group({k: _FakeH5._Dset(a, at) for k, (a, at) in sorted(s["images"].items())})}
         if "flow" in s:
             self._groups["flow"] = _FakeH5._Group({k: _FakeH5._Dset(a, at) for k, (a, at) in sorted(s["flow"].items())})
-        for k in ("frames", "events_cache"):                  # a voxel cache (TestH5CacheDataset): top-level datasets `frames`, `events`
+        for k in ("frames", "events_cache", "flow_top"):      # a voxel cache: top-level datasets `frames`, `events` (, `flow`)
             if k in s:
-                self._groups["events" if k == "events_cache" else k] = _FakeH5._Dset(s[k])
+                self._groups[{"events_cache": "events", "flow_top": "flow"}.get(k, k)] = _FakeH5._Dset(s[k])
 
     def keys(self):
         return self._groups.keys()
@@ -602,6 +602,38 @@ def g20_flow_and_cache_loaders():
     save("g20_flow_and_cache_loaders.npz", **out)
 
 
+def g21_esim_h5_dataset():
+    """ESIMH5Dataset (data/esim_dataset.py:49-152), the training loader over the cached voxels scripts/esim_to_voxel.py writes, run by the
+    REFERENCE on a small cache after random.seed / np.random.seed: random crop, flip, pause schedule, Gaussian or integer noise on every
+    step, hot pixels.  The cache (frames / flow / events) is stored; the samples are the reference's outputs."""
+    import random
+    ref_esim = _load("ref_esim_dataset", os.path.join(REF, "data/esim_dataset.py"))
+    g = np.random.default_rng(2121)
+    n, H, W = 14, 20, 24
+    cache = {"frames": g.random((n, 1, H, W)).astype(np.float32), "flow": g.normal(0, 1, (n, 2, H, W)).astype(np.float32),
+             "events_cache": np.round(g.normal(0, 1.5, (n, 5, H, W))).astype(np.float32), "attrs": {"sensor_resolution": np.array([H, W])}}
+    cache["flow_top"] = cache.pop("flow")
+    _FakeH5.store = cache
+    sys.modules["h5py"].File = _FakeH5
+    out = {"frames": cache["frames"], "flow": cache["flow_top"], "events": cache["events_cache"], "attrs/sensor_resolution": np.array([H, W])}
+    cfgs = {"a": {"sequence_length": 6, "random_crop_size": 16, "noise_std": 0.1, "hot_pixel_std": 0.1, "max_hot_pixel_fraction": 0.05},
+            "b": {"sequence_length": 5, "step_size": 3, "random_crop_size": None, "random_flip": False, "noise_std": 0.7, "noise_fraction": 0.3,
+                  "proba_pause_when_running": 0.4, "proba_pause_when_paused": 0.6, "hot_pixel_std": 2.0, "max_hot_pixel_fraction": 0.1, "integer_noise": True}}
+    for tag, cfg in cfgs.items():
+        ds = ref_esim.ESIMH5Dataset("/fake/esim_h5/seq.h5", cfg)
+        out[f"ds_{tag}__len"] = np.array(len(ds))
+        out[f"ds_{tag}__samples"] = np.array(ds.samples)
+        for i in range(len(ds)):
+            random.seed(100 + i)
+            np.random.seed(200 + i)
+            s = ds[i]
+            assert set(s) == {"frame", "flow", "events", "data_source_idx"}
+            for k in ("frame", "flow", "events"):
+                out[f"ds_{tag}__{i}__{k}"] = s[k].numpy()
+            out[f"ds_{tag}__{i}__source"] = np.array(int(s["data_source_idx"]))
+    save("g21_esim_h5_dataset.npz", **out)
+
+
 def torch_mod():
     import torch
     return torch
@@ -682,9 +714,9 @@ def g17_degrade_video():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
     fns = {"g1": g1_luts, "g2": g2_g3_esim_clean, "g4": g4_esim_noisy, "g5": g5_floor_divide,
-           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g15": g15_bgr_to_gray, "g16": g16_monash_sequence, "g19": g19_event_and_fps_loaders, "g20": g20_flow_and_cache_loaders, "g17": g17_degrade_video, "g18": g18_unet_modules, "g12": g12_events_to_voxel_torch,
+           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g15": g15_bgr_to_gray, "g16": g16_monash_sequence, "g19": g19_event_and_fps_loaders, "g20": g20_flow_and_cache_loaders, "g21": g21_esim_h5_dataset, "g17": g17_degrade_video, "g18": g18_unet_modules, "g12": g12_events_to_voxel_torch,
            "g13": g13_normalize_batch_voxel}
     for w in which:
         fns[w]()
