@@ -187,6 +187,20 @@ def g12_events_to_voxel_torch():
     save("g12_events_to_voxel_torch.npz", ts=ts, xs=xs, ys=ys, ps=ps, bilinear=bil.numpy(), discrete=disc.numpy())
 
 
+def g22_voxel_grid_lists():
+    """The list-of-grids helpers around events_to_voxel_torch (utils/event_utils.py:378-464): voxel_grids_fixed_n_torch,
+    voxel_grids_fixed_t_torch, events_to_voxel_timesync_torch, run by the REFERENCE on golden G12's 600 events (inputs not stored again)."""
+    import torch
+    z = np.load(os.path.join(HERE, "g12_events_to_voxel_torch.npz"))
+    tt, tp, tx, ty = (torch.from_numpy(z[k]) for k in ("ts", "ps", "xs", "ys"))
+    out = {}
+    for tag, tb in (("bil", True), ("disc", False)):
+        out[f"fixed_n_{tag}"] = torch.stack(ref_eu.voxel_grids_fixed_n_torch(tx, ty, tt, tp, 5, 100, sensor_size=(16, 24), temporal_bilinear=tb)).numpy()
+        out[f"fixed_t_{tag}"] = torch.stack(ref_eu.voxel_grids_fixed_t_torch(tx, ty, tt, tp, 4, 0.007, sensor_size=(16, 24), temporal_bilinear=tb)).numpy()
+        out[f"timesync_{tag}"] = ref_eu.events_to_voxel_timesync_torch(tx, ty, tt, tp, 3, 0.004, 0.0215, sensor_size=(16, 24), temporal_bilinear=tb).numpy()
+    save("g22_voxel_grid_lists.npz", **out)
+
+
 def g13_normalize_batch_voxel():
     """normalize_batch_voxel (model/train_utils.py:147-166).  The module needs torchvision/torchmetrics/skimage, which
     are absent, so ONLY that function is compiled from the reference file (AST extraction at run time; no source kept)."""
@@ -714,9 +728,9 @@ def g17_degrade_video():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22"]
     fns = {"g1": g1_luts, "g2": g2_g3_esim_clean, "g4": g4_esim_noisy, "g5": g5_floor_divide,
-           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g15": g15_bgr_to_gray, "g16": g16_monash_sequence, "g19": g19_event_and_fps_loaders, "g20": g20_flow_and_cache_loaders, "g21": g21_esim_h5_dataset, "g17": g17_degrade_video, "g18": g18_unet_modules, "g12": g12_events_to_voxel_torch,
+           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g15": g15_bgr_to_gray, "g16": g16_monash_sequence, "g19": g19_event_and_fps_loaders, "g20": g20_flow_and_cache_loaders, "g21": g21_esim_h5_dataset, "g17": g17_degrade_video, "g18": g18_unet_modules, "g12": g12_events_to_voxel_torch, "g22": g22_voxel_grid_lists,
            "g13": g13_normalize_batch_voxel}
     for w in which:
         fns[w]()

@@ -293,6 +293,33 @@ def test_g12_events_to_voxel_torch(golden):
     assert np.array_equal(disc.cpu().numpy(), g["discrete"])                      # +-1 sums: exact
 
 
+@pytest.mark.parametrize("tag,tb", [("bil", True), ("disc", False)])
+def test_g22_lists_of_voxel_grids(golden, tag, tb):
+    """voxel_grids_fixed_n_torch / voxel_grids_fixed_t_torch / events_to_voxel_timesync_torch (utils/event_utils.py:378-464) on G12's events
+    against the reference's own lists (golden G22).  The fixed-n list is one segmented launch; its grids equal one events_to_voxel_torch call
+    per group bit for bit (same per-event float32 terms, same kernel)."""
+    from v2v_amd import voxel
+    e, g = golden("g12_events_to_voxel_torch.npz"), golden("g22_voxel_grid_lists.npz")
+    xs, ys, ts, ps = (torch.from_numpy(e[k]) for k in ("xs", "ys", "ts", "ps"))
+    tol = dict(rtol=1e-5, atol=1e-5) if tb else dict(rtol=0, atol=0)
+    fixed_n = voxel.voxel_grids_fixed_n_torch(xs, ys, ts, ps, 5, 100, sensor_size=(16, 24), temporal_bilinear=tb)
+    assert isinstance(fixed_n, list) and len(fixed_n) == 5 and fixed_n[0].is_cuda and fixed_n[0].dtype == torch.float32
+    np.testing.assert_allclose(torch.stack(fixed_n).cpu().numpy(), g[f"fixed_n_{tag}"], **tol)
+    if not tb:
+        for i, grid in enumerate(fixed_n):
+            sl = slice(100 * i, 100 * i + 100)
+            assert torch.equal(grid, voxel.events_to_voxel_torch(xs[sl], ys[sl], ts[sl], ps[sl], 5, sensor_size=(16, 24), temporal_bilinear=False))
+    fixed_t = voxel.voxel_grids_fixed_t_torch(xs, ys, ts, ps, 4, 0.007, sensor_size=(16, 24), temporal_bilinear=tb)
+    assert len(fixed_t) == 4
+    np.testing.assert_allclose(torch.stack(fixed_t).cpu().numpy(), g[f"fixed_t_{tag}"], **tol)
+    one = voxel.events_to_voxel_timesync_torch(xs, ys, ts, ps, 3, 0.004, 0.0215, sensor_size=(16, 24), temporal_bilinear=tb)
+    np.testing.assert_allclose(one.cpu().numpy(), g[f"timesync_{tag}"], **tol)
+    with pytest.raises(AssertionError):
+        voxel.events_to_voxel_timesync_torch(xs, ys, ts, ps, 3, 0.02, 0.01)
+    with pytest.raises(AssertionError):
+        voxel.events_to_voxel_timesync_torch(xs, ys, ts, ps, 3, 5.0, 6.0)                  # no event in the window
+
+
 @pytest.mark.parametrize("interp", [False, True])
 def test_make_voxels_segmented_equals_per_interval_calls(interp):
     """One launch for all image intervals == one make_voxel per interval (data/testh5.py:111-119), incl. empty ones."""

@@ -4,6 +4,7 @@ Mirrors (same names, argument order, shapes and dtypes):
     make_voxel(evs, H, W, num_bins=5, interpolate_bins=True)     scripts/visualize_esim_sample.py:113-135
     MakeVoxelMixin.make_voxel(self, evs)                         data/testh5.py:60-90  (TestH5Dataset.make_voxel)
     events_to_voxel(xs, ys, ts, ps, B, sensor_size, temporal_bilinear)   utils/event_utils.py:692-728
+    events_to_voxel_torch / events_to_voxel_timesync_torch / voxel_grids_fixed_n_torch / voxel_grids_fixed_t_torch   utils/event_utils.py:378-507
 NumPy in -> NumPy float64 out; CUDA tensors in -> CUDA float64 tensor out.  The scatter runs in the HIP kernel
 (v2v_amd/csrc/v2v_events.hpp); nothing here computes on the CPU.
 """
@@ -120,6 +121,61 @@ def events_to_neg_pos_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(1
     pos_w, neg_w = torch.where(ps > 0, one, zero), torch.where(ps <= 0, one, zero)
     return (events_to_voxel_torch(xs, ys, ts, pos_w, B, device, sensor_size, temporal_bilinear),
             events_to_voxel_torch(xs, ys, ts, neg_w, B, device, sensor_size, temporal_bilinear))
+
+
+def _grids_of_ranges(xs, ys, ts, ps, B, ranges, device, sensor_size, temporal_bilinear):
+    """float32 grids of the event ranges [a, b): ONE segmented launch when the ranges tile a contiguous stretch (grid f = events
+    [seg[f], seg[f+1]), each with its own time normalisation, exactly one events_to_voxel_torch call per range), one call per range
+    otherwise."""
+    dev = torch.device(device) if device is not None else (xs.device if getattr(xs, "is_cuda", False) else torch.device("cuda"))
+    if len(ranges) > 1 and all(ranges[i][1] == ranges[i + 1][0] for i in range(len(ranges) - 1)):
+        _lib.require_gpu()
+        lo, hi = ranges[0][0], ranges[-1][1]
+        ts_d = _dev(ts[lo:hi], torch.float64, dev)                                    # float32 in: ts - ts[seg] is exact in float64, then cast (:194 rule)
+        xs_d, ys_d, ps_d = _dev(xs[lo:hi], torch.int64, dev), _dev(ys[lo:hi], torch.int64, dev), _dev(ps[lo:hi], torch.float32, dev)
+        seg = torch.tensor([a - lo for a, _ in ranges] + [hi - lo], dtype=torch.int64, device=dev)
+        h, w = sensor_size
+        out = torch.empty((len(ranges), B, h, w), dtype=torch.float32, device=dev)
+        dropped = torch.empty((1,), dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().v2v_events_to_voxel_f32_segmented_hip(
+                C.c_void_p(ts_d.data_ptr()), C.c_void_p(xs_d.data_ptr()), C.c_void_p(ys_d.data_ptr()), C.c_void_p(ps_d.data_ptr()), hi - lo,
+                C.c_void_p(seg.data_ptr()), len(ranges), 0, 0 if temporal_bilinear else 1, B, h, w, C.c_void_p(out.data_ptr()),
+                C.c_void_p(dropped.data_ptr()), _lib.stream_ptr())
+        _lib.check(rc)
+        if int(dropped.item()) != 0:
+            raise IndexError(f"{int(dropped.item())} event(s) outside the sensor / bin range")
+        return list(out.unbind(0))
+    return [events_to_voxel_torch(xs[a:b], ys[a:b], ts[a:b], ps[a:b], B, dev, sensor_size, temporal_bilinear) for a, b in ranges]
+
+
+def voxel_grids_fixed_n_torch(xs, ys, ts, ps, B, n, sensor_size=(180, 240), temporal_bilinear=True):
+    """utils/event_utils.py:378-402: a list of voxel grids of `n` consecutive events each (the last, incomplete group is dropped, and
+    so is a complete one that ends exactly at the last event: `range(0, len - n, n)`).  One launch for the list."""
+    return _grids_of_ranges(xs, ys, ts, ps, B, [(i, i + n) for i in range(0, len(xs) - n, n)], None, sensor_size, temporal_bilinear)
+
+
+def events_to_voxel_timesync_torch(xs, ys, ts, ps, B, t0, t1, device=None, np_ts=None, sensor_size=(180, 240), temporal_bilinear=True):
+    """utils/event_utils.py:440-464: the grid of the events with t0 <= t < t1 (np.searchsorted on the timestamps; both asserts kept)."""
+    assert t1 > t0
+    if np_ts is None:
+        np_ts = ts.cpu().numpy() if isinstance(ts, torch.Tensor) else np.asarray(ts)
+    a, b = int(np.searchsorted(np_ts, t0)), int(np.searchsorted(np_ts, t1))
+    assert a < b
+    return events_to_voxel_torch(xs[a:b], ys[a:b], ts[a:b], ps[a:b], B, device, sensor_size, temporal_bilinear)
+
+
+def voxel_grids_fixed_t_torch(xs, ys, ts, ps, B, t, sensor_size=(180, 240), temporal_bilinear=True):
+    """utils/event_utils.py:404-438: a list of voxel grids of temporal width `t`, starting at np.arange(ts[0], ts[-1] - t, t); every window's
+    borders are looked up on their own (t_start + t is not bit-for-bit the next t_start), so the windows go out as one segmented launch only
+    when the lookups happen to tile the events."""
+    np_ts = ts.cpu().numpy() if isinstance(ts, torch.Tensor) else np.asarray(ts)
+    ranges = []
+    for t_start in np.arange(float(ts[0]), float(ts[-1]) - t, t):
+        a, b = int(np.searchsorted(np_ts, t_start)), int(np.searchsorted(np_ts, t_start + t))
+        assert a < b
+        ranges.append((a, b))
+    return _grids_of_ranges(xs, ys, ts, ps, B, ranges, None, sensor_size, temporal_bilinear)
 
 
 def make_voxels_segmented(evs, event_idx, H, W, num_bins=5, interpolate_bins=False, device="cuda"):
