@@ -60,7 +60,6 @@ class TestH5Dataset(torch.utils.data.Dataset, voxel.MakeVoxelMixin):
         with monash.open_sequence(self.h5_path) as f:
             frames = [torch.tensor(self.get_img(f, i + 1), dtype=torch.float32).unsqueeze(0) for i in range(begin, end)]   # :105-106
             ev_idx = [int(f.image_attr(self.img_keys[i], "event_idx")) for i in range(begin, end + 1)]                    # :108-109
-            first = begin
             if self.output_additional_evs:                                               # :133-143: the interval before `begin`
                 pre_idx = max(0, begin - 1)
                 ev_idx = [int(f.image_attr(self.img_keys[pre_idx], "event_idx"))] + ev_idx
