@@ -201,6 +201,30 @@ def g22_voxel_grid_lists():
     save("g22_voxel_grid_lists.npz", **out)
 
 
+def g23_events_to_image():
+    """events_to_image (utils/event_utils.py:155-174, NumPy, float64) and events_to_image_torch (:330-376, float32: plain accumulation,
+    and bilinear splatting of fractional coordinates through interpolate_to_image :176-184, with and without the one-pixel padding) run by
+    the REFERENCE.  Integer events = golden G12's; the fractional coordinates and real-valued weights are stored here."""
+    import torch
+    z = np.load(os.path.join(HERE, "g12_events_to_voxel_torch.npz"))
+    g = np.random.default_rng(23)
+    n = len(z["xs"])
+    wts = g.normal(0, 1.5, size=n)
+    fx = g.uniform(0, 24.6, size=n).astype(np.float32)                    # some beyond the 24-pixel width: clipped by the mask
+    fy = g.uniform(0, 16.4, size=n).astype(np.float32)
+    out = {"weights": wts, "fx": fx, "fy": fy}
+    out["np_pol"] = ref_eu.events_to_image(z["xs"], z["ys"], z["ps"].astype(np.float64), sensor_size=(16, 24))
+    out["np_weights"] = ref_eu.events_to_image(z["xs"], z["ys"], wts, sensor_size=(16, 24))
+    tx, ty, tp = torch.from_numpy(z["xs"]), torch.from_numpy(z["ys"]), torch.from_numpy(z["ps"])
+    out["torch_plain"] = ref_eu.events_to_image_torch(tx, ty, tp, sensor_size=(16, 24)).numpy()
+    tw = torch.from_numpy(wts.astype(np.float32))
+    out["torch_weights"] = ref_eu.events_to_image_torch(tx, ty, tw, sensor_size=(16, 24), padding=False).numpy()
+    for pad in (True, False):
+        out[f"torch_bilinear_pad{int(pad)}"] = ref_eu.events_to_image_torch(torch.from_numpy(fx), torch.from_numpy(fy), tw, sensor_size=(16, 24),
+                                                                             interpolation="bilinear", padding=pad).numpy()
+    save("g23_events_to_image.npz", **out)
+
+
 def g13_normalize_batch_voxel():
     """normalize_batch_voxel (model/train_utils.py:147-166).  The module needs torchvision/torchmetrics/skimage, which
     are absent, so ONLY that function is compiled from the reference file (AST extraction at run time; no source kept)."""
@@ -728,9 +752,9 @@ def g17_degrade_video():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22", "g23"]
     fns = {"g1": g1_luts, "g2": g2_g3_esim_clean, "g4": g4_esim_noisy, "g5": g5_floor_divide,
-           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g15": g15_bgr_to_gray, "g16": g16_monash_sequence, "g19": g19_event_and_fps_loaders, "g20": g20_flow_and_cache_loaders, "g21": g21_esim_h5_dataset, "g17": g17_degrade_video, "g18": g18_unet_modules, "g12": g12_events_to_voxel_torch, "g22": g22_voxel_grid_lists,
+           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g15": g15_bgr_to_gray, "g16": g16_monash_sequence, "g19": g19_event_and_fps_loaders, "g20": g20_flow_and_cache_loaders, "g21": g21_esim_h5_dataset, "g17": g17_degrade_video, "g18": g18_unet_modules, "g12": g12_events_to_voxel_torch, "g22": g22_voxel_grid_lists, "g23": g23_events_to_image,
            "g13": g13_normalize_batch_voxel}
     for w in which:
         fns[w]()

@@ -293,6 +293,34 @@ def test_g12_events_to_voxel_torch(golden):
     assert np.array_equal(disc.cpu().numpy(), g["discrete"])                      # +-1 sums: exact
 
 
+def test_g23_events_to_image(golden):
+    """events_to_image (float64, NumPy in / out) and events_to_image_torch (float32: plain accumulation, real-valued weights, bilinear
+    splatting of fractional coordinates with and without the one-pixel padding) against the reference's own images (golden G23).  Integer
+    weights: exact; real weights: the same terms summed by atomics in another order."""
+    from v2v_amd import voxel
+    e, g = golden("g12_events_to_voxel_torch.npz"), golden("g23_events_to_image.npz")
+    pol = voxel.events_to_image(e["xs"], e["ys"], e["ps"].astype(np.float64), sensor_size=(16, 24))
+    assert isinstance(pol, np.ndarray) and pol.dtype == np.float64 and np.array_equal(pol, g["np_pol"])
+    np.testing.assert_allclose(voxel.events_to_image(e["xs"], e["ys"], g["weights"], sensor_size=(16, 24)), g["np_weights"], rtol=1e-12, atol=1e-12)
+    one = voxel.events_to_image(e["xs"][:1], e["ys"][:1], np.array([2.5]), sensor_size=(16, 24))
+    assert one.sum() == 2.5 and one[e["ys"][0], e["xs"][0]] == 2.5
+    assert not voxel.events_to_image(e["xs"][:0], e["ys"][:0], e["ps"][:0], sensor_size=(16, 24)).any()
+    with pytest.raises(ValueError):
+        voxel.events_to_image(np.array([24]), np.array([3]), np.array([1.0]), sensor_size=(16, 24))
+    tx, ty, tp = (torch.from_numpy(e[k]) for k in ("xs", "ys", "ps"))
+    plain = voxel.events_to_image_torch(tx, ty, tp, sensor_size=(16, 24))
+    assert plain.is_cuda and plain.dtype == torch.float32 and np.array_equal(plain.cpu().numpy(), g["torch_plain"])
+    tw = torch.from_numpy(g["weights"].astype(np.float32))
+    np.testing.assert_allclose(voxel.events_to_image_torch(tx, ty, tw, sensor_size=(16, 24), padding=False).cpu().numpy(), g["torch_weights"], rtol=1e-5, atol=1e-5)
+    for pad in (True, False):
+        img = voxel.events_to_image_torch(torch.from_numpy(g["fx"]), torch.from_numpy(g["fy"]), tw, sensor_size=(16, 24), interpolation="bilinear", padding=pad)
+        want = g[f"torch_bilinear_pad{int(pad)}"]
+        assert tuple(img.shape) == want.shape
+        np.testing.assert_allclose(img.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    via_np = voxel.events_to_image(g["fx"], g["fy"], g["weights"].astype(np.float32), sensor_size=(16, 24), interpolation="bilinear", padding=False)
+    np.testing.assert_allclose(via_np, g["torch_bilinear_pad0"], rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("tag,tb", [("bil", True), ("disc", False)])
 def test_g22_lists_of_voxel_grids(golden, tag, tb):
     """voxel_grids_fixed_n_torch / voxel_grids_fixed_t_torch / events_to_voxel_timesync_torch (utils/event_utils.py:378-464) on G12's events

@@ -5,6 +5,7 @@ Mirrors (same names, argument order, shapes and dtypes):
     MakeVoxelMixin.make_voxel(self, evs)                         data/testh5.py:60-90  (TestH5Dataset.make_voxel)
     events_to_voxel(xs, ys, ts, ps, B, sensor_size, temporal_bilinear)   utils/event_utils.py:692-728
     events_to_voxel_torch / events_to_voxel_timesync_torch / voxel_grids_fixed_n_torch / voxel_grids_fixed_t_torch   utils/event_utils.py:378-507
+    events_to_image / events_to_image_torch / interpolate_to_image                                              utils/event_utils.py:155-184, 330-376
 NumPy in -> NumPy float64 out; CUDA tensors in -> CUDA float64 tensor out.  The scatter runs in the HIP kernel
 (v2v_amd/csrc/v2v_events.hpp); nothing here computes on the CPU.
 """
@@ -121,6 +122,81 @@ def events_to_neg_pos_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(1
     pos_w, neg_w = torch.where(ps > 0, one, zero), torch.where(ps <= 0, one, zero)
     return (events_to_voxel_torch(xs, ys, ts, pos_w, B, device, sensor_size, temporal_bilinear),
             events_to_voxel_torch(xs, ys, ts, neg_w, B, device, sensor_size, temporal_bilinear))
+
+
+def events_to_image(xs, ys, ps, sensor_size=(180, 240), interpolation=None, padding=False, device="cuda"):
+    """utils/event_utils.py:155-174: img[y, x] = sum of the weights `ps` of the events at (x, y), float64 [H, W] (np.bincount over the
+    raveled coordinates).  It is the one-bin case of the temporal-bilinear voxel grid -- with a single bin every event's weight is 1 -- so it
+    runs on the same scatter kernel; an event outside the sensor raises ValueError as np.ravel_multi_index does.
+    interpolation='bilinear' (fractional coordinates) goes through events_to_image_torch, as in the reference."""
+    if interpolation == "bilinear" and np.asarray(xs).dtype.kind == "f":
+        img = events_to_image_torch(torch.from_numpy(np.asarray(xs)).float(), torch.from_numpy(np.asarray(ys)).float(), torch.from_numpy(np.asarray(ps)).float(),
+                                    clip_out_of_range=True, interpolation="bilinear", padding=padding, sensor_size=sensor_size)
+        return img.cpu().numpy().reshape(sensor_size)
+    xs_a, ys_a, ps_a = (np.asarray(v).reshape(-1) for v in (xs, ys, ps))
+    n = xs_a.size
+    # two zero-weight sentinel events at t = 0 and t = 1 (the real ones at t = 0) give the kernel a time span whatever n is; with one bin
+    # they change no weight
+    ts_a = np.concatenate([np.zeros(n + 1), [1.0]])
+    try:
+        out = _scatter(ts_a, np.concatenate([[0], xs_a, [0]]), np.concatenate([[0], ys_a, [0]]), np.concatenate([[0.0], ps_a.astype(np.float64), [0.0]]),
+                       _lib.EV_BILINEAR, 1, sensor_size[0], sensor_size[1], device)
+    except IndexError as e:
+        raise ValueError(str(e)) from None                                                # np.ravel_multi_index: "invalid entry in coordinates array"
+    return out[0].cpu().numpy()
+
+
+def _scatter_f32(xs_d, ys_d, w_d, h, w, dev):
+    """sum of float32 weights at integer coordinates -> [h, w] float32: the one-bin discrete case of the float32 voxel kernel."""
+    n = xs_d.numel()
+    out = torch.empty((1, h, w), dtype=torch.float32, device=dev)
+    dropped = torch.empty((1,), dtype=torch.int64, device=dev)
+    ts_d = torch.zeros((max(n, 1),), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().v2v_events_to_voxel_f32_hip(C.c_void_p(ts_d.data_ptr()) if n else None, C.c_void_p(xs_d.data_ptr()) if n else None,
+                                                    C.c_void_p(ys_d.data_ptr()) if n else None, C.c_void_p(w_d.data_ptr()) if n else None, n, 1, 1, h, w,
+                                                    C.c_void_p(out.data_ptr()), C.c_void_p(dropped.data_ptr()), _lib.stream_ptr())
+    _lib.check(rc)
+    if n and int(dropped.item()) != 0:
+        raise IndexError(f"{int(dropped.item())} event(s) outside the {h}x{w} image")   # index_put_ would raise
+    return out[0]
+
+
+def interpolate_to_image(pxs, pys, dxs, dys, weights, img):
+    """utils/event_utils.py:176-184: bilinear splatting -- every event adds weights * {(1-dx)(1-dy), dx(1-dy), (1-dx)dy, dx dy} to the four
+    pixels around it, accumulated into `img` (float32 CUDA [H, W]) in place.  The four weight products are formed in float32 exactly as the
+    reference writes them; the sums run in the scatter kernel."""
+    if not (isinstance(img, torch.Tensor) and img.is_cuda and img.dtype == torch.float32 and img.dim() == 2):
+        raise ValueError("img must be a float32 CUDA tensor [H, W] (the scatter runs in the HIP kernel; there is no CPU fallback)")
+    dev = img.device
+    h, w = img.shape
+    px, py = _dev(pxs, torch.int64, dev), _dev(pys, torch.int64, dev)
+    dx, dy, wt = _dev(dxs, torch.float32, dev), _dev(dys, torch.float32, dev), _dev(weights, torch.float32, dev)
+    for ox, oy, wk in ((0, 0, wt * (1.0 - dx) * (1.0 - dy)), (1, 0, wt * dx * (1.0 - dy)), (0, 1, wt * (1.0 - dx) * dy), (1, 1, wt * dx * dy)):
+        img += _scatter_f32((px + ox).contiguous(), (py + oy).contiguous(), wk.contiguous(), h, w, dev)
+    return img
+
+
+def events_to_image_torch(xs, ys, ps, device=None, sensor_size=(180, 240), clip_out_of_range=True, interpolation=None, padding=True):
+    """utils/event_utils.py:330-376: float32 image of the event weights; interpolation='bilinear' splats fractional coordinates over the
+    four neighbours (the image is one pixel larger with `padding`; events at or beyond the last row / column are masked out: moved to (0,0)
+    with weight 0, as the reference does).  Returns a CUDA tensor (the accumulation runs in the HIP kernel)."""
+    _lib.require_gpu()
+    dev = torch.device(device) if device is not None else (xs.device if getattr(xs, "is_cuda", False) else torch.device("cuda"))
+    if dev.type != "cuda":
+        raise RuntimeError("events_to_image_torch runs on the GPU only (no CPU fallback)")
+    bilinear = interpolation == "bilinear"
+    h, w = (sensor_size[0] + 1, sensor_size[1] + 1) if (bilinear and padding) else (sensor_size[0], sensor_size[1])
+    xs_d, ys_d = xs.to(dev), ys.to(dev)
+    if bilinear and xs.dtype is not torch.long:
+        mask = torch.ones(xs_d.shape, device=dev)
+        if clip_out_of_range:                                                            # :349-354
+            mask = torch.where(xs_d >= w - 1, 0.0, 1.0) * torch.where(ys_d >= h - 1, 0.0, 1.0)
+        pxs, pys = xs_d.floor().float(), ys_d.floor().float()
+        dxs, dys = (xs_d - pxs).float(), (ys_d - pys).float()
+        img = torch.zeros((h, w), dtype=torch.float32, device=dev)
+        return interpolate_to_image((pxs * mask).long(), (pys * mask).long(), dxs, dys, ps.to(dev).squeeze() * mask, img)
+    return _scatter_f32(_dev(xs_d, torch.int64, dev), _dev(ys_d, torch.int64, dev), _dev(ps, torch.float32, dev), h, w, dev)
 
 
 def _grids_of_ranges(xs, ys, ts, ps, B, ranges, device, sensor_size, temporal_bilinear):
