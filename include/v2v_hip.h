@@ -292,7 +292,8 @@ int v2v_events_to_voxel_f32_segmented_hip(const double *ts, const int64_t *xs, c
  * dtype the module's input had, :202-203) for the stock layers downstream.
  * h_prev == NULL and c_prev == NULL mean the zero state (prev_state=None, :196-209).  c_state may alias c_prev; h_state must
  * not alias h_prev.  tile_rows: pixels per workgroup tile, 64, 128 or 256; 0 = pick by image size.
- * Requirements (else V2V_ERR_SHAPE): C % 64 == 0, (B*H*W) % 64 == 0 (% tile_rows when given), (H*W) % 4 == 0. */
+ * Requirements (else V2V_ERR_SHAPE): C % 64 == 0, (H*W) % 4 == 0.  Any B*H*W: the last pixel tile of a launch may be partial (its rows
+ * past the end read zeros and are not stored), so real-data frame sizes (180x240, 260x346 padded to multiples of 16) run at batch 1. */
 int v2v_convlstm_packed_bytes(int64_t C, uint64_t *bytes);   /* size of the packed weight buffer: 4C*2C*9 bf16 */
 /* gates_weight: the module's Gates.weight, fp32 [4C, 2C, 3, 3] on the device -> packed bf16 (once per weight update) */
 int v2v_convlstm_pack_weights_hip(const float *gates_weight, int64_t C, void *packed, void *stream);
@@ -304,9 +305,9 @@ int v2v_convlstm_step_hip(const void *x, const void *h_prev, const float *c_prev
  * ConvLSTM step -- out = [relu]( conv(x) + bias [+ residual] ), x [B,H,W,Cin] / residual, out [B,H,W,Cout] bf16 NHWC,
  * weight = the module's conv weight fp32 [Cout,Cin,3,3] packed once by v2v_conv3x3_pack_weights_hip (Cout*Cin*9 bf16).
  * Two calls make a block: conv1 with relu, conv2 with residual = the block's input and relu.
- * Requirements (else V2V_ERR_SHAPE): Cin % 64 == 0, Cout % 256 == 0 (or 128 / 64 / 32), (B*H*W) % 32 == 0 (% 128 for Cout 128 /
- * 64 / 32; % tile_rows when given: 32, 64, 128 or 256 pixels per workgroup, the first two for Cout % 256 == 0 only; 0 = the
- * largest tile that still fills the CUs);
+ * Requirements (else V2V_ERR_SHAPE): Cin % 64 == 0, Cout % 256 == 0 (or 128 / 64 / 32), (H*W) % 4 == 0 (any B*H*W: a partial last
+ * tile); tile_rows: 32, 64, 128 or 256 pixels per workgroup, the first two for Cout % 256 == 0 only; 0 = the largest tile that
+ * still fills the CUs;
  * out must not alias x (neighbouring tiles read x); it may alias residual. */
 int v2v_conv3x3_pack_weights_hip(const float *weight, int64_t Cin, int64_t Cout, void *packed, void *stream);   /* = conv_pack, ks 3 */
 int v2v_conv3x3_nhwc_hip(const void *x, const void *packed, const float *bias, const void *residual, int relu, int64_t B, int64_t H,
@@ -315,7 +316,7 @@ int v2v_conv3x3_nhwc_hip(const void *x, const void *packed, const float *bias, c
 /* The general form: the encoder / decoder convolutions around those blocks (ConvLayer, model/submodules.py:10-50 as built at
  * model/unet.py:34-60, 83-87: 5x5, stride 2 in the encoders, stride 1 after the bilinear upsampling in the decoders, ReLU).
  * ks = 3 or 5 (pad ks/2), stride 1 or 2; x [B,Hin,Win,Cin] -> out [B,Hout,Wout,Cout] with Hout = (Hin-1)/stride + 1; Cin % 64 == 0;
- * Cout a multiple of 256, or 128 / 64 / 32 (then (B*Hout*Wout) % 128 == 0); weight fp32 [Cout,Cin,ks,ks].
+ * Cout a multiple of 256, or 128 / 64 / 32; (Hout*Wout) % 4 == 0, any B*Hout*Wout; weight fp32 [Cout,Cin,ks,ks].
  * Cin = 32 with Cout 64 / 128 (the UNet's first encoder, model/unet.py:34-44 with base 32) packs two taps per 64-wide K chunk.
  * tile_rows 16 = halo tiles (a 16x16 pixel patch staged once per channel chunk with its halo; stride 1, H and W multiples of
  * 16, Cout 32 / 64, or 128 for 3x3): what 0 picks for the 5x5 decoders with 32 / 64 output channels. */

@@ -43,7 +43,10 @@ def _case(b, c, h, w, seed, scale=1.0):
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,tile_rows", [((2, 64, 16, 16), 0), ((2, 64, 16, 16), 128), ((2, 64, 16, 16), 64), ((1, 128, 8, 24), 0),
                                                ((3, 64, 12, 16), 64), ((1, 256, 8, 8), 0), ((2, 64, 64, 64), 0), ((2, 64, 16, 16), 256), ((1, 128, 16, 32), 256), ((4, 128, 32, 32), 128), ((4, 128, 32, 32), 0),
-                                               ((8, 64, 64, 64), 0)])
+                                               ((8, 64, 64, 64), 0),
+                                               # pixel counts that are not multiples of the tile (a partial last tile): 180 x 240 real-data frames at 1/8
+                                               # (720 pixels), 36 pixels on every tile size, 3 x 10 x 14 on the 256-pixel tile
+                                               ((1, 256, 24, 30), 0), ((1, 64, 6, 6), 0), ((1, 64, 6, 6), 64), ((1, 128, 6, 6), 128), ((3, 64, 10, 14), 256), ((5, 128, 12, 10), 0)])
 def test_step_matches_reference_semantics(shape, tile_rows):
     import torch
     from v2v_amd import convlstm as CL
@@ -51,7 +54,7 @@ def test_step_matches_reference_semantics(shape, tile_rows):
     x, hp, cp, weight, bias = _case(b, c, h, w, seed=sum(shape) + tile_rows)
     dev = "cuda"
     packed = CL.pack_gate_weights(weight.to(dev))
-    xn, hn = CL.nchw_to_nhwc_bf16(x.to(dev)), CL.nchw_to_nhwc_bf16(hp.to(dev))
+    xn, hn = CL._to_nhwc_bf16(x.to(dev)).contiguous(), CL._to_nhwc_bf16(hp.to(dev)).contiguous()      # the layout kernel where it applies (H*W % 64), a torch copy otherwise
     cn = cp.to(dev).permute(0, 2, 3, 1).contiguous()
     h_state, c_state, h_nchw = CL.convlstm_step(xn, hn, cn, packed, bias.to(dev), tile_rows=tile_rows)
     torch.cuda.synchronize()
@@ -195,8 +198,7 @@ def test_shape_errors_are_reported_without_a_gpu():
     buf = (C.c_char * 4096)()
     p = C.cast(buf, C.c_void_p)
     assert L.v2v_convlstm_step_hip(p, None, None, p, p, 1, 8, 8, 32, p, p, None, 1, 0, None) == _lib.ERR_SHAPE          # C % 64
-    assert L.v2v_convlstm_step_hip(p, None, None, p, p, 1, 5, 5, 64, p, p, None, 1, 0, None) == _lib.ERR_SHAPE          # B*H*W % 64
-    assert L.v2v_convlstm_step_hip(p, None, None, p, p, 1, 8, 8, 64, p, p, None, 1, 128, None) == _lib.ERR_SHAPE        # 64 px, tile 128
+    assert L.v2v_convlstm_step_hip(p, None, None, p, p, 1, 5, 5, 64, p, p, None, 1, 0, None) == _lib.ERR_SHAPE          # H*W % 4
     assert L.v2v_convlstm_step_hip(p, None, None, p, p, 1, 8, 8, 64, p, p, None, 1, 32, None) == _lib.ERR_PARAM
     assert L.v2v_convlstm_step_hip(p, p, None, p, p, 1, 8, 8, 64, p, p, None, 1, 0, None) == _lib.ERR_PARAM             # h_state aliases
     assert L.v2v_convlstm_step_hip(None, None, None, p, p, 1, 8, 8, 64, p, p, None, 1, 0, None) == _lib.ERR_NULL
@@ -347,11 +349,11 @@ def test_residual_block_is_a_drop_in():
     ((1, 128, 16, 16), 64, 5, 1, 0, True, True),        # dec2: 128 -> 64
     ((1, 64, 16, 32), 32, 5, 1, 0, False, True),        # dec3: 64 -> 32
     ((1, 64, 16, 16), 32, 3, 1, 0, True, False),
-    ((2, 64, 24, 40), 64, 3, 2, 0, False, True),        # Wout = 20, 480 pixels -> rejected (not % 128)
+    ((2, 64, 24, 40), 64, 3, 2, 0, False, True),        # Wout = 20, 480 pixels: 3.75 tiles of 128 (a partial last tile)
     ((2, 64, 32, 24), 64, 3, 2, 0, True, True),         # 2 x 16 x 12 = 384 pixels: three 128-pixel tiles
     ((1, 128, 16, 16), 32, 5, 1, 256, False, True),     # pinned 256-pixel tile
     ((1, 64, 32, 32), 128, 5, 1, 128, True, False),     # pinned 128-pixel tile
-    ((2, 64, 31, 33), 256, 5, 2, 64, False, True),      # odd input size: Hout x Wout = 16 x 17 -> 544 pixels -> rejected (not % 64)
+    ((2, 64, 31, 33), 256, 5, 2, 64, False, True),      # odd input size: Hout x Wout = 16 x 17 -> 544 pixels = 8.5 tiles of 64
     ((4, 64, 15, 31), 256, 5, 2, 128, True, True),      # odd input size, 4 x 8 x 16 = 512 output pixels
     ((2, 64, 31, 33), 256, 5, 2, 0, True, True),        # 544 = 17 x 32 output pixels: the 32-pixel tile
     ((1, 256, 16, 16), 256, 3, 1, 32, True, True),      # residual-block shape on the 32-pixel tile
@@ -359,16 +361,20 @@ def test_residual_block_is_a_drop_in():
     ((2, 256, 16, 16), 256, 3, 1, 0, True, True),       # small layer: 64 px x 128 columns (half a packed column tile per workgroup)
     ((2, 32, 32, 32), 64, 5, 2, 0, False, True),        # 32 input channels (enc1): two taps per K chunk, 25 taps -> the last half chunk is zero
     ((1, 32, 16, 16), 128, 3, 1, 256, True, False),     # 32 input channels, 3x3, 128 columns, pinned 256-pixel tile
-    ((1, 32, 33, 31), 64, 5, 2, 128, True, True),       # 32 input channels, odd input size, 17 x 16 = 272 pixels -> rejected on the 128-pixel tile
+    ((1, 32, 33, 31), 64, 5, 2, 128, True, True),       # 32 input channels, odd input size, 17 x 16 = 272 pixels = 2.125 tiles of 128
     ((1, 64, 16, 16), 32, 3, 1, 16, True, False),       # halo tiles (16 x 16 patch + halo staged once per channel chunk), pinned
     ((1, 128, 32, 16), 128, 3, 1, 16, False, True),     # halo tiles, 3x3, 128 columns, two channel chunks
     ((2, 192, 16, 32), 64, 5, 1, 16, True, True),       # halo tiles, 5x5, three channel chunks, one tap per weight group
     ((1, 64, 48, 16), 32, 5, 1, 0, False, True),        # halo tiles picked by the launcher (5x5, 32 columns)
     ((1, 64, 24, 16), 32, 5, 1, 128, False, True),      # same layer on the 128-pixel tile when H is not a multiple of 16
+    ((1, 64, 18, 10), 64, 3, 2, 0, False, True),        # 9 x 5 = 45 output pixels per image: not whole groups of 4 -> rejected
+    ((3, 64, 6, 6), 256, 3, 1, 0, True, True),          # 108 pixels: less than one tile of any size
+    ((1, 128, 20, 36), 128, 5, 1, 256, False, True),    # 720 pixels on the pinned 256-pixel tile: 2.8 tiles
+    ((5, 64, 12, 20), 32, 3, 1, 0, True, False),        # 1,200 pixels, 32 columns
 ])
 def test_conv_nhwc_matches_reference_semantics(shape, cout, ks, stride, tile_rows, res, relu):
     """out = [relu](conv_ks(x, stride, pad ks // 2) + bias [+ residual]) (ConvLayer.forward, model/submodules.py:25-33) against
-    the float64 evaluation of the same bf16-rounded operands, at 1 bf16 ulp (2^-8 relative); unsupported tilings are loud."""
+    the float64 evaluation of the same bf16-rounded operands, at 1 bf16 ulp (2^-8 relative).  Any B*H*W runs (the last pixel tile may be partial: its rows past the end read zeros and are not stored); only an output image that is not whole groups of 4 pixels is refused, loudly."""
     import torch
     import torch.nn.functional as F
     from v2v_amd import convlstm as CL
@@ -382,8 +388,7 @@ def test_conv_nhwc_matches_reference_semantics(shape, cout, ks, stride, tile_row
     xn = _bf16_round(x).cuda().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
     rn = _bf16_round(r).cuda().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous() if res else None
     packed = CL.pack_conv_weights(weight.cuda())
-    need = (128 if cout % 256 else 32) if tile_rows in (0, 16) else tile_rows     # halo tiles (16) need H, W % 16 == 0: chosen so here
-    if (b * ho * wo) % need:
+    if (ho * wo) % 4:                                          # the only tiling constraint left: whole groups of 4 output pixels per image
         with pytest.raises(ValueError):
             CL.conv_nhwc(xn, packed, bias.cuda(), ks, stride, residual=rn, relu=relu, tile_rows=tile_rows)
         return
@@ -473,8 +478,8 @@ def test_conv_layer_is_a_drop_in():
 @pytest.mark.gpu
 def test_conv_nhwc_random_shapes():
     """Seeded sweep over (batch, input size, Cin, Cout tile, kernel size, stride, pixel tile, residual, relu): every shape the
-    entry point takes is within 1 bf16 ulp of the float64 convolution of the same bf16 operands; every shape it does not take
-    (pixel count not a multiple of the tile) raises ValueError instead of computing something else."""
+    entry point takes -- any pixel count, the last tile partial more often than not -- is within 1 bf16 ulp of the float64 convolution
+    of the same bf16 operands; the shapes it does not take (an output image that is not whole groups of 4 pixels) raise ValueError."""
     import torch
     import torch.nn.functional as F
     from v2v_amd import convlstm as CL
@@ -501,8 +506,7 @@ def test_conv_nhwc_random_shapes():
         xn = _bf16_round(x).cuda().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
         rn = _bf16_round(r).cuda().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous() if res else None
         packed = CL.pack_conv_weights(weight.cuda())
-        need = (128 if cout % 256 else 32) if tile in (0, 16) else tile
-        if (b * ho * wo) % need:
+        if (ho * wo) % 4:                                      # whole groups of 4 output pixels per image: the one tiling constraint
             with pytest.raises(ValueError):
                 CL.conv_nhwc(xn, packed, bias.cuda(), ks, stride, residual=rn, relu=relu, tile_rows=tile)
             rejected += 1
@@ -515,7 +519,7 @@ def test_conv_nhwc_random_shapes():
         err = float(((got - want).abs() / (want.abs() + 1.0)).max())
         assert err < 2.0 ** -8, (case, (b, cin, h, w), cout, ks, stride, tile, res, relu, err)
         ran += 1
-    assert ran >= 25 and rejected >= 5, (ran, rejected)
+    assert ran >= 40 and rejected >= 3, (ran, rejected)
 
 
 @pytest.mark.gpu

@@ -297,6 +297,43 @@ def test_cfg5_pipeline_feeds_the_consumer():
 
 
 @gpu
+@pytest.mark.parametrize("b,h,w", [(1, 192, 240), (1, 272, 352), (3, 48, 80), (1, 16, 16), (5, 16, 32), (2, 48, 208)])
+def test_network_at_real_data_frame_sizes(b, h, w):
+    """The package network at the sizes the reference EVALUATES on, batch 1: HQF / IJRR 180 x 240 and MVSEC 260 x 346 frames padded to
+    multiples of 16 (model/train_utils.py:322-326) -- pixel counts that are no multiple of any workgroup tile at the deeper levels (e.g.
+    24 x 30 = 720 at level 3), so the last tile of nearly every launch is partial -- and a few small odd batches down to a 2 x 2 level-3
+    map.  Three recurrent steps as the step loop, as forward_sequence and as its hipGraph replay, against the all-stock float32 network
+    on G18's weights; same absolute bar as config 5 (6e-2 max, 8e-3 rms)."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from e2vid_consumer import E2VIDShapedConsumer, forward_sequence, reference_to_stock_keys
+    from seeded_weights import seeded_state
+    from v2v_amd.unet import E2VIDRecurrent
+    kw = dict(num_bins=5, skip_type="sum", recurrent_block_type="convlstm", num_encoders=3, base_num_channels=32, num_residual_blocks=2,
+              use_upsample_conv=True, final_activation="", norm=None)
+    product = E2VIDRecurrent(kw).cuda().eval()
+    ref_sd = {k: torch.from_numpy(v) for k, v in seeded_state({k: tuple(v.shape) for k, v in product.unetrecurrent.state_dict().items()}, 1805, 1.7).items()}
+    product.unetrecurrent.load_state_dict(ref_sd, strict=True)
+    stock = E2VIDShapedConsumer(num_bins=5).cuda().eval()
+    stock.load_state_dict(reference_to_stock_keys(ref_sd), strict=True)
+    g = torch.Generator().manual_seed(b * 1000 + h + w)
+    voxels = torch.round(torch.randn((b, 3, 5, h, w), generator=g) * 1.5).cuda()
+    with torch.no_grad():
+        want = torch.stack(forward_sequence(stock, voxels), dim=1)
+        product.reset_states()
+        loop = torch.stack([product(voxels[:, t])["image"] for t in range(3)], dim=1)
+        product.reset_states()
+        seq = product.forward_sequence(voxels)
+        graph = product.forward_sequence(voxels, graph=True).clone()
+    assert torch.equal(loop, seq) and torch.equal(seq, graph) and bool(torch.isfinite(loop).all())
+    d = (loop.float() - want).abs()
+    assert float(d.max()) <= 6e-2 and float((d ** 2).mean().sqrt()) <= 8e-3, f"max {float(d.max()):.4g} rms {float((d ** 2).mean().sqrt()):.4g} std {float(want.std()):.3g}"
+
+
+@gpu
 def test_training_batch_packed_clips_with_statistics(oracle_c, luts):
     """The reference's training shape (config/train_v2v_e2vid_10k.yaml:50-76: B = 12, 201 frames of 128 x 128, 40 x 5 SUM bins) as the
     loader launches it: every decoded frame stored once + the pause-index row (proba_pause_when_running 0.0102 / _when_paused 0.9791),

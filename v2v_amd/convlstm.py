@@ -16,7 +16,7 @@ v2v_upsample2x_nhwc_hip.
 
 The 3x3 gate convolution runs as an implicit GEMM on the bf16 matrix cores with fp32 accumulation and the gate / cell / hidden
 update fused on the accumulators (v2v_amd/csrc/v2v_convlstm.hpp).  Inference only (no autograd through the kernel: a call
-that would need a gradient raises).  No fallback: shapes the kernel does not take (hidden_size % 64, B*H*W % 64, kernel_size
+that would need a gradient raises).  No fallback: shapes the kernel does not take (hidden_size % 64, H*W % 4, kernel_size
 != 3, input_size != hidden_size) raise ValueError.
 """
 from __future__ import annotations

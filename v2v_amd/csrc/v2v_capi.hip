@@ -850,8 +850,8 @@ int v2v_convlstm_step_hip(const void *x, const void *h_prev, const float *c_prev
     if (!x || !packed || !gates_bias || !h_state || !c_state) return fail(V2V_ERR_NULL, "v2v_convlstm_step_hip: x/packed/gates_bias/h_state/c_state is NULL");
     if (B < 1 || H < 1 || W < 1 || C < 64 || C % 64 != 0 || C > 4096) return fail(V2V_ERR_SHAPE, "need B,H,W >= 1 and C %% 64 == 0, C <= 4096");
     if (tile_rows != 0 && tile_rows != 64 && tile_rows != 128 && tile_rows != 256) return fail(V2V_ERR_PARAM, "tile_rows must be 0 (auto), 64, 128 or 256");
-    if ((B * H * W) % (tile_rows ? tile_rows : 64) != 0 || (H * W) % 4 != 0 || B * H * W * C > 0x7FFFFFFFLL)
-        return fail(V2V_ERR_SHAPE, "ConvLSTM kernel needs (B*H*W) %% 64 == 0 (%% tile_rows when given), (H*W) %% 4 == 0 and B*H*W*C < 2^31 (got %lldx%lldx%lldx%lld)",
+    if ((H * W) % 4 != 0 || B * H * W * C > 0x7FFFFFFFLL)
+        return fail(V2V_ERR_SHAPE, "ConvLSTM kernel needs (H*W) %% 4 == 0 and B*H*W*C < 2^31 (got %lldx%lldx%lldx%lld)",
                     (long long)B, (long long)H, (long long)W, (long long)C);
     if (h_state == h_prev || h_state == x) return fail(V2V_ERR_PARAM, "h_state must not alias h_prev or x (neighbouring tiles read them)");
     if (!aligned(x, 16) || !aligned(h_prev, 16) || !aligned(packed, 16) || !aligned(h_state, 2) || !aligned(c_prev, 4) || !aligned(c_state, 4) ||
@@ -898,9 +898,8 @@ int v2v_conv_nhwc_hip(const void *x, const void *packed, const float *bias, cons
     const bool halo_fits = Cin % 64 == 0 && Cout % 256 != 0 && stride == 1 && H % 16 == 0 && W % 16 == 0 && (ks == 3 || Cout <= 64);   // see launch_conv_nhwc
     const bool halo = halo_fits && (tile_rows == 16 || (tile_rows == 0 && ks == 5));
     if (tile_rows == 16 && !halo) return fail(V2V_ERR_PARAM, "tile_rows 16 (halo tiles) needs stride 1, H and W multiples of 16 and Cout 32 / 64 (128 for 3x3)");
-    const int64_t need = halo ? 256 : tile_rows ? tile_rows : Cout % 256 == 0 ? 32 : 128;
-    if ((B * H * W) % need != 0 || B * Hin * Win * Cin > 0x7FFFFFFFLL || B * H * W * Cout > 0x7FFFFFFFLL)
-        return fail(V2V_ERR_SHAPE, "conv kernel needs (B*Hout*Wout) %% %lld == 0 and tensors below 2^31 elements", (long long)need);
+    if ((H * W) % 4 != 0 || B * Hin * Win * Cin > 0x7FFFFFFFLL || B * H * W * Cout > 0x7FFFFFFFLL)
+        return fail(V2V_ERR_SHAPE, "conv kernel needs (Hout*Wout) %% 4 == 0 and tensors below 2^31 elements");
     if (out == x) return fail(V2V_ERR_PARAM, "out must not alias x (neighbouring tiles read it)");
     if (!aligned(x, 16) || !aligned(packed, 16) || !aligned(out, 2) || !aligned(residual, 2) || !aligned(bias, 4))
         return fail(V2V_ERR_ALIGN, "x/packed need 16-byte alignment");

@@ -75,7 +75,7 @@ __device__ __forceinline__ void cl_glds16(const void *src, unsigned char *lds_wa
 
 // plain-convolution epilogue: accumulator g of the wave holds output channels col0 + 32 g .. + 31 (col0 = this lane's first)
 template <int MF, int NF>
-__device__ __forceinline__ void cl_epilogue_conv(const ConvLstmArgs &a, cl_f32x16 (&acc)[MF][NF], int64_t mw0, int col0, int fh)
+__device__ __forceinline__ void cl_epilogue_conv(const ConvLstmArgs &a, cl_f32x16 (&acc)[MF][NF], int64_t mw0, int col0, int fh, int64_t M)
 {
     // one 64-bit element index per lane; every element adds a wave-uniform 32-bit offset (pixel row x column count) to it
     const uint32_t N = (uint32_t)a.n_cols;
@@ -89,6 +89,8 @@ __device__ __forceinline__ void cl_epilogue_conv(const ConvLstmArgs &a, cl_f32x1
         for (int i = 0; i < MF; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                // the last tile of a launch may reach past the M = B*H*W pixels (M % 4 == 0, so 4 consecutive rows are in or out together)
+                if (mw0 + 4 * fh + i * 32 + 8 * (r >> 2) >= M) continue;
                 const uint32_t eo = (uint32_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * N + (uint32_t)(g * 32);
                 float v = acc[i][g][r] + bias;
                 if (rbase) v += __uint_as_float((uint32_t)rbase[eo] << 16);
@@ -133,6 +135,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
     const int n_ct = EPI == 0 ? C / kStepCh : a.n_cols / kBN;     // column tiles
     const int ct = blockIdx.x % n_ct;
     const int64_t m0 = (int64_t)(blockIdx.x / n_ct) * kClBM;      // first pixel of the tile (flattened b,y,x)
+    const int64_t M = (int64_t)a.B * HW;                          // pixels of the launch: the LAST tile may reach past them (any B*H*W with H*W % 4 == 0)
     const int cc_x = TPC == 2 ? 1 : C / kClBK, cc_all = EPI == 0 ? 2 * cc_x : cc_x;
     const int cc_eff = (EPI == 0 && a.h_prev) ? cc_all : cc_x;    // zero state: skip h's chunks
     const int n_chunks = TPC == 2 ? (n_taps + 1) / 2 : n_taps * cc_eff;
@@ -149,7 +152,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
         const int row = (wave * NA + j) * 8 + srow;
         const int64_t m = m0 + row;
         const int p = (int)(m % HW), bimg = (int)(m / HW);
-        ay[j] = (p / a.W) * stride;                               // the tap centre in INPUT coordinates
+        ay[j] = m < M ? (p / a.W) * stride : -(1 << 28);          // the tap centre in INPUT coordinates; a row past the last pixel: every tap out of the image (zero line)
         ax[j] = (p % a.W) * stride;
         apix[j] = (((int64_t)bimg * Hin + ay[j]) * Win + ax[j]) * C;    // element offset of the centre pixel's channel vector
         aswz[j] = (uint32_t)((sslot ^ ((row >> 1) & 7)) * 8);     // source channel offset inside the 64-channel chunk
@@ -264,7 +267,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int64_t mrow = m0 + wm * 32 * MF + i * 32 + (r >> 2) * 8 + fh * 4 + (r & 3);
-                    cpre[i][r] = a.c_prev ? a.c_prev[mrow * C + ch] : 0.0f;
+                    cpre[i][r] = (a.c_prev && mrow < M) ? a.c_prev[mrow * C + ch] : 0.0f;
                 }
         }
     };
@@ -331,7 +334,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
                 for (int r = 0; r < 16; ++r) acc[i][g][r] += red[((i * NF + g) * 16 + r) * 64];
     }
     if constexpr (EPI == 1) {
-        cl_epilogue_conv<MF, NF>(a, acc, m0 + wm * 32 * MF, ct * kBN + wn * 32 * NF + fr, fh);
+        cl_epilogue_conv<MF, NF>(a, acc, m0 + wm * 32 * MF, ct * kBN + wn * 32 * NF + fr, fh, M);
         return;
     }
     if constexpr (EPI == 0) {
@@ -345,6 +348,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS, KS == 2 || WM * WN == 16 ? 
         for (int q = 0; q < 4; ++q) {
             float hv[4];
             const int64_t mq = m0 + wm * 32 * MF + i * 32 + q * 8 + fh * 4;       // first of 4 consecutive pixels
+            if (mq >= M) continue;                                               // past the last pixel (partial last tile)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = q * 4 + e;

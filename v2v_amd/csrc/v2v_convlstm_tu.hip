@@ -21,7 +21,8 @@ hipError_t launch_step_t(const ConvLstmArgs &a, hipStream_t s)
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) raised[dev].store(true, std::memory_order_release);
     }
-    const int64_t tiles = (int64_t)a.B * a.H * a.W / (32 * MF * WM) * (EPI == 0 ? a.C / (WN * 32) : a.n_cols / (WN * NF * 32));
+    // ceil: the last pixel tile may be partial (rows past B*H*W read the zero line and are not stored)
+    const int64_t tiles = (((int64_t)a.B * a.H * a.W + 32 * MF * WM - 1) / (32 * MF * WM)) * (EPI == 0 ? a.C / (WN * 32) : a.n_cols / (WN * NF * 32));
     hipLaunchKernelGGL((convlstm_step_kernel<MF, WM, STAGES, EPI, WN, NF, TPC, KS>), dim3((unsigned)tiles), dim3(64 * WM * WN * KS), lds, s, a);
     return hipGetLastError();
 }
@@ -37,7 +38,7 @@ hipError_t launch_convlstm_step(const ConvLstmArgs &a, int tile_rows, hipStream_
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const int64_t m = (int64_t)a.B * a.H * a.W, ct = a.C / kClCh;
-        tile_rows = (m % 256 == 0 && m / 256 * ct >= cus) ? 256 : (m % 128 == 0 && m / 128 * ct >= cus) ? 128 : 64;
+        tile_rows = (m / 256 * ct >= cus) ? 256 : (m / 128 * ct >= cus) ? 128 : 64;      // (a partial last tile is fine: any B*H*W)
         // when even 64-pixel tiles give a CU at most one workgroup: that workgroup as two K groups (KS = 2; same box, 8 clips:
         // 128 ch @32^2 0.039 -> 0.033 ms, 256 ch @16^2 0.067 -> 0.053 ms; slower where more tiles exist: 0.115 -> 0.144 ms)
         if (tile_rows == 64 && m / 64 * ct <= cus) tile_rows = 65;
@@ -89,8 +90,7 @@ hipError_t launch_conv_nhwc(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
         return hipGetLastError();
     }
     if (a.C == 32) {                                                 // two taps per chunk (the UNet's first encoder: 32 -> 64, 5x5, stride 2)
-        if (tile_rows == 0) tile_rows = (m % 256 == 0 && m / 256 >= cus) ? 256 : 128;
-        if (m % tile_rows != 0) return hipErrorInvalidValue;
+        if (tile_rows == 0) tile_rows = (m / 256 >= cus) ? 256 : 128;
         if (a.n_cols == 64) return tile_rows == 256 ? launch_step_t<2, 4, 2, 1, 1, 2, 2>(a, s) : tile_rows == 128 ? launch_step_t<1, 4, 3, 1, 1, 2, 2>(a, s) : hipErrorInvalidValue;
         if (a.n_cols == 128) return tile_rows == 256 ? launch_step_t<2, 4, 2, 1, 1, 4, 2>(a, s) : tile_rows == 128 ? launch_step_t<1, 4, 3, 1, 1, 4, 2>(a, s) : hipErrorInvalidValue;
         return hipErrorInvalidValue;
@@ -99,8 +99,7 @@ hipError_t launch_conv_nhwc(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
         // one column tile of 4 / 2 / 1 B fragments per wave: 256 pixels (8 fragment rows of 4 waves x MF 2), or 128 pixels on
         // three stages when 256-pixel tiles leave CUs idle (8 clips at 64^2, same box: 5x5 256 -> 128 121 -> 88 us, 5x5
         // stride-2 64 -> 128 41 -> 30 us).  Measured and not kept for 32 columns: 512- and 256-pixel tiles of MF 4 (+26 / +41 %)
-        if (tile_rows == 0) tile_rows = (m % 256 == 0 && m / 256 >= cus) ? 256 : 128;
-        if (m % tile_rows != 0) return hipErrorInvalidValue;
+        if (tile_rows == 0) tile_rows = (m / 256 >= cus) ? 256 : 128;
         if (tile_rows == 256) {
             if (a.n_cols == 128) return launch_step_t<2, 4, 2, 1, 1, 4>(a, s);
             if (a.n_cols == 64) return launch_step_t<2, 4, 2, 1, 1, 2>(a, s);
@@ -121,8 +120,7 @@ hipError_t launch_conv_nhwc(const ConvLstmArgs &a, int tile_rows, hipStream_t s)
         // ... and better still 64 px x 128 columns, i.e. half a packed column tile per workgroup (4 waves of 32 x 64, three
         // stages): a third fewer LDS-DMA pieces per MFMA than 32 px x 256 columns (30.1 -> 27.4 us, 39.2 -> 36.0 us), and with the
         // workgroup as two K groups of 4 waves (KS = 2: 8 waves, 144 KB) 31.0 -> 24.3 us and 39.7 -> 30.2 us on the same box
-        tile_rows = (m % 256 == 0 && m / 256 * ct >= cus) ? 256 : (m % 128 == 0 && m / 128 * ct >= cus) ? 128
-                    : (m % 64 != 0) ? 32 : (m / 64 * ct < cus) ? 66 : 64;
+        tile_rows = (m / 256 * ct >= cus) ? 256 : (m / 128 * ct >= cus) ? 128 : (m / 64 * ct < cus) ? 66 : 64;
     }
     if (tile_rows == 256) return launch_step_t<2, 4, 2, 1>(a, s);
     if (tile_rows == 32) return launch_step_t<1, 1, 3, 1, 4, 2>(a, s); // 4 waves of 32 px x 64 columns, three stages

@@ -191,7 +191,7 @@ class UNetRecurrent(nn.Module):
         return out
 
     def forward(self, x, event_scales=None):
-        """x: [N, num_bins, H, W] float voxel grid (any layout), H and W multiples of 2^num_encoders -> {'image': [N,1,H,W]}.
+        """x: [N, num_bins, H, W] float voxel grid (any layout), H and W multiples of 16 (what forward_sequence pads to, model/train_utils.py:322-326; anything else raises) -> {'image': [N,1,H,W]}.
         event_scales (this implementation only): float32 [N,2] = (neg_max, pos_max) per sample, e.g. RingLoader(normalize='scales')'s
         batch['event_scales'] -- normalize_batch_voxel (model/train_utils.py:147-166) is then applied by the head while it reads the
         RAW voxel grid; None = x is used as it is."""
