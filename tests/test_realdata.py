@@ -329,3 +329,39 @@ def test_flow_and_cache_loaders_over_the_h5_container(tmp_path, monkeypatch, gol
     testh5_to_cache(str(seq), str(out), {"num_bins": 5, "dataset_name": "hqf"})
     ds = TestH5CacheDataset(str(out), {"sequence_length": 3, "num_bins": 5})
     assert len(ds) == int(g["cache__len"]) and all(np.array_equal(ds[i]["events"].numpy(), g[f"cache__{i}__events"]) for i in range(len(ds)))
+
+
+@pytest.mark.gpu
+def test_evaluation_loop_on_a_real_data_sequence(golden):
+    """The reference's evaluation path end to end on the fixture sequence (test_e2vid.py's loop over model/train_utils.py:318-345): a
+    TestH5Dataset sample -> events [1,L,5,36,48] -> zero padding to multiples of 16 (postops.pad_events, :322-326) -> the package
+    E2VIDRecurrent step by step at batch 1 (a 48 x 48 input: 6 x 6 = 36 pixels at the third level, far below any workgroup tile) -> crop.
+    The step loop, forward_sequence and its hipGraph replay agree bit for bit and the padding does not leak into the kept region's
+    finiteness; a second sample continues from the first one's states as the harness does (no reset in between)."""
+    from v2v_amd import postops
+    from v2v_amd.testh5 import TestH5Dataset
+    from v2v_amd.unet import E2VIDRecurrent
+    torch.manual_seed(3)
+    net = E2VIDRecurrent(dict(num_bins=5, skip_type="sum", recurrent_block_type="convlstm", num_encoders=3, base_num_channels=32,
+                              num_residual_blocks=2, use_upsample_conv=True, final_activation="", norm=None)).cuda().eval()
+    ds = TestH5Dataset(FIX, {"sequence_length": 4, "num_bins": 5, "dataset_name": "hqf"})
+    net.reset_states()
+    for i in range(2):
+        s = ds[i]
+        events = postops.pad_events(s["events"][None].cuda(), 16)                       # [1, L, 5, 48, 48]
+        assert events.shape[-2:] == (48, 48) and torch.equal(events[..., :36, :48], s["events"][None].cuda())
+        before = net.states
+        with torch.no_grad():
+            loop = torch.stack([net(events[:, t])["image"] for t in range(events.shape[1])], dim=1)
+            after = net.states
+            net.states = before
+            seq = net.forward_sequence(events)
+        assert torch.equal(loop, seq) and bool(torch.isfinite(loop).all()) and loop.shape == (1, events.shape[1], 1, 48, 48)
+        assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(after, net.states))
+        pred = loop[..., :36, :48]
+        assert pred.shape[-2:] == tuple(s["frame"].shape[-2:])
+    with torch.no_grad():
+        net.reset_states()
+        fresh = net.forward_sequence(postops.pad_events(ds[0]["events"][None].cuda(), 16))
+        graph = net.forward_sequence(postops.pad_events(ds[0]["events"][None].cuda(), 16), graph=True)
+    assert torch.equal(fresh, graph)
