@@ -672,6 +672,27 @@ def g21_esim_h5_dataset():
     save("g21_esim_h5_dataset.npz", **out)
 
 
+def g24_yaml_dataset_blocks():
+    """Every dataset block (a mapping with `class_name`) of the reference's 15 experiment YAMLs (config/*.yaml), as data: the configuration
+    keys and values a drop-in dataset class must accept.  Stored as JSON inside an .npz (one string); no reference code."""
+    import glob
+    import json
+    import yaml
+    blocks = []
+    for f in sorted(glob.glob(os.path.join(REF, "config", "*.yaml"))):
+        def walk(o, path):
+            if isinstance(o, dict):
+                if "class_name" in o:
+                    blocks.append({"yaml": os.path.basename(f), "path": path, "block": o})
+                for k, v in o.items():
+                    walk(v, path + "/" + str(k))
+            elif isinstance(o, list):
+                for i, v in enumerate(o):
+                    walk(v, f"{path}[{i}]")
+        walk(yaml.safe_load(open(f)), "")
+    save("g24_yaml_dataset_blocks.npz", blocks=np.array(json.dumps(blocks, sort_keys=True)))
+
+
 def torch_mod():
     import torch
     return torch
@@ -752,9 +773,9 @@ def g17_degrade_video():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22", "g23"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22", "g23", "g24"]
     fns = {"g1": g1_luts, "g2": g2_g3_esim_clean, "g4": g4_esim_noisy, "g5": g5_floor_divide,
-           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g15": g15_bgr_to_gray, "g16": g16_monash_sequence, "g19": g19_event_and_fps_loaders, "g20": g20_flow_and_cache_loaders, "g21": g21_esim_h5_dataset, "g17": g17_degrade_video, "g18": g18_unet_modules, "g12": g12_events_to_voxel_torch, "g22": g22_voxel_grid_lists, "g23": g23_events_to_image,
+           "g6": g6_imgs_to_voxels, "g7": g7_bilinear, "g8": g8_make_voxel, "g9": g9_v2e, "g11": g11_philox_fed, "g14": g14_v2e_native, "g15": g15_bgr_to_gray, "g16": g16_monash_sequence, "g19": g19_event_and_fps_loaders, "g20": g20_flow_and_cache_loaders, "g21": g21_esim_h5_dataset, "g17": g17_degrade_video, "g18": g18_unet_modules, "g12": g12_events_to_voxel_torch, "g22": g22_voxel_grid_lists, "g23": g23_events_to_image, "g24": g24_yaml_dataset_blocks,
            "g13": g13_normalize_batch_voxel}
     for w in which:
         fns[w]()
