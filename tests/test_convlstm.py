@@ -206,7 +206,8 @@ def test_shape_errors_are_reported_without_a_gpu():
     assert L.v2v_convlstm_step_hip(p, None, None, p, p, 1, 8, 8, 64, p, p, p, _lib.U8, 0, None) == _lib.ERR_DTYPE
     assert L.v2v_nchw_to_nhwc_bf16_hip(p, _lib.F64, 1, 64, 8, 8, 0, p, None) == _lib.ERR_DTYPE
     assert L.v2v_nchw_to_nhwc_bf16_hip(p, _lib.F32, 1, 32, 8, 8, 0, p, None) == _lib.ERR_SHAPE
-    assert L.v2v_conv3x3_nhwc_hip(p, p, p, None, 1, 1, 8, 8, 64, 128, C.cast((C.c_char * 64)(), C.c_void_p), 0, None) == _lib.ERR_SHAPE    # Cout % 256
+    assert L.v2v_conv3x3_nhwc_hip(p, p, p, None, 1, 1, 5, 5, 64, 128, C.cast((C.c_char * 64)(), C.c_void_p), 0, None) == _lib.ERR_SHAPE    # H*W % 4
+    assert L.v2v_conv3x3_nhwc_hip(p, p, p, None, 1, 1, 8, 8, 64, 96, C.cast((C.c_char * 64)(), C.c_void_p), 0, None) == _lib.ERR_SHAPE     # Cout not 32 / 64 / 128 / 256k
     assert L.v2v_conv3x3_nhwc_hip(p, p, p, None, 1, 1, 8, 8, 64, 256, p, 0, None) == _lib.ERR_PARAM                                       # out aliases x
     assert L.v2v_conv3x3_pack_weights_hip(p, 48, 256, p, None) == _lib.ERR_SHAPE
 
