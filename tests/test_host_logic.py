@@ -175,29 +175,67 @@ def test_bench_contract_line_for_eight_ranks_is_small_and_complete():
     assert len(bench.line_text(fat).encode()) <= bench.MAX_LINE_BYTES and "parity_check" not in slim and slim["value"] == one["value"] and "roofline" in slim
 
 
+_START_METHOD_CHILD = r"""
+import json, multiprocessing, sys, warnings
+sys.path.insert(0, sys.argv[1])
+from torch.utils.data import DataLoader
+from v2v_amd.datasets import WebvidDatasetV2, synthetic_frame_source
+tmp = sys.argv[2]
+open(tmp + "/videos.txt", "w").write("clip_a.mp4 450 0.2 0.3\n")
+cfg = {"video_list_file": tmp + "/videos.txt", "sequence_length": 4, "crop_size": 32, "data_source_name": "webvid", "frame_source": synthetic_frame_source,
+       "video_size": (1280, 720), "video_reader": "opencv"}
+out = {"unset_before": multiprocessing.get_start_method(allow_none=True)}
+plain = WebvidDatasetV2(tmp, cfg)
+out["plain_leaves_it_unset"] = multiprocessing.get_start_method(allow_none=True) is None and plain.worker_start_method is None and plain.multiprocessing_context is None
+ds = WebvidDatasetV2(tmp, dict(cfg, worker_start_method="spawn"))
+out["after"] = multiprocessing.get_start_method(allow_none=True)
+out["context"] = type(ds.multiprocessing_context).__name__
+it = iter(DataLoader(ds, batch_size=1, num_workers=1))                   # what train.py builds (train.py:52-65): the default context is now spawn
+out["popen"] = type(it._workers[0]._popen).__module__
+it._shutdown_workers()
+with warnings.catch_warnings(record=True) as w:                           # a second dataset asking for something else: warned, nothing forced
+    warnings.simplefilter("always")
+    WebvidDatasetV2(tmp, dict(cfg, worker_start_method="forkserver"))
+out["warned"] = [str(x.message)[:60] for x in w if issubclass(x.category, RuntimeWarning)]
+out["still"] = multiprocessing.get_start_method(allow_none=True)
+try:
+    WebvidDatasetV2(tmp, dict(cfg, worker_start_method="threads"))
+    out["bad_refused"] = False
+except AssertionError:
+    out["bad_refused"] = True
+print(json.dumps(out))
+"""
+
+
 def test_worker_start_method_yaml_key_sets_how_train_pys_dataloader_starts_workers(tmp_path):
     """`worker_start_method: spawn` in the dataset's YAML block: train.py's own DataLoader (train.py:52-65 passes no multiprocessing_context)
-    then spawns its workers -- each owns a HIP context and simulates its samples itself -- with train.py untouched."""
+    then spawns its workers -- each owns a HIP context and simulates its samples itself -- with train.py untouched.  The key fixes the
+    process-wide default ONLY while the program has not chosen one (no force=True: a later, different request is warned about and changes
+    nothing); `dataset.multiprocessing_context` is the explicit handle.  Run in a fresh interpreter, as train.py is one."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", _START_METHOD_CHILD, root, str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    assert out["unset_before"] is None and out["plain_leaves_it_unset"]
+    assert out["after"] == "spawn" and out["context"] == "SpawnContext" and "popen_spawn" in out["popen"]
+    assert len(out["warned"]) == 1 and out["still"] == "spawn" and out["bad_refused"]
+
+
+def test_worker_start_method_never_overrides_a_choice_the_program_already_made(tmp_path):
+    """In THIS process (pytest has long fixed its start method by the time this runs, or fixes it here): the key warns and changes nothing."""
     import multiprocessing
-    from torch.utils.data import DataLoader
     from v2v_amd.datasets import WebvidDatasetV2, synthetic_frame_source
-    lst = tmp_path / "videos.txt"
-    lst.write_text("clip_a.mp4 450 0.2 0.3\n")
-    cfg = {"video_list_file": str(lst), "sequence_length": 4, "crop_size": 32, "data_source_name": "webvid", "frame_source": synthetic_frame_source,
-           "video_size": (1280, 720), "video_reader": "opencv"}
-    before = multiprocessing.get_start_method()
-    try:
-        ds = WebvidDatasetV2(str(tmp_path), dict(cfg, worker_start_method="spawn"))
-        assert multiprocessing.get_start_method() == "spawn"
-        it = iter(DataLoader(ds, batch_size=1, num_workers=1))               # what train.py builds: the default context is now spawn
-        assert "popen_spawn" in type(it._workers[0]._popen).__module__
-        it._shutdown_workers()
-        with pytest.raises(AssertionError):
-            WebvidDatasetV2(str(tmp_path), dict(cfg, worker_start_method="threads"))
-    finally:
-        multiprocessing.set_start_method(before, force=True)
+    (tmp_path / "videos.txt").write_text("clip_a.mp4 450 0.2 0.3\n")
+    cfg = {"video_list_file": str(tmp_path / "videos.txt"), "sequence_length": 4, "crop_size": 32, "data_source_name": "webvid",
+           "frame_source": synthetic_frame_source, "video_size": (1280, 720), "video_reader": "opencv"}
+    before = multiprocessing.get_start_method()                          # fixes the default (fork on Linux) if nothing has yet
+    other = "spawn" if before != "spawn" else "forkserver"
+    with pytest.warns(RuntimeWarning, match="already fixed"):
+        ds = WebvidDatasetV2(str(tmp_path), dict(cfg, worker_start_method=other))
     assert multiprocessing.get_start_method() == before
-    assert WebvidDatasetV2(str(tmp_path), cfg).worker_start_method is None and multiprocessing.get_start_method() == before
+    assert ds.multiprocessing_context.get_start_method() == other        # the explicit handle still says what the YAML asked for
 
 
 def _npy_videos(tmp_path, n=3, t=60, h=96, w=160):

@@ -194,19 +194,21 @@ def run_yaml_only(tmp, src, n_batches, batch, dev, workers=0, worker_output="cpu
     host (`output_device: cpu`) through the worker queue, pin_memory thread and H2D copy like the reference's."""
     from torch.utils.data import DataLoader, RandomSampler
     spawn = workers > 0
-    ds = make_dataset(tmp, (n_batches + 8) * batch, src, defer_sim=False, output_device=worker_output if spawn else "cuda",
-                      **(dict(worker_start_method="spawn") if spawn else {}), **cfg)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)          # "start method already fixed to 'fork'": expected here, see below
+        ds = make_dataset(tmp, (n_batches + 8) * batch, src, defer_sim=False, output_device=worker_output if spawn else "cuda",
+                          **(dict(worker_start_method="spawn") if spawn else {}), **cfg)
+    # this process has started fork()ed loaders before (the ring / collator legs), so the YAML key cannot change its default start method any
+    # more (the dataset warns and leaves it); the loader is built like train.py's, with the dataset's context passed explicitly
     mk = lambda: DataLoader(ds, batch_size=batch, sampler=RandomSampler(ds), num_workers=workers, persistent_workers=spawn,   # noqa: E731
-                            pin_memory=spawn and worker_output == "cpu", drop_last=True)
+                            pin_memory=spawn and worker_output == "cpu", drop_last=True, multiprocessing_context=ds.multiprocessing_context if spawn else None)
     t0 = time.perf_counter()
     out = run_loader(mk, n_batches, batch, dev)
     out["seconds_with_startup"] = time.perf_counter() - t0
     out["workers"] = workers
     out["yaml"] = ("class_name: v2v_amd.datasets.WebvidDatasetV2, " + ("worker_start_method: spawn, output_device: %s; num_workers: %d, persistent_workers: true, "
                    "pin_memory: %s" % (worker_output, workers, "true" if worker_output == "cpu" else "false") if spawn else "output_device: cuda; num_workers: 0, persistent_workers: false, pin_memory: false"))
-    if spawn:
-        import multiprocessing as mp
-        mp.set_start_method("fork", force=True)                  # what the dataset's YAML key changed, put back for the other legs
     return out
 
 

@@ -83,6 +83,62 @@ def synthetic_frame_source(dataset, sample_idx, start_frame, end_frame, crop_siz
     return out
 
 
+_worker_exit_hook_installed = False
+
+
+def _worker_exit(dataset_ref, join_timeout_s=5.0):
+    """atexit hook of a SPAWNED DataLoader worker that used the GPU (installed by the first simulating __getitem__ in such a process).
+
+    Why it exists: a spawned child ends through the interpreter's full finalisation (multiprocessing/spawn.py: `sys.exit(exitcode)`;
+    a fork()ed child ends with `os._exit`).  torch's worker loop ends with `data_queue.cancel_join_thread(); data_queue.close()`
+    (torch/utils/data/_utils/worker.py), so the result queue's feeder thread -- a daemon thread that PICKLES the batches, which for
+    `output_device: cuda` means `storage._share_cuda_()` (hipIpcGetMemHandle, GIL released) -- may still be inside that C++ call when
+    finalisation starts.  CPython 3.10 ends a daemon thread that asks for the GIL after that point with pthread_exit(); the forced
+    unwind crosses a noexcept C++ frame and the worker dies in std::terminate ("terminate called without an active exception",
+    SIGABRT), which train.py's DataLoader reports as "worker killed by signal: Aborted".  atexit callbacks run BEFORE finalisation,
+    while threads may still take the GIL, so here the worker (1) lets the feeder thread(s) send what is buffered and return (the
+    queue is already closed: the sentinel is in its buffer), (2) waits for its own launches, drops the page-locked staging slots and
+    device buffers and returns the IPC blocks whose consumers have released them.  If a feeder cannot finish (the training process
+    stopped reading and the pipe is full) the worker ends the way a fork()ed one does, with os._exit(0), rather than abort."""
+    import gc
+    import multiprocessing.queues as mpq
+    stuck = False
+    for q in [o for o in gc.get_objects() if isinstance(o, mpq.Queue)]:
+        t = getattr(q, "_thread", None)
+        if t is not None and t.is_alive():
+            if not getattr(q, "_closed", False):
+                q.close()
+            t.join(join_timeout_s)
+            stuck = stuck or t.is_alive()
+    ds = dataset_ref()
+    if ds is not None:
+        ds.__dict__.pop("_staging", None)
+    if torch.cuda.is_initialized():
+        try:
+            torch.cuda.synchronize()
+            torch.cuda.ipc_collect()
+        except Exception:  # noqa: BLE001 - the process is ending; nothing useful to do with a device error here
+            pass
+    if stuck:
+        import sys
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
+
+
+def _install_worker_exit_hook(dataset):
+    """Called from __getitem__: only does something inside a DataLoader worker (torch.utils.data.get_worker_info())."""
+    global _worker_exit_hook_installed
+    if _worker_exit_hook_installed:
+        return
+    _worker_exit_hook_installed = True
+    if torch.utils.data.get_worker_info() is None or os.environ.get("V2V_WORKER_EXIT_HOOK", "1") == "0":
+        return
+    import atexit
+    import weakref
+    atexit.register(_worker_exit, weakref.ref(dataset))
+
+
 class WebvidDatasetV2(torch.utils.data.Dataset):
     """Same constructor, config keys, defaults, `__len__`, `__getitem__` contract as the reference class.
 
@@ -100,7 +156,9 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
                        'gray', 3 for 'gray_in_bgr_out'); replaces OpenCV decoding (tests, synthetic benches).  Must be
                        picklable (a module-level function) when DataLoader workers are spawned; see synthetic_frame_source
         video_size     (width, height) reported for every video when frame_source is used
-        worker_start_method  'spawn': train.py's own DataLoader then starts spawned workers (each owns a HIP context) -- see load_configs
+        worker_start_method  'spawn': train.py's own DataLoader then starts spawned workers (each owns a HIP context).  Sets the process-wide
+                       default start method ONLY if the program has not fixed one yet (warns otherwise); `dataset.multiprocessing_context`
+                       is the explicit form for programs that build the loader themselves -- see load_configs
     """
 
     def load_configs(self, configs):
@@ -177,8 +235,19 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
         self.worker_start_method = g("worker_start_method", None)
         if self.worker_start_method is not None:
             assert self.worker_start_method in ["spawn", "forkserver", "fork"]
+            # The YAML-only route has no other handle on train.py's DataLoader than the process-wide default, so the key fixes the default
+            # -- ONLY while the program has not chosen one (never force=True, nothing restored behind the user's back).  A program that
+            # already started fork()ed pools or loaders keeps its choice and gets a warning; a program that builds the loader itself passes
+            # `multiprocessing_context=dataset.multiprocessing_context` instead (v2v_amd.loader.create_dataloader does).
             import multiprocessing
-            multiprocessing.set_start_method(self.worker_start_method, force=True)
+            current = multiprocessing.get_start_method(allow_none=True)
+            if current is None:
+                multiprocessing.set_start_method(self.worker_start_method)
+            elif current != self.worker_start_method:
+                import warnings
+                warnings.warn(f"worker_start_method: {self.worker_start_method} -- this process already fixed its multiprocessing start method to "
+                              f"'{current}'; it is left as it is.  Pass multiprocessing_context=dataset.multiprocessing_context to the DataLoader "
+                              f"(fork()ed workers cannot use HIP).", RuntimeWarning, stacklevel=3)
         assert not (self.gpu_frontend and self.defer_sim), "gpu_frontend runs in the process that owns the GPU; defer_sim is for fork()ed workers"
 
     def __init__(self, dataset_path, configs):
@@ -214,6 +283,14 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
 
     def __len__(self):
         return len(self.sample_video_name)
+
+    @property
+    def multiprocessing_context(self):
+        """What a program that builds its own DataLoader passes as `multiprocessing_context=` (None without the YAML key: torch's default)."""
+        if self.worker_start_method is None:
+            return None
+        import multiprocessing
+        return multiprocessing.get_context(self.worker_start_method)
 
     # ------------------------------------------------------------------ decode (host; "next" row of SURVEY §8f)
     def _probe_size(self, video_path):
@@ -549,6 +626,8 @@ class WebvidDatasetV2(torch.utils.data.Dataset):
         return {"frame": frame.to(out_dev), "events": vox.to(out_dev), "data_source_idx": torch.tensor(self.data_source_idx), "v2e_params": v2e_params}
 
     def __getitem__(self, sample_idx):
+        if not self.defer_sim and not _worker_exit_hook_installed:
+            _install_worker_exit_hook(self)                                 # a DataLoader worker that simulates: clean teardown (see _worker_exit)
         if self._staged_ok():
             return self._getitem_staged(sample_idx)
         old_state = None

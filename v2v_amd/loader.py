@@ -455,5 +455,7 @@ def create_dataloader(dataset, configs, batch_size, local_rank):
         return RingLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers or 0, drop_last=True,
                           persistent_workers=bool(persistent_workers and num_workers), pad_to=configs.get("pad_events_to", 1),
                           normalize=configs.get("normalize_in_loader", False), device=device)
-    return DataLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers or 0,
+    # a dataset that asks for spawned workers (`worker_start_method`, v2v_amd/datasets.py) gets them through the loader's own argument here
+    ctx = next((c for c in (getattr(d, "multiprocessing_context", None) for d in leaves) if c is not None), None) if num_workers else None
+    return DataLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers or 0, multiprocessing_context=ctx,
                       persistent_workers=bool(persistent_workers and num_workers), pin_memory=configs.get("pin_memory", False), drop_last=True)
