@@ -124,14 +124,16 @@ def bgr_to_gray(img):
 
 
 def esim_voxel(frames, params, luts, *, noise_external=False, rng_mode=RNG_PHILOX, seed=0, clip_id0=0,
-               bin_mode=BIN_SUM, num_bins=5, frames_per_bin=1, replay=None, threads=None):
+               bin_mode=BIN_SUM, num_bins=5, frames_per_bin=1, replay=None, threads=None, check_integer=True, timing=None):
     """frames [B,N,H,W] uint8 or float32 (integer-valued); params [5] or [B,5].
-    Returns (voxel float64 [B,L,Tb,H,W] | [B,Tb,H,W], totals int64 [B,2])."""
+    Returns (voxel float64 [B,L,Tb,H,W] | [B,Tb,H,W], totals int64 [B,2]).
+    check_integer=False skips the (single-threaded NumPy) validation of float32 content -- bench.py's timed leg, whose clips the parity guard
+    has already been through; timing: a dict that receives `call_s`, the seconds spent inside the library call alone."""
     frames = np.ascontiguousarray(frames)
     b, n, h, w = frames.shape
     k = n - 1
     in_dtype = {np.dtype(np.uint8): IN_U8, np.dtype(np.float32): IN_F32}[frames.dtype]
-    if in_dtype == IN_F32:
+    if in_dtype == IN_F32 and check_integer:
         iv = frames.astype(np.int64)
         assert np.array_equal(iv, frames) and iv.min() >= 0 and iv.max() <= 255, "C oracle is LUT-only"
     params = np.ascontiguousarray(params, dtype=np.float64)
@@ -157,10 +159,14 @@ def esim_voxel(frames, params, luts, *, noise_external=False, rng_mode=RNG_PHILO
     else:
         if threads is not None:
             os.environ["OMP_NUM_THREADS"] = str(threads)
+        import time
+        t0 = time.perf_counter()
         rc = L.oracle_esim_voxel_batch(_p(frames), in_dtype, C.c_int64(b), C.c_int64(n), C.c_int64(h * w),
                                        _p(lut64), _p(lut32), _p(params), C.c_int64(stride), int(noise_external),
                                        rng_mode, C.c_uint64(seed), C.c_uint64(clip_id0), bin_mode, num_bins,
                                        frames_per_bin, _p(out), _p(totals))
+        if timing is not None:
+            timing["call_s"] = time.perf_counter() - t0
     if rc != 0:
         raise RuntimeError(f"oracle_esim_voxel rc={rc}")
     return out, totals

@@ -24,6 +24,19 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* threads the batch drivers below run on (libgomp: OMP_NUM_THREADS, else the cores of the affinity mask): bench.py reports this as `cores` */
+int oracle_omp_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
 
 /* ------------------------------------------------------------------ np.floor_divide (float64) */
 double oracle_floor_divide(double a, double b)

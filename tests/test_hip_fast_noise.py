@@ -1,6 +1,6 @@
 """The device-native base-noise field as the simulator injects it (external-noise mode exposes it exactly): standard normal,
-uncorrelated across pixels and time steps, equal to the C oracle's field bit for bit; and V2V_RNG_PHILOX_FAST, kept as an
-alias of V2V_RNG_PHILOX, gives the same launch."""
+uncorrelated across pixels and time steps, equal to the C oracle's field bit for bit; and the event statistics it produces against the
+statistics of the reference's own generator (MT19937 + polar Box-Muller) on the same clips."""
 import numpy as np
 import pytest
 import torch
@@ -38,19 +38,42 @@ def test_fast_noise_is_standard_normal():
     assert np.array_equal(exact.reshape(8, -1).astype(np.float32), want)
 
 
-def test_fast_noise_event_statistics_match_exact_mode():
+def test_noise_free_launches_ignore_the_rng_mode():
     from v2v_amd import esim as E
     frames = E.synth_clips(8, 32, 128, 128, dtype=torch.uint8, seed=5)
-    p = [0.2, 0.25, 0.08, 1e-3, 1.0]
-    tot = {}
-    for mode in ("philox", "philox_fast"):
-        c = torch.zeros((8, 2), dtype=torch.int64, device="cuda")
-        v = E.esim_voxel_batch(frames, p, bin_mode="bilinear", num_bins=5, rng_mode=mode, seed=9, counts=c)
-        tot[mode] = (c.sum(0).cpu().numpy().astype(np.float64), float(v.abs().sum()))
-    on_off_exact, on_off_fast = tot["philox"][0], tot["philox_fast"][0]
-    assert np.array_equal(on_off_fast, on_off_exact)
-    assert abs(tot["philox_fast"][1] - tot["philox"][1]) / tot["philox"][1] < 0.01
-    # noise-free launches ignore the mode entirely
     a = E.esim_voxel_batch(frames, [0.2, 0.25, 0, 0, 0], bin_mode="bilinear", rng_mode="philox", seed=9)
-    b = E.esim_voxel_batch(frames, [0.2, 0.25, 0, 0, 0], bin_mode="bilinear", rng_mode="philox_fast", seed=9)
+    b = E.esim_voxel_batch(frames, [0.2, 0.25, 0, 0, 0], bin_mode="bilinear", rng_mode="philox", seed=10)
     assert torch.equal(a, b)
+
+
+# bounds of the statistical tie below: |t| of one clip's statistic (Student t, 14 degrees of freedom: P(|t| > 7) = 6e-6, 896 statistics)
+# and |z| of a statistic summed over the 64 clips.  Seeds are fixed, so the test is deterministic; the bounds say how far from "equal
+# in distribution" a pass can be.
+T_BOUND, Z_BOUND = 7.0, 4.0
+
+
+def test_native_rng_event_statistics_match_the_references_generator():
+    """The device-native generator (Philox4x32-7/10 words, 2^14-point table Gaussians cut at 4.009 sigma) against the REFERENCE'S
+    generator (MT19937 + 53-bit polar Box-Muller, data/v2v_core_esim.py:29,37-39,44, replayed through the same kernel) on the same 64
+    clips of config 2's shape: per-clip ON / OFF totals and the |voxel| mass of every bin agree within sampling error at the reference's
+    defaults AND at the dataset's extremes (thresholds 0.05, base_noise_std 0.2: v2v_datasets.py:26-92), where truncation and table
+    steps matter most.  tools/rng_statistics.py; the measured differences are quoted in DESIGN.md §4.3."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("rng_statistics", os.path.join(root, "tools", "rng_statistics.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.run(clips=64, numpy_reps=4, philox_seeds=12)
+    out_dir = os.path.join(root, "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+        with open(os.path.join(out_dir, "rng_statistics.json"), "w") as f:
+            json.dump(res, f, indent=1)
+    assert res["degrees_of_freedom"] == 14
+    for name, r in res["parameter_sets"].items():
+        assert r["events_per_pixel_step_philox"] > 0.01, (name, r)                     # the comparison is not about empty grids
+        worst_t = max(r["per_clip_max_abs_t"].values())
+        worst_z = max(abs(v) for v in r["aggregate_z"].values())
+        assert worst_t < T_BOUND, (name, r["per_clip_max_abs_t"])
+        assert worst_z < Z_BOUND, (name, r["aggregate_z"], r["relative_difference_numpy_minus_philox"])

@@ -143,6 +143,7 @@ def run_loader(make_iterable, n_batches, batch, dev, timers=None, gpu_ms_per_bat
         out["h2d_bytes_per_batch"] = loader.bytes_copied / loader.batches_copied
     shape = {k: (tuple(v.shape), str(v.dtype)) for k, v in last.items() if isinstance(v, torch.Tensor)}
     out["batch"] = {k: f"{s} {d}" for k, (s, d) in shape.items()}
+    del last, b                    # batches of spawned workers are the PRODUCERS' blocks (CUDA IPC): released before the workers are told to go
     del it, loader
     return out
 
@@ -197,7 +198,9 @@ def run_yaml_only(tmp, src, n_batches, batch, dev, workers=0, worker_output="cpu
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)          # "start method already fixed to 'fork'": expected here, see below
-        ds = make_dataset(tmp, (n_batches + 8) * batch, src, defer_sim=False, output_device=worker_output if spawn else "cuda",
+        # exactly the batches run_loader draws (3 warm-up + n_batches): the epoch is exhausted like train.py's loop exhausts it, nothing stays
+        # prefetched in the workers when they are shut down
+        ds = make_dataset(tmp, (n_batches + 3) * batch, src, defer_sim=False, output_device=worker_output if spawn else "cuda",
                           **(dict(worker_start_method="spawn") if spawn else {}), **cfg)
     # this process has started fork()ed loaders before (the ring / collator legs), so the YAML key cannot change its default start method any
     # more (the dataset warns and leaves it); the loader is built like train.py's, with the dataset's context passed explicitly
@@ -249,8 +252,8 @@ def gpu_ms_of_batch(batch, dev, pad_to=16):
 
 
 def measure(batches=200, workers=9, batch=12, modes=("ring", "simulating"), cpu_port=True, dev=None, cpu_port_budget_s=60.0, simulating_batches=None, ring_kw=None, consumer=True,
-            consumer_batches=20, yaml_only_batches=10, yaml_only_spawn_batches=40):
-    """simulating_batches = 0 skips the round-2/3 collator leg; yaml_only_* = 0 skips the zero-edit legs."""
+            consumer_batches=20, yaml_only_batches=10, yaml_only_spawn_batches=40, yaml_only_host_return_batches=10):
+    """simulating_batches = 0 skips the round-2/3 collator leg; yaml_only_* = 0 skips the zero-edit legs (each spawned leg costs ~9 s of worker start-up)."""
     ring_kw = ring_kw or {}
     from torch.utils.data import DataLoader
     from v2v_amd.datasets import SimulatingCollator, SimulatingLoader
@@ -301,7 +304,7 @@ def measure(batches=200, workers=9, batch=12, modes=("ring", "simulating"), cpu_
         if cpu_port:
             res["cpu_port_in_workers"] = run_cpu_port(ds, workers, batch, budget_s=cpu_port_budget_s)
         for key, nb, wk, wo in (("yaml_only_workers0", yaml_only_batches, 0, "cuda"), ("yaml_only_spawn_workers", yaml_only_spawn_batches, workers, "cuda"),
-                                ("yaml_only_spawn_workers_host_return", min(yaml_only_spawn_batches, 10), workers, "cpu")):
+                                ("yaml_only_spawn_workers_host_return", yaml_only_host_return_batches, workers, "cpu")):
             if nb:
                 try:
                     res[key] = run_yaml_only(tmp, src, nb, batch, dev, workers=wk, worker_output=wo)
