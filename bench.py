@@ -169,12 +169,10 @@ def cpu_baseline_all_cores(frames_host, wl, budget_s=8.0, distinct_clips=32):
         np.save(path, frames_host[:distinct_clips])
         ctx = mp.get_context("spawn")
         with ctx.Pool(cores, initializer=_pool_init, initargs=(path, wl_small)) as pool:
-            t0 = time.perf_counter()
             pool.map(_pool_clip, range(cores), chunksize=1)            # imports, page-in, one clip each: outside the timed part
-            warm = time.perf_counter() - t0
-            rounds = int(max(1, min(8, budget_s / max(warm, 1e-3))))
-            t0 = time.perf_counter()
-            done = sum(pool.map(_pool_clip, range(cores * rounds), chunksize=1))
+            done, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < budget_s:                 # rounds of two clips per worker until the budget is spent
+                done += sum(pool.map(_pool_clip, range(done, done + 2 * cores), chunksize=1))
             dt = time.perf_counter() - t0
     grids = done * (1 if wl["bin"] == "bilinear" else (frames_host.shape[1] - 1) // (wl["tb"] * wl["fpb"]))
     return {"value": grids / dt, "unit": "voxel grids/s", "cores": cores, "kind": "port",

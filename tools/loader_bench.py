@@ -198,13 +198,13 @@ def run_yaml_only(tmp, src, n_batches, batch, dev, workers=0, worker_output="cpu
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)          # "start method already fixed to 'fork'": expected here, see below
-        # exactly the batches run_loader draws (3 warm-up + n_batches): the epoch is exhausted like train.py's loop exhausts it, nothing stays
-        # prefetched in the workers when they are shut down
         ds = make_dataset(tmp, (n_batches + 3) * batch, src, defer_sim=False, output_device=worker_output if spawn else "cuda",
                           **(dict(worker_start_method="spawn") if spawn else {}), **cfg)
     # this process has started fork()ed loaders before (the ring / collator legs), so the YAML key cannot change its default start method any
     # more (the dataset warns and leaves it); the loader is built like train.py's, with the dataset's context passed explicitly
-    mk = lambda: DataLoader(ds, batch_size=batch, sampler=RandomSampler(ds), num_workers=workers, persistent_workers=spawn,   # noqa: E731
+    # the sampler draws exactly the batches run_loader asks for (3 warm-up + n_batches): the epoch is exhausted like train.py's loop exhausts
+    # it, so nothing stays prefetched in the workers (as producers' CUDA IPC blocks) when they are shut down
+    mk = lambda: DataLoader(ds, batch_size=batch, sampler=RandomSampler(ds, num_samples=(n_batches + 3) * batch), num_workers=workers, persistent_workers=spawn,   # noqa: E731
                             pin_memory=spawn and worker_output == "cpu", drop_last=True, multiprocessing_context=ds.multiprocessing_context if spawn else None)
     t0 = time.perf_counter()
     out = run_loader(mk, n_batches, batch, dev)

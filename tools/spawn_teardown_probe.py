@@ -38,7 +38,7 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         ds = loader_bench.make_dataset(tmp, a.batches * a.batch, src, defer_sim=False, output_device=a.output_device, worker_start_method="spawn")
         for _ in range(a.rounds):
-            loader = DataLoader(ds, batch_size=a.batch, sampler=RandomSampler(ds), num_workers=a.workers, persistent_workers=bool(a.persistent),
+            loader = DataLoader(ds, batch_size=a.batch, sampler=RandomSampler(ds, num_samples=a.batches * a.batch), num_workers=a.workers, persistent_workers=bool(a.persistent),
                                 pin_memory=a.output_device == "cpu", drop_last=True, multiprocessing_context=ds.multiprocessing_context)
             it = iter(loader)
             workers = list(it._workers)

@@ -103,7 +103,7 @@ def _worker_exit(dataset_ref, join_timeout_s=5.0):
     import gc
     import multiprocessing.queues as mpq
     stuck = False
-    for q in [o for o in gc.get_objects() if isinstance(o, mpq.Queue)]:
+    for q in [o for o in gc.get_objects() if type(o) is mpq.Queue]:       # type(), not isinstance(): lazy module attributes must not be woken here
         t = getattr(q, "_thread", None)
         if t is not None and t.is_alive():
             if not getattr(q, "_closed", False):
