@@ -185,6 +185,7 @@ def cpu_baseline_c(frames_host, wl):
     library call alone: round 5's 112 grids/s "on 256 cores" was mostly the wrapper's single-threaded NumPy validation of the float32
     content (astype + array_equal + min + max over 0.5 G elements) inside the timed bracket."""
     from oracle import clib, v2v_oracle as O
+    clib.lib().oracle_omp_set_threads(host_cores()[0])       # libgomp's default is the machine's core count, not what the cgroup lets this process use
     threads = int(clib.lib().oracle_omp_max_threads())
     bm = clib.BIN_BILINEAR if wl["bin"] == "bilinear" else clib.BIN_SUM
     timing = {}

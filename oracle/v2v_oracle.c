@@ -38,6 +38,15 @@ int oracle_omp_max_threads(void)
 #endif
 }
 
+void oracle_omp_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* ------------------------------------------------------------------ np.floor_divide (float64) */
 double oracle_floor_divide(double a, double b)
 {

@@ -213,3 +213,46 @@ def test_forward_sequence_pipelined_over_two_streams_equals_the_step_loop(shape)
             g.replay()
             torch.cuda.synchronize()
             assert torch.equal(out, want), rep
+
+
+@pytest.mark.gpu
+def test_forward_sequence_as_the_first_call_and_after_a_weight_update():
+    """the layers pack their weights lazily inside forward(); when forward_sequence is the FIRST call on a network (or
+    follows load_state_dict / a weight update) the decoder halves would pack on side stream 0 while side streams 1 and 2 read the packed
+    copies ordered only after the caller's event.  forward_sequence now packs everything on the caller's stream before the fork: a fresh
+    network's first overlapped call equals the step loop of an identical twin, repeatedly, and again after the weights change in place.
+    Also (low): an eager call between two graph replays must not leak its states into the next replay's result."""
+    import torch
+    from v2v_amd.unet import E2VIDRecurrent
+    kw = dict(num_bins=5, skip_type="sum", recurrent_block_type="convlstm", num_encoders=3, base_num_channels=32,
+              num_residual_blocks=2, use_upsample_conv=True, final_activation="", norm=None)
+    n, t, h, w = 4, 6, 64, 64
+    ev = torch.round(torch.randn((n, t, 5, h, w), device="cuda", generator=torch.Generator("cuda").manual_seed(3)) * 2)
+    with torch.no_grad():
+        for trial in range(4):
+            torch.manual_seed(10 + trial)
+            fresh = E2VIDRecurrent(kw).cuda().eval()
+            twin = E2VIDRecurrent(kw).cuda().eval()
+            twin.load_state_dict(fresh.state_dict())
+            got = fresh.forward_sequence(ev)                                   # FIRST call of this network: packs, then forks
+            twin.reset_states()
+            want = torch.stack([twin(ev[:, i])["image"] for i in range(t)], 1)
+            assert torch.equal(got, want), trial
+            for p, q in zip(fresh.parameters(), twin.parameters()):            # in-place update: every packed copy is stale now
+                p.mul_(0.5)
+                q.mul_(0.5)
+            fresh.reset_states()
+            twin.reset_states()
+            got = fresh.forward_sequence(ev)
+            want = torch.stack([twin(ev[:, i])["image"] for i in range(t)], 1)
+            assert torch.equal(got, want), trial
+        # graph replays with an eager call in between
+        net = fresh
+        net.reset_states()
+        want_a = torch.stack([net(ev[:, i])["image"] for i in range(t)], 1)
+        states_a = net.states
+        assert torch.equal(net.forward_sequence(ev, graph=True), want_a)
+        net(ev[:, 0])                                                          # eager step: writes into the live state list
+        assert torch.equal(net.forward_sequence(ev, graph=True), want_a)       # the replay resets and recomputes
+        for a, b in zip(net.states, states_a):                                 # and hands back ITS final states, not the eager call's
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

@@ -20,7 +20,8 @@ struct ClipBounds {
 __device__ __forceinline__ bool clip_frame_ok(const ClipBounds &cb, int b, int f, int64_t clip_off, int64_t frame_stride, int64_t frame_bytes)
 {
     if (!cb.stored) return true;
-    if ((unsigned)f >= (unsigned)cb.stored[b]) return false;
+    const int32_t stored = cb.stored[b];
+    if (stored <= 0 || (unsigned)f >= (unsigned)stored) return false;      // a negative (corrupted) count must not pass as a huge unsigned one
     const int64_t first = clip_off + (int64_t)f * frame_stride;
     return cb.src_elems <= 0 || (first >= 0 && first + frame_bytes <= cb.src_elems);
 }

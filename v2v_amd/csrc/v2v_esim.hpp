@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(kBlock, (SYMONLY || esim_asym4<VEC, RNG, NOISE
         const int stored = a.stored_frames ? a.stored_frames[cb] : 0x7FFFFFFF;
         for (int i = threadIdx.x; i <= a.K; i += kBlock) {
             const int f = row[i];
-            fidx_bad |= (int)((unsigned)f >= (unsigned)stored);            // negative or >= stored (the reference's gather cannot, v2v_datasets.py:286-311)
+            fidx_bad |= (int)(stored < 1 || (unsigned)f >= (unsigned)stored);   // negative or >= stored (the reference's gather cannot, v2v_datasets.py:286-311); a negative stored count is poison whatever frames_elems says
             s_fidx[i] = f;
         }
         if (a.stored_frames && a.frames_elems > 0 && threadIdx.x == 0) {

@@ -120,6 +120,19 @@ class UNetRecurrent(nn.Module):
             img = self.final_activation(img)
         return img
 
+    def _pack_weights(self):
+        """Every layer's packed weight copy made (or found current) on the CALLER's stream.  The layers pack lazily inside forward(); a first
+        call, or one after load_state_dict / a weight update, would otherwise pack the decoder halves' weights on the side stream of step
+        0 -- and step 1's decoder half, on ANOTHER side stream ordered only after the caller's `ready` event, could read them before the
+        pack kernels have written them (and the packed tensors would live in one side stream's allocator pool while every stream reads
+        them).  Packed here, they are ordered before every side stream by the wait_stream() that follows."""
+        for m in self.modules():
+            if isinstance(m, ResidualBlock):
+                m._weights(m.conv1, "conv1")
+                m._weights(m.conv2, "conv2")
+            elif isinstance(m, ConvLSTM) or (isinstance(m, ConvLayer) and m.conv2d.kernel_size[0] != 1):   # the 1x1 prediction layer has no packed copy
+                m._weights()
+
     def forward_sequence(self, events, event_scales=None, out=None, overlap=True):
         """The time loop of model/train_utils.py:339-345 (`for t in range(T): pred = model(events[:, t]); pred_imgs[:, t] = pred['image']`)
         as ONE call: events [N,T,num_bins,H,W] -> images [N,T,1,H,W] (events' dtype, or `out`), the states advanced by T steps.
@@ -168,6 +181,7 @@ class UNetRecurrent(nn.Module):
         if key not in pool:
             pool[key] = [torch.cuda.Stream(device=events.device) for _ in range(n_side)]
         sides = pool[key]
+        self._pack_weights()                                    # on `cur`, BEFORE the fork: see _pack_weights
         for side in sides:
             side.wait_stream(cur)                               # `out`, the weights' packed copies, whatever the caller queued before
         held = []                                               # (tensors of a step a side stream reads, its completion event)
@@ -271,11 +285,11 @@ class E2VIDRecurrent(nn.Module):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     res = run()
-            entry = cache[key] = (g, ev, sc, res, self.unetrecurrent.states)
-        g, ev, sc, res, states = entry
+            entry = cache[key] = (g, ev, sc, res, tuple(self.unetrecurrent.states))   # an immutable copy: eager calls between two replays
+        g, ev, sc, res, states = entry                                                # assign into the live list (self.states[i] = state)
         ev.copy_(events)
         if sc is not None:
             sc.copy_(event_scales)
         g.replay()
-        self.unetrecurrent.states = states                      # the graph's own state tensors: what the last captured step wrote
+        self.unetrecurrent.states = list(states)                # the graph's own state tensors: what the last captured step wrote
         return res

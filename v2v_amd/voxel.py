@@ -128,8 +128,10 @@ def events_to_image(xs, ys, ps, sensor_size=(180, 240), interpolation=None, padd
     """utils/event_utils.py:155-174: img[y, x] = sum of the weights `ps` of the events at (x, y), float64 [H, W] (np.bincount over the
     raveled coordinates).  It is the one-bin case of the temporal-bilinear voxel grid -- with a single bin every event's weight is 1 -- so it
     runs on the same scatter kernel; an event outside the sensor raises ValueError as np.ravel_multi_index does.
-    interpolation='bilinear' (fractional coordinates) goes through events_to_image_torch, as in the reference."""
-    if interpolation == "bilinear" and np.asarray(xs).dtype.kind == "f":
+    interpolation='bilinear' goes through events_to_image_torch for EVERY NumPy dtype, integer coordinates included, as in the reference
+    (:160 tests `xs.dtype is not torch.long` on a NumPy array, which is always true): events at x >= W-1 or y >= H-1 are masked out
+    (clip_out_of_range), not counted."""
+    if interpolation == "bilinear":
         img = events_to_image_torch(torch.from_numpy(np.asarray(xs)).float(), torch.from_numpy(np.asarray(ys)).float(), torch.from_numpy(np.asarray(ps)).float(),
                                     clip_out_of_range=True, interpolation="bilinear", padding=padding, sensor_size=sensor_size)
         return img.cpu().numpy().reshape(sensor_size)
