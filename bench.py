@@ -359,6 +359,170 @@ class Workload:
         self.frames = self.out = self.raw = self.step = None
 
 
+# ---------------------------------------------------------------------------------------------------------------- host-fed streams
+# BASELINE configs 4 and 5 are STREAMS: the clips arrive in host memory and cross PCIe before the kernels see them.  The headline workload
+# shards a device-resident batch (trivially N x); these two put the host side -- worker processes, page-locked rings, one PCIe link per
+# rank -- inside the timed region, so that a multi-GPU run measures something that can fail to scale (DESIGN.md §7 names what to check).
+STREAM_WORKLOADS = {
+    # the reference's training shape through the one-line integration level: RingLoader per rank (9 fork()ed workers writing pre-generated
+    # 201x128x128 uint8 clips into page-locked shared slots; one H2D copy, simulator + statistics + scales + scaling pass + frames per batch)
+    "train_loader_b12": dict(kind="ring", b=12, n=201, h=128, w=128, tb=5, fpb=1, workers=9),
+    # config 4 per rank: decoded 720p BGR frames resident in PAGE-LOCKED HOST memory -> HostStager (copy of batch k+1 under the kernels of
+    # batch k) -> GPU front-end (cvtColor, crop, resize to 256x256, flip) -> fused simulator, 40 frames -> 5 temporal-bilinear bins
+    "cfg4_stream_staged": dict(kind="cfg4", b=8, n=40, h=256, w=256, tb=5, fpb=1, src_hw=(720, 1280), params=DATASET_STYLE, zero_copy=False),
+    # the same stream without the staging copy: the front-end kernel stages each clip's CROP RECTANGLE straight out of the page-locked host
+    # frames over PCIe (v2v_amd/frontend.py: zero-copy host input) -- only the bytes the resize reads cross the link
+    "cfg4_stream": dict(kind="cfg4", b=8, n=40, h=256, w=256, tb=5, fpb=1, src_hw=(720, 1280), params=DATASET_STYLE, zero_copy=True),
+}
+
+
+class StreamWorkload:
+    """One rank's host-fed stream.  step() = one batch from host memory to finished voxel grids on the device (asynchronous on the GPU side;
+    the caller synchronises at the end of the timed region).  h2d_bytes() = bytes that crossed PCIe per step so far."""
+
+    def __init__(self, name, dev, rank, world, steps_needed):
+        import torch
+        from v2v_amd import esim
+        self.name, self.cfg, self.dev = name, STREAM_WORKLOADS[name], dev
+        cfg = self.cfg
+        b, n, h, w, tb = cfg["b"], cfg["n"], cfg["h"], cfg["w"], cfg["tb"]
+        self.b = b
+        self._tmp = None
+        if cfg["kind"] == "ring":
+            import tempfile
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import loader_bench
+            from torch.utils.data import DistributedSampler
+            from v2v_amd.loader import RingLoader
+            self._tmp = tempfile.TemporaryDirectory()
+            n_samples = (steps_needed + 4) * b * world
+            ds = loader_bench.make_dataset(self._tmp.name, (n_samples + 1) // 2, loader_bench.PooledFrameSource(), defer_sim=True)   # 2 samples per listed video
+            sampler = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, seed=0) if world > 1 else None
+            self.loader = RingLoader(ds, batch_size=b, sampler=sampler, shuffle=sampler is None, num_workers=cfg["workers"], drop_last=True, pad_to=16,
+                                     normalize=True, device=dev)
+            self._it = iter(self.loader)
+            self.grids_per_step = b * ((n - 1) // (tb * cfg["fpb"]))
+            self.alg_bytes = esim.algorithmic_bytes(torch.uint8, b, n, h, w, "sum", tb, cfg["fpb"])
+            self.kernel_name = "esim_voxel_kernel (writer statistics) + count_pick_kernel + normalize_pad_rows_kernel + clip_frames kernel, fed by RingLoader"
+            self.last = None
+
+            def step():
+                self.last = next(self._it)                                       # events [12,40,5,128,128] + frame on the device, normalised
+            self.step = step
+            self.gpu_only_ms = lambda: loader_bench.gpu_ms_of_batch(b, dev)
+        else:
+            import numpy as np
+            from v2v_amd import frontend, staging
+            sh, sw = cfg["src_hw"]
+            clip_id0 = rank * b
+            raw = torch.empty((b, n, sh, sw, 3), dtype=torch.uint8, device=dev)
+            for ch in range(3):
+                raw[..., ch] = esim.synth_clips(b, n, sh, sw, dtype=torch.uint8, seed=20240001 + 7919 * ch, clip_id0=clip_id0, device=dev)
+            self.host = raw.cpu().pin_memory()                                   # the "decoded video" of this rank, page-locked
+            g = np.random.default_rng(20240001 + rank)
+            keep_h = int(sh * 0.54)                                              # keep_top_percentile (v2v_datasets.py:73)
+            min_scale = max(0, h / keep_h, h / sw)
+            scale = g.uniform(min_scale, max(1.3, min_scale), size=b)            # :260-272
+            cb = (h / scale).astype(np.int64)
+            table = np.stack([[g.integers(0, keep_h - c + 1), g.integers(0, sw - c + 1), c, int(g.random() > 0.5)] for c in cb]).astype(np.int32)
+            table_d = torch.as_tensor(table, device=dev)
+            idx_d = torch.as_tensor(np.tile(np.arange(n, dtype=np.int32), (b, 1)), device=dev)
+            cb_max = int(cb.max())
+            ptensor = torch.tensor(cfg["params"], dtype=torch.float64, device=dev)
+            self.out = out = torch.empty((b, tb, h, w), dtype=torch.float32, device=dev)
+            stager = staging.HostStager(dev)
+            self.raw_bytes = raw.numel()
+            self.grids_per_step = b
+            self.alg_bytes = esim.algorithmic_bytes(torch.uint8, b, n, h, w, "bilinear", tb, cfg["fpb"]) + int((cb ** 2).sum()) * 3 * n + b * n * h * w
+            self.kernel_name = "frontend_tile_kernel + esim_voxel_kernel, fed by HostStager from page-locked host frames"
+            self.steps_done = 0
+
+            def compute(raw_d):
+                gray = frontend.prepare_clips_batch(raw_d, table_d, idx_d, h, "gray", validate=False, max_crop_before=cb_max)[1]
+                esim.esim_voxel_batch(gray, ptensor, bin_mode="bilinear", num_bins=tb, frames_per_bin=cfg["fpb"], rng_mode="philox", seed=20240001,
+                                      clip_id0=clip_id0, out=out, validate=False, no_noise=False)
+            self.crop_bytes = int((cb ** 2).sum()) * 3 * n
+            if cfg["zero_copy"]:
+                self.kernel_name = "frontend_tile_kernel (reads the crop rectangles out of page-locked host frames) + esim_voxel_kernel"
+
+                def step():
+                    compute(self.host)                                           # no copy: the kernel's staging loads ARE the PCIe transfer
+                    self.steps_done += 1
+            else:
+                self._handle = stager.stage(self.host)
+
+                def step():
+                    cur, self._handle = self._handle, stager.stage(self.host)   # batch k+1 crosses PCIe under batch k's kernels
+                    compute(stager.ready(cur))
+                    self.steps_done += 1
+            self.step = step
+
+            def gpu_only_ms():
+                for _ in range(2):
+                    compute(raw)
+                ms = time_launches(lambda: compute(raw), 10, torch)
+                return sum(ms) / len(ms)
+            self.gpu_only_ms = gpu_only_ms
+
+    def h2d_bytes_per_step(self):
+        if self.cfg["kind"] == "ring":
+            return self.loader.bytes_copied / max(1, self.loader.batches_copied)
+        return float(self.crop_bytes if self.cfg["zero_copy"] else self.raw_bytes)   # zero-copy: algorithmic (the rectangles once; tile halos re-read a little)
+
+    def close(self):
+        if self.cfg["kind"] == "ring":
+            self._it = self.last = None
+            self.loader.close()
+        if self._tmp is not None:
+            self._tmp.cleanup()
+
+
+def run_stream(args, torch, dev, rank, local_rank, world, dist, backend):
+    """`--workload train_loader_b12 | cfg4_stream`: every rank runs its own host-fed stream; same barrier + max-over-ranks protocol, same line
+    (`value` = voxel grids of all ranks per second), plus `stream`: aggregate samples/s, and per rank ms per step and PCIe GB/s."""
+    from v2v_amd import sharding
+    S = StreamWorkload(args.workload, dev, rank, world, args.warmup + args.steps)
+    for _ in range(args.warmup):
+        S.step()
+    torch.cuda.synchronize()
+    sharding.barrier(dist, local_rank)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        S.step()
+    torch.cuda.synchronize()
+    my_elapsed = time.perf_counter() - t0
+    sharding.barrier(dist, local_rank)
+    elapsed = sharding.max_over_ranks(dist, my_elapsed, dev)
+    per_rank_ms = sharding.gather_floats(dist, my_elapsed / args.steps * 1e3, dev)
+    h2d = S.h2d_bytes_per_step()
+    per_rank_gbps = sharding.gather_floats(dist, h2d / (my_elapsed / args.steps) / 1e9, dev)
+    gpu_ms = S.gpu_only_ms() if rank == 0 else None                        # the same launches on device-resident input: what the kernels alone take
+    if rank == 0:
+        cfg = S.cfg
+        achieved = S.alg_bytes / (gpu_ms * 1e-3) / 1e9
+        line = {
+            "metric": "voxel grids/sec", "value": S.grids_per_step * world * args.steps / elapsed, "unit": "voxel grids/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic", "dist_backend": backend, "dist_world_size": world,
+            "ms_per_step_per_rank": [round(v, 4) for v in per_rank_ms],
+            "config": {"workload": args.workload, "host_fed": True, "clips_per_gpu_per_step": cfg["b"], "frames": cfg["n"], "height": cfg["h"], "width": cfg["w"],
+                       "num_bins": cfg["tb"], "bin_mode": "sum" if cfg["kind"] == "ring" else "bilinear", "input_dtype": "uint8",
+                       "source": ("pre-generated 201x128x128 uint8 clips, 9 fork()ed workers per rank -> page-locked shared ring (video decode excluded)" if cfg["kind"] == "ring"
+                                  else "decoded 1280x720 BGR frames in page-locked host memory; " + ("the front-end kernel reads the crop rectangles over PCIe (zero-copy)" if cfg.get("zero_copy") else "whole frames cross PCIe (HostStager)")),
+                       "sharding": f"one stream per rank, {world} rank(s), no collective"},
+            "stream": {"samples_per_s": cfg["b"] * world * args.steps / elapsed, "h2d_bytes_per_step_per_rank": h2d,
+                       "pcie_GBps_per_rank": [round(v, 2) for v in per_rank_gbps], "gpu_only_ms_per_step": gpu_ms,
+                       "gpu_busy_fraction_rank0": gpu_ms / per_rank_ms[0]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": S.kernel_name, "algorithmic_bytes_per_launch": S.alg_bytes, "kernel_ms_avg": gpu_ms,
+                         "note": "the step's kernels timed on device-resident input (HIP events); the stream itself is PCIe / host bound, see `stream`"},
+            "cpu_baseline": None, "parity_check": None, "extra": None,
+        }
+        sys.stderr.flush()
+        print(line_text(line), flush=True)
+    S.close()
+
+
 def time_launches(step, steps, torch):
     """Per-launch HIP events on the stream the kernels are launched on (torch's current stream)."""
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
@@ -647,7 +811,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS) + sorted(STREAM_WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads of the default run")
@@ -681,6 +845,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = sharding.init_process_group(args.backend, dev)  # RCCL; used for the barrier + max-over-ranks only
     backend = dist.get_backend() if dist is not None else None
+
+    if args.workload in STREAM_WORKLOADS:
+        run_stream(args, torch, dev, rank, local_rank, world, dist, backend)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     W = Workload(args.workload, dev, rank, world, args.batch)
     wl = W.wl

@@ -196,6 +196,30 @@ def test_hip_frontend_tiled_batch_mixed_rectangles():
         assert np.array_equal(gray[c].cpu().numpy(), want), c
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("color_mode", ["gray", "gray_in_bgr_out"])
+def test_hip_frontend_reads_page_locked_host_frames_zero_copy(color_mode):
+    """BASELINE config 4's stream: the decoded frames sit in PAGE-LOCKED HOST memory and the front-end kernel stages each clip's crop
+    rectangle straight out of it over PCIe (no copy of the whole frames, no host-side slicing).  Same results as with device-resident
+    frames, bit for bit; pageable host memory is refused."""
+    import torch
+    from v2v_amd import frontend
+    g = np.random.default_rng(12)
+    b, t, hs, ws, crop = 3, 4, 360, 640, 96
+    raw = torch.from_numpy(g.integers(0, 256, size=(b, t, hs, ws, 3), dtype=np.uint8))
+    table = np.array([[5, 7, 120, 0], [100, 300, 190, 1], [0, 0, 96, 1]], dtype=np.int32)
+    idx = np.array([[0, 1, 1, 2, 3]] * b, dtype=np.int32)
+    want_imgs, want_gray = frontend.prepare_clips_batch(raw.cuda(), table, idx, crop, color_mode, want_imgs=color_mode != "gray")
+    pinned = raw.pin_memory()
+    for rep in range(3):
+        got_imgs, got_gray = frontend.prepare_clips_batch(pinned, table, idx, crop, color_mode, want_imgs=color_mode != "gray")
+        assert got_gray.is_cuda and torch.equal(got_gray, want_gray), rep
+        if want_imgs is not None:
+            assert torch.equal(got_imgs, want_imgs), rep
+    with pytest.raises(ValueError):
+        frontend.prepare_clips_batch(raw, table, idx, crop, color_mode)              # pageable host memory: not device-accessible
+
+
 def test_bgr2gray_known_answers():
     """Hand-worked known answers of the two fixed-point BGR2GRAY forms (oracle/frontend_oracle.py header): OpenCV >= 4.0
     (B*3735 + G*19235 + R*9798 + 16384) >> 15 and OpenCV 2.x/3.x (B*1868 + G*9617 + R*4899 + 8192) >> 14.

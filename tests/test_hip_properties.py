@@ -136,6 +136,35 @@ def test_bench_two_ranks_under_torch_distributed_run():
     assert s1["dist_backend"] is None and 0.3 < d["value"] / s1["value"] < 2.5                          # two ranks on ONE device: ~1x, never 0
 
 
+@pytest.mark.parametrize("workload,clips,grids_per_clip", [("train_loader_b12", 12, 40), ("cfg4_stream", 8, 1), ("cfg4_stream_staged", 8, 1)])
+def test_bench_host_fed_stream_workloads_on_two_ranks(workload, clips, grids_per_clip):
+    """`bench.py --gpus 2 --workload train_loader_b12 | cfg4_stream` as the driver would launch it (torch.distributed.run, two ranks sharing
+    cuda:0 over gloo on this 1-GPU box): BASELINE configs 4 / 5 are host-fed streams, so these workloads put the host side -- worker
+    processes, page-locked rings / staging buffers, the PCIe copy -- INSIDE the timed region (the headline shards a device-resident batch,
+    which cannot fail to scale).  One line from rank 0: aggregate grids/s of both ranks, per-rank ms per step and PCIe GB/s."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--workload", workload,
+           "--share-gpu", "--backend", "gloo"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0].encode()) <= 4096, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["metric"] == "voxel grids/sec" and d["n_gpus"] == 2 and d["dist_backend"] == "gloo" and d["config"]["workload"] == workload and d["config"]["host_fed"]
+    assert abs(d["value"] - 2 * clips * grids_per_clip * 6 / (d["ms_per_step"] * 6e-3)) / d["value"] < 1e-6      # whole-job aggregate over both ranks
+    st = d["stream"]
+    assert abs(st["samples_per_s"] * grids_per_clip - d["value"]) / d["value"] < 1e-6
+    assert len(st["pcie_GBps_per_rank"]) == 2 and all(0.05 < v < 70 for v in st["pcie_GBps_per_rank"]) and len(d["ms_per_step_per_rank"]) == 2
+    assert st["h2d_bytes_per_step_per_rank"] > 1e6 and 0 < st["gpu_busy_fraction_rank0"] <= 1.5
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+
+
 def test_shapes_at_the_edges_vs_oracle(oracle_c, luts):
     """The reference's training shape (201 frames, 128x128, 40x5 bins), an odd-sized frame (scalar path, 101x203),
     and many tiny clips in one launch -- all bit-exact against the scalar C oracle."""

@@ -57,18 +57,26 @@ def prepare_clip(raw: torch.Tensor, crop_before: int, min_i: int, min_j: int, fl
 
 
 def prepare_clips_batch(raw: torch.Tensor, clip_table, img_idxes, crop_size: int, color_mode: str = "gray",
-                        want_imgs: bool = False, validate: bool = True, max_crop_before: int = 0, cv_version: str = "cv4"):
+                        want_imgs: bool = False, validate: bool = True, max_crop_before: int = 0, cv_version: str = "cv4", device=None):
     """Batch form of prepare_clip (no shake): raw [B,T,Hs,Ws,C] uint8 CUDA; clip_table [B,4] int = {min_i, min_j,
     crop_before, flip}; img_idxes [B,N].  Returns (imgs [B,N,crop,crop,Cout] or None, gray [B,N,crop,crop]) -- ONE launch.
     max_crop_before: optional upper bound of crop_before for device-resident tables (taken from the table when it is on
-    the host); it only sizes the kernel's LDS tile."""
+    the host); it only sizes the kernel's LDS tile.
+    ZERO-COPY HOST INPUT (round 6): `raw` may be a contiguous PAGE-LOCKED host tensor (`raw.is_pinned()`); the kernel then stages each crop
+    rectangle straight out of host memory over PCIe -- only the cb x cb x C bytes the resize reads cross the link, no staging copy of the
+    whole 720p frames, no host-side slicing (BASELINE config 4's stream: 11x fewer bytes than shipping the frames).  Results are placed on
+    `device` (default: the current CUDA device).  The host buffer must stay untouched until the launch has finished (stream-ordered, like
+    any asynchronous copy out of page-locked memory)."""
     _lib.require_gpu()
-    if raw.ndim != 5 or raw.dtype != torch.uint8 or not raw.is_cuda:
-        raise ValueError("raw must be a [B,T,Hs,Ws,C] uint8 CUDA tensor")
+    host_input = (not raw.is_cuda) and raw.is_pinned()
+    if raw.ndim != 5 or raw.dtype != torch.uint8 or not (raw.is_cuda or host_input):
+        raise ValueError("raw must be a [B,T,Hs,Ws,C] uint8 CUDA tensor (or a page-locked host tensor: zero-copy input)")
     assert color_mode in ["gray", "gray_in_bgr_out"]
+    if host_input and not raw.is_contiguous():
+        raise ValueError("a page-locked host `raw` must be contiguous (a .contiguous() copy would not be page-locked)")
     raw = raw.contiguous()
     b, t, hs, ws, cs = raw.shape
-    dev = raw.device
+    dev = raw.device if raw.is_cuda else (torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device()))
     def on_device(x):
         return isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.int32 and x.is_contiguous()
     if not validate and on_device(clip_table) and on_device(img_idxes):
