@@ -168,12 +168,16 @@ def cpu_baseline_all_cores(frames_host, wl, budget_s=8.0, distinct_clips=32):
         path = os.path.join(tmp, "clips.npy")
         np.save(path, frames_host[:distinct_clips])
         ctx = mp.get_context("spawn")
-        with ctx.Pool(cores, initializer=_pool_init, initargs=(path, wl_small)) as pool:
+        pool = ctx.Pool(cores, initializer=_pool_init, initargs=(path, wl_small))
+        try:
             pool.map(_pool_clip, range(cores), chunksize=1)            # imports, page-in, one clip each: outside the timed part
             done, t0 = 0, time.perf_counter()
             while time.perf_counter() - t0 < budget_s:                 # rounds of two clips per worker until the budget is spent
                 done += sum(pool.map(_pool_clip, range(done, done + 2 * cores), chunksize=1))
             dt = time.perf_counter() - t0
+        finally:
+            pool.close()                                               # workers leave through their own exit, not through Pool.terminate()'s SIGTERM
+            pool.join()
     grids = done * (1 if wl["bin"] == "bilinear" else (frames_host.shape[1] - 1) // (wl["tb"] * wl["fpb"]))
     return {"value": grids / dt, "unit": "voxel grids/s", "cores": cores, "kind": "port",
             "sample": f"{done} clip simulations ({min(distinct_clips, frames_host.shape[0])} distinct clips of the batch) over {cores} single-threaded worker "
