@@ -326,6 +326,20 @@ def test_g23_events_to_image(golden):
         np.testing.assert_allclose(img.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
     via_np = voxel.events_to_image(g["fx"], g["fy"], g["weights"].astype(np.float32), sensor_size=(16, 24), interpolation="bilinear", padding=False)
     np.testing.assert_allclose(via_np, g["torch_bilinear_pad0"], rtol=1e-5, atol=1e-5)
+    # against torch's own index_put_ (what the reference accumulates with) -- negative coordinates wrap like any torch
+    # index; events_to_image(interpolation='bilinear') takes the torch route for INTEGER NumPy coordinates too (utils/event_utils.py:160
+    # tests a NumPy dtype against torch.long), which masks events in the last row / column instead of counting them
+    nx, ny, nw = torch.tensor([-1, 3, -24, 5]), torch.tensor([-16, -1, 2, 0]), torch.tensor([1.0, 2.0, 4.0, 8.0])
+    want = torch.zeros((16, 24)).index_put_((ny, nx), nw, accumulate=True)
+    assert torch.equal(voxel.events_to_image_torch(nx, ny, nw, sensor_size=(16, 24), padding=False).cpu(), want)
+    with pytest.raises(IndexError):
+        voxel.events_to_image_torch(torch.tensor([-25]), torch.tensor([0]), torch.tensor([1.0]), sensor_size=(16, 24), padding=False)
+    ix, iy, iw = np.array([2, 23, 5, 7]), np.array([3, 4, 15, 8]), np.array([1.0, 2.0, 4.0, 8.0])
+    ref = torch.zeros((16, 24))
+    for k in (0, 3):                                                   # x = 23 (last column) and y = 15 (last row) are masked to weight 0
+        ref[iy[k], ix[k]] += float(iw[k])
+    got = voxel.events_to_image(ix, iy, iw, sensor_size=(16, 24), interpolation="bilinear", padding=False)
+    assert np.array_equal(got, ref.numpy().astype(got.dtype))
 
 
 @pytest.mark.parametrize("tag,tb", [("bil", True), ("disc", False)])
