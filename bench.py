@@ -941,7 +941,7 @@ def main():
         # the line itself, the rest of tools/loader_bench.py's output in the sidecar
         lv = ((extra.get("also_measured") or {}).get("train_loader_b12_201x128x128") or {}).get("integration_levels_samples_per_s")
         if lv:
-            line["train_loader_samples_per_s"] = {k: (round(v, 1) if isinstance(v, float) else v) for k, v in lv.items() if k != "decode_caveat"}
+            line["train_loader_samples_per_s"] = {k: (round(v, 1) if isinstance(v, float) else v) for k, v in lv.items() if k != "decode_caveat" and v is not None}
             line["train_loader_samples_per_s"]["note"] = "B=12, 201x128x128 -> [12,40,5,128,128]; video decode excluded at every level"
             e2 = (extra["also_measured"]["train_loader_b12_201x128x128"].get("ring_loader_feeding_e2vid") or {}).get("samples_per_s")
             if e2:

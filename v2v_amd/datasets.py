@@ -86,7 +86,7 @@ def synthetic_frame_source(dataset, sample_idx, start_frame, end_frame, crop_siz
 _worker_exit_hook_installed = False
 
 
-def _worker_exit(dataset_ref, join_timeout_s=5.0):
+def _worker_exit(dataset_ref, join_timeout_s=2.0):
     """atexit hook of a SPAWNED DataLoader worker that used the GPU (installed by the first simulating __getitem__ in such a process).
 
     Why it exists: a spawned child ends through the interpreter's full finalisation (multiprocessing/spawn.py: `sys.exit(exitcode)`;
@@ -98,8 +98,9 @@ def _worker_exit(dataset_ref, join_timeout_s=5.0):
     SIGABRT), which train.py's DataLoader reports as "worker killed by signal: Aborted".  atexit callbacks run BEFORE finalisation,
     while threads may still take the GIL, so here the worker (1) lets the feeder thread(s) send what is buffered and return (the
     queue is already closed: the sentinel is in its buffer), (2) waits for its own launches, drops the page-locked staging slots and
-    device buffers and returns the IPC blocks whose consumers have released them.  If a feeder cannot finish (the training process
-    stopped reading and the pipe is full) the worker ends the way a fork()ed one does, with os._exit(0), rather than abort."""
+    device buffers and returns the IPC blocks whose consumers have released them.  If a feeder cannot finish within `join_timeout_s`
+    (the training process stopped reading and the pipe is full; the timeout stays below the 5 s torch's DataLoader grants a worker
+    before it terminate()s it) the worker ends the way a fork()ed one does, with os._exit(0), rather than abort."""
     import gc
     import multiprocessing.queues as mpq
     stuck = False
