@@ -151,9 +151,8 @@ def events_to_image(xs, ys, ps, sensor_size=(180, 240), interpolation=None, padd
 def _scatter_f32(xs_d, ys_d, w_d, h, w, dev):
     """sum of float32 weights at integer coordinates -> [h, w] float32: the one-bin discrete case of the float32 voxel kernel."""
     n = xs_d.numel()
-    # index_put_ (the reference's accumulator, utils/event_utils.py:180-183, :375) wraps negative indices like any torch index: -1 is the last
-    # row / column; below -size it raises, as here
-    xs_d, ys_d = torch.where(xs_d < 0, xs_d + w, xs_d), torch.where(ys_d < 0, ys_d + h, ys_d)
+    # (negative indices wrap ONCE inside the kernel, like index_put_ -- the reference's accumulator, utils/event_utils.py:180-183, :375;
+    # below -size the event is counted in `dropped` and raises here, as torch does)
     out = torch.empty((1, h, w), dtype=torch.float32, device=dev)
     dropped = torch.empty((1,), dtype=torch.int64, device=dev)
     ts_d = torch.zeros((max(n, 1),), dtype=torch.float32, device=dev)
