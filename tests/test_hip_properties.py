@@ -90,7 +90,15 @@ def test_bench_default_command_prints_a_small_last_line_and_a_sidecar(tmp_path):
                 "config", "roofline", "cpu_baseline", "parity_check", "dist_backend", "ms_per_step_per_rank"):
         assert key in d, key
     assert d["config"]["workload"] == "cfg2_esim_f32_256x32x256x256_bilinear5" and d["config"]["clips_per_gpu"] == 256 and d["steps"] == 20
-    assert d["parity_check"] == "ok" and d["cpu_baseline"]["value"] > 0
+    assert d["parity_check"] == "ok" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == 1
+    # north_star: "the reference CPU path timed on the same box's host cores in the same run (core count stated)" -- the NumPy port in a pool
+    # over every core this process may USE (affinity mask cut by the cgroup quota, not os.cpu_count())
+    ca = d["cpu_baseline_all_cores"]
+    usable = len(os.sched_getaffinity(0))
+    assert ca["kind"] == "port" and 1 <= ca["cores"] <= usable and ca["value"] > 0 and "worker processes" in ca["sample"]
+    assert ca["cores"] == 1 or ca["value"] > d["cpu_baseline"]["value"]                                  # more cores, more grids per second
+    for stream in (res.stderr,):                                                                       # the driver keeps stderr: nothing may abort
+        assert "terminate called" not in stream and "Aborted" not in stream and "killed by signal" not in stream, stream[-2000:]
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "algorithmic_bytes_per_launch", "kernel_ms_avg", "kernel_ms_p50"):
         assert key in r, key
