@@ -232,6 +232,34 @@ def test_cfg4_720p_to_256_pipeline(oracle_c, luts, n, bin_mode, b):
 
 
 @pytest.mark.gpu
+def test_cfg4_stream_zero_copy_from_page_locked_host_frames_at_full_geometry():
+    """BASELINE config 4 as a host-fed stream at bench.py's per-rank geometry (`--workload cfg4_stream`): 8 clips x 40 decoded 1280x720 BGR
+    frames (885 MB) in PAGE-LOCKED HOST memory; the front-end kernel reads the crop rectangles straight out of it over PCIe.  The gray
+    clips and the 5-bin grids of the simulator behind them equal those of the device-resident frames bit for bit, for every clip."""
+    import torch
+    from v2v_amd import esim, frontend
+    b, n, sh, sw, crop = 8, 40, 720, 1280, 256
+    g = np.random.default_rng(909)
+    base = esim.synth_clips(b, n, sh, sw, dtype=torch.uint8, seed=SEED + 11, clip_id0=0)
+    raw = torch.stack([base, base.flip(-1), 255 - base], dim=-1).contiguous()
+    del base
+    keep_h = int(sh * 0.54)
+    scale = g.uniform(max(crop / keep_h, crop / sw), 1.3, size=b)
+    cb = (crop / scale).astype(np.int64)
+    table = np.stack([[g.integers(0, keep_h - c + 1), g.integers(0, sw - c + 1), c, int(g.random() > 0.5)] for c in cb]).astype(np.int32)
+    idx = np.tile(np.arange(n, dtype=np.int32), (b, 1))
+    _, want_gray = frontend.prepare_clips_batch(raw, table, idx, crop, "gray")
+    host = raw.cpu().pin_memory()
+    del raw
+    torch.cuda.empty_cache()
+    _, got_gray = frontend.prepare_clips_batch(host, table, idx, crop, "gray")
+    assert got_gray.is_cuda and torch.equal(got_gray, want_gray)
+    p = [0.2, 0.3, 0.05, 5e-4, 1.0]
+    kw = dict(bin_mode="bilinear", num_bins=5, seed=SEED, clip_id0=7)
+    assert torch.equal(esim.esim_voxel_batch(got_gray, p, **kw), esim.esim_voxel_batch(want_gray, p, **kw))
+
+
+@pytest.mark.gpu
 def test_cfg5_pipeline_feeds_the_consumer():
     """BASELINE config 5 at its per-GPU geometry: 8 clips of 41 decoded 1280x720x3 frames -> GPU front-end -> simulator (SUM, 5 bins
     -> [8,8,5,256,256]) -> the E2VID-shaped recurrent network of tools/e2vid_consumer.py over the 8 time steps, with its three
