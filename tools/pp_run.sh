@@ -1,5 +1,5 @@
 #!/bin/bash
-# EXPERIMENT driver (GPU box) for tools/experiments/convlstm_pingpong_schedule.patch: race screen (bit-identity with the shipped
+# EXPERIMENT driver (GPU box) for docs/experiments/convlstm_pingpong_schedule.patch: race screen (bit-identity with the shipped
 # 256-pixel tile over many launches), timings of every tile, and -- with gpurun_variants/lib_*timing.so built with
 # -DV2V_CL_TIMING -- the per-segment cycle breakdown.  usage: pp_run.sh [rounds]
 cd $GRAFT_REPO_ROOT

@@ -28,7 +28,7 @@
 // on the SOURCE address of the LDS-DMA (its LDS destination is lane-linear) and on the ds_read_b128 address -- which makes
 // every 16-lane group of a fragment read hit 16 distinct (row parity, slot) pairs = all 64 banks once.
 // The launcher picks the largest tile that still gives every CU a workgroup (256 -> 128 -> 64 pixels).  Where a wave's cycles
-// go (cycle stamps of a -DV2V_CL_TIMING build: tools/experiments/convlstm_ablation_and_timing_switches.patch re-adds them; 256-pixel tile): 7-16 % in the vmcnt wait, 16-17 % in the
+// go (cycle stamps of a -DV2V_CL_TIMING build: docs/experiments/convlstm_ablation_and_timing_switches.patch re-adds them; 256-pixel tile): 7-16 % in the vmcnt wait, 16-17 % in the
 // barrier, the rest in LDS-DMA issue + fragment reads + MFMA -- the 8 LDS-DMA instructions a wave issues per chunk cost about
 // as much issue time as half of its 32 MFMAs.
 #pragma once
