@@ -601,13 +601,13 @@ def convlstm_roofline(torch, dev):
 
 def load_valu(name, kernel_ms):
     """VALU-issue view of a launch, next to the HBM one (the noise-on kernels are issue-bound, not bandwidth-bound): the kernel's
-    dynamic vector-instruction count per launch (SQ_INSTS_VALU of the rocprofv3 --pmc pass in profiles/r04|r03/<workload>/summary.json --
+    dynamic vector-instruction count per launch (SQ_INSTS_VALU of the rocprofv3 --pmc pass in profiles/r06|r05|r04|r03/<workload>/summary.json --
     static per binary, like `traffic`) over this run's kernel time, against what 4 SIMDs x 256 CUs can issue at the 2.4 GHz peak
     clock: one wave-instruction per 2 cycles for the cheap class (add/sub/mul/logic/shift/mov) and per 4 cycles for everything else
     (all float64, fma, convert, compare, select, packed: profiles/valu_rates_ubench.txt).  The true ceiling of a kernel lies between
     the two by its instruction mix and is lowered further by the clock the chip holds under load (~1.7-1.9 GHz here)."""
     insts = rel = None
-    for tag in ("r05", "r04", "r03"):              # the latest profile of this workload's kernels
+    for tag in ("r06", "r05", "r04", "r03"):       # the latest profile of this workload's kernels
         try:
             rel = f"profiles/{tag}/{name}/summary.json"
             insts = json.load(open(os.path.join(ROOT, rel)))["sq_counters_per_step"]["SQ_INSTS_VALU"]
