@@ -94,12 +94,21 @@ def host_cores():
         n = os.cpu_count() or 1
     detail = f"affinity mask {n} of {os.cpu_count()} logical CPUs"
     try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        text = open("/sys/fs/cgroup/cpu.max").read()
+    except OSError:
+        text = ""
+    return apply_cpu_quota(n, detail, text)
+
+
+def apply_cpu_quota(n, detail, cpu_max_text):
+    """cgroup v2 `cpu.max` ("<quota> <period>" in microseconds, or "max <period>") applied to an affinity count (pure: unit-tested)."""
+    try:
+        quota, period = cpu_max_text.split()
         if quota != "max":
             q = float(quota) / float(period)
             detail += f", cgroup quota {q:.1f} CPUs"
             n = max(1, min(n, int(q)))
-    except (OSError, ValueError):
+    except ValueError:
         pass
     return n, detail
 

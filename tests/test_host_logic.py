@@ -295,3 +295,17 @@ def test_opencv_decode_branch_runs_against_a_stand_in_cv2(tmp_path, monkeypatch,
         assert a["sim_frames"].shape == (16, 32, 32) and a["sim_frames"].dtype == torch.uint8 and float(a["sim_frames"].float().std()) > 1
     names = [c[0] for c in fake_cv2.calls]
     assert names.count("VideoCapture") == names.count("release") and "set_pos" in names      # every capture is released; the clip is sought, not read from frame 0
+
+
+def test_bench_core_count_is_what_the_process_may_use():
+    """bench.py's `cores`: the affinity mask cut by the cgroup CPU quota -- the pool's 1-GPU boxes report os.cpu_count() = 256 and grant 16."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.apply_cpu_quota(256, "m", "1600000 100000\n") == (16, "m, cgroup quota 16.0 CPUs")
+    assert bench.apply_cpu_quota(8, "m", "max 100000\n") == (8, "m")
+    assert bench.apply_cpu_quota(8, "m", "1600000 100000") == (8, "m, cgroup quota 16.0 CPUs")            # a quota above the mask changes nothing
+    assert bench.apply_cpu_quota(8, "m", "50000 100000")[0] == 1 and bench.apply_cpu_quota(8, "m", "")[0] == 8
+    n, detail = bench.host_cores()
+    assert 1 <= n <= len(os.sched_getaffinity(0)) and "affinity mask" in detail
