@@ -873,10 +873,10 @@ def main():
     step, use_graph = maybe_graph(step, torch, dev, args.hip_graph == "on" or (args.hip_graph == "auto" and wl["model"] in ("pipeline", "train_batch")))
     sharding.barrier(dist, local_rank)
     t0 = time.perf_counter()
-    kern_trace = time_launches(step, args.steps, torch)
-    kern_ms = sorted(kern_trace)
-    sharding.barrier(dist, local_rank)
+    kern_trace = time_launches(step, args.steps, torch)           # ends with torch.cuda.synchronize(): this rank's K steps are done
     my_elapsed = time.perf_counter() - t0
+    kern_ms = sorted(kern_trace)
+    sharding.barrier(dist, local_rank)                            # the closing bracket; the job's time is the MAX over ranks of their own K steps
     elapsed = sharding.max_over_ranks(dist, my_elapsed, dev)
     per_rank_ms = sharding.gather_floats(dist, my_elapsed / args.steps * 1e3, dev)        # every rank's own ms per step
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
